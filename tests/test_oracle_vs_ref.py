@@ -1,0 +1,24 @@
+"""CPU, dev container only: the oracle against the live reference build (oracle/_ref) on fresh seeds.
+Skipped where oracle/_ref is absent."""
+import numpy as np
+import pytest
+
+from _golden import rel
+from abip_amd import problems
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+@pytest.mark.parametrize("linsys", ["indirect", "direct"])
+def test_random_lp_against_live_reference(oracle_built, seed, linsys):
+    po = oracle_built
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    A, b, c = problems.lp_random_sparse(m=120, n=400, per_col=5, seed=seed)
+    r = po.solve("ref", A, b, c, linsys=linsys, eps=1e-5)
+    o = po.solve("oracle", A, b, c, linsys=linsys, eps=1e-5)
+    assert r.info["status_val"] == o.info["status_val"] == 1
+    assert r.info["admm_iter"] == o.info["admm_iter"] and r.info["ipm_iter"] == o.info["ipm_iter"]
+    tol = 1e-12 if linsys == "indirect" else 1e-7
+    for k in "xys":
+        assert rel(getattr(o, k), getattr(r, k)) < tol
+    assert r.settings_after == o.settings_after   # the solver mutates caller-owned settings identically
