@@ -1,0 +1,187 @@
+// dev_common.h -- shared device-side building blocks for the ABIP hot path on gfx950.
+//
+// Conventions
+//  * every kernel is launched with BS = 256 threads (4 wavefronts of 64) and a
+//    persistent grid of NB <= MAXNB blocks that grid-strides over its work;
+//  * a reduction never uses atomics: the producer kernel writes one partial per block
+//    into a slot of the partials table, and the CONSUMER kernel re-reduces those NB
+//    numbers in a fixed order at its start (every block gets the bit-identical scalar).
+//    That costs one 8 KB L2 read per block instead of a kernel boundary or a fence,
+//    and makes every run bit-reproducible;
+//  * "l-vectors" (u, v, u_t, ... of length m+n+1, reference layout [y | x | tau],
+//    src/abip-lp/src/abip.c:368-378) are stored as [y(m) | pad | x(n) | tau] with the
+//    x block starting at the 256-byte aligned offset MP so that both blocks vectorise.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace abip {
+
+constexpr int BS = 256;        // threads per block
+constexpr int WAVES = BS / 64; // wavefronts per block
+constexpr int CHUNK = 1024;    // non-zeros staged through LDS per row block (4 per thread)
+constexpr int MAXNB = 1024;    // upper bound on the persistent grid == partials per slot
+
+// CSR view (A' is the CSC of A read as CSR; A is the explicit transpose, indirect.c:81-139).
+struct Csr {
+  const int *ptr;    // nrows+1
+  const int *idx;    // nnz
+  const double *val; // nnz
+  const int *rb;     // row-block boundaries, nrb+1 (host-built: <= CHUNK nnz per block, or one long row)
+  int nrb;
+  int nrows;
+};
+
+// partial-sum slots (each MAXNB doubles)
+enum Slot : int {
+  S_WG = 0,   // sum rho*(u+v)_y*g_y + (u+v)_x*g_x          (next rhs, abip.c:557)
+  S_BN,       // ||rhs_y||^2                                  (cg_tol, indirect.c:406)
+  S_RR0, S_RR1, // ||r||^2, ping-pong by CG iteration parity   (indirect.c:359,375)
+  S_ZR0, S_ZR1, // z'r                                         (indirect.c:263-280)
+  S_PG,       // p'Gp                                         (indirect.c:371)
+  S_DH,       // u_t[0:l-1)'h                                 (abip.c:560)
+  S_NU, S_NV, S_CX, S_BY,         // ||u||^2, ||v||^2, c'x, b'y    (abip.c:1993-1996)
+  S_NUA, S_NVA, S_CXA, S_BYA,     // the same for the averaged iterate (abip.c:2031-2036)
+  S_QP, S_RP, S_NAX,              // sum (Ax-b tau)^2, D-weighted, ||D Ax||^2   (abip.c:1984-1987, 407-413)
+  S_QD, S_RD, S_NATY,             // sum (A'y+s-c tau)^2, E-weighted, ||E(A'y+s)||^2 (abip.c:1989-1992, 443-449)
+  S_QPA, S_RPA, S_NAXA, S_QDA, S_RDA, S_NATYA, // averaged iterate
+  S_XS, S_XMIN,                   // sum u_i v_i, min u_i v_i       (abip.c:962-965)
+  S_A0, S_A1, S_A2, S_A3, S_A4,   // BB search: utut, utv, uu, vv, uv (adaptive.c:170-174)
+  S_T0, S_T1,                     // scratch dots
+  S_COUNT
+};
+
+// device-resident control block (also copied to the host once per ADMM iteration)
+struct Ctl {
+  int halt;      // 1: every gated kernel returns immediately
+  int cg_done;   // set by the first kernel that sees ||r|| < tol (idempotent: every block decides alike)
+  int cg_it;     // CG updates completed so far (written by the update kernel, read by the next SpMV)
+  int it_cur;    // iteration index the current SpMV pair works on (written by spmv_At, read by the others)
+  double beta_cur; // z'r / z'r_old of the current iteration
+  double zr_cur;   // z'r entering the current iteration
+  double zr_hist[2];
+  double cg_tol;
+  double out[96];  // finalised reductions, index = Slot
+};
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  return x;
+}
+
+// Sum NS per-thread values over the block; every thread receives the totals (fixed order).
+template <int NS>
+__device__ __forceinline__ void block_sum(double (&v)[NS], double *sm /* NS*WAVES */) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) v[s] = wave_sum(v[s]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sm[s * WAVES + wave] = v[s];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    double t = sm[s * WAVES];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) t += sm[s * WAVES + w];
+    v[s] = t;
+  }
+}
+
+template <int NS>
+__device__ __forceinline__ void write_partials(double *part, const int (&slots)[NS], double (&v)[NS], double *sm) {
+  block_sum<NS>(v, sm);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) part[slots[s] * MAXNB + blockIdx.x] = v[s];
+  }
+}
+
+// Re-reduce the nb per-block partials of NS slots; all threads of all blocks get identical totals.
+template <int NS>
+__device__ __forceinline__ void read_partials(const double *part, const int (&slots)[NS], int nb, double (&out)[NS], double *sm) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nb; i += BS) acc += part[slots[s] * MAXNB + i];
+    out[s] = acc;
+  }
+  block_sum<NS>(out, sm);
+}
+
+__device__ __forceinline__ int pow2_floor(int x) { return x <= 1 ? 1 : 1 << (31 - __clz(x)); }
+
+// CSR-stream SpMV skeleton.  For every row block: all 256 threads stream the block's
+// non-zeros (coalesced: lane k reads entry k) and write NV products per entry into LDS;
+// then groups of `lpr` lanes reduce one row each from LDS and one lane per row runs the
+// row epilogue.  A block holding a single row longer than CHUNK is reduced by the whole
+// workgroup instead.  prod(col, a, out[NV]) forms the products; rowf(row, acc[NV]) consumes a row.
+template <int NV, class ProdF, class RowF>
+__device__ __forceinline__ void spmv_stream(const Csr M, double *lds /* NV*CHUNK */, double *sm /* NV*WAVES */, ProdF prod, RowF rowf) {
+  for (int b = blockIdx.x; b < M.nrb; b += gridDim.x) {
+    const int r0 = M.rb[b], r1 = M.rb[b + 1];
+    const int k0 = M.ptr[r0], k1 = M.ptr[r1];
+    const int nn = k1 - k0;
+    if (nn <= CHUNK) {
+      double a[4];
+      int c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = threadIdx.x + u * BS;
+        a[u] = 0.0; c[u] = 0;
+        if (k < nn) { a[u] = M.val[k0 + k]; c[u] = M.idx[k0 + k]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = threadIdx.x + u * BS;
+        if (k < nn) {
+          double pr[NV];
+          prod(c[u], a[u], pr);
+#pragma unroll
+          for (int v = 0; v < NV; ++v) lds[v * CHUNK + k] = pr[v];
+        }
+      }
+      __syncthreads();
+      const int R = r1 - r0;
+      int lpr = pow2_floor(BS / (R > 0 ? R : 1));
+      if (lpr > 64) lpr = 64;
+      const int ngrp = BS / lpr, grp = threadIdx.x / lpr, q = threadIdx.x % lpr;
+      for (int base = 0; base < R; base += ngrp) {
+        const int r = base + grp;
+        double acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+        if (r < R) {
+          const int s = M.ptr[r0 + r] - k0, e = M.ptr[r0 + r + 1] - k0;
+          for (int k = s + q; k < e; k += lpr) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] += lds[v * CHUNK + k];
+          }
+        }
+        for (int off = lpr >> 1; off > 0; off >>= 1) {
+#pragma unroll
+          for (int v = 0; v < NV; ++v) acc[v] += __shfl_xor(acc[v], off, 64);
+        }
+        if (r < R && q == 0) rowf(r0 + r, acc);
+      }
+      __syncthreads();
+    } else { // one long row
+      double acc[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+      for (int k = k0 + threadIdx.x; k < k1; k += BS) {
+        double pr[NV];
+        prod(M.idx[k], M.val[k], pr);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] += pr[v];
+      }
+      block_sum<NV>(acc, sm);
+      if (threadIdx.x == 0) rowf(r0, acc);
+      __syncthreads();
+    }
+  }
+}
+
+} // namespace abip

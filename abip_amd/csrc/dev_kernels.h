@@ -1,0 +1,569 @@
+// dev_kernels.h -- the HIP kernels of the ABIP-LP hot path (gfx950, fp64, wave64).
+//
+// One inner ADMM iteration (reference: src/abip-lp/src/abip.c:2131-2215) is the kernel chain
+//
+//   k_rhs                      project_lin_sys prologue, abip.c:552-558
+//   [indirect] k_cg_init_At, k_cg_init_A, { k_cg_spmv_At, k_cg_spmv_A, k_cg_update }*, k_post_At
+//                              solve_lin_sys / pcg, linsys/indirect.c:321-434
+//   [direct]   k_sptrsv_*      _ldl_solve, linsys/direct.c:172-198 ; then k_post_dot
+//   k_admm_update              u_t tau recovery abip.c:560, project_barrier 717-748, update_dual_vars
+//                              567-584, restart sums 602-606, compute_avg 649-656 (+ the reductions the
+//                              NEXT k_rhs and the inner stopping test need)
+//   k_q_A, k_q_At              iterate_Q_norm_resd 1976-1996 and calc_residuals 385-453 in one pass each
+//   k_finalize                 partials -> scalars for the host's once-per-iteration control read
+//
+// All reductions go through the partials table (dev_common.h); no atomics, no fences.
+#pragma once
+#include "dev_common.h"
+
+namespace abip {
+
+struct Dims { int m, n, MP; }; // MP = offset of the x block inside an l-vector; tau sits at MP+n
+
+#define ABIP_GATE_HALT(ctl) do { if ((ctl)->halt) return; } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// S_WG <- sum_y rho*(u+v)*g + sum_x (u+v)*g        (the part of abip.c:557's dot that does not
+// depend on tau; k_rhs adds the tau term analytically: (w - t h)'g = w'g - t g_th)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BS) void k_dot_wg(const double *__restrict__ u, const double *__restrict__ v,
+                                               const double *__restrict__ g, double rho, Dims d, double *part) {
+  __shared__ double sm[WAVES];
+  double acc[1] = {0.0};
+  const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
+  for (int i = t0; i < d.m; i += stride) acc[0] += rho * (u[i] + v[i]) * g[i];
+  for (int j = t0; j < d.n; j += stride) acc[0] += (u[d.MP + j] + v[d.MP + j]) * g[d.MP + j];
+  const int slots[1] = {S_WG};
+  write_partials<1>(part, slots, acc, sm);
+}
+
+// ||y||^2 of an l-vector's y block -> S_BN (setup solve only; k_rhs produces it in the loop)
+__global__ __launch_bounds__(BS) void k_norm_y(const double *__restrict__ x, Dims d, double *part) {
+  __shared__ double sm[WAVES];
+  double acc[1] = {0.0};
+  for (int i = blockIdx.x * BS + threadIdx.x; i < d.m; i += gridDim.x * BS) acc[0] += x[i] * x[i];
+  const int slots[1] = {S_BN};
+  write_partials<1>(part, slots, acc, sm);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rhs: u_t <- rhs of the KKT system (abip.c:552-558).
+//   u_t = u + v; u_t[y] *= rho; u_t[0:l-1) -= tau~ h; u_t[0:l-1) -= (u_t'g/(g_th+1)) h; u_t[x] *= -1
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BS) void k_rhs(const double *__restrict__ u, const double *__restrict__ v, double *__restrict__ ut,
+                                            const double *__restrict__ h, double rho, double g_th, Dims d,
+                                            double *part, int nb, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  __shared__ double sm[WAVES];
+  double wg[1];
+  const int rs[1] = {S_WG};
+  read_partials<1>(part, rs, nb, wg, sm);
+  const int tail = d.MP + d.n;
+  const double tsum = u[tail] + v[tail];
+  const double coef = (wg[0] - tsum * g_th) / (g_th + 1.0);
+  double acc[1] = {0.0};
+  const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
+  for (int i = t0; i < d.m; i += stride) {
+    double t = (u[i] + v[i]) * rho;
+    t += -tsum * h[i];
+    t += -coef * h[i];
+    ut[i] = t;
+    acc[0] += t * t;
+  }
+  for (int j = t0; j < d.n; j += stride) {
+    double t = u[d.MP + j] + v[d.MP + j];
+    t += -tsum * h[d.MP + j];
+    t += -coef * h[d.MP + j];
+    ut[d.MP + j] = -t;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) ut[tail] = tsum;
+  const int ws[1] = {S_BN};
+  write_partials<1>(part, ws, acc, sm);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PCG set-up (indirect.c:345-365).  tmp = A' s ; then in ONE pass over the rows of A:
+//   b_i = rhs_y[i] + (A rhs_x)_i      (indirect.c:415)
+//   r_i = b_i - ((A tmp)_i + rho s_i) (indirect.c:352-354)      x0 = s
+//   z_i = M_i r_i ; p = z             (indirect.c:364-365)
+// Without a warm start (s == nullptr): r = b, x0 = 0 (indirect.c:347-348).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BS) void k_cg_init_At(Csr At /* rows = columns of A */, const double *__restrict__ s,
+                                                   double *__restrict__ tmp, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  __shared__ double lds[CHUNK];
+  __shared__ double sm[WAVES];
+  spmv_stream<1>(
+      At, lds, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * s[c]; },
+      [&](int row, double(&acc)[1]) { tmp[row] = acc[0]; });
+}
+
+__global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rhs /* l-vector: y in/out (x0), x read */,
+                                                  const double *__restrict__ tmp, const double *__restrict__ s,
+                                                  const double *__restrict__ Minv, double *__restrict__ r, double *__restrict__ z,
+                                                  double *__restrict__ p, double rho, double tol_factor, Dims d,
+                                                  double *part, int nb, Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  __shared__ double lds[2 * CHUNK];
+  __shared__ double sm[2 * WAVES];
+  double bn[1];
+  const int rs[1] = {S_BN};
+  read_partials<1>(part, rs, nb, bn, sm);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double tol = sqrt(bn[0]) * tol_factor; // indirect.c:406-409
+    tol = fmax(tol, 1e-7);
+    ctl->cg_tol = fmax(tol, 1e-9);         // indirect.c:418
+    ctl->cg_it = 0;
+    ctl->cg_done = 0;
+  }
+  const double *bx = rhs + d.MP;
+  double acc2[2] = {0.0, 0.0};
+  if (s) {
+    spmv_stream<2>(
+        A, lds, sm, [&](int c, double a, double(&pr)[2]) { pr[0] = a * bx[c]; pr[1] = a * tmp[c]; },
+        [&](int i, double(&acc)[2]) {
+          const double si = s[i];
+          const double b = rhs[i] + acc[0];
+          const double ri = b - (acc[1] + rho * si);
+          const double zi = ri * Minv[i];
+          rhs[i] = si; r[i] = ri; z[i] = zi; p[i] = zi;
+          acc2[0] += ri * ri; acc2[1] += zi * ri;
+        });
+  } else {
+    spmv_stream<1>(
+        A, lds, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * bx[c]; },
+        [&](int i, double(&acc)[1]) {
+          const double ri = rhs[i] + acc[0];
+          const double zi = ri * Minv[i];
+          rhs[i] = 0.0; r[i] = ri; z[i] = zi; p[i] = zi;
+          acc2[0] += ri * ri; acc2[1] += zi * ri;
+        });
+  }
+  const int ws[2] = {S_RR0, S_ZR0};
+  write_partials<2>(part, ws, acc2, sm);
+}
+
+// Convergence test shared by the first SpMV of an iteration and by the post-solve kernel.
+// Every block evaluates it on the same partials, so all blocks agree (idempotent flag write).
+__device__ __forceinline__ bool cg_converged(Ctl *ctl, const double *part, int nb, int max_its, double *sm, int &it, double &zr) {
+  it = ctl->cg_it;
+  const int par = it & 1;
+  double v[2];
+  const int rs[2] = {S_RR0 + par, S_ZR0 + par};
+  read_partials<2>(part, rs, nb, v, sm);
+  zr = v[1];
+  const double nr = sqrt(v[0]), tol = ctl->cg_tol;
+  bool done = (it == 0) ? (nr < fmin(tol, 1e-18)) : (nr < tol); // indirect.c:359, 375
+  if (it >= max_its) done = true;                               // indirect.c:368
+  return done;
+}
+
+// tmp = A' p_new with p_new = z + beta p formed on the fly (indirect.c:386-387 folded into 216)
+__global__ __launch_bounds__(BS) void k_cg_spmv_At(Csr At, const double *__restrict__ z, const double *__restrict__ p,
+                                                   double *__restrict__ tmp, int max_its, double *part, int nb, Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (ctl->cg_done) return;
+  __shared__ double lds[CHUNK];
+  __shared__ double sm[2 * WAVES];
+  int it; double zr;
+  if (cg_converged(ctl, part, nb, max_its, sm, it, zr)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->cg_done = 1;
+    return;
+  }
+  const int par = it & 1;
+  const double beta = (it == 0) ? 0.0 : zr / ctl->zr_hist[par ^ 1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->it_cur = it; ctl->beta_cur = beta; ctl->zr_cur = zr; ctl->zr_hist[par] = zr; }
+  spmv_stream<1>(
+      At, lds, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * (z[c] + beta * p[c]); },
+      [&](int row, double(&acc)[1]) { tmp[row] = acc[0]; });
+}
+
+// p <- z + beta p ; Gp = A tmp + rho p ; S_PG <- p'Gp            (indirect.c:214-219, 371)
+__global__ __launch_bounds__(BS) void k_cg_spmv_A(Csr A, const double *__restrict__ tmp, const double *__restrict__ z,
+                                                  double *__restrict__ p, double *__restrict__ Gp, double rho, double *part, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (ctl->cg_done) return;
+  __shared__ double lds[CHUNK];
+  __shared__ double sm[WAVES];
+  const double beta = ctl->beta_cur;
+  double acc1[1] = {0.0};
+  spmv_stream<1>(
+      A, lds, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * tmp[c]; },
+      [&](int i, double(&acc)[1]) {
+        const double pn = z[i] + beta * p[i];
+        const double gp = acc[0] + rho * pn;
+        p[i] = pn; Gp[i] = gp;
+        acc1[0] += pn * gp;
+      });
+  const int ws[1] = {S_PG};
+  write_partials<1>(part, ws, acc1, sm);
+}
+
+// x += alpha p ; r -= alpha Gp ; z = M r ; S_RR, S_ZR (next parity)          (indirect.c:371-385)
+__global__ __launch_bounds__(BS) void k_cg_update(double *__restrict__ x, double *__restrict__ r, double *__restrict__ z,
+                                                  const double *__restrict__ p, const double *__restrict__ Gp,
+                                                  const double *__restrict__ Minv, int m, double *part, int nb, Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (ctl->cg_done) return;
+  __shared__ double sm[2 * WAVES];
+  double pg[1];
+  const int rs[1] = {S_PG};
+  read_partials<1>(part, rs, nb, pg, sm);
+  const int it = ctl->it_cur;
+  const double alpha = ctl->zr_cur / pg[0];
+  double acc[2] = {0.0, 0.0};
+  for (int i = blockIdx.x * BS + threadIdx.x; i < m; i += gridDim.x * BS) {
+    x[i] += alpha * p[i];
+    const double ri = r[i] - alpha * Gp[i];
+    const double zi = ri * Minv[i];
+    r[i] = ri; z[i] = zi;
+    acc[0] += ri * ri; acc[1] += zi * ri;
+  }
+  const int par = (it + 1) & 1;
+  const int ws[2] = {S_RR0 + par, S_ZR0 + par};
+  write_partials<2>(part, ws, acc, sm);
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctl->cg_it = it + 1;
+}
+
+// Post-solve: rhs_x <- A' rhs_y - rhs_x (indirect.c:419-420) and S_DH <- rhs[0:l-1)'h (abip.c:560).
+// Runs only once the CG has converged; re-checks convergence itself because the last update of a
+// chunk has no SpMV behind it.
+__global__ __launch_bounds__(BS) void k_post_At(Csr At, double *__restrict__ rhs, const double *__restrict__ h, Dims d,
+                                                int max_its, double *part, int nb, Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  __shared__ double lds[CHUNK];
+  __shared__ double sm[2 * WAVES];
+  if (!ctl->cg_done) {
+    int it; double zr;
+    if (!cg_converged(ctl, part, nb, max_its, sm, it, zr)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->cg_done = 1;
+  }
+  double *bx = rhs + d.MP;
+  const double *hx = h + d.MP;
+  double acc1[1] = {0.0};
+  spmv_stream<1>(
+      At, lds, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * rhs[c]; },
+      [&](int j, double(&acc)[1]) {
+        const double v = acc[0] - bx[j];
+        bx[j] = v;
+        acc1[0] += v * hx[j];
+      });
+  for (int i = blockIdx.x * BS + threadIdx.x; i < d.m; i += gridDim.x * BS) acc1[0] += rhs[i] * h[i];
+  const int ws[1] = {S_DH};
+  write_partials<1>(part, ws, acc1, sm);
+}
+
+// Direct back-end: only the dot with h is left to do after the triangular solves.
+__global__ __launch_bounds__(BS) void k_post_dot(const double *__restrict__ rhs, const double *__restrict__ h, Dims d, double *part, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  __shared__ double sm[WAVES];
+  double acc[1] = {0.0};
+  const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
+  for (int i = t0; i < d.m; i += stride) acc[0] += rhs[i] * h[i];
+  for (int j = t0; j < d.n; j += stride) acc[0] += rhs[d.MP + j] * h[d.MP + j];
+  const int ws[1] = {S_DH};
+  write_partials<1>(part, ws, acc, sm);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_admm_update: everything element-wise between the KKT solve and the stopping test.
+// ---------------------------------------------------------------------------------------------
+struct UpdArgs {
+  double *u, *v, *ut;
+  double *u_avg, *v_avg, *u_sum, *v_sum, *u_avgc, *v_avgc;
+  const double *g, *b, *c;
+  double alpha, mu_over_beta, rho, dom;
+  int half_update; // abip.c:2143-2149
+  int fuse_avg;    // 1: also do compute_avg + the statistics (no restart this iteration)
+  int avg_stats;   // 1: (j+1)%10==0 -> statistics of the averaged iterate too (abip.c:2000)
+};
+
+// statistics of one (u, v) element pair; tail = the tau/kappa entry (in the norms, not in the dots)
+struct Stat { double wg, nu, nv, cx, by, nua, nva, cxa, bya; };
+
+__device__ __forceinline__ void avg_and_stats_y(const UpdArgs &a, int i, double un, double vn, Stat &st) {
+  const double us = a.u_sum[i] + un, vs = a.v_sum[i] + vn; // compute_avg, abip.c:649-656
+  a.u_sum[i] = us; a.v_sum[i] = vs;
+  const double ua = us / a.dom, va = vs / a.dom;
+  a.u_avgc[i] = ua; a.v_avgc[i] = va;
+  st.wg += a.rho * (un + vn) * a.g[i];
+  st.nu += un * un; st.nv += vn * vn; st.by += a.b[i] * un;
+  if (a.avg_stats) { st.nua += ua * ua; st.nva += va * va; st.bya += a.b[i] * ua; }
+}
+__device__ __forceinline__ void avg_and_stats_x(const UpdArgs &a, int q /* MP + j */, int j, bool tail, double un, double vn, Stat &st) {
+  const double us = a.u_sum[q] + un, vs = a.v_sum[q] + vn;
+  a.u_sum[q] = us; a.v_sum[q] = vs;
+  const double ua = us / a.dom, va = vs / a.dom;
+  a.u_avgc[q] = ua; a.v_avgc[q] = va;
+  st.nu += un * un; st.nv += vn * vn;
+  if (a.avg_stats) { st.nua += ua * ua; st.nva += va * va; }
+  if (!tail) {
+    st.wg += (un + vn) * a.g[q];
+    st.cx += a.c[j] * un;
+    if (a.avg_stats) st.cxa += a.c[j] * ua;
+  }
+}
+__device__ __forceinline__ void prox_x(const UpdArgs &a, int q, double utq, double &un, double &vn) {
+  const double uo = a.u[q], vo = a.v[q];
+  if (!a.half_update) {
+    const double t = a.alpha * utq + (1.0 - a.alpha) * uo - vo; // abip.c:738
+    const double hlf = t / 2;
+    un = hlf + sqrt(hlf * hlf + a.mu_over_beta);                // abip.c:743-744: the barrier prox ("orthant clip")
+    vn = vo + (un - a.alpha * utq - (1.0 - a.alpha) * uo);      // abip.c:580
+  } else {
+    double vh = vo + 0.5 * (uo - utq);                          // abip.c:675
+    const double hlf = (utq - vh) / 2;                          // abip.c:695,700
+    un = hlf + sqrt(hlf * hlf + a.mu_over_beta);
+    vn = vh + (un - utq);                                       // abip.c:707
+  }
+}
+
+__global__ __launch_bounds__(BS) void k_admm_update(UpdArgs a, Dims d, double *part, int nb, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (!ctl->cg_done) return;
+  __shared__ double sm[9 * WAVES];
+  double dh[1];
+  const int rs[1] = {S_DH};
+  read_partials<1>(part, rs, nb, dh, sm);
+  Stat st = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
+  for (int i = t0; i < d.m; i += stride) {
+    double un, vn;
+    const double uti = a.ut[i];
+    if (!a.half_update) { vn = a.v[i]; un = uti - vn; }                                    // abip.c:731-734
+    else { double vh = a.v[i] + 0.5 * (a.u[i] - uti); un = uti - vh; vn = vh + (un - uti); } // abip.c:675,695,707
+    a.u[i] = un; a.v[i] = vn;
+    a.u_avg[i] += un; a.v_avg[i] += vn;                                                    // abip.c:602-606
+    if (a.fuse_avg) avg_and_stats_y(a, i, un, vn, st);
+  }
+  for (int j = t0; j < d.n; j += stride) {
+    const int q = d.MP + j;
+    double un, vn;
+    prox_x(a, q, a.ut[q], un, vn);
+    a.u[q] = un; a.v[q] = vn;
+    a.u_avg[q] += un; a.v_avg[q] += vn;
+    if (a.fuse_avg) avg_and_stats_x(a, q, j, false, un, vn, st);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { // the tau / kappa entry
+    const int q = d.MP + d.n;
+    const double utq = a.ut[q] + dh[0];      // abip.c:560
+    a.ut[q] = utq;
+    double un, vn;
+    prox_x(a, q, utq, un, vn);
+    a.u[q] = un; a.v[q] = vn;
+    a.u_avg[q] += un; a.v_avg[q] += vn;
+    if (a.fuse_avg) avg_and_stats_x(a, q, d.n, true, un, vn, st);
+  }
+  if (a.fuse_avg) {
+    double vals[9] = {st.wg, st.nu, st.nv, st.cx, st.by, st.nua, st.nva, st.cxa, st.bya};
+    const int ws[9] = {S_WG, S_NU, S_NV, S_CX, S_BY, S_NUA, S_NVA, S_CXA, S_BYA};
+    write_partials<9>(part, ws, vals, sm);
+  }
+}
+
+// restart from the running mean (abip.c:613-627): u,v <- u_avg/fre, v_avg/fre ; sums zeroed
+__global__ __launch_bounds__(BS) void k_restart_apply(double *u, double *v, double *u_avg, double *v_avg, double fre, int len) {
+  for (int i = blockIdx.x * BS + threadIdx.x; i < len; i += gridDim.x * BS) {
+    const double a = u_avg[i] / fre, b = v_avg[i] / fre;
+    u[i] = a; v[i] = b; u_avg[i] = 0.0; v_avg[i] = 0.0;
+  }
+}
+
+// compute_avg + statistics as a separate pass (used on restart iterations, where (u,v) change after the prox)
+__global__ __launch_bounds__(BS) void k_avg_stats(UpdArgs a, Dims d, double *part, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (!ctl->cg_done) return;
+  __shared__ double sm[9 * WAVES];
+  Stat st = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
+  for (int i = t0; i < d.m; i += stride) avg_and_stats_y(a, i, a.u[i], a.v[i], st);
+  for (int j = t0; j < d.n; j += stride) avg_and_stats_x(a, d.MP + j, j, false, a.u[d.MP + j], a.v[d.MP + j], st);
+  if (blockIdx.x == 0 && threadIdx.x == 0) avg_and_stats_x(a, d.MP + d.n, d.n, true, a.u[d.MP + d.n], a.v[d.MP + d.n], st);
+  double vals[9] = {st.wg, st.nu, st.nv, st.cx, st.by, st.nua, st.nva, st.cxa, st.bya};
+  const int ws[9] = {S_WG, S_NU, S_NV, S_CX, S_BY, S_NUA, S_NVA, S_CXA, S_BYA};
+  write_partials<9>(part, ws, vals, sm);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Residual SpMV pair: the inner stopping metric (abip.c:1976-1992) and the D/E-weighted outer
+// residuals (abip.c:407-413, 443-449) from ONE pass over each matrix; pr/dr are never stored.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BS) void k_q_A(Csr A, const double *__restrict__ uu /* l-vector */, const double *__restrict__ b,
+                                            const double *__restrict__ wD /* D_i/(sc_b*scale) or null */, Dims d, int slot0,
+                                            double *part, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (!ctl->cg_done) return;
+  __shared__ double lds[CHUNK];
+  __shared__ double sm[3 * WAVES];
+  const double *x = uu + d.MP;
+  const double tau = uu[d.MP + d.n];
+  double acc3[3] = {0.0, 0.0, 0.0};
+  spmv_stream<1>(
+      A, lds, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
+      [&](int i, double(&acc)[1]) {
+        const double pri = acc[0], e = pri - b[i] * tau;
+        double sc = wD ? wD[i] : 1.0;
+        sc = sc * sc;
+        acc3[0] += e * e; acc3[1] += (e * e) * sc; acc3[2] += (pri * pri) * sc;
+      });
+  const int ws[3] = {slot0, slot0 + 1, slot0 + 2};
+  write_partials<3>(part, ws, acc3, sm);
+}
+__global__ __launch_bounds__(BS) void k_q_At(Csr At, const double *__restrict__ uu, const double *__restrict__ vv, const double *__restrict__ c,
+                                             const double *__restrict__ wE /* E_j/(sc_c*scale) or null */, Dims d, int slot0,
+                                             double *part, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (!ctl->cg_done) return;
+  __shared__ double lds[CHUNK];
+  __shared__ double sm[3 * WAVES];
+  const double *s = vv + d.MP;
+  const double tau = uu[d.MP + d.n];
+  double acc3[3] = {0.0, 0.0, 0.0};
+  spmv_stream<1>(
+      At, lds, sm, [&](int cidx, double a, double(&pr)[1]) { pr[0] = a * uu[cidx]; },
+      [&](int j, double(&acc)[1]) {
+        const double drj = acc[0] + s[j], e = drj - c[j] * tau;
+        double sc = wE ? wE[j] : 1.0;
+        sc = sc * sc;
+        acc3[0] += e * e; acc3[1] += (e * e) * sc; acc3[2] += (drj * drj) * sc;
+      });
+  const int ws[3] = {slot0, slot0 + 1, slot0 + 2};
+  write_partials<3>(part, ws, acc3, sm);
+}
+
+// One block: fold the listed slots into ctl->out[slot] and append the tau/kappa entries the host needs.
+struct FinArgs { int nslots; int slots[40]; const double *u, *v, *ua, *va; };
+__global__ __launch_bounds__(BS) void k_finalize(FinArgs f, Dims d, const double *part, int nb, Ctl *ctl) {
+  __shared__ double sm[WAVES];
+  for (int s = 0; s < f.nslots; ++s) {
+    const int slot = f.slots[s];
+    double v[1] = {0.0};
+    for (int i = threadIdx.x; i < nb; i += BS) v[0] += part[slot * MAXNB + i];
+    block_sum<1>(v, sm);
+    if (threadIdx.x == 0) ctl->out[slot] = v[0];
+  }
+  if (threadIdx.x == 0) {
+    const int q = d.MP + d.n;
+    ctl->out[80] = f.u[q]; ctl->out[81] = f.v[q];
+    ctl->out[82] = f.ua ? f.ua[q] : 0.0; ctl->out[83] = f.va ? f.va[q] : 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// outer-iteration element-wise kernels
+// ---------------------------------------------------------------------------------------------
+// reinitialize_vars, abip.c:996-1075 (x block and tau entry: indices m..l-1)
+__global__ __launch_bounds__(BS) void k_reinit(double *u, double *v, double sigma, int indx, Dims d) {
+  const int cnt = d.n + 1;
+  const double sq = (indx == 1) ? sqrt(sigma) : sqrt(1.0 / sigma);
+  for (int j = blockIdx.x * BS + threadIdx.x; j < cnt; j += gridDim.x * BS) {
+    const int q = d.MP + j;
+    if (indx == 0) { if (u[q] > v[q]) v[q] = sigma * v[q]; else u[q] = sigma * u[q]; }
+    else { u[q] = sq * u[q]; v[q] = sq * v[q]; }
+  }
+}
+// LOQO statistics, abip.c:962-965: sum and min of u_i v_i over i >= m.  One block per partial; the min is
+// folded by the host from the per-block minima (exact, order-free).
+__global__ __launch_bounds__(BS) void k_xs(const double *u, const double *v, Dims d, double *part) {
+  __shared__ double sm[WAVES];
+  __shared__ double smin[WAVES];
+  const int cnt = d.n + 1;
+  double acc[1] = {0.0};
+  double mn = 1e+10;
+  for (int j = blockIdx.x * BS + threadIdx.x; j < cnt; j += gridDim.x * BS) {
+    const double x = u[d.MP + j] * v[d.MP + j];
+    acc[0] += x; mn = fmin(mn, x);
+  }
+  for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_down(mn, off, 64));
+  if ((threadIdx.x & 63) == 0) smin[threadIdx.x >> 6] = mn;
+  const int ws[1] = {S_XS};
+  write_partials<1>(part, ws, acc, sm);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = smin[0];
+    for (int w = 1; w < WAVES; ++w) t = fmin(t, smin[w]);
+    part[S_XMIN * MAXNB + blockIdx.x] = t;
+  }
+}
+__global__ void k_min_fold(const double *part, int nb, Ctl *ctl) { // single thread: tiny
+  double t = 1e+10;
+  for (int i = 0; i < nb; ++i) t = fmin(t, part[S_XMIN * MAXNB + i]);
+  ctl->out[S_XMIN] = t;
+}
+// x block of an l-vector *= -1 (abip.c:1923)
+__global__ __launch_bounds__(BS) void k_neg_x(double *g, Dims d) {
+  for (int j = blockIdx.x * BS + threadIdx.x; j < d.n; j += gridDim.x * BS) g[d.MP + j] = -g[d.MP + j];
+}
+__global__ __launch_bounds__(BS) void k_dot_full(const double *a, const double *b, Dims d, int slot, double *part) { // over l-1 entries
+  __shared__ double sm[WAVES];
+  double acc[1] = {0.0};
+  const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
+  for (int i = t0; i < d.m; i += stride) acc[0] += a[i] * b[i];
+  for (int j = t0; j < d.n; j += stride) acc[0] += a[d.MP + j] * b[d.MP + j];
+  const int ws[1] = {slot};
+  write_partials<1>(part, ws, acc, sm);
+}
+// half_update clean-up on an inner break (abip.c:2175-2185)
+__global__ __launch_bounds__(BS) void k_clip_v(double *v, Dims d) {
+  const int len = d.MP + d.n + 1;
+  for (int i = blockIdx.x * BS + threadIdx.x; i < len; i += gridDim.x * BS) {
+    const bool live = (i < d.m) || (i >= d.MP);
+    if (live && v[i] < 0) v[i] = 1e-6;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Barzilai-Borwein look-ahead (adaptive.c:101-178)
+// ---------------------------------------------------------------------------------------------
+// one ADMM step on scratch vectors: (ut, u_prev, v_prev) -> (u, v) with penalty beta_prev
+__global__ __launch_bounds__(BS) void k_adapt_step(const double *ut_in, double *ut_tail_fix, const double *__restrict__ up,
+                                                   const double *__restrict__ vp, double *__restrict__ u, double *__restrict__ v,
+                                                   double alpha, double mu_over_beta, Dims d, const double *part, int nb) {
+  __shared__ double sm[WAVES];
+  double dh[1];
+  const int rs[1] = {S_DH};
+  read_partials<1>(part, rs, nb, dh, sm);
+  const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
+  for (int i = t0; i < d.m; i += stride) u[i] = ut_in[i] - vp[i]; // adaptive.c:101-104 (v[0:m) is left untouched, :118-121)
+  for (int j = t0; j <= d.n; j += stride) {
+    const int q = d.MP + j;
+    double utq = ut_in[q];
+    if (j == d.n) { utq += dh[0]; ut_tail_fix[q] = utq; }           // adaptive.c:99
+    const double t = alpha * utq + (1 - alpha) * up[q] - vp[q];
+    const double hlf = t / 2;
+    const double un = hlf + sqrt(hlf * hlf + mu_over_beta);
+    u[q] = un;
+    v[q] = vp[q] + (un - alpha * utq - (1 - alpha) * up[q]);
+  }
+}
+// the five inner products of the difference vectors, formed on the fly (adaptive.c:154-174)
+__global__ __launch_bounds__(BS) void k_adapt_dots(const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ un,
+                                                   const double *__restrict__ vn, const double *__restrict__ vp, double alpha, Dims d, double *part) {
+  __shared__ double sm[5 * WAVES];
+  double a[5] = {0, 0, 0, 0, 0};
+  const int len = d.MP + d.n + 1;
+  for (int i = blockIdx.x * BS + threadIdx.x; i < len; i += gridDim.x * BS) {
+    if (i >= d.m && i < d.MP) continue; // padding
+    const double dut = 2.0 * v[i] + un[i] - u[i] - vn[i] - vp[i];
+    const double du = u[i] - un[i];
+    const double dv = (un[i] - u[i]) * (alpha - 1.0) + vn[i] - v[i];
+    a[0] += dut * dut; a[1] += dut * dv; a[2] += du * du; a[3] += dv * dv; a[4] += du * dv;
+  }
+  const int ws[5] = {S_A0, S_A1, S_A2, S_A3, S_A4};
+  write_partials<5>(part, ws, a, sm);
+}
+// v_prev[x,tau] = (mu/beta)/u_prev  (adaptive.c:238-241); y block copied by the caller
+__global__ __launch_bounds__(BS) void k_adapt_vprev(double *vp, const double *up, double mu_over_beta, Dims d) {
+  for (int j = blockIdx.x * BS + threadIdx.x; j <= d.n; j += gridDim.x * BS) vp[d.MP + j] = mu_over_beta / up[d.MP + j];
+}
+
+// plain y += A x for the unit-level ABI and the direct back-end's accumulations
+__global__ __launch_bounds__(BS) void k_spmv_acc(Csr M, const double *__restrict__ x, double *__restrict__ y) {
+  __shared__ double lds[CHUNK];
+  __shared__ double sm[WAVES];
+  spmv_stream<1>(
+      M, lds, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
+      [&](int row, double(&acc)[1]) { y[row] += acc[0]; });
+}
+
+} // namespace abip

@@ -1,0 +1,88 @@
+// dev_sptrsv.h -- device side of the direct KKT back-end: x = P' L^-T D^-1 L^-1 P b
+// (reference: _ldl_solve, linsys/direct.c:172-198 -> LDL_perm / lsolve / dsolve / ltsolve / permt,
+//  external/ldl/ldl.c:357-550).  The factor is computed once on the host (host_setup.cpp); here both
+// triangular solves run in GATHER form over level sets:
+//   forward  (L z = b):  z_i = b_i - sum_{j<i} L_ij z_j      rows of L   (CSR)
+//   backward (L' x = z): x_j = z_j - sum_{i>j} L_ij x_i      columns of L (CSC)
+// A level is a set of rows whose dependencies are all in earlier levels.  Small systems run the whole
+// solve in ONE 1024-thread workgroup (levels separated by workgroup barriers, no launches in between);
+// large systems launch wide levels as grids and runs of thin levels as single-workgroup segments.
+#pragma once
+#include "dev_common.h"
+
+namespace abip {
+
+constexpr int TBS = 1024; // threads of the single-workgroup triangular kernels
+
+struct Tri {
+  const int *ptr, *idx;
+  const double *val;
+  const int *lev_ptr, *lev_rows, *lev_g;
+  int nlev;
+};
+
+// rows [a, b) of one level, `g` lanes per row (power of two <= 64), executed by `nthr` threads starting at `tid`
+__device__ __forceinline__ void tri_level(const Tri &T, double *x, int a, int b, int g, int tid, int nthr) {
+  const int ngrp = nthr / g, grp = tid / g, q = tid % g;
+  for (int base = a; base < b; base += ngrp) {
+    const int r = base + grp;
+    double acc = 0.0;
+    int row = -1;
+    if (r < b) {
+      row = T.lev_rows[r];
+      const int e = T.ptr[row + 1];
+      for (int k = T.ptr[row] + q; k < e; k += g) acc += T.val[k] * x[T.idx[k]];
+    }
+    for (int off = g >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (row >= 0 && q == 0) x[row] -= acc;
+  }
+}
+
+// whole solve in one workgroup
+__global__ __launch_bounds__(TBS) void k_ldl_solve_small(Tri F, Tri B, const int *__restrict__ Pmap, const double *__restrict__ D,
+                                                         double *b /* l-vector */, double *x /* work, N */, int N, const Ctl *ctl) {
+  if (ctl->halt) return;
+  const int tid = threadIdx.x;
+  for (int j = tid; j < N; j += TBS) x[j] = b[Pmap[j]]; // LDL_perm
+  __syncthreads();
+  for (int l = 0; l < F.nlev; ++l) {                    // LDL_lsolve
+    tri_level(F, x, F.lev_ptr[l], F.lev_ptr[l + 1], F.lev_g[l], tid, TBS);
+    __syncthreads();
+  }
+  for (int j = tid; j < N; j += TBS) x[j] /= D[j];      // LDL_dsolve
+  __syncthreads();
+  for (int l = 0; l < B.nlev; ++l) {                    // LDL_ltsolve
+    tri_level(B, x, B.lev_ptr[l], B.lev_ptr[l + 1], B.lev_g[l], tid, TBS);
+    __syncthreads();
+  }
+  for (int j = tid; j < N; j += TBS) b[Pmap[j]] = x[j]; // LDL_permt
+}
+
+// segmented variant for systems too large for one workgroup
+__global__ __launch_bounds__(BS) void k_perm_in(const int *__restrict__ Pmap, const double *__restrict__ b, double *__restrict__ x, int N, const Ctl *ctl) {
+  if (ctl->halt) return;
+  for (int j = blockIdx.x * BS + threadIdx.x; j < N; j += gridDim.x * BS) x[j] = b[Pmap[j]];
+}
+__global__ __launch_bounds__(BS) void k_perm_out(const int *__restrict__ Pmap, double *__restrict__ b, const double *__restrict__ x, int N, const Ctl *ctl) {
+  if (ctl->halt) return;
+  for (int j = blockIdx.x * BS + threadIdx.x; j < N; j += gridDim.x * BS) b[Pmap[j]] = x[j];
+}
+__global__ __launch_bounds__(BS) void k_dscale(double *__restrict__ x, const double *__restrict__ D, int N, const Ctl *ctl) {
+  if (ctl->halt) return;
+  for (int j = blockIdx.x * BS + threadIdx.x; j < N; j += gridDim.x * BS) x[j] /= D[j];
+}
+// one wide level over a grid
+__global__ __launch_bounds__(BS) void k_tri_wide(Tri T, double *x, int lev, const Ctl *ctl) {
+  if (ctl->halt) return;
+  tri_level(T, x, T.lev_ptr[lev], T.lev_ptr[lev + 1], T.lev_g[lev], blockIdx.x * BS + threadIdx.x, gridDim.x * BS);
+}
+// a run of thin levels [l0, l1) in one workgroup
+__global__ __launch_bounds__(TBS) void k_tri_thin(Tri T, double *x, int l0, int l1, const Ctl *ctl) {
+  if (ctl->halt) return;
+  for (int l = l0; l < l1; ++l) {
+    tri_level(T, x, T.lev_ptr[l], T.lev_ptr[l + 1], T.lev_g[l], threadIdx.x, TBS);
+    __syncthreads();
+  }
+}
+
+} // namespace abip

@@ -1,0 +1,373 @@
+// host_setup.cpp -- host-side, once-per-init work: data validation, the reference's scaling of A,
+// the 32-bit CSR/CSC images the kernels stream, their row blocks, the Jacobi preconditioner, and the
+// sparse LDL' factorisation + level schedule for the direct back-end.
+#include "host_setup.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+namespace abip {
+namespace host {
+
+namespace {
+constexpr double kMinScale = 1e-3; // linsys/common.c:4
+constexpr double kMaxScale = 1e3;  // linsys/common.c:5
+
+inline double clamp_scale(double e, double lo, double hi) { // common.c:224-229 and its repeats
+  if (e < lo) return 1.0;
+  if (e > hi) return hi;
+  return e;
+}
+inline double col_norm1(const double *v, abip_int len) { double s = 0; for (abip_int i = 0; i < len; ++i) s += std::fabs(v[i]); return s; }
+inline double col_norm2(const double *v, abip_int len) { double s = 0; for (abip_int i = 0; i < len; ++i) s += v[i] * v[i]; return std::sqrt(s); }
+inline double col_norminf(const double *v, abip_int len) { double mx = 0; for (abip_int i = 0; i < len; ++i) { double t = std::fabs(v[i]); if (t >= mx) mx = t; } return mx; }
+inline void col_scale(double *v, double sc, abip_int len) { for (abip_int i = 0; i < len; ++i) v[i] *= sc; }
+} // namespace
+
+int validate(const ABIPData *d) {
+  const ABIPSettings *s = d->stgs;
+  if (d->m <= 0 || d->n <= 0) { printf("m and n must both be greater than 0; m = %li, n = %li\n", (long)d->m, (long)d->n); return -1; }
+  if (d->m > d->n) { printf("WARN: m larger than n, problem likely degenerate\n"); return -1; }
+  const ABIPMatrix *A = d->A;
+  if (!A || !A->x || !A->i || !A->p) { printf("ERROR: incomplete data!\n"); printf("invalid linear system input data\n"); return -1; }
+  for (abip_int i = 0; i < A->n; ++i) {
+    if (A->p[i] == A->p[i + 1]) printf("WARN: the %li-th column empty!\n", (long)i);
+    else if (A->p[i] > A->p[i + 1]) { printf("ERROR: the column pointers decreases!\n"); printf("invalid linear system input data\n"); return -1; }
+  }
+  const abip_int nnz = A->p[A->n];
+  if (((double)nnz / A->m > A->n) || nnz <= 0) {
+    printf("ERROR: the number of nonzeros in A = %li, outside of valid range!\n", (long)nnz);
+    printf("invalid linear system input data\n");
+    return -1;
+  }
+  abip_int rmax = 0;
+  for (abip_int i = 0; i < nnz; ++i) if (A->i[i] > rmax) rmax = A->i[i];
+  if (rmax > A->m - 1) { printf("ERROR: the number of rows in A is inconsistent with input dimension!\n"); printf("invalid linear system input data\n"); return -1; }
+  if (nnz >= 2147483647L || A->n >= 2147483647L - 4096) { printf("ERROR: problem too large for the 32-bit device index space\n"); return -1; }
+  if (s->max_ipm_iters <= 0) { printf("max_ipm_iters must be positive\n"); return -1; }
+  if (s->max_admm_iters <= 0) { printf("max_admm_iters must be positive\n"); return -1; }
+  if (s->eps <= 0) { printf("eps tolerance must be positive\n"); return -1; }
+  if (s->alpha <= 0 || s->alpha >= 2) { printf("alpha must be in (0,2)\n"); return -1; }
+  if (s->rho_y <= 0) { printf("rho_y must be positive (1e-3 works well).\n"); return -1; }
+  if (s->scale <= 0) { printf("scale must be positive (1 works well).\n"); return -1; }
+  if (s->eps_cor <= 0) { printf("eps_cor tolerance must be positive.\n"); return -1; }
+  if (s->eps_pen <= 0) { printf("eps_pen tolerance must be positive.\n"); return -1; }
+  if (s->adaptive_lookback <= 0) { printf("adaptive_lookback must be positive.\n"); return -1; }
+  if (s->hybrid_mu > 0 && s->dynamic_sigma >= 0) { printf("when use hybrid mu strategy, dynamic_sigma must be negative.\n"); return -1; }
+  return 0;
+}
+
+void normalize_A(ABIPMatrix *A, const ABIPSettings *stgs, std::vector<double> &D, std::vector<double> &E,
+                 double *mean_norm_row, double *mean_norm_col) {
+  const abip_int m = A->m, n = A->n;
+  std::vector<double> Dk(m, 0.0), Ek(n, 0.0), Dt(m, 0.0);
+  std::vector<double> D_pc(m, 1.0), E_pc(n, 1.0), D_or(m, 1.0), E_or(n, 1.0), D_rz(m, 1.0), E_rz(n, 1.0), D_qp(m, 1.0), E_qp(n, 1.0);
+  const double min_row = kMinScale * std::sqrt((double)n), max_row = kMaxScale * std::sqrt((double)n); // common.c:172-175
+  const double min_col = kMinScale * std::sqrt((double)m), max_col = kMaxScale * std::sqrt((double)m);
+  auto rows_div = [&](const std::vector<double> &R) { for (abip_int q = 0; q < A->p[n]; ++q) A->x[q] /= R[A->i[q]]; };
+
+  if (stgs->pc_ruiz_rescale) { // common.c:217-266
+    for (abip_int j = 0; j < n; ++j) {
+      const abip_int len = A->p[j + 1] - A->p[j];
+      const double e = clamp_scale(std::sqrt(col_norm1(&A->x[A->p[j]], len)), min_col, max_col);
+      col_scale(&A->x[A->p[j]], 1.0 / e, len);
+      E_pc[j] = e;
+    }
+    std::fill(Dk.begin(), Dk.end(), 0.0);
+    for (abip_int q = 0; q < A->p[n]; ++q) Dk[A->i[q]] += std::fabs(A->x[q]);
+    for (abip_int i = 0; i < m; ++i) D_pc[i] = clamp_scale(std::sqrt(Dk[i]), min_row, max_row);
+    rows_div(D_pc);
+    printf("Done the pc rescaling!\n");
+  }
+  if (stgs->origin_rescale) { // common.c:279-327
+    for (abip_int j = 0; j < n; ++j) {
+      const abip_int len = A->p[j + 1] - A->p[j];
+      const double e = clamp_scale(col_norm2(&A->x[A->p[j]], len), min_col, max_col);
+      col_scale(&A->x[A->p[j]], 1.0 / e, len);
+      E_or[j] = e;
+    }
+    std::fill(Dk.begin(), Dk.end(), 0.0);
+    for (abip_int q = 0; q < A->p[n]; ++q) Dk[A->i[q]] += A->x[q] * A->x[q];
+    for (abip_int i = 0; i < m; ++i) D_or[i] = clamp_scale(std::sqrt(Dk[i]), min_row, max_row);
+    rows_div(D_or);
+    printf("Done the origin rescaling!\n");
+  }
+  if (stgs->pc_ruiz_rescale) { // common.c:339-413
+    for (abip_int it = 0; it < stgs->ruiz_iter; ++it) {
+      for (abip_int j = 0; j < n; ++j) {
+        const abip_int len = A->p[j + 1] - A->p[j];
+        const double e = clamp_scale(std::sqrt(col_norminf(&A->x[A->p[j]], len)), min_col, max_col);
+        col_scale(&A->x[A->p[j]], 1.0 / e, len);
+        Ek[j] = e;
+      }
+      std::fill(Dk.begin(), Dk.end(), 0.0);
+      for (abip_int q = 0; q < A->p[n]; ++q) { const double w = std::fabs(A->x[q]); if (w >= Dk[A->i[q]]) Dk[A->i[q]] = w; }
+      for (abip_int i = 0; i < m; ++i) Dk[i] = clamp_scale(std::sqrt(Dk[i]), min_row, max_row);
+      rows_div(Dk);
+      for (abip_int j = 0; j < n; ++j) E_rz[j] = E_rz[j] * Ek[j];
+      for (abip_int i = 0; i < m; ++i) D_rz[i] = D_rz[i] * Dk[i];
+    }
+    printf("Done the ruiz rescaling!\n");
+  }
+  if (stgs->qp_rescale) { // common.c:415-499
+    std::fill(D_qp.begin(), D_qp.end(), 0.0);
+    for (abip_int j = 0; j < n; ++j) {
+      const abip_int len = A->p[j + 1] - A->p[j];
+      double *col = &A->x[A->p[j]];
+      double e = col_norminf(col, len), ref = e;
+      for (abip_int i = 0; i < len; ++i) { const double t = std::fabs(col[i]); if (t <= ref && t > 0) ref = t; } // linalg.c:126-144
+      e = clamp_scale(std::sqrt(ref) * std::sqrt(e), min_col, max_col);
+      col_scale(col, 1.0 / e, len);
+      E_qp[j] = e;
+    }
+    for (abip_int q = 0; q < A->p[n]; ++q) { const double w = std::fabs(A->x[q]); if (w >= D_qp[A->i[q]]) D_qp[A->i[q]] = w; }
+    Dt = D_qp;
+    for (abip_int q = 0; q < A->p[n]; ++q) { const double w = std::fabs(A->x[q]); if (w <= Dt[A->i[q]] && w > 0) Dt[A->i[q]] = w; }
+    for (abip_int i = 0; i < m; ++i) D_qp[i] = clamp_scale(std::sqrt(D_qp[i] * Dt[i]), min_row, max_row);
+    rows_div(D_qp);
+    printf("Done the QP rescaling\n");
+  }
+  D.resize(m); E.resize(n);
+  for (abip_int i = 0; i < m; ++i) D[i] = D_pc[i] * D_rz[i] * D_or[i] * D_qp[i]; // common.c:512-520
+  for (abip_int j = 0; j < n; ++j) E[j] = E_pc[j] * E_rz[j] * E_or[j] * E_qp[j];
+
+  std::fill(Dk.begin(), Dk.end(), 0.0); // common.c:523-545
+  for (abip_int q = 0; q < A->p[n]; ++q) Dk[A->i[q]] += A->x[q] * A->x[q];
+  *mean_norm_row = 0.0;
+  for (abip_int i = 0; i < m; ++i) *mean_norm_row += std::sqrt(Dk[i]) / m;
+  *mean_norm_col = 0.0;
+  for (abip_int j = 0; j < n; ++j) *mean_norm_col += col_norm2(&A->x[A->p[j]], A->p[j + 1] - A->p[j]) / n;
+  if (stgs->scale != 1) col_scale(A->x, stgs->scale, A->p[n]); // common.c:547-550
+}
+
+void un_normalize_A(ABIPMatrix *A, const ABIPSettings *stgs, const std::vector<double> &D, const std::vector<double> &E) {
+  const abip_int n = A->n;
+  for (abip_int q = 0; q < A->p[n]; ++q) A->x[q] *= D[A->i[q]];
+  for (abip_int j = 0; j < n; ++j) col_scale(&A->x[A->p[j]], E[j] / stgs->scale, A->p[j + 1] - A->p[j]);
+}
+
+void csc_as_csr(const ABIPMatrix *A, HostCsr &out) {
+  const abip_int n = A->n, nnz = A->p[n];
+  out.nrows = (int)n; out.ncols = (int)A->m;
+  out.ptr.resize(n + 1); out.idx.resize(nnz); out.val.assign(A->x, A->x + nnz);
+  for (abip_int j = 0; j <= n; ++j) out.ptr[j] = (int)A->p[j];
+  for (abip_int q = 0; q < nnz; ++q) out.idx[q] = (int)A->i[q];
+}
+
+void transpose_to_csr(const ABIPMatrix *A, HostCsr &out) {
+  const abip_int m = A->m, n = A->n, nnz = A->p[n];
+  out.nrows = (int)m; out.ncols = (int)n;
+  out.ptr.assign(m + 1, 0); out.idx.resize(nnz); out.val.resize(nnz);
+  for (abip_int q = 0; q < nnz; ++q) out.ptr[A->i[q] + 1]++;
+  for (abip_int i = 0; i < m; ++i) out.ptr[i + 1] += out.ptr[i];
+  std::vector<int> pos(out.ptr.begin(), out.ptr.end() - 1);
+  for (abip_int j = 0; j < n; ++j)
+    for (abip_int q = A->p[j]; q < A->p[j + 1]; ++q) { const int dst = pos[A->i[q]]++; out.idx[dst] = (int)j; out.val[dst] = A->x[q]; }
+}
+
+void build_row_blocks(HostCsr &M, int chunk) {
+  M.rb.clear();
+  M.rb.push_back(0);
+  int r = 0;
+  while (r < M.nrows) {
+    int nn = 0, rows = 0, e = r;
+    while (e < M.nrows) {
+      const int len = M.ptr[e + 1] - M.ptr[e];
+      if (rows > 0 && (nn + len > chunk || rows >= chunk)) break;
+      nn += len; ++rows; ++e;
+      if (nn > chunk) break; // a single long row forms its own block
+    }
+    M.rb.push_back(e);
+    r = e;
+  }
+}
+
+void jacobi_preconditioner(const ABIPMatrix *A, std::vector<double> &Minv) {
+  Minv.assign(A->m, 0.0);
+  for (abip_int q = 0; q < A->p[A->n]; ++q) Minv[A->i[q]] += A->x[q] * A->x[q];
+  for (abip_int i = 0; i < A->m; ++i) Minv[i] = 1 / Minv[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// direct back-end: ordering + LDL'
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// Minimum external degree on the quotient graph (element absorption, exact degrees).  The reference calls
+// SuiteSparse AMD here (direct.c:106-119); any symmetric permutation is admissible because K is quasi-definite.
+void min_degree(int N, const std::vector<int> &Gp, const std::vector<int> &Gi, std::vector<int> &perm) {
+  std::vector<std::vector<int>> adjv(N), adje(N), elem(N);
+  std::vector<int> deg(N), mark(N, -1), head(N + 1, -1), nxt(N, -1), prv(N, -1);
+  std::vector<char> elim(N, 0), dead(N, 0);
+  for (int i = 0; i < N; ++i) { adjv[i].assign(Gi.begin() + Gp[i], Gi.begin() + Gp[i + 1]); deg[i] = (int)adjv[i].size(); }
+  auto ins = [&](int x) { const int d = deg[x]; nxt[x] = head[d]; prv[x] = -1; if (head[d] >= 0) prv[head[d]] = x; head[d] = x; };
+  auto del = [&](int x) { const int d = deg[x]; if (prv[x] >= 0) nxt[prv[x]] = nxt[x]; else head[d] = nxt[x]; if (nxt[x] >= 0) prv[nxt[x]] = prv[x]; };
+  for (int i = N - 1; i >= 0; --i) ins(i);
+  perm.resize(N);
+  int stamp = 0, mindeg = 0;
+  std::vector<int> Lp;
+  for (int k = 0; k < N; ++k) {
+    while (mindeg <= N && head[mindeg] < 0) ++mindeg;
+    const int p = head[mindeg];
+    del(p);
+    elim[p] = 1; perm[k] = p;
+    ++stamp; mark[p] = stamp;
+    Lp.clear();
+    for (int x : adjv[p]) if (!elim[x] && mark[x] != stamp) { mark[x] = stamp; Lp.push_back(x); }
+    for (int e : adje[p]) {
+      if (dead[e]) continue;
+      for (int x : elem[e]) if (!elim[x] && mark[x] != stamp) { mark[x] = stamp; Lp.push_back(x); }
+      dead[e] = 1; std::vector<int>().swap(elem[e]);
+    }
+    std::vector<int>().swap(adjv[p]); std::vector<int>().swap(adje[p]);
+    elem[p] = Lp;
+    for (int x : Lp) {
+      auto &av = adjv[x];
+      av.erase(std::remove_if(av.begin(), av.end(), [&](int y) { return elim[y] || mark[y] == stamp; }), av.end());
+      auto &ae = adje[x];
+      ae.erase(std::remove_if(ae.begin(), ae.end(), [&](int e) { return dead[e] != 0; }), ae.end());
+      ae.push_back(p);
+    }
+    for (int x : Lp) {
+      del(x);
+      const int st2 = ++stamp; mark[x] = st2;
+      int d = 0;
+      for (int y : adjv[x]) if (mark[y] != st2) { mark[y] = st2; ++d; }
+      for (int e : adje[x]) for (int y : elem[e]) if (!elim[y] && mark[y] != st2) { mark[y] = st2; ++d; }
+      deg[x] = d;
+      ins(x);
+      if (d < mindeg) mindeg = d;
+    }
+  }
+}
+
+inline int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+void level_sets(int N, TriHost &T, bool backward) {
+  std::vector<int> lev(N, 0);
+  int maxlev = 0;
+  if (!backward) {
+    for (int i = 0; i < N; ++i) { int l = 0; for (int q = T.ptr[i]; q < T.ptr[i + 1]; ++q) l = std::max(l, lev[T.idx[q]] + 1); lev[i] = l; maxlev = std::max(maxlev, l); }
+  } else {
+    for (int j = N - 1; j >= 0; --j) { int l = 0; for (int q = T.ptr[j]; q < T.ptr[j + 1]; ++q) l = std::max(l, lev[T.idx[q]] + 1); lev[j] = l; maxlev = std::max(maxlev, l); }
+  }
+  // bucket rows that have work (level >= 1 <=> at least one entry)
+  std::vector<int> cnt(maxlev + 2, 0);
+  for (int i = 0; i < N; ++i) if (lev[i] >= 1) cnt[lev[i]]++;
+  T.lev_ptr.assign(1, 0);
+  for (int l = 1; l <= maxlev; ++l) T.lev_ptr.push_back(T.lev_ptr.back() + cnt[l]);
+  T.lev_rows.resize(T.lev_ptr.back());
+  std::vector<int> pos(T.lev_ptr.begin(), T.lev_ptr.end());
+  for (int i = 0; i < N; ++i) if (lev[i] >= 1) T.lev_rows[pos[lev[i] - 1]++] = i;
+  const int nlev = (int)T.lev_ptr.size() - 1;
+  T.lev_g.resize(nlev);
+  for (int l = 0; l < nlev; ++l) {
+    const int rows = T.lev_ptr[l + 1] - T.lev_ptr[l];
+    long nn = 0;
+    for (int r = T.lev_ptr[l]; r < T.lev_ptr[l + 1]; ++r) nn += T.ptr[T.lev_rows[r] + 1] - T.ptr[T.lev_rows[r]];
+    int g = std::min(64, pow2_ceil((int)((nn + rows - 1) / std::max(rows, 1))));
+    while (g > 1 && (long)rows * g > 4096) g >>= 1;
+    T.lev_g[l] = std::max(g, 1);
+  }
+}
+
+} // namespace
+
+int factor_kkt(const ABIPMatrix *A, double rho_y, LdlHost &out) {
+  const int m = (int)A->m, n = (int)A->n, N = m + n;
+  const long nnzA = (long)A->p[n];
+  out.N = N;
+  // upper triangle of K by columns (direct.c:49-104)
+  std::vector<int> Kp(N + 1), Ki(N + nnzA);
+  std::vector<double> Kx(N + nnzA);
+  long kk = 0;
+  for (int i = 0; i < m; ++i) { Kp[i] = (int)kk; Ki[kk] = i; Kx[kk] = rho_y; ++kk; }
+  for (int j = 0; j < n; ++j) {
+    Kp[m + j] = (int)kk;
+    for (abip_int q = A->p[j]; q < A->p[j + 1]; ++q) { Ki[kk] = (int)A->i[q]; Kx[kk] = A->x[q]; ++kk; }
+    Ki[kk] = m + j; Kx[kk] = -1.0; ++kk;
+  }
+  Kp[N] = (int)kk;
+  // symmetric adjacency (no diagonal)
+  std::vector<int> Gp(N + 1, 0);
+  for (int j = 0; j < N; ++j) for (int q = Kp[j]; q < Kp[j + 1]; ++q) if (Ki[q] != j) { Gp[Ki[q] + 1]++; Gp[j + 1]++; }
+  for (int i = 0; i < N; ++i) Gp[i + 1] += Gp[i];
+  std::vector<int> Gi(Gp[N]), pos(Gp.begin(), Gp.end() - 1);
+  for (int j = 0; j < N; ++j) for (int q = Kp[j]; q < Kp[j + 1]; ++q) if (Ki[q] != j) { Gi[pos[Ki[q]]++] = j; Gi[pos[j]++] = Ki[q]; }
+  min_degree(N, Gp, Gi, out.P);
+  std::vector<int> Pinv(N);
+  for (int i = 0; i < N; ++i) Pinv[out.P[i]] = i;
+  // C = upper triangle of P K P' by columns (cs_symperm, direct.c:259-260)
+  std::vector<int> Cp(N + 1, 0);
+  for (int j = 0; j < N; ++j) for (int q = Kp[j]; q < Kp[j + 1]; ++q) Cp[std::max(Pinv[Ki[q]], Pinv[j]) + 1]++;
+  for (int i = 0; i < N; ++i) Cp[i + 1] += Cp[i];
+  std::vector<int> Ci(kk), cpos(Cp.begin(), Cp.end() - 1);
+  std::vector<double> Cx(kk);
+  for (int j = 0; j < N; ++j) for (int q = Kp[j]; q < Kp[j + 1]; ++q) {
+    const int a = Pinv[Ki[q]], b = Pinv[j], r = std::min(a, b), c = std::max(a, b);
+    Ci[cpos[c]] = r; Cx[cpos[c]] = Kx[q]; cpos[c]++;
+  }
+  // elimination tree + column counts
+  std::vector<int> parent(N, -1), anc(N, -1), flag(N, -1), lnz(N, 0);
+  for (int j = 0; j < N; ++j)
+    for (int q = Cp[j]; q < Cp[j + 1]; ++q) {
+      int r = Ci[q];
+      while (r != -1 && r < j) { const int nx = anc[r]; anc[r] = j; if (nx == -1) parent[r] = j; r = nx; }
+    }
+  for (int j = 0; j < N; ++j) {
+    flag[j] = j;
+    for (int q = Cp[j]; q < Cp[j + 1]; ++q) { int r = Ci[q]; while (r < j && flag[r] != j) { lnz[r]++; flag[r] = j; r = parent[r]; } }
+  }
+  std::vector<int> Lp(N + 1, 0);
+  for (int j = 0; j < N; ++j) Lp[j + 1] = Lp[j] + lnz[j];
+  const long Lnnz = Lp[N];
+  out.lnnz = Lnnz;
+  std::vector<int> Li(std::max<long>(Lnnz, 1));
+  std::vector<double> Lx(std::max<long>(Lnnz, 1));
+  out.D.assign(N, 0.0);
+  // numeric: row k of L by a sparse triangular solve against the leading block (up-looking)
+  std::vector<double> Y(N, 0.0);
+  std::vector<int> stack(N), pat(N), fill(N, 0);
+  std::fill(flag.begin(), flag.end(), -1);
+  for (int k = 0; k < N; ++k) {
+    int top = N; flag[k] = k;
+    double dk = 0.0;
+    for (int q = Cp[k]; q < Cp[k + 1]; ++q) {
+      int r = Ci[q];
+      if (r == k) { dk += Cx[q]; continue; }
+      Y[r] += Cx[q];
+      int len = 0;
+      while (flag[r] != k) { pat[len++] = r; flag[r] = k; r = parent[r]; }
+      while (len > 0) stack[--top] = pat[--len];
+    }
+    for (; top < N; ++top) {
+      const int c = stack[top];
+      const double yc = Y[c];
+      Y[c] = 0.0;
+      const int e = Lp[c] + fill[c];
+      for (int q = Lp[c]; q < e; ++q) Y[Li[q]] -= Lx[q] * yc;
+      const double lkc = yc / out.D[c];
+      dk -= lkc * yc;
+      Li[e] = k; Lx[e] = lkc; fill[c]++;
+    }
+    out.D[k] = dk;
+    if (dk == 0.0) return -1;
+  }
+  // backward form = CSC of L as built; forward form = CSR of L
+  out.bwd.ptr = Lp; out.bwd.idx.assign(Li.begin(), Li.begin() + Lnnz); out.bwd.val.assign(Lx.begin(), Lx.begin() + Lnnz);
+  out.fwd.ptr.assign(N + 1, 0);
+  for (long q = 0; q < Lnnz; ++q) out.fwd.ptr[Li[q] + 1]++;
+  for (int i = 0; i < N; ++i) out.fwd.ptr[i + 1] += out.fwd.ptr[i];
+  out.fwd.idx.resize(Lnnz); out.fwd.val.resize(Lnnz);
+  std::vector<int> rpos(out.fwd.ptr.begin(), out.fwd.ptr.end() - 1);
+  for (int j = 0; j < N; ++j) for (int q = Lp[j]; q < Lp[j + 1]; ++q) { const int dst = rpos[Li[q]]++; out.fwd.idx[dst] = j; out.fwd.val[dst] = Lx[q]; }
+  level_sets(N, out.fwd, false);
+  level_sets(N, out.bwd, true);
+  return 0;
+}
+
+} // namespace host
+} // namespace abip

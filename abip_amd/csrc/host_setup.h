@@ -1,0 +1,51 @@
+// host_setup.h -- one-off host-side preparation for the device solver (runs once per abip_init).
+#pragma once
+#include <vector>
+
+#include "../../include/abip.h"
+
+namespace abip {
+namespace host {
+
+// A <- D^-1 A E^-1 * scale, in place (reference: ABIP(_normalize_A), linsys/common.c:150-565).
+void normalize_A(ABIPMatrix *A, const ABIPSettings *stgs, std::vector<double> &D, std::vector<double> &E,
+                 double *mean_norm_row, double *mean_norm_col);
+// inverse of the above (reference: ABIP(_un_normalize_A), linsys/common.c:569-594)
+void un_normalize_A(ABIPMatrix *A, const ABIPSettings *stgs, const std::vector<double> &D, const std::vector<double> &E);
+// validate_lin_sys (linsys/common.c:45-95) + validate (src/abip.c:1646-1734); prints the reference's messages
+int validate(const ABIPData *d);
+
+// CSR with 32-bit indices for the device + the row blocks the CSR-stream kernels walk.
+struct HostCsr {
+  int nrows = 0, ncols = 0;
+  std::vector<int> ptr, idx;
+  std::vector<double> val;
+  std::vector<int> rb; // row-block boundaries
+};
+// CSC arrays of A read as the CSR of A' (n rows)
+void csc_as_csr(const ABIPMatrix *A, HostCsr &out);
+// explicit transpose: CSR of A (m rows), columns ascending inside a row (reference: indirect.c:81-139)
+void transpose_to_csr(const ABIPMatrix *A, HostCsr &out);
+// greedy row blocks: <= chunk non-zeros and <= chunk rows per block; a longer row gets a block of its own
+void build_row_blocks(HostCsr &M, int chunk);
+// M_i = 1 / sum_j A_ij^2 (reference: get_preconditioner, indirect.c:36-79)
+void jacobi_preconditioner(const ABIPMatrix *A, std::vector<double> &Minv);
+
+// LDL' = P K P' of K = [[rho_y I, A],[A', -I]] (reference: form_kkt / factorize, linsys/direct.c:49-104,218-270),
+// delivered in the two gather forms the device triangular solves use, with their level sets.
+struct TriHost {
+  std::vector<int> ptr, idx;      // CSR of strictly-lower L (forward) or CSC of L (backward)
+  std::vector<double> val;
+  std::vector<int> lev_ptr, lev_rows, lev_g; // level sets (only rows with at least one entry), lanes per row
+};
+struct LdlHost {
+  int N = 0;
+  long lnnz = 0;
+  std::vector<int> P;    // P[k] = original KKT index of pivot k
+  std::vector<double> D;
+  TriHost fwd, bwd;
+};
+int factor_kkt(const ABIPMatrix *A, double rho_y, LdlHost &out);
+
+} // namespace host
+} // namespace abip

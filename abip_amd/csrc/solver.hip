@@ -1,0 +1,1204 @@
+// solver.hip -- libabip_hip.so: the reference's C entry points (include/abip.h) and the device-level ABI
+// (include/abip_hip.h) on top of the HIP kernels in dev_kernels.h / dev_sptrsv.h.
+//
+// Control structure.  The reference's solver is one nested loop on one CPU thread
+// (src/abip-lp/src/abip.c:2102-2294).  Here every vector lives in HBM for the whole solve; the host only
+//   * enqueues the kernel chain of one inner ADMM iteration on a private stream,
+//   * reads back ONE small control block per iteration (the finalised reductions), and
+//   * takes the reference's scalar decisions (inner stop, convergence, mu update, BB penalty).
+// Inside the PCG loop nothing comes back to the host: convergence is decided on the device and the remaining
+// kernels of an enqueued chunk turn into no-ops (dev_kernels.h, cg_converged).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+#include "../../include/abip.h"
+#include "../../include/abip_hip.h"
+#include "dev_kernels.h"
+#include "dev_sptrsv.h"
+#include "host_setup.h"
+
+using namespace abip;
+
+#define HIP_OK(expr)                                                                                  \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) {                                                                           \
+      fprintf(stderr, "abip_hip: HIP error %s at %s:%d (%s)\n", hipGetErrorString(e_), __FILE__, __LINE__, #expr); \
+      return -1;                                                                                      \
+    }                                                                                                 \
+  } while (0)
+
+namespace {
+
+int g_linsys = -1; // -1: not chosen yet -> environment / default
+
+int chosen_linsys() {
+  if (g_linsys >= 0) return g_linsys;
+  const char *e = getenv("ABIP_HIP_LINSYS");
+  if (e && (!strcmp(e, "indirect") || !strcmp(e, "pcg") || !strcmp(e, "1"))) return ABIP_HIP_LINSYS_INDIRECT;
+  return ABIP_HIP_LINSYS_DIRECT;
+}
+
+double now_ms() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec / 1e6; }
+
+template <class T>
+struct DBuf { // device buffer
+  T *p = nullptr;
+  size_t n = 0;
+  int alloc(size_t cnt) { n = cnt; if (!cnt) cnt = 1; HIP_OK(hipMalloc((void **)&p, cnt * sizeof(T))); return 0; }
+  int upload(const std::vector<T> &h, hipStream_t s) {
+    if (alloc(h.size())) return -1;
+    if (!h.empty()) HIP_OK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct DevCsr {
+  DBuf<int> ptr, idx, rb;
+  DBuf<double> val;
+  int nrows = 0, nrb = 0;
+  int upload(const host::HostCsr &h, hipStream_t s) {
+    nrows = h.nrows; nrb = (int)h.rb.size() - 1;
+    if (ptr.upload(h.ptr, s) || idx.upload(h.idx, s) || val.upload(h.val, s) || rb.upload(h.rb, s)) return -1;
+    return 0;
+  }
+  Csr view() const { return Csr{ptr.p, idx.p, val.p, rb.p, nrb, nrows}; }
+  void release() { ptr.release(); idx.release(); rb.release(); val.release(); }
+};
+
+struct DevTri {
+  DBuf<int> ptr, idx, lev_ptr, lev_rows, lev_g;
+  DBuf<double> val;
+  int nlev = 0;
+  std::vector<int> h_lev_ptr; // host copy for launch planning
+  int upload(const host::TriHost &h, hipStream_t s) {
+    nlev = (int)h.lev_ptr.size() - 1; h_lev_ptr = h.lev_ptr;
+    if (ptr.upload(h.ptr, s) || idx.upload(h.idx, s) || val.upload(h.val, s) || lev_ptr.upload(h.lev_ptr, s) ||
+        lev_rows.upload(h.lev_rows, s) || lev_g.upload(h.lev_g, s)) return -1;
+    return 0;
+  }
+  Tri view() const { return Tri{ptr.p, idx.p, val.p, lev_ptr.p, lev_rows.p, lev_g.p, nlev}; }
+  void release() { ptr.release(); idx.release(); val.release(); lev_ptr.release(); lev_rows.release(); lev_g.release(); }
+};
+
+struct Segment { bool wide; int l0, l1; };
+
+struct Resid { // ABIPResiduals, include/abip.h:178-195
+  abip_int last_ipm_iter = -1, last_admm_iter = -1;
+  double res_pri = 0, res_dual = 0, rel_gap = 0, res_infeas = 0, res_unbdd = 0, ct_x_by_tau = 0, bt_y_by_tau = 0, tau = 0, kap = 0;
+};
+
+enum Phase { PH_IDLE, PH_OUTER_BEGIN, PH_INNER, PH_OUTER_END, PH_DONE };
+
+const char *kHeader[] = {" ipm iter ", " admm iter ", "     mu ", " pri res ", " dua res ", " rel gap ", " pri obj ", " dua obj ", " kap/tau ", " time (s)"};
+constexpr int kHSpace = 9, kHeaderLen = 10, kLineLen = 150;
+void print_line(char c) { for (int i = 0; i < kLineLen; ++i) putchar(c); putchar('\n'); }
+
+constexpr double EPS_TOL = 1E-18; // glbopts.h:157
+inline double safediv_pos(double x, double y) { return y < EPS_TOL ? x / EPS_TOL : x / y; }
+
+} // namespace
+
+struct ABIP_WORK {
+  // ---- problem / settings ------------------------------------------------------------------
+  abip_int m = 0, n = 0;
+  int MP = 0, LV = 0; // x offset inside an l-vector, allocated length
+  int NB = 1;         // persistent grid size == partials per slot
+  int linsys = ABIP_HIP_LINSYS_DIRECT;
+  ABIPSettings *stgs = nullptr;
+  ABIPMatrix *A = nullptr; // caller's matrix, scaled in place until abip_finish
+  double sp = 0;
+  std::vector<double> D, E; // host copies of the scalings
+  double mean_norm_row_A = 0, mean_norm_col_A = 0;
+  double sc_b = 1, sc_c = 1, nm_b = 0, nm_c = 0, g_th = 0;
+  // ---- algorithm scalars (struct ABIP_WORK of the reference) ----------------------------
+  double sigma = 0, gamma = 0, mu = 1, beta = 1;
+  abip_int final_check = 0, double_check = 0, fre_old = 0;
+  // ---- device state --------------------------------------------------------------------------
+  hipStream_t stream = nullptr;
+  DevCsr dAt; // CSC of A read as CSR of A' (n rows): y_n = A' x_m
+  DevCsr dA;  // explicit CSR of A (m rows):          y_m = A x_n
+  DBuf<double> u, v, ut, u_avg, v_avg, u_sum, v_sum, u_avgc, v_avgc, h, g, b, c, wD, wE;
+  DBuf<double> cg_p, cg_r, cg_Gp, cg_z, cg_M, cg_tmp; // indirect.h:14-29
+  DBuf<double> a_up, a_vp, a_ut, a_u, a_v, a_utn, a_un, a_vn; // adaptive.c:13-32 (the three delta vectors are never stored)
+  DBuf<double> part;
+  DBuf<Ctl> ctl;
+  Ctl *hctl = nullptr; // pinned mirror
+  // direct
+  DBuf<int> Pmap; DBuf<double> Dg, xw;
+  DevTri triF, triB;
+  std::vector<Segment> segF, segB;
+  bool small_solve = false;
+  long lnnz = 0;
+  // ---- loop state (locals of ABIP(solve)) ------------------------------------------------
+  Phase phase = PH_IDLE;
+  abip_int i = 0, j = 0, k = 0, inner_stopper = 0;
+  bool wg_valid = false;
+  Resid r;
+  abip_int status = 0;
+  double t_solve0 = 0, cpu0 = 0;
+  bool stats_valid = false, avg_stats_valid = false; // ctl.out holds the sums of the current (averaged) iterate
+  int last_cg_its = 6;
+  long tot_cg_its = 0, tot_solves = 0;
+  // solution staged on the host by finish_solution()
+  std::vector<double> sol_x, sol_y, sol_s;
+  ABIPInfo last_info;
+  bool have_solution = false;
+  // ---- profiling -----------------------------------------------------------------------------
+  unsigned prof_mask = 0;
+  struct Ev { hipEvent_t a, b; int cls; };
+  std::vector<Ev> ev_pool; size_t ev_used = 0;
+  AbipHipProfile prof{};
+  std::vector<double> scratch; // host scratch (LV)
+};
+
+namespace {
+
+typedef ABIP_WORK W;
+
+// ------------------------------------------------------------------------------------------------
+// launch helper: optional hipEvent bracket per kernel class
+// ------------------------------------------------------------------------------------------------
+template <class K, class... Args>
+inline void launch(W *w, int cls, K kern, int grid, int block, Args... args) {
+  const bool timed = (w->prof_mask >> cls) & 1u;
+  W::Ev *ev = nullptr;
+  if (timed) {
+    if (w->ev_used == w->ev_pool.size()) {
+      W::Ev e; e.cls = cls;
+      (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
+      w->ev_pool.push_back(e);
+    }
+    ev = &w->ev_pool[w->ev_used++];
+    ev->cls = cls;
+    (void)hipEventRecord(ev->a, w->stream);
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, w->stream, args...);
+  if (timed) (void)hipEventRecord(ev->b, w->stream);
+  w->prof.launches[cls]++;
+}
+
+void harvest_events(W *w) { // call only after the stream has been synchronised
+  for (size_t q = 0; q < w->ev_used; ++q) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, w->ev_pool[q].a, w->ev_pool[q].b) == hipSuccess) w->prof.ms[w->ev_pool[q].cls] += ms;
+  }
+  w->ev_used = 0;
+}
+
+int sync_ctl(W *w) { // the once-per-iteration control read
+  HIP_OK(hipMemcpyAsync(w->hctl, w->ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, w->stream));
+  HIP_OK(hipStreamSynchronize(w->stream));
+  harvest_events(w);
+  return 0;
+}
+
+inline Dims dims(const W *w) { return Dims{(int)w->m, (int)w->n, w->MP}; }
+
+// ------------------------------------------------------------------------------------------------
+// KKT solve on an l-vector already holding the rhs.  S_BN must hold ||rhs_y||^2 (indirect).
+// enqueue-only pieces + a synchronising driver
+// ------------------------------------------------------------------------------------------------
+double cg_tol_factor(const W *w, abip_int iter) { // indirect.c:406-407
+  return iter < 0 ? 1e-9 : 1e-1 / std::pow((double)iter + 1, w->stgs->cg_rate);
+}
+
+void enqueue_cg_begin(W *w, double *rhs, const double *warm, abip_int iter) {
+  const Dims d = dims(w);
+  if (warm) launch(w, ABIP_HIP_K_SPMV_AT, k_cg_init_At, w->NB, BS, w->dAt.view(), warm, w->cg_tmp.p, (const Ctl *)w->ctl.p);
+  launch(w, ABIP_HIP_K_SPMV_A, k_cg_init_A, w->NB, BS, w->dA.view(), rhs, (const double *)w->cg_tmp.p, warm, (const double *)w->cg_M.p,
+         w->cg_r.p, w->cg_z.p, w->cg_p.p, w->stgs->rho_y, cg_tol_factor(w, iter), d, w->part.p, w->NB, w->ctl.p);
+}
+void enqueue_cg_chunk(W *w, double *rhs, int its) {
+  const int max_its = (int)w->m; // indirect.c:418
+  for (int q = 0; q < its; ++q) {
+    launch(w, ABIP_HIP_K_SPMV_AT, k_cg_spmv_At, w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, (const double *)w->cg_p.p, w->cg_tmp.p,
+           max_its, w->part.p, w->NB, w->ctl.p);
+    launch(w, ABIP_HIP_K_SPMV_A, k_cg_spmv_A, w->NB, BS, w->dA.view(), (const double *)w->cg_tmp.p, (const double *)w->cg_z.p, w->cg_p.p,
+           w->cg_Gp.p, w->stgs->rho_y, w->part.p, (const Ctl *)w->ctl.p);
+    launch(w, ABIP_HIP_K_CG_VEC, k_cg_update, w->NB, BS, rhs, w->cg_r.p, w->cg_z.p, (const double *)w->cg_p.p, (const double *)w->cg_Gp.p,
+           (const double *)w->cg_M.p, (int)w->m, w->part.p, w->NB, w->ctl.p);
+  }
+}
+void enqueue_cg_post(W *w, double *rhs) {
+  launch(w, ABIP_HIP_K_SPMV_AT, k_post_At, w->NB, BS, w->dAt.view(), rhs, (const double *)w->h.p, dims(w), (int)w->m, w->part.p, w->NB, w->ctl.p);
+}
+void enqueue_direct(W *w, double *rhs) {
+  const int N = (int)(w->m + w->n);
+  const Ctl *ctl = w->ctl.p;
+  if (w->small_solve) {
+    launch(w, ABIP_HIP_K_SPTRSV, k_ldl_solve_small, 1, TBS, w->triF.view(), w->triB.view(), (const int *)w->Pmap.p, (const double *)w->Dg.p, rhs, w->xw.p, N, ctl);
+  } else {
+    const int gN = std::min(w->NB, (N + BS - 1) / BS);
+    launch(w, ABIP_HIP_K_SPTRSV, k_perm_in, gN, BS, (const int *)w->Pmap.p, (const double *)rhs, w->xw.p, N, ctl);
+    auto run = [&](const DevTri &T, const std::vector<Segment> &segs) {
+      for (const Segment &s : segs) {
+        if (s.wide) {
+          const int rows = T.h_lev_ptr[s.l0 + 1] - T.h_lev_ptr[s.l0];
+          const int grid = std::max(1, std::min(MAXNB, (rows * 8 + BS - 1) / BS));
+          launch(w, ABIP_HIP_K_SPTRSV, k_tri_wide, grid, BS, T.view(), w->xw.p, s.l0, ctl);
+        } else {
+          launch(w, ABIP_HIP_K_SPTRSV, k_tri_thin, 1, TBS, T.view(), w->xw.p, s.l0, s.l1, ctl);
+        }
+      }
+    };
+    run(w->triF, w->segF);
+    launch(w, ABIP_HIP_K_SPTRSV, k_dscale, gN, BS, w->xw.p, (const double *)w->Dg.p, N, ctl);
+    run(w->triB, w->segB);
+    launch(w, ABIP_HIP_K_SPTRSV, k_perm_out, gN, BS, (const int *)w->Pmap.p, rhs, (const double *)w->xw.p, N, ctl);
+  }
+  launch(w, ABIP_HIP_K_VEC, k_post_dot, w->NB, BS, (const double *)rhs, (const double *)w->h.p, dims(w), w->part.p, ctl);
+}
+
+int next_chunk(const W *w) { return std::max(2, std::min((int)w->m, w->last_cg_its + (w->last_cg_its >> 2) + 2)); }
+
+// Solve K z = rhs in place and leave S_DH = z[0:l-1)'h; synchronises with the host (used outside the hot loop:
+// the set-up solve for g and the BB look-ahead).  Returns CG iterations, <0 on error.
+int kkt_solve_sync(W *w, double *rhs, const double *warm, abip_int iter) {
+  w->tot_solves++;
+  w->prof.kkt_solves++;
+  if (w->linsys == ABIP_HIP_LINSYS_DIRECT) {
+    enqueue_direct(w, rhs);
+    if (sync_ctl(w)) return -1;
+    return 0;
+  }
+  enqueue_cg_begin(w, rhs, warm, iter);
+  int chunk = next_chunk(w);
+  for (;;) {
+    enqueue_cg_chunk(w, rhs, chunk);
+    enqueue_cg_post(w, rhs);
+    if (sync_ctl(w)) return -1;
+    if (w->hctl->cg_done) break;
+    chunk = std::max(4, chunk);
+  }
+  const int its = w->hctl->cg_it;
+  w->last_cg_its = its;
+  if (iter >= 0) { w->tot_cg_its += its; w->prof.cg_iters += its; } // indirect.c:422-425
+  return its;
+}
+
+// ------------------------------------------------------------------------------------------------
+// residuals from the finalised sums (calc_residuals, abip.c:458-535)
+// ------------------------------------------------------------------------------------------------
+void calc_residuals(W *w, abip_int ipm_iter, abip_int admm_iter) {
+  Resid &r = w->r;
+  if (admm_iter && r.last_admm_iter == admm_iter) return;
+  r.last_ipm_iter = ipm_iter; r.last_admm_iter = admm_iter;
+  const bool avg = w->stgs->avg_criterion != 0;
+  const double *o = w->hctl->out;
+  const double den = w->stgs->normalize ? (w->stgs->scale * w->sc_c * w->sc_b) : 1.0;
+  const double ut = avg ? o[82] : o[80], vt = avg ? o[83] : o[81];
+  r.tau = std::fabs(ut);
+  r.kap = std::fabs(vt) / den;
+  const double nmpr_tau = std::sqrt(avg ? o[S_RPA] : o[S_RP]), nm_A_x_tau = std::sqrt(avg ? o[S_NAXA] : o[S_NAX]);
+  const double nmdr_tau = std::sqrt(avg ? o[S_RDA] : o[S_RD]), nm_At_ys_tau = std::sqrt(avg ? o[S_NATYA] : o[S_NATY]);
+  r.bt_y_by_tau = (avg ? o[S_BYA] : o[S_BY]) / den;
+  r.ct_x_by_tau = (avg ? o[S_CXA] : o[S_CX]) / den;
+  r.res_infeas = r.bt_y_by_tau > 0 ? w->nm_b * nm_At_ys_tau / r.bt_y_by_tau : NAN;
+  r.res_unbdd = r.ct_x_by_tau < 0 ? w->nm_c * nm_A_x_tau / -r.ct_x_by_tau : NAN;
+  const double bt_y = safediv_pos(r.bt_y_by_tau, r.tau), ct_x = safediv_pos(r.ct_x_by_tau, r.tau);
+  r.res_pri = safediv_pos(nmpr_tau / (1 + w->nm_b), r.tau);
+  r.res_dual = safediv_pos(nmdr_tau / (1 + w->nm_c), r.tau);
+  r.rel_gap = std::fabs(ct_x - bt_y) / (1 + std::fabs(ct_x) + std::fabs(bt_y));
+}
+
+abip_int has_converged(const W *w, abip_int ipm_iter, abip_int admm_iter) { // abip.c:1613-1641
+  const Resid &r = w->r;
+  const double eps = w->stgs->eps;
+  if (r.res_pri < eps && (r.res_dual < eps || w->stgs->pfeasopt) && r.rel_gap < eps) return ABIP_SOLVED;
+  if (r.res_unbdd < eps && ipm_iter > 0 && admm_iter > 0) return ABIP_UNBOUNDED;
+  if (r.res_infeas < eps && ipm_iter > 0 && admm_iter > 0) return ABIP_INFEASIBLE;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// statistics pass on the current iterate(s): the two residual SpMVs + finalise + control read
+// ------------------------------------------------------------------------------------------------
+void enqueue_q_and_finalize(W *w, bool avg_stats) {
+  const Dims d = dims(w);
+  const Ctl *ctl = w->ctl.p;
+  const double *wD = w->stgs->normalize ? w->wD.p : nullptr, *wE = w->stgs->normalize ? w->wE.p : nullptr;
+  launch(w, ABIP_HIP_K_QNORM, k_q_A, w->NB, BS, w->dA.view(), (const double *)w->u.p, (const double *)w->b.p, wD, d, (int)S_QP, w->part.p, ctl);
+  launch(w, ABIP_HIP_K_QNORM, k_q_At, w->NB, BS, w->dAt.view(), (const double *)w->u.p, (const double *)w->v.p, (const double *)w->c.p, wE, d, (int)S_QD, w->part.p, ctl);
+  FinArgs f;
+  int ns = 0;
+  const int base[] = {S_NU, S_NV, S_CX, S_BY, S_QP, S_RP, S_NAX, S_QD, S_RD, S_NATY};
+  for (int s : base) f.slots[ns++] = s;
+  if (avg_stats) {
+    launch(w, ABIP_HIP_K_QNORM, k_q_A, w->NB, BS, w->dA.view(), (const double *)w->u_avgc.p, (const double *)w->b.p, wD, d, (int)S_QPA, w->part.p, ctl);
+    launch(w, ABIP_HIP_K_QNORM, k_q_At, w->NB, BS, w->dAt.view(), (const double *)w->u_avgc.p, (const double *)w->v_avgc.p, (const double *)w->c.p, wE, d, (int)S_QDA, w->part.p, ctl);
+    const int extra[] = {S_NUA, S_NVA, S_CXA, S_BYA, S_QPA, S_RPA, S_NAXA, S_QDA, S_RDA, S_NATYA};
+    for (int s : extra) f.slots[ns++] = s;
+  }
+  f.nslots = ns;
+  f.u = w->u.p; f.v = w->v.p; f.ua = w->u_avgc.p; f.va = w->v_avgc.p;
+  launch(w, ABIP_HIP_K_VEC, k_finalize, 1, BS, f, d, (const double *)w->part.p, w->NB, w->ctl.p);
+}
+
+UpdArgs upd_args(W *w, bool fuse_avg, bool avg_stats) {
+  UpdArgs a;
+  a.u = w->u.p; a.v = w->v.p; a.ut = w->ut.p;
+  a.u_avg = w->u_avg.p; a.v_avg = w->v_avg.p; a.u_sum = w->u_sum.p; a.v_sum = w->v_sum.p; a.u_avgc = w->u_avgc.p; a.v_avgc = w->v_avgc.p;
+  a.g = w->g.p; a.b = w->b.p; a.c = w->c.p;
+  a.alpha = w->stgs->alpha; a.mu_over_beta = w->mu / w->beta; a.rho = w->stgs->rho_y; a.dom = (double)(w->j + 1);
+  a.half_update = (int)w->stgs->half_update; a.fuse_avg = fuse_avg ? 1 : 0; a.avg_stats = avg_stats ? 1 : 0;
+  return a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// one inner ADMM iteration (abip.c:2133-2173 up to and including the stopping metric); returns the metric
+// ------------------------------------------------------------------------------------------------
+int admm_iteration(W *w, double *metric_out) {
+  const Dims d = dims(w);
+  const Ctl *ctl = w->ctl.p;
+  ABIPSettings *st = w->stgs;
+  if (!w->wg_valid) launch(w, ABIP_HIP_K_VEC, k_dot_wg, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->g.p, st->rho_y, d, w->part.p);
+  launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, w->ut.p, (const double *)w->h.p, st->rho_y, w->g_th, d,
+         w->part.p, w->NB, ctl);
+  const bool avg_stats = ((w->j + 1) % 10 == 0);                                                   // abip.c:2000
+  const bool restart = !(w->k < st->restart_thresh || (w->j + 1 - w->fre_old) % st->restart_fre != 0); // abip.c:608-609
+  auto tail = [&]() {
+    launch(w, ABIP_HIP_K_VEC, k_admm_update, w->NB, BS, upd_args(w, !restart, avg_stats), d, w->part.p, w->NB, ctl);
+    if (restart) {
+      launch(w, ABIP_HIP_K_VEC, k_restart_apply, w->NB, BS, w->u.p, w->v.p, w->u_avg.p, w->v_avg.p, (double)st->restart_fre, w->LV);
+      launch(w, ABIP_HIP_K_VEC, k_avg_stats, w->NB, BS, upd_args(w, true, avg_stats), d, w->part.p, ctl);
+    }
+    enqueue_q_and_finalize(w, avg_stats);
+  };
+  w->tot_solves++;
+  w->prof.kkt_solves++;
+  if (w->linsys == ABIP_HIP_LINSYS_DIRECT) {
+    enqueue_direct(w, w->ut.p);
+    tail();
+    if (sync_ctl(w)) return -1;
+  } else {
+    enqueue_cg_begin(w, w->ut.p, w->u.p, w->k); // warm start = current u[0:m), abip.c:559
+    int chunk = next_chunk(w);
+    for (;;) {
+      enqueue_cg_chunk(w, w->ut.p, chunk);
+      enqueue_cg_post(w, w->ut.p);
+      tail();
+      if (sync_ctl(w)) return -1;
+      if (w->hctl->cg_done) break;
+      chunk = std::max(4, chunk); // not converged inside the chunk: everything behind it was a no-op; go on
+    }
+    w->last_cg_its = w->hctl->cg_it;
+    w->tot_cg_its += w->hctl->cg_it;
+    w->prof.cg_iters += w->hctl->cg_it;
+  }
+  if (restart) w->fre_old = st->restart_fre; // abip.c:627
+  w->wg_valid = true;
+  w->stats_valid = true; w->avg_stats_valid = avg_stats;
+  w->prof.admm_iters++;
+  // iterate_Q_norm_resd, abip.c:1951-2051 (scalar part)
+  const double *o = w->hctl->out;
+  const double tau = o[80], kap = o[81];
+  (void)tau;
+  double Qres = o[S_QP] + o[S_QD];
+  const double gap = o[S_BY] - o[S_CX] - kap;
+  Qres += gap * gap;
+  const double norm = 1 + std::sqrt(o[S_NU] + o[S_NV]);
+  double Qres_avg = (double)st->max_admm_iters, norm_avg = 1;
+  if (avg_stats) {
+    const double kap_a = o[83];
+    Qres_avg = o[S_QPA] + o[S_QDA];
+    const double gap_a = o[S_BYA] - o[S_CXA] - kap_a;
+    Qres_avg += gap_a * gap_a;
+    norm_avg = 1 + std::sqrt(o[S_NUA] + o[S_NVA]);
+  }
+  if (std::sqrt(Qres_avg) / norm_avg < std::sqrt(Qres) / norm) { st->avg_criterion = 1; *metric_out = std::sqrt(Qres_avg) / norm_avg; }
+  else { st->avg_criterion = 0; *metric_out = std::sqrt(Qres) / norm; }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// barrier-parameter strategies (abip.c:753-992) -- host scalars; the LOQO rule needs one device reduction
+// ------------------------------------------------------------------------------------------------
+double gamma_ladder(double ratio, double top) {
+  if (ratio > 10.0) return top;
+  if (ratio > 1.0) return 1.0;
+  if (ratio > 0.5) return 0.9;
+  if (ratio > 0.1) return 0.8;
+  if (ratio > 0.05) return 0.7;
+  if (ratio > 0.01) return 0.6;
+  if (ratio > 0.005) return 0.5;
+  if (ratio > 0.001) return 0.4;
+  return 0.3;
+}
+void update_barrier(W *w) { // "tedious" table, abip.c:753-921
+  const Resid &r = w->r;
+  double sigma, gamma;
+  const double ratio = w->mu / w->stgs->eps;
+  const double err_ratio = std::max(std::max(r.res_pri, r.res_dual), r.rel_gap) / w->stgs->eps;
+  const double mx = std::max(w->sp, w->stgs->sparsity_ratio), mn = std::min(w->sp, w->stgs->sparsity_ratio);
+  if (mx > 0.4 || mn > 0.1) {
+    gamma = gamma_ladder(ratio, 2.0);
+    if (err_ratio > 6 && err_ratio <= 10) sigma = 0.5;
+    else if (err_ratio > 3 && err_ratio <= 6) { sigma = 0.6; gamma *= 0.8; }
+    else if (err_ratio > 1 && err_ratio <= 3) { w->final_check = 1; gamma *= 0.4; sigma = ratio < 0.1 ? 0.8 : 0.7; }
+    else sigma = w->sigma;
+  } else {
+    gamma = gamma_ladder(ratio, 3.0);
+    if (err_ratio > 6 && err_ratio <= 10) { sigma = 0.82; gamma *= 0.8; }
+    else if (err_ratio > 4 && err_ratio <= 6) { sigma = 0.84; gamma *= 0.6; }
+    else if (err_ratio > 3 && err_ratio <= 4) { sigma = 0.85; gamma *= 0.5; w->final_check = 1; }
+    else if (err_ratio > 1 && err_ratio <= 3) {
+      w->final_check = 1;
+      if (ratio < 0.1) {
+        if (w->double_check) { sigma = 0.9; gamma *= 0.4; w->double_check = 0; }
+        else { sigma = 1.0; gamma *= 0.1; w->double_check = 1; }
+      } else { sigma = 0.88; gamma *= 0.4; }
+    } else sigma = w->sigma;
+  }
+  w->mu *= sigma; w->sigma = sigma; w->gamma = gamma;
+}
+int update_barrier_dynamic(W *w) { // LOQO, abip.c:930-977
+  const bool avg = w->stgs->avg_criterion != 0;
+  const double *uu = avg ? w->u_avgc.p : w->u.p, *vv = avg ? w->v_avgc.p : w->v.p;
+  launch(w, ABIP_HIP_K_VEC, k_xs, w->NB, BS, uu, vv, dims(w), w->part.p);
+  launch(w, ABIP_HIP_K_VEC, k_min_fold, 1, 1, (const double *)w->part.p, w->NB, w->ctl.p);
+  FinArgs f; f.nslots = 1; f.slots[0] = S_XS; f.u = w->u.p; f.v = w->v.p; f.ua = w->u_avgc.p; f.va = w->v_avgc.p;
+  launch(w, ABIP_HIP_K_VEC, k_finalize, 1, BS, f, dims(w), (const double *)w->part.p, w->NB, w->ctl.p);
+  if (sync_ctl(w)) return -2;
+  double xs = w->hctl->out[S_XS];
+  const double minxs = w->hctl->out[S_XMIN];
+  if (minxs <= 0.0) { printf("Invalid xisi < 0 \n"); return -1; } // the reference asserts here
+  xs /= (double)(w->n + 1);
+  const double ksi = minxs / xs;
+  double sigma = std::min(0.05 * (1 - ksi) / ksi, 2.0);
+  sigma = std::max(0.1 * sigma * sigma * sigma, w->stgs->dynamic_sigma);
+  w->mu *= sigma;
+  return 0;
+}
+void update_barrier_dynamic_2(W *w) { // abip.c:982-992 (reads dynamic_sigma as the exponent)
+  w->mu *= std::min(w->stgs->dynamic_x * w->mu, std::pow(w->mu, w->stgs->dynamic_sigma));
+}
+void reinitialize_vars(W *w, int indx) { // abip.c:996-1075
+  const bool avg = w->stgs->avg_criterion != 0;
+  launch(w, ABIP_HIP_K_VEC, k_reinit, w->NB, BS, avg ? w->u_avgc.p : w->u.p, avg ? w->v_avgc.p : w->v.p, w->sigma, indx, dims(w));
+  w->wg_valid = false; w->stats_valid = false;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Barzilai-Borwein penalty search (update_adapt_params, adaptive.c:34-256)
+// ------------------------------------------------------------------------------------------------
+int lin_projection(W *w, double *ut, const double *u, const double *v, abip_int iter) { // abip.c:552-560 on scratch vectors
+  const Dims d = dims(w);
+  launch(w, ABIP_HIP_K_VEC, k_dot_wg, w->NB, BS, u, v, (const double *)w->g.p, w->stgs->rho_y, d, w->part.p);
+  launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, u, v, ut, (const double *)w->h.p, w->stgs->rho_y, w->g_th, d, w->part.p, w->NB, (const Ctl *)w->ctl.p);
+  return kkt_solve_sync(w, ut, u, iter) < 0 ? -1 : 0; // S_DH is left for k_adapt_step
+}
+int adaptive_search(W *w, abip_int iter) {
+  const Dims d = dims(w);
+  const size_t bytes = sizeof(double) * (size_t)w->LV;
+  ABIPSettings *st = w->stgs;
+  double beta_prev = 1.0, beta = 0.0;
+  HIP_OK(hipMemcpyAsync(w->a_up.p, w->u.p, bytes, hipMemcpyDeviceToDevice, w->stream));
+  HIP_OK(hipMemcpyAsync(w->a_vp.p, w->v.p, bytes, hipMemcpyDeviceToDevice, w->stream));
+  for (abip_int it = 0; it < st->adaptive_lookback; ++it) {
+    if (lin_projection(w, w->a_ut.p, w->a_up.p, w->a_vp.p, iter)) return -1;
+    launch(w, ABIP_HIP_K_VEC, k_adapt_step, w->NB, BS, (const double *)w->a_ut.p, w->a_ut.p, (const double *)w->a_up.p, (const double *)w->a_vp.p,
+           w->a_u.p, w->a_v.p, st->alpha, w->mu / beta_prev, d, (const double *)w->part.p, w->NB);
+    if (lin_projection(w, w->a_utn.p, w->a_u.p, w->a_v.p, iter)) return -1;
+    launch(w, ABIP_HIP_K_VEC, k_adapt_step, w->NB, BS, (const double *)w->a_utn.p, w->a_utn.p, (const double *)w->a_u.p, (const double *)w->a_v.p,
+           w->a_un.p, w->a_vn.p, st->alpha, w->mu / beta_prev, d, (const double *)w->part.p, w->NB);
+    launch(w, ABIP_HIP_K_VEC, k_adapt_dots, w->NB, BS, (const double *)w->a_u.p, (const double *)w->a_v.p, (const double *)w->a_un.p,
+           (const double *)w->a_vn.p, (const double *)w->a_vp.p, st->alpha, d, w->part.p);
+    FinArgs f; f.nslots = 5;
+    const int sl[5] = {S_A0, S_A1, S_A2, S_A3, S_A4};
+    for (int q = 0; q < 5; ++q) f.slots[q] = sl[q];
+    f.u = w->u.p; f.v = w->v.p; f.ua = nullptr; f.va = nullptr;
+    launch(w, ABIP_HIP_K_VEC, k_finalize, 1, BS, f, d, (const double *)w->part.p, w->NB, w->ctl.p);
+    if (sync_ctl(w)) return -1;
+    const double utut = w->hctl->out[S_A0], utv = w->hctl->out[S_A1], uu = w->hctl->out[S_A2], vv = w->hctl->out[S_A3], uv = w->hctl->out[S_A4];
+    const double norm_ut = std::sqrt(utut), norm_u = std::sqrt(uu), norm_v = std::sqrt(vv);
+    const double alpha_SD = vv / utv, alpha_MG = utv / utut, gamma_SD = vv / uv, gamma_MG = uv / uu;
+    const double alpha_ss = (2 * alpha_MG > alpha_SD) ? alpha_MG : alpha_SD - 0.5 * alpha_MG;
+    const double gamma_ss = (2 * gamma_MG > gamma_SD) ? gamma_MG : gamma_SD - 0.5 * gamma_MG;
+    const double alpha_cor = utv / (norm_v * norm_ut), gamma_cor = uv / (norm_v * norm_u);
+    const double ec = st->eps_cor;
+    if (alpha_cor > ec && gamma_cor > ec) beta = std::sqrt(alpha_ss * gamma_ss);
+    else if (alpha_cor > ec && gamma_cor <= ec) beta = alpha_ss;
+    else if (alpha_cor <= ec && gamma_cor > ec) beta = gamma_ss;
+    else beta = beta_prev;
+    const double diff = std::fabs(beta - beta_prev);
+    if (diff > 0 && diff <= st->eps_pen) { beta = (beta + beta_prev) / 2; break; }
+    else if (diff > st->eps_pen) {
+      beta_prev = beta;
+      HIP_OK(hipMemcpyAsync(w->a_up.p, w->a_u.p, bytes, hipMemcpyDeviceToDevice, w->stream));
+      HIP_OK(hipMemcpyAsync(w->a_vp.p, w->a_v.p, sizeof(double) * (size_t)w->m, hipMemcpyDeviceToDevice, w->stream));
+      launch(w, ABIP_HIP_K_VEC, k_adapt_vprev, w->NB, BS, w->a_vp.p, (const double *)w->a_up.p, w->mu / beta_prev, d);
+    } else {
+      HIP_OK(hipMemcpyAsync(w->a_up.p, w->a_u.p, bytes, hipMemcpyDeviceToDevice, w->stream));
+      HIP_OK(hipMemcpyAsync(w->a_vp.p, w->a_v.p, bytes, hipMemcpyDeviceToDevice, w->stream));
+    }
+  }
+  w->beta = beta;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// solution extraction (get_solution / get_info, abip.c:1296-1414) -- host side on downloaded iterates
+// ------------------------------------------------------------------------------------------------
+bool st_solved(abip_int s) { return s == ABIP_SOLVED || s == ABIP_SOLVED_INACCURATE; }
+bool st_infeas(abip_int s) { return s == ABIP_INFEASIBLE || s == ABIP_INFEASIBLE_INACCURATE; }
+bool st_unbdd(abip_int s) { return s == ABIP_UNBOUNDED || s == ABIP_UNBOUNDED_INACCURATE; }
+
+int ensure_stats(W *w) { // make ctl.out describe the CURRENT iterate and the averaged one (off the hot path:
+                         // only after an out-of-band change of (u, v) such as the half-update clip, or for a mid-run snapshot)
+  if (w->stats_valid && (!w->stgs->avg_criterion || w->avg_stats_valid)) return 0;
+  std::vector<double> hu(w->LV), hua(w->LV), hb(w->m), hc(w->n);
+  HIP_OK(hipMemcpyAsync(hu.data(), w->u.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream));
+  HIP_OK(hipMemcpyAsync(hua.data(), w->u_avgc.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream));
+  HIP_OK(hipMemcpyAsync(hb.data(), w->b.p, sizeof(double) * w->m, hipMemcpyDeviceToHost, w->stream));
+  HIP_OK(hipMemcpyAsync(hc.data(), w->c.p, sizeof(double) * w->n, hipMemcpyDeviceToHost, w->stream));
+  // the residual SpMV pair is gated on (!halt && cg_done): force both
+  const int zero = 0, one = 1;
+  HIP_OK(hipMemcpyAsync(&w->ctl.p->halt, &zero, sizeof(int), hipMemcpyHostToDevice, w->stream));
+  HIP_OK(hipMemcpyAsync(&w->ctl.p->cg_done, &one, sizeof(int), hipMemcpyHostToDevice, w->stream));
+  enqueue_q_and_finalize(w, true);
+  if (sync_ctl(w)) return -1;
+  double *o = w->hctl->out;
+  double by = 0, cx = 0, bya = 0, cxa = 0;
+  for (abip_int i = 0; i < w->m; ++i) { by += hb[i] * hu[i]; bya += hb[i] * hua[i]; }
+  for (abip_int j = 0; j < w->n; ++j) { cx += hc[j] * hu[w->MP + j]; cxa += hc[j] * hua[w->MP + j]; }
+  o[S_BY] = by; o[S_CX] = cx; o[S_BYA] = bya; o[S_CXA] = cxa;
+  w->stats_valid = true; w->avg_stats_valid = true;
+  w->r.last_admm_iter = -1;
+  return 0;
+}
+
+void fail_fill(W *w, ABIPInfo *info, abip_int status_val, const char *ststr) { // populate_on_failure, abip.c:219-277
+  if (info) {
+    info->res_pri = NAN; info->res_dual = NAN; info->rel_gap = NAN; info->res_infeas = NAN; info->res_unbdd = NAN;
+    info->pobj = NAN; info->dobj = NAN; info->ipm_iter = -1; info->admm_iter = -1; info->status_val = status_val; info->solve_time = NAN;
+    strcpy(info->status, ststr);
+  }
+  if (w) {
+    w->sol_x.assign(w->n, NAN); w->sol_y.assign(w->m, NAN); w->sol_s.assign(w->n, NAN);
+    w->have_solution = true;
+    if (info) w->last_info = *info;
+  }
+}
+
+int finish_solution(W *w, ABIPInfo *info, abip_int ipm_iter, abip_int admm_iter) {
+  const abip_int m = w->m, n = w->n, l = m + n + 1;
+  ABIPSettings *st = w->stgs;
+  if (ensure_stats(w)) return -1;
+  calc_residuals(w, ipm_iter, admm_iter);
+  Resid &r = w->r;
+  const bool avg = st->avg_criterion != 0;
+  std::vector<double> hu(w->LV), hv(w->LV);
+  HIP_OK(hipMemcpyAsync(hu.data(), avg ? w->u_avgc.p : w->u.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream));
+  HIP_OK(hipMemcpyAsync(hv.data(), avg ? w->v_avgc.p : w->v.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream));
+  HIP_OK(hipStreamSynchronize(w->stream));
+  w->sol_x.assign(hu.begin() + w->MP, hu.begin() + w->MP + n);
+  w->sol_y.assign(hu.begin(), hu.begin() + m);
+  w->sol_s.assign(hv.begin() + w->MP, hv.begin() + w->MP + n);
+  int kind; // 0 solved, 1 indeterminate, 2 infeasible, 3 unbounded
+  if (info->status_val == ABIP_UNFINISHED) {
+    double nrm2 = 0;
+    for (abip_int i = 0; i < m; ++i) nrm2 += hu[i] * hu[i];
+    for (abip_int j = 0; j <= n; ++j) nrm2 += hu[w->MP + j] * hu[w->MP + j];
+    if (r.tau > 1e-9 && r.tau > r.kap) kind = 0;
+    else if (std::sqrt(nrm2) < 1e-9 * std::sqrt((double)l)) kind = 1;
+    else if (-r.bt_y_by_tau < r.ct_x_by_tau) kind = 2;
+    else kind = 3;
+  } else if (st_solved(info->status_val)) kind = 0;
+  else if (st_infeas(info->status_val)) kind = 2;
+  else kind = 3;
+  const bool inacc = (info->status_val == 0);
+  auto scale = [](std::vector<double> &a, double sc) { for (double &x : a) x *= sc; };
+  if (kind == 0) {
+    const double sc = safediv_pos(1.0, r.tau);
+    scale(w->sol_x, sc); scale(w->sol_y, sc); scale(w->sol_s, sc);
+    strcpy(info->status, inacc ? "Solved/Inaccurate" : "Solved");
+    info->status_val = inacc ? ABIP_SOLVED_INACCURATE : ABIP_SOLVED;
+  } else if (kind == 1) {
+    strcpy(info->status, "Indeterminate");
+    scale(w->sol_x, NAN); scale(w->sol_y, NAN); scale(w->sol_s, NAN);
+    info->status_val = ABIP_INDETERMINATE;
+  } else if (kind == 2) {
+    scale(w->sol_y, 1 / r.bt_y_by_tau); scale(w->sol_s, 1 / r.bt_y_by_tau); scale(w->sol_x, NAN);
+    strcpy(info->status, inacc ? "Infeasible/Inaccurate" : "Infeasible");
+    info->status_val = inacc ? ABIP_INFEASIBLE_INACCURATE : ABIP_INFEASIBLE;
+  } else {
+    scale(w->sol_x, -1 / r.ct_x_by_tau); scale(w->sol_y, NAN); scale(w->sol_s, NAN);
+    strcpy(info->status, inacc ? "Unbounded/Inaccurate" : "Unbounded");
+    info->status_val = inacc ? ABIP_UNBOUNDED_INACCURATE : ABIP_UNBOUNDED;
+  }
+  if (st->normalize) { // un_normalize_sol, normalize.c:133-158
+    for (abip_int j = 0; j < n; ++j) w->sol_x[j] /= (w->E[j] * w->sc_b);
+    for (abip_int i = 0; i < m; ++i) w->sol_y[i] /= (w->D[i] * w->sc_c);
+    for (abip_int j = 0; j < n; ++j) w->sol_s[j] *= w->E[j] / (w->sc_c * st->scale);
+  }
+  info->ipm_iter = ipm_iter + 1; info->admm_iter = admm_iter + 1; // get_info, abip.c:1296-1340
+  info->res_infeas = r.res_infeas; info->res_unbdd = r.res_unbdd;
+  if (st_solved(info->status_val)) {
+    info->rel_gap = r.rel_gap; info->res_pri = r.res_pri; info->res_dual = r.res_dual;
+    info->pobj = r.ct_x_by_tau / r.tau; info->dobj = r.bt_y_by_tau / r.tau;
+  } else if (st_unbdd(info->status_val)) {
+    info->rel_gap = NAN; info->res_pri = NAN; info->res_dual = NAN; info->pobj = -INFINITY; info->dobj = -INFINITY;
+  } else if (st_infeas(info->status_val)) {
+    info->rel_gap = NAN; info->res_pri = NAN; info->res_dual = NAN; info->pobj = INFINITY; info->dobj = INFINITY;
+  }
+  info->solve_time = now_ms() - w->t_solve0;
+  w->have_solution = true;
+  w->last_info = *info;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// printing (abip.c:159-215, 1418-1607) -- same rows and columns as the reference
+// ------------------------------------------------------------------------------------------------
+void print_init_header(const ABIPData *d, int linsys) {
+  const ABIPSettings *s = d->stgs;
+  print_line('-');
+  printf("\tABIP v%s - First-Order Interior-Point Solver (MI355X-native HIP back-end)\n", abip_version());
+  print_line('-');
+  if (linsys == ABIP_HIP_LINSYS_INDIRECT) printf("Lin-sys: sparse-indirect (device PCG), nnz in A = %li, CG tol ~ 1/iter^(%2.2f)\n", (long)d->A->p[d->A->n], s->cg_rate);
+  else printf("Lin-sys: sparse-direct (host LDL', device SpTRSV), nnz in A = %li\n", (long)d->A->p[d->A->n]);
+  if (s->normalize)
+    printf("eps = %.2e, alpha = %.2f, max_ipm_iters = %i, max_admm_iters = %i, normalize = %i\nscale = %2.2f, adaptive = %i, adaptive_lookback = %i, rho_y = %.2e\n",
+           s->eps, s->alpha, (int)s->max_ipm_iters, (int)s->max_admm_iters, (int)s->normalize, s->scale, (int)s->adaptive, (int)s->adaptive_lookback, s->rho_y);
+  else
+    printf("eps = %.2e, alpha = %.2f, max_ipm_iters = %i, max_admm_iters = %i, normalize = %i\nadaptive = %i, adaptive_lookback = %i, rho_y = %.2e\n",
+           s->eps, s->alpha, (int)s->max_ipm_iters, (int)s->max_admm_iters, (int)s->normalize, (int)s->adaptive, (int)s->adaptive_lookback, s->rho_y);
+  printf("Variables n = %i, constraints m = %i\n", (int)d->n, (int)d->m);
+}
+void print_header(const W *w) {
+  if (w->stgs->warm_start) printf("ABIP using variable warm-starting\n");
+  print_line('-');
+  for (int q = 0; q < kHeaderLen - 1; ++q) printf("%s|", kHeader[q]);
+  printf("%s\n", kHeader[kHeaderLen - 1]);
+  print_line('-');
+}
+void print_summary(const W *w, abip_int i, abip_int j) {
+  const Resid &r = w->r;
+  printf("%*i|", (int)strlen(kHeader[0]), (int)i);
+  printf("%*i|", (int)strlen(kHeader[1]), (int)j);
+  printf("%*.2e|", (int)strlen(kHeader[2]), w->mu);
+  printf("%*.2e|", kHSpace, r.res_pri); printf("%*.2e|", kHSpace, r.res_dual); printf("%*.2e|", kHSpace, r.rel_gap);
+  printf("%*.2e|", kHSpace, safediv_pos(r.ct_x_by_tau, r.tau)); printf("%*.2e|", kHSpace, safediv_pos(r.bt_y_by_tau, r.tau));
+  printf("%*.2e|", kHSpace, safediv_pos(r.kap, r.tau));
+  printf("%*.2e ", kHSpace, (now_ms() - w->t_solve0) / 1e3);
+  printf("\n");
+}
+void print_footer(const W *w, const ABIPInfo *info) {
+  print_line('-');
+  printf("Status: %s\n", info->status);
+  if (info->ipm_iter + 1 == w->stgs->max_ipm_iters) printf("Hit max_ipm_iters, solution may be inaccurate\n");
+  if (info->admm_iter + 1 >= w->stgs->max_admm_iters) printf("Hit max_admm_iters, solution may be inaccurate\n");
+  printf("Timing: Solve time: %1.2es\n", info->solve_time / 1e3);
+  if (w->linsys == ABIP_HIP_LINSYS_INDIRECT) printf("\tLin-sys: avg # CG iterations: %2.2f\n", (double)w->tot_cg_its / (info->admm_iter + 1));
+  else printf("\tLin-sys: nnz in L factor: %li\n", (long)(w->lnnz + w->m + w->n));
+  print_line('-');
+  if (st_infeas(info->status_val)) { printf("Certificate of primal infeasibility:\n|A'y + s|_2 * |b|_2 = %.4e\n", info->res_infeas); }
+  else if (st_unbdd(info->status_val)) { printf("Certificate of dual infeasibility:\n|Ax|_2 * |c|_2 = %.4e\n", info->res_unbdd); }
+  else {
+    printf("Error metrics:\n");
+    printf("primal res: |Ax - b|_2 / (1 + |b|_2) = %.4e\n", info->res_pri);
+    printf("dual res: |A'y + s - c|_2 / (1 + |c|_2) = %.4e\n", info->res_dual);
+    printf("rel gap: |c'x - b'y| / (1 + |c'x| + |b'y|) = %.4e\n", info->rel_gap);
+    print_line('-');
+    printf("c'x = %.4e, b'y = %.4e\n", info->pobj, info->dobj);
+  }
+  print_line('=');
+}
+
+void free_work(W *w) {
+  if (!w) return;
+  w->dAt.release(); w->dA.release();
+  DBuf<double> *bufs[] = {&w->u, &w->v, &w->ut, &w->u_avg, &w->v_avg, &w->u_sum, &w->v_sum, &w->u_avgc, &w->v_avgc, &w->h, &w->g, &w->b, &w->c,
+                          &w->wD, &w->wE, &w->cg_p, &w->cg_r, &w->cg_Gp, &w->cg_z, &w->cg_M, &w->cg_tmp, &w->a_up, &w->a_vp, &w->a_ut, &w->a_u,
+                          &w->a_v, &w->a_utn, &w->a_un, &w->a_vn, &w->part, &w->Dg, &w->xw};
+  for (auto *b : bufs) b->release();
+  w->ctl.release(); w->Pmap.release(); w->triF.release(); w->triB.release();
+  if (w->hctl) (void)hipHostFree(w->hctl);
+  for (auto &e : w->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (w->stream) (void)hipStreamDestroy(w->stream);
+  delete w;
+}
+
+std::vector<Segment> plan_segments(const std::vector<int> &lev_ptr) {
+  std::vector<Segment> segs;
+  const int nlev = (int)lev_ptr.size() - 1;
+  int l = 0;
+  while (l < nlev) {
+    const int rows = lev_ptr[l + 1] - lev_ptr[l];
+    if (rows >= 2048) { segs.push_back(Segment{true, l, l + 1}); ++l; }
+    else { int e = l; while (e < nlev && lev_ptr[e + 1] - lev_ptr[e] < 2048) ++e; segs.push_back(Segment{false, l, e}); l = e; }
+  }
+  return segs;
+}
+
+int upload_lvec(W *w, DBuf<double> &dst, const double *y, const double *x, double tail) { // host [y|x|tau] pieces -> padded device layout
+  std::vector<double> &s = w->scratch;
+  s.assign(w->LV, 0.0);
+  if (y) std::copy(y, y + w->m, s.begin());
+  if (x) std::copy(x, x + w->n, s.begin() + w->MP);
+  s[w->MP + w->n] = tail;
+  HIP_OK(hipMemcpyAsync(dst.p, s.data(), sizeof(double) * w->LV, hipMemcpyHostToDevice, w->stream));
+  HIP_OK(hipStreamSynchronize(w->stream));
+  return 0;
+}
+
+} // namespace
+
+// ==================================================================================================
+// public C ABI
+// ==================================================================================================
+extern "C" {
+
+const char *abip_version(void) { return ABIP_VERSION; }
+
+void abip_hip_set_linsys(int which) { g_linsys = which ? ABIP_HIP_LINSYS_INDIRECT : ABIP_HIP_LINSYS_DIRECT; }
+int abip_hip_get_linsys(void) { return chosen_linsys(); }
+
+int abip_hip_device_info(char *name, int name_len, long *total_mem_bytes, int *num_cu) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return -1;
+  hipDeviceProp_t p;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return -2;
+  if (name && name_len > 0) { snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName); }
+  if (total_mem_bytes) *total_mem_bytes = (long)p.totalGlobalMem;
+  if (num_cu) *num_cu = p.multiProcessorCount;
+  return 0;
+}
+
+void abip_set_default_settings(ABIPData *d) { // util.c:288-329
+  ABIPSettings *s = d->stgs;
+  s->max_ipm_iters = 500; s->max_admm_iters = 1000000; s->eps = 1e-3; s->alpha = 1.8; s->cg_rate = 2.0;
+  s->normalize = 1; s->scale = 1.0; s->rho_y = 1e-3; s->sparsity_ratio = 0.01;
+  s->adaptive = 1; s->eps_cor = 0.2; s->eps_pen = 0.1; s->adaptive_lookback = 20;
+  s->dynamic_x = 0.8; s->dynamic_eta = 1.1; s->restart_fre = 1000; s->restart_thresh = 100000;
+  s->origin_rescale = 0; s->pc_ruiz_rescale = 1; s->qp_rescale = 0; s->ruiz_iter = 10;
+  s->hybrid_mu = 1; s->dynamic_sigma = -1.0; s->hybrid_thresh = 1000; s->dynamic_sigma_second = 0.5;
+  s->half_update = 0; s->avg_criterion = 0; s->verbose = 1; s->warm_start = 0;
+}
+
+void abip_free_data(ABIPData *d) { // util.c:229-262
+  if (!d) return;
+  if (d->b) free(d->b);
+  if (d->c) free(d->c);
+  if (d->stgs) free(d->stgs);
+  if (d->A) { if (d->A->x) free(d->A->x); if (d->A->i) free(d->A->i); if (d->A->p) free(d->A->p); free(d->A); }
+  free(d);
+}
+void abip_free_sol(ABIPSolution *sol) { // util.c:264-283
+  if (!sol) return;
+  if (sol->x) free(sol->x);
+  if (sol->y) free(sol->y);
+  if (sol->s) free(sol->s);
+  free(sol);
+}
+
+ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + init_work 1739-1839
+  if (!d || !info) { printf("ERROR: Missing ABIPData or ABIPInfo input\n"); return nullptr; }
+  if (host::validate(d) < 0) { printf("ERROR: Validation returned failure\n"); return nullptr; }
+  char devname[128];
+  if (abip_hip_device_info(devname, sizeof(devname), nullptr, nullptr) != 0) {
+    printf("ERROR: no usable HIP device: libabip_hip has no CPU fallback\n");
+    return nullptr;
+  }
+  const double t0 = now_ms();
+  W *w = new W();
+  w->linsys = chosen_linsys();
+  if (d->stgs->verbose) print_init_header(d, w->linsys);
+  w->stgs = d->stgs; w->m = d->m; w->n = d->n; w->A = d->A; w->sp = d->sp;
+  const abip_int m = d->m, n = d->n;
+  w->MP = (int)(((m + 31) / 32) * 32);
+  w->LV = w->MP + (int)n + 1;
+  w->LV = ((w->LV + 31) / 32) * 32;
+  {
+    const long work = std::max<long>(std::max<long>(m, n), (long)d->A->p[n] / 4);
+    w->NB = (int)std::max<long>(1, std::min<long>(MAXNB, (work + BS - 1) / BS));
+  }
+  auto fail = [&](const char *msg) -> ABIPWork * { printf("ERROR: %s\n", msg); free_work(w); return nullptr; };
+  if (hipStreamCreate(&w->stream) != hipSuccess) return fail("hipStreamCreate failed");
+  if (w->stgs->normalize) host::normalize_A(w->A, w->stgs, w->D, w->E, &w->mean_norm_row_A, &w->mean_norm_col_A);
+  // device images of the (scaled) matrix
+  host::HostCsr hAt, hA;
+  host::csc_as_csr(w->A, hAt); host::build_row_blocks(hAt, CHUNK);
+  host::transpose_to_csr(w->A, hA); host::build_row_blocks(hA, CHUNK);
+  if (w->dAt.upload(hAt, w->stream) || w->dA.upload(hA, w->stream)) return fail("device allocation failure (matrix)");
+  DBuf<double> *lvecs[] = {&w->u, &w->v, &w->ut, &w->u_avg, &w->v_avg, &w->u_sum, &w->v_sum, &w->u_avgc, &w->v_avgc, &w->h, &w->g,
+                           &w->a_up, &w->a_vp, &w->a_ut, &w->a_u, &w->a_v, &w->a_utn, &w->a_un, &w->a_vn};
+  for (auto *b : lvecs) {
+    if (b->alloc(w->LV)) return fail("work memory allocation failure");
+    if (hipMemsetAsync(b->p, 0, sizeof(double) * w->LV, w->stream) != hipSuccess) return fail("memset failure");
+  }
+  if (w->b.alloc(m) || w->c.alloc(n) || w->wD.alloc(m) || w->wE.alloc(n) || w->part.alloc((size_t)S_COUNT * MAXNB) || w->ctl.alloc(1))
+    return fail("work memory allocation failure");
+  if (hipMemsetAsync(w->part.p, 0, sizeof(double) * S_COUNT * MAXNB, w->stream) != hipSuccess) return fail("memset failure");
+  if (hipMemsetAsync(w->ctl.p, 0, sizeof(Ctl), w->stream) != hipSuccess) return fail("memset failure");
+  if (hipHostMalloc((void **)&w->hctl, sizeof(Ctl), hipHostMallocDefault) != hipSuccess) return fail("pinned allocation failure");
+  memset(w->hctl, 0, sizeof(Ctl));
+  if (w->linsys == ABIP_HIP_LINSYS_INDIRECT) { // init_lin_sys_work, indirect.c:282-318
+    std::vector<double> Minv;
+    host::jacobi_preconditioner(w->A, Minv);
+    if (w->cg_M.upload(Minv, w->stream) || w->cg_p.alloc(m) || w->cg_r.alloc(m) || w->cg_Gp.alloc(m) || w->cg_z.alloc(m) || w->cg_tmp.alloc(n))
+      return fail("init_lin_sys_work failure");
+    if (hipMemsetAsync(w->cg_tmp.p, 0, sizeof(double) * n, w->stream) != hipSuccess) return fail("memset failure");
+  } else { // init_lin_sys_work / factorize, direct.c:218-303
+    host::LdlHost F;
+    if (host::factor_kkt(w->A, w->stgs->rho_y, F) < 0) return fail("init_lin_sys_work failure");
+    w->lnnz = F.lnnz;
+    std::vector<int> pmap(F.N);
+    for (int q = 0; q < F.N; ++q) pmap[q] = F.P[q] < m ? F.P[q] : w->MP + (F.P[q] - (int)m);
+    if (w->Pmap.upload(pmap, w->stream) || w->Dg.upload(F.D, w->stream) || w->xw.alloc(F.N) || w->triF.upload(F.fwd, w->stream) ||
+        w->triB.upload(F.bwd, w->stream))
+      return fail("init_lin_sys_work failure");
+    w->segF = plan_segments(F.fwd.lev_ptr); w->segB = plan_segments(F.bwd.lev_ptr);
+    w->small_solve = (w->segF.size() <= 1 && w->segB.size() <= 1 && (w->segF.empty() || !w->segF[0].wide) && (w->segB.empty() || !w->segB[0].wide) && F.N <= 65536);
+    const int one = 1; // the post-solve kernels are gated on cg_done: permanently set for the direct back-end
+    if (hipMemcpyAsync(&w->ctl.p->cg_done, &one, sizeof(int), hipMemcpyHostToDevice, w->stream) != hipSuccess) return fail("memcpy failure");
+  }
+  if (hipStreamSynchronize(w->stream) != hipSuccess) return fail("device set-up failed");
+  info->setup_time = now_ms() - t0;
+  if (d->stgs->verbose) printf("Setup time: %1.2es\n", info->setup_time / 1e3);
+  return w;
+}
+
+abip_int abip_hip_solve_begin(ABIPWork *w, const ABIPData *d, const ABIPSolution *sol, ABIPInfo *info) { // update_work, abip.c:1843-1927
+  if (!w || !d || !info || !d->b || !d->c) { printf("ERROR: ABIP_NULL input\n"); return ABIP_FAILED; }
+  ABIPSettings *st = w->stgs;
+  const abip_int m = w->m, n = w->n;
+  w->t_solve0 = now_ms(); w->cpu0 = (double)clock();
+  info->status_val = ABIP_UNFINISHED; w->status = 0;
+  w->r = Resid();
+  std::vector<double> hb(d->b, d->b + m), hc(d->c, d->c + n);
+  auto nrm = [](const std::vector<double> &v) { double s = 0; for (double x : v) s += x * x; return std::sqrt(s); };
+  w->nm_b = nrm(hb); w->nm_c = nrm(hc);
+  if (st->normalize) { // normalize_b_c, normalize.c:11-40
+    for (abip_int j = 0; j < n; ++j) hc[j] /= w->E[j];
+    w->sc_c = w->mean_norm_row_A / std::max(nrm(hc), 1e-3);
+    for (abip_int i = 0; i < m; ++i) hb[i] /= w->D[i];
+    w->sc_b = w->mean_norm_col_A / std::max(nrm(hb), 1e-3);
+    for (abip_int j = 0; j < n; ++j) hc[j] *= w->sc_c * st->scale;
+    for (abip_int i = 0; i < m; ++i) hb[i] *= w->sc_b * st->scale;
+  } else { w->sc_b = 1; w->sc_c = 1; }
+  const double mx = std::max(w->sp, st->sparsity_ratio), mn = std::min(w->sp, st->sparsity_ratio); // abip.c:1886-1900
+  if (mx > 0.4 || (mn > 0.1 && mn < 0.2)) { w->sigma = 0.3; w->gamma = 2.0; }
+  else if (mn > 0.2) { w->sigma = 0.5; w->gamma = 3.0; }
+  else { w->sigma = 0.8; w->gamma = 3.0; }
+  w->final_check = 0; w->double_check = 0; w->mu = 1.0; w->beta = 1.0;
+  HIP_OK(hipMemcpyAsync(w->b.p, hb.data(), sizeof(double) * m, hipMemcpyHostToDevice, w->stream));
+  HIP_OK(hipMemcpyAsync(w->c.p, hc.data(), sizeof(double) * n, hipMemcpyHostToDevice, w->stream));
+  if (st->normalize) { // weights of the un-scaled residual norms, abip.c:409,445
+    std::vector<double> wD(m), wE(n);
+    for (abip_int i = 0; i < m; ++i) wD[i] = w->D[i] / (w->sc_b * st->scale);
+    for (abip_int j = 0; j < n; ++j) wE[j] = w->E[j] / (w->sc_c * st->scale);
+    HIP_OK(hipMemcpyAsync(w->wD.p, wD.data(), sizeof(double) * m, hipMemcpyHostToDevice, w->stream));
+    HIP_OK(hipMemcpyAsync(w->wE.p, wE.data(), sizeof(double) * n, hipMemcpyHostToDevice, w->stream));
+    HIP_OK(hipStreamSynchronize(w->stream));
+  }
+  // start point
+  {
+    std::vector<double> uy(m, 0.0), ux(n), vy(m, 0.0), vx(n);
+    double ut = std::sqrt(w->mu / w->beta), vt = ut;
+    if (st->warm_start && sol && sol->x && sol->y && sol->s) { // warm_start_vars, abip.c:307-357 (quirk kept: the loop overwrites the guess)
+      for (abip_int i = 0; i < m; ++i) { const double y = sol->y[i]; uy[i] = (y != y) ? 0.0 : std::sqrt(w->mu / w->beta); vy[i] = std::sqrt(w->mu / w->beta); }
+      for (abip_int j = 0; j < n; ++j) { ux[j] = std::sqrt(w->mu / w->beta); const double s = sol->s[j]; vx[j] = (s != s) ? 0.0 : std::sqrt(w->mu / w->beta); }
+      ut = std::sqrt(w->mu / w->beta); vt = std::sqrt(w->mu / w->beta);
+      if (st->normalize) { // normalize_warm_start, normalize.c:101-128
+        for (abip_int j = 0; j < n; ++j) ux[j] *= (w->E[j] * w->sc_b);
+        for (abip_int i = 0; i < m; ++i) uy[i] *= (w->D[i] * w->sc_c);
+        for (abip_int j = 0; j < n; ++j) vx[j] /= (w->E[j] / (w->sc_c * st->scale));
+      }
+    } else { // cold_start_vars, abip.c:361-381
+      std::fill(ux.begin(), ux.end(), std::sqrt(w->mu / w->beta));
+      std::fill(vx.begin(), vx.end(), std::sqrt(w->mu / w->beta));
+    }
+    if (upload_lvec(w, w->u, uy.data(), ux.data(), ut) || upload_lvec(w, w->v, vy.data(), vx.data(), vt)) return ABIP_FAILED;
+  }
+  // h = (-b, c); g = K^-1 h with the x block negated; g_th = h'g   (abip.c:1917-1924)
+  {
+    std::vector<double> hy(m);
+    for (abip_int i = 0; i < m; ++i) hy[i] = -hb[i];
+    if (upload_lvec(w, w->h, hy.data(), hc.data(), 0.0) || upload_lvec(w, w->g, hy.data(), hc.data(), 0.0)) return ABIP_FAILED;
+    launch(w, ABIP_HIP_K_VEC, k_norm_y, w->NB, BS, (const double *)w->g.p, dims(w), w->part.p);
+    if (kkt_solve_sync(w, w->g.p, nullptr, -1) < 0) return ABIP_FAILED;
+    launch(w, ABIP_HIP_K_VEC, k_neg_x, w->NB, BS, w->g.p, dims(w));
+    launch(w, ABIP_HIP_K_VEC, k_dot_full, w->NB, BS, (const double *)w->h.p, (const double *)w->g.p, dims(w), (int)S_T0, w->part.p);
+    FinArgs f; f.nslots = 1; f.slots[0] = S_T0; f.u = w->u.p; f.v = w->v.p; f.ua = nullptr; f.va = nullptr;
+    launch(w, ABIP_HIP_K_VEC, k_finalize, 1, BS, f, dims(w), (const double *)w->part.p, w->NB, w->ctl.p);
+    if (sync_ctl(w)) return ABIP_FAILED;
+    w->g_th = w->hctl->out[S_T0];
+  }
+  w->i = 0; w->j = 0; w->k = 0; w->phase = PH_OUTER_BEGIN; w->wg_valid = false; w->stats_valid = false; w->have_solution = false;
+  w->tot_cg_its = 0; w->tot_solves = 0; w->last_cg_its = 6;
+  if (st->verbose) print_header(w);
+  return 0;
+}
+
+abip_int abip_hip_step(ABIPWork *w, abip_int max_admm_steps, abip_int *steps_done, ABIPInfo *info) { // the loops of abip.c:2102-2294
+  abip_int steps = 0;
+  if (steps_done) *steps_done = 0;
+  if (!w || !info || w->phase == PH_IDLE) return 1;
+  ABIPSettings *st = w->stgs;
+  const size_t lbytes = sizeof(double) * (size_t)w->LV;
+  auto done = [&](abip_int rc) { if (steps_done) *steps_done = steps; return rc; };
+  auto hard_fail = [&](const char *msg) { // failure(), abip.c:282-303
+    fail_fill(w, info, ABIP_FAILED, "Failure");
+    printf("Failure:%s\n", msg);
+    w->phase = PH_DONE;
+    return done(1);
+  };
+  for (;;) {
+    switch (w->phase) {
+      case PH_DONE: return done(1);
+      case PH_IDLE: return done(1);
+      case PH_OUTER_BEGIN: {
+        if (w->i >= st->max_ipm_iters) { info->status_val = w->status; w->phase = PH_DONE; return done(1); } // abip.c:2296
+        const double mn = std::min(w->sp, st->sparsity_ratio); // abip.c:2104-2115
+        if (mn > 0.5) w->inner_stopper = (int)std::round(std::pow(w->mu, -0.35));
+        else if (mn > 0.2) w->inner_stopper = (int)std::round(std::pow(w->mu, -1));
+        else w->inner_stopper = st->max_admm_iters;
+        w->fre_old = 0;
+        if (hipMemsetAsync(w->u_avg.p, 0, lbytes, w->stream) != hipSuccess || hipMemsetAsync(w->v_avg.p, 0, lbytes, w->stream) != hipSuccess ||
+            hipMemsetAsync(w->u_sum.p, 0, lbytes, w->stream) != hipSuccess || hipMemsetAsync(w->v_sum.p, 0, lbytes, w->stream) != hipSuccess)
+          return hard_fail("device memset");
+        if (st->avg_criterion) { // abip.c:2125-2129
+          if (hipMemcpyAsync(w->u.p, w->u_avgc.p, lbytes, hipMemcpyDeviceToDevice, w->stream) != hipSuccess ||
+              hipMemcpyAsync(w->v.p, w->v_avgc.p, lbytes, hipMemcpyDeviceToDevice, w->stream) != hipSuccess)
+            return hard_fail("device copy");
+          w->wg_valid = false;
+        }
+        w->j = 0;
+        w->phase = PH_INNER;
+        break;
+      }
+      case PH_INNER: {
+        if (w->j >= w->inner_stopper) { w->phase = PH_OUTER_END; break; }
+        if (steps >= max_admm_steps) return done(0);
+        double metric = 0;
+        if (admm_iteration(w, &metric)) return hard_fail("error in project_lin_sys");
+        ++steps;
+        w->k += 1;
+        if (metric < w->gamma * w->mu) { // abip.c:2173-2188
+          if (st->half_update) { launch(w, ABIP_HIP_K_VEC, k_clip_v, w->NB, BS, w->v.p, dims(w)); w->wg_valid = false; w->stats_valid = false; }
+          w->phase = PH_OUTER_END;
+          break;
+        }
+        if (w->final_check) { // abip.c:2190-2213
+          calc_residuals(w, w->i, w->k);
+          if ((info->status_val = has_converged(w, w->i, w->k)) != 0 || w->k + 1 >= st->max_admm_iters || w->i + 1 >= st->max_ipm_iters) {
+            if (st->verbose && w->k > 0) print_summary(w, w->i, w->k);
+            if (finish_solution(w, info, w->i, w->k)) return hard_fail("device error in get_solution");
+            if (st->verbose) print_footer(w, info);
+            w->phase = PH_DONE;
+            return done(1);
+          }
+        }
+        w->j += 1;
+        break;
+      }
+      case PH_OUTER_END: {
+        if (steps > 0 && steps >= max_admm_steps) return done(0); // hand back right after the last requested iteration
+        const double elapsed = ((double)clock() - w->cpu0) / CLOCKS_PER_SEC; // abip.c:2217-2221
+        if (elapsed > st->max_time) { printf("Timelimit reached. \n"); st->max_admm_iters = (abip_int)(w->k * 1.05); }
+        if (w->mu < st->eps) w->final_check = 1;
+        if (!w->stats_valid) { if (ensure_stats(w)) return hard_fail("device error in calc_residuals"); }
+        calc_residuals(w, w->i, w->k);
+        if (st->verbose) print_summary(w, w->i, w->k);
+        if ((info->status_val = has_converged(w, w->i, w->k)) != 0 || w->k + 1 >= st->max_admm_iters) {
+          if (finish_solution(w, info, w->i, w->k)) return hard_fail("device error in get_solution");
+          if (st->verbose) print_footer(w, info);
+          w->phase = PH_DONE;
+          return done(1);
+        }
+        w->status = info->status_val;
+        int rc = 0;
+        if (st->hybrid_mu) { // abip.c:2251-2277
+          if (st->dynamic_sigma_second > 0.0 && w->mu < st->hybrid_thresh * st->eps) { st->dynamic_sigma = st->dynamic_sigma_second; rc = update_barrier_dynamic(w); }
+          else if (st->dynamic_sigma_second == 0.0 && w->mu < st->hybrid_thresh * st->eps) { st->dynamic_sigma = st->dynamic_sigma_second; update_barrier(w); }
+          else if (st->dynamic_sigma < 0.0) update_barrier_dynamic_2(w);
+        } else {
+          if (st->dynamic_sigma == 0.0) update_barrier(w);
+          else if (st->dynamic_sigma < 0.0) update_barrier_dynamic_2(w);
+          else rc = update_barrier_dynamic(w);
+        }
+        if (rc) return hard_fail("invalid complementarity products in the LOQO barrier update");
+        reinitialize_vars(w, 0);
+        if (st->adaptive) { // abip.c:2281-2293
+          reinitialize_vars(w, 1);
+          w->beta = 1;
+          if (adaptive_search(w, w->k) < 0) return hard_fail("error in adaptive");
+          reinitialize_vars(w, 2);
+        }
+        w->i += 1;
+        w->phase = PH_OUTER_BEGIN;
+        break;
+      }
+    }
+  }
+}
+
+abip_int abip_hip_solve_end(ABIPWork *w, ABIPSolution *sol, ABIPInfo *info) {
+  if (!w || !sol || !info) return ABIP_FAILED;
+  if (!w->have_solution) { // called before termination: extract the current iterate the way get_solution would
+    ABIPInfo tmp = *info;
+    tmp.status_val = ABIP_UNFINISHED;
+    if (finish_solution(w, &tmp, w->i, w->k)) return ABIP_FAILED;
+    *info = tmp;
+    w->have_solution = false; // a later, real termination overwrites this snapshot
+  } else {
+    const double setup = info->setup_time;
+    *info = w->last_info;
+    info->setup_time = setup;
+  }
+  if (!sol->x) sol->x = (abip_float *)malloc(sizeof(abip_float) * w->n);
+  if (!sol->y) sol->y = (abip_float *)malloc(sizeof(abip_float) * w->m);
+  if (!sol->s) sol->s = (abip_float *)malloc(sizeof(abip_float) * w->n);
+  if (!sol->x || !sol->y || !sol->s) return ABIP_FAILED;
+  memcpy(sol->x, w->sol_x.data(), sizeof(double) * w->n);
+  memcpy(sol->y, w->sol_y.data(), sizeof(double) * w->m);
+  memcpy(sol->s, w->sol_s.data(), sizeof(double) * w->n);
+  return info->status_val;
+}
+
+abip_int abip_solve(ABIPWork *w, const ABIPData *d, ABIPSolution *sol, ABIPInfo *info) { // abip.c:2056-2297
+  if (!d || !sol || !info || !w || !d->b || !d->c) { printf("ERROR: ABIP_NULL input\n"); return ABIP_FAILED; }
+  const double setup = info->setup_time;
+  if (abip_hip_solve_begin(w, d, sol, info) != 0) {
+    fail_fill(w, info, ABIP_FAILED, "Failure");
+    printf("Failure:%s\n", "error in update_work");
+    abip_hip_solve_end(w, sol, info);
+    return ABIP_FAILED;
+  }
+  while (!abip_hip_step(w, 1L << 40, nullptr, info)) {}
+  if (w->have_solution) abip_hip_solve_end(w, sol, info);
+  info->setup_time = setup;
+  return info->status_val;
+}
+
+void abip_finish(ABIPWork *w) { // abip.c:2301-2337
+  if (!w) return;
+  if (w->stgs && w->stgs->normalize && w->A) host::un_normalize_A(w->A, w->stgs, w->D, w->E);
+  free_work(w);
+}
+
+abip_int abip_main(const ABIPData *d, ABIPSolution *sol, ABIPInfo *info) { // abip.c:2393-2422
+  abip_int status;
+  ABIPWork *w = abip_init(d, info);
+  if (w) { abip_solve(w, d, sol, info); status = info->status_val; }
+  else {
+    status = ABIP_FAILED;
+    if (info) {
+      info->res_pri = NAN; info->res_dual = NAN; info->rel_gap = NAN; info->res_infeas = NAN; info->res_unbdd = NAN; info->pobj = NAN; info->dobj = NAN;
+      info->ipm_iter = -1; info->admm_iter = -1; info->status_val = status; info->solve_time = NAN; strcpy(info->status, "Failure");
+    }
+    if (sol && d) { // populate_on_failure, abip.c:249-274
+      if (d->n > 0) { if (!sol->x) sol->x = (abip_float *)malloc(sizeof(abip_float) * d->n); if (!sol->s) sol->s = (abip_float *)malloc(sizeof(abip_float) * d->n);
+        for (abip_int j = 0; j < d->n; ++j) { sol->x[j] = NAN; sol->s[j] = NAN; } }
+      if (d->m > 0) { if (!sol->y) sol->y = (abip_float *)malloc(sizeof(abip_float) * d->m); for (abip_int i = 0; i < d->m; ++i) sol->y[i] = NAN; }
+    }
+    printf("Failure:%s\n", "could not initialize work");
+  }
+  abip_finish(w);
+  return status;
+}
+
+// ---- unit-level device access --------------------------------------------------------------------
+abip_int abip_hip_accum_by_A(ABIPWork *w, const abip_float *x, abip_float *y) {
+  if (!w || !x || !y) return -1;
+  DBuf<double> dx, dy;
+  if (dx.alloc(w->n) || dy.alloc(w->m)) return -1;
+  HIP_OK(hipMemcpyAsync(dx.p, x, sizeof(double) * w->n, hipMemcpyHostToDevice, w->stream));
+  HIP_OK(hipMemcpyAsync(dy.p, y, sizeof(double) * w->m, hipMemcpyHostToDevice, w->stream));
+  launch(w, ABIP_HIP_K_SPMV_A, k_spmv_acc, w->NB, BS, w->dA.view(), (const double *)dx.p, dy.p);
+  HIP_OK(hipMemcpyAsync(y, dy.p, sizeof(double) * w->m, hipMemcpyDeviceToHost, w->stream));
+  HIP_OK(hipStreamSynchronize(w->stream));
+  harvest_events(w);
+  dx.release(); dy.release();
+  return 0;
+}
+abip_int abip_hip_accum_by_Atrans(ABIPWork *w, const abip_float *x, abip_float *y) {
+  if (!w || !x || !y) return -1;
+  DBuf<double> dx, dy;
+  if (dx.alloc(w->m) || dy.alloc(w->n)) return -1;
+  HIP_OK(hipMemcpyAsync(dx.p, x, sizeof(double) * w->m, hipMemcpyHostToDevice, w->stream));
+  HIP_OK(hipMemcpyAsync(dy.p, y, sizeof(double) * w->n, hipMemcpyHostToDevice, w->stream));
+  launch(w, ABIP_HIP_K_SPMV_AT, k_spmv_acc, w->NB, BS, w->dAt.view(), (const double *)dx.p, dy.p);
+  HIP_OK(hipMemcpyAsync(y, dy.p, sizeof(double) * w->n, hipMemcpyDeviceToHost, w->stream));
+  HIP_OK(hipStreamSynchronize(w->stream));
+  harvest_events(w);
+  dx.release(); dy.release();
+  return 0;
+}
+abip_int abip_hip_kkt_solve(ABIPWork *w, abip_float *rhs, const abip_float *warm, abip_int iter) {
+  if (!w || !rhs) return -1;
+  // a_ut holds the rhs, a_u the warm start (scratch vectors of the BB search; not live outside it)
+  if (upload_lvec(w, w->a_ut, rhs, rhs + w->m, 0.0)) return -1;
+  if (warm && upload_lvec(w, w->a_u, warm, nullptr, 0.0)) return -1;
+  launch(w, ABIP_HIP_K_VEC, k_norm_y, w->NB, BS, (const double *)w->a_ut.p, dims(w), w->part.p);
+  const int its = kkt_solve_sync(w, w->a_ut.p, warm ? w->a_u.p : nullptr, iter);
+  if (its < 0) return -1;
+  std::vector<double> hbuf(w->LV);
+  HIP_OK(hipMemcpyAsync(hbuf.data(), w->a_ut.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream));
+  HIP_OK(hipStreamSynchronize(w->stream));
+  std::copy(hbuf.begin(), hbuf.begin() + w->m, rhs);
+  std::copy(hbuf.begin() + w->MP, hbuf.begin() + w->MP + w->n, rhs + w->m);
+  return its;
+}
+abip_int abip_hip_get_vector(ABIPWork *w, const char *name, abip_float *out, abip_int cap) {
+  if (!w || !name || !out) return -1;
+  const abip_int m = w->m, n = w->n, l = m + n + 1;
+  struct { const char *nm; DBuf<double> *b; } lv[] = {{"u", &w->u}, {"v", &w->v}, {"u_t", &w->ut}, {"h", &w->h}, {"g", &w->g},
+                                                      {"u_avgcon", &w->u_avgc}, {"v_avgcon", &w->v_avgc}};
+  for (auto &e : lv)
+    if (!strcmp(name, e.nm)) {
+      const bool full = strcmp(name, "h") && strcmp(name, "g");
+      const abip_int len = full ? l : l - 1;
+      if (cap < len) return -1;
+      std::vector<double> hbuf(w->LV);
+      HIP_OK(hipMemcpyAsync(hbuf.data(), e.b->p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream));
+      HIP_OK(hipStreamSynchronize(w->stream));
+      std::copy(hbuf.begin(), hbuf.begin() + m, out);
+      std::copy(hbuf.begin() + w->MP, hbuf.begin() + w->MP + n + (full ? 1 : 0), out + m);
+      return len;
+    }
+  struct { const char *nm; const double *p; abip_int len; } sv[] = {{"b", w->b.p, m}, {"c", w->c.p, n}, {"Ax", w->dAt.val.p, (abip_int)w->dAt.val.n}};
+  for (auto &e : sv)
+    if (!strcmp(name, e.nm)) {
+      if (cap < e.len) return -1;
+      HIP_OK(hipMemcpyAsync(out, e.p, sizeof(double) * e.len, hipMemcpyDeviceToHost, w->stream));
+      HIP_OK(hipStreamSynchronize(w->stream));
+      return e.len;
+    }
+  if (!strcmp(name, "D")) { if (cap < m || w->D.empty()) return -1; std::copy(w->D.begin(), w->D.end(), out); return m; }
+  if (!strcmp(name, "E")) { if (cap < n || w->E.empty()) return -1; std::copy(w->E.begin(), w->E.end(), out); return n; }
+  return -1;
+}
+abip_float abip_hip_get_scalar(ABIPWork *w, const char *name) {
+  if (!w || !name) return NAN;
+#define RET(nm, val) if (!strcmp(name, nm)) return (abip_float)(val);
+  RET("mu", w->mu) RET("beta", w->beta) RET("sigma", w->sigma) RET("gamma", w->gamma) RET("g_th", w->g_th)
+  RET("sc_b", w->sc_b) RET("sc_c", w->sc_c) RET("nm_b", w->nm_b) RET("nm_c", w->nm_c) RET("tot_cg_its", w->tot_cg_its)
+  RET("lnnz", w->lnnz) RET("levels_fwd", w->triF.nlev) RET("levels_bwd", w->triB.nlev) RET("admm_iter", w->k) RET("ipm_iter", w->i)
+  RET("nb", w->NB) RET("small_solve", w->small_solve ? 1 : 0)
+#undef RET
+  return NAN;
+}
+
+void abip_hip_profile_enable(ABIPWork *w, unsigned mask) { if (w) w->prof_mask = mask; }
+void abip_hip_profile_read(ABIPWork *w, AbipHipProfile *out, int reset) {
+  if (!w || !out) return;
+  *out = w->prof;
+  if (reset) w->prof = AbipHipProfile{};
+}
+void abip_hip_sync(ABIPWork *w) { if (w && w->stream) { (void)hipStreamSynchronize(w->stream); harvest_events(w); } }
+
+} // extern "C"

@@ -1,0 +1,81 @@
+/*
+ * abip_hip.h -- device-level C ABI of libabip_hip.so (handle-based, host pointers only).
+ *
+ * abip.h carries the reference's own entry points (abip_init / abip_solve / ...).
+ * This header adds what the reference does not have because its loop never leaves
+ * one CPU thread: a stepping interface over the SAME solver state machine
+ * (src/abip-lp/src/abip.c:2056-2297), unit-level access to the device kernels of
+ * the hot path for parity tests, and timing hooks for bench.py.  Callers: the
+ * library's own abip_solve(), tests/, bench.py.  No torch / HIP types appear.
+ *
+ * Reference site each entry point stands for:
+ *   abip_hip_solve_begin .. update_work, abip.c:1843-1927 (+ the loop prologue 2084-2100)
+ *   abip_hip_step ......... inner/outer loop body, abip.c:2102-2294
+ *   abip_hip_solve_end .... get_solution / get_info, abip.c:1296-1414
+ *   abip_hip_accum_by_A / _Atrans .. linsys/common.c:598-695 (y += A x, y += A' x)
+ *   abip_hip_kkt_solve .... ABIP(solve_lin_sys), linsys/direct.c:305-328, linsys/indirect.c:393-434
+ *   abip_hip_get_vector ... read-only view of ABIPWork's vectors, include/abip.h:126-176
+ */
+#ifndef ABIP_HIP_DEVICE_H
+#define ABIP_HIP_DEVICE_H
+
+#include "abip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 0 when a usable gfx950 device is present, else a negative code; fills name (<=127 chars). */
+int abip_hip_device_info(char *name, int name_len, long *total_mem_bytes, int *num_cu);
+
+/* --- stepping (abip_solve == begin; while (!step) ; end) ------------------- */
+/* Scale b, c, build h, g = K^{-1} h, cold/warm start.  0 on success. */
+abip_int abip_hip_solve_begin(ABIPWork *w, const ABIPData *d, const ABIPSolution *sol, ABIPInfo *info);
+/* Advance by at most max_admm_steps inner ADMM iterations (outer-iteration work that
+ * falls between them -- residuals, mu update, BB search -- is executed as it comes).
+ * Returns 0 while the solve is unfinished, 1 once it has terminated (info->status_val
+ * then holds the reference's status).  *steps_done (may be NULL) = iterations executed. */
+abip_int abip_hip_step(ABIPWork *w, abip_int max_admm_steps, abip_int *steps_done, ABIPInfo *info);
+/* Extract (x, y, s) and info exactly as get_solution does; callable at any time. */
+abip_int abip_hip_solve_end(ABIPWork *w, ABIPSolution *sol, ABIPInfo *info);
+
+/* --- unit-level kernels (host vectors in, host vectors out) ---------------- */
+/* y (m) += A x (n)  /  y (n) += A' x (m), on the SCALED matrix held by w. */
+abip_int abip_hip_accum_by_A(ABIPWork *w, const abip_float *x, abip_float *y);
+abip_int abip_hip_accum_by_Atrans(ABIPWork *w, const abip_float *x, abip_float *y);
+/* rhs (m+n) <- K^{-1} rhs with K = [[rho_y I, A],[A', -I]]; warm (m) may be NULL; iter as in
+ * solve_lin_sys (-1 = setup accuracy).  Returns CG iterations used (0 for the direct back-end), <0 on error. */
+abip_int abip_hip_kkt_solve(ABIPWork *w, abip_float *rhs, const abip_float *warm, abip_int iter);
+/* Copy a device vector to out.  name: "u","v","u_t","h","g","b","c","D","E","Ax" (scaled CSC values),
+ * "u_avgcon","v_avgcon".  Layout of the l-vectors is the reference's [y(m) | x(n) | tau].  Returns length or -1. */
+abip_int abip_hip_get_vector(ABIPWork *w, const char *name, abip_float *out, abip_int cap);
+/* Scalars: "mu","beta","sigma","gamma","g_th","sc_b","sc_c","nm_b","nm_c","tot_cg_its","lnnz","levels_fwd","levels_bwd","admm_iter","ipm_iter". */
+abip_float abip_hip_get_scalar(ABIPWork *w, const char *name);
+
+/* --- measurement ------------------------------------------------------------ */
+/* Kernel classes timed with hipEvents on the solver's own stream. */
+#define ABIP_HIP_K_SPMV_AT 0   /* tmp = A' p   (CSC gather, n rows)  -- PCG inner product 1 */
+#define ABIP_HIP_K_SPMV_A 1    /* Gp = A tmp + rho p (CSR gather, m rows) -- PCG inner product 2 */
+#define ABIP_HIP_K_CG_VEC 2    /* x,r,z update + 2 reductions */
+#define ABIP_HIP_K_SPTRSV 3    /* permuted L / D / L' solve (direct back-end) */
+#define ABIP_HIP_K_VEC 4       /* fused rhs / barrier prox / dual / averages passes */
+#define ABIP_HIP_K_QNORM 5     /* residual SpMV pair + reductions */
+#define ABIP_HIP_K_CLASSES 6
+typedef struct {
+  double ms[ABIP_HIP_K_CLASSES];     /* summed device time per class, milliseconds */
+  long launches[ABIP_HIP_K_CLASSES]; /* launches per class */
+  long admm_iters;                   /* inner iterations covered */
+  long cg_iters;                     /* CG iterations covered */
+  long kkt_solves;                   /* linear solves covered */
+} AbipHipProfile;
+/* mask = bitmask of classes to bracket with events (0 disables).  Timing a class adds two event
+ * records per launch of that class only. */
+void abip_hip_profile_enable(ABIPWork *w, unsigned mask);
+void abip_hip_profile_read(ABIPWork *w, AbipHipProfile *out, int reset);
+/* Block until everything queued on the solver's stream has finished. */
+void abip_hip_sync(ABIPWork *w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABIP_HIP_DEVICE_H */
