@@ -50,12 +50,12 @@ class ABIPInfo(C.Structure):  # src/abip-lp/include/abip.h:88-105
                 ("res_infeas", c_flt), ("res_unbdd", c_flt), ("setup_time", c_flt), ("solve_time", c_flt)]
 
 
-K_CLASSES = ("spmv_At", "spmv_A", "cg_vec", "sptrsv", "vec", "qnorm")  # include/abip_hip.h ABIP_HIP_K_*
+K_CLASSES = ("spmv_At", "spmv_A", "cg_vec", "sptrsv", "vec", "qnorm", "cg_edge")  # include/abip_hip.h ABIP_HIP_K_*
 
 
 class AbipHipProfile(C.Structure):
-    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_long * 6), ("admm_iters", C.c_long), ("cg_iters", C.c_long),
-                ("kkt_solves", C.c_long)]
+    _fields_ = [("ms", C.c_double * 7), ("launches", C.c_long * 7), ("noop_ms", C.c_double), ("noop_launches", C.c_long),
+                ("admm_iters", C.c_long), ("cg_iters", C.c_long), ("kkt_solves", C.c_long)]
 
 
 # every symbol include/abip.h and include/abip_hip.h declare

@@ -148,6 +148,7 @@ struct ABIP_WORK {
   double t_solve0 = 0, cpu0 = 0;
   bool stats_valid = false, avg_stats_valid = false; // ctl.out holds the sums of the current (averaged) iterate
   int last_cg_its = 6;
+  int cg_enq = 0; // CG iterations enqueued so far for the solve in flight
   long tot_cg_its = 0, tot_solves = 0;
   // solution staged on the host by finish_solution()
   std::vector<double> sol_x, sol_y, sol_s;
@@ -155,7 +156,8 @@ struct ABIP_WORK {
   bool have_solution = false;
   // ---- profiling -----------------------------------------------------------------------------
   unsigned prof_mask = 0;
-  struct Ev { hipEvent_t a, b; int cls; };
+  struct Ev { hipEvent_t a, b; int cls; int tag; };
+  int ev_tag = -1; // CG iteration index of the launches being enqueued (-1: always effective)
   std::vector<Ev> ev_pool; size_t ev_used = 0;
   AbipHipProfile prof{};
   std::vector<double> scratch; // host scratch (LV)
@@ -179,18 +181,21 @@ inline void launch(W *w, int cls, K kern, int grid, int block, Args... args) {
       w->ev_pool.push_back(e);
     }
     ev = &w->ev_pool[w->ev_used++];
-    ev->cls = cls;
+    ev->cls = cls; ev->tag = w->ev_tag;
     (void)hipEventRecord(ev->a, w->stream);
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, w->stream, args...);
   if (timed) (void)hipEventRecord(ev->b, w->stream);
-  w->prof.launches[cls]++;
 }
 
 void harvest_events(W *w) { // call only after the stream has been synchronised
   for (size_t q = 0; q < w->ev_used; ++q) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, w->ev_pool[q].a, w->ev_pool[q].b) == hipSuccess) w->prof.ms[w->ev_pool[q].cls] += ms;
+    if (hipEventElapsedTime(&ms, w->ev_pool[q].a, w->ev_pool[q].b) != hipSuccess) continue;
+    const W::Ev &e = w->ev_pool[q];
+    // a PCG launch tagged with iteration index t did work iff t < (iterations the device actually ran)
+    if (e.tag >= 0 && e.tag >= w->hctl->cg_it) { w->prof.noop_ms += ms; w->prof.noop_launches++; }
+    else { w->prof.ms[e.cls] += ms; w->prof.launches[e.cls]++; }
   }
   w->ev_used = 0;
 }
@@ -214,13 +219,15 @@ double cg_tol_factor(const W *w, abip_int iter) { // indirect.c:406-407
 
 void enqueue_cg_begin(W *w, double *rhs, const double *warm, abip_int iter) {
   const Dims d = dims(w);
-  if (warm) launch(w, ABIP_HIP_K_SPMV_AT, k_cg_init_At, w->NB, BS, w->dAt.view(), warm, w->cg_tmp.p, (const Ctl *)w->ctl.p);
-  launch(w, ABIP_HIP_K_SPMV_A, k_cg_init_A, w->NB, BS, w->dA.view(), rhs, (const double *)w->cg_tmp.p, warm, (const double *)w->cg_M.p,
+  w->cg_enq = 0;
+  if (warm) launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_At, w->NB, BS, w->dAt.view(), warm, w->cg_tmp.p, (const Ctl *)w->ctl.p);
+  launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_A, w->NB, BS, w->dA.view(), rhs, (const double *)w->cg_tmp.p, warm, (const double *)w->cg_M.p,
          w->cg_r.p, w->cg_z.p, w->cg_p.p, w->stgs->rho_y, cg_tol_factor(w, iter), d, w->part.p, w->NB, w->ctl.p);
 }
 void enqueue_cg_chunk(W *w, double *rhs, int its) {
   const int max_its = (int)w->m; // indirect.c:418
   for (int q = 0; q < its; ++q) {
+    w->ev_tag = w->cg_enq++;
     launch(w, ABIP_HIP_K_SPMV_AT, k_cg_spmv_At, w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, (const double *)w->cg_p.p, w->cg_tmp.p,
            max_its, w->part.p, w->NB, w->ctl.p);
     launch(w, ABIP_HIP_K_SPMV_A, k_cg_spmv_A, w->NB, BS, w->dA.view(), (const double *)w->cg_tmp.p, (const double *)w->cg_z.p, w->cg_p.p,
@@ -228,9 +235,10 @@ void enqueue_cg_chunk(W *w, double *rhs, int its) {
     launch(w, ABIP_HIP_K_CG_VEC, k_cg_update, w->NB, BS, rhs, w->cg_r.p, w->cg_z.p, (const double *)w->cg_p.p, (const double *)w->cg_Gp.p,
            (const double *)w->cg_M.p, (int)w->m, w->part.p, w->NB, w->ctl.p);
   }
+  w->ev_tag = -1;
 }
 void enqueue_cg_post(W *w, double *rhs) {
-  launch(w, ABIP_HIP_K_SPMV_AT, k_post_At, w->NB, BS, w->dAt.view(), rhs, (const double *)w->h.p, dims(w), (int)w->m, w->part.p, w->NB, w->ctl.p);
+  launch(w, ABIP_HIP_K_CG_EDGE, k_post_At, w->NB, BS, w->dAt.view(), rhs, (const double *)w->h.p, dims(w), (int)w->m, w->part.p, w->NB, w->ctl.p);
 }
 void enqueue_direct(W *w, double *rhs) {
   const int N = (int)(w->m + w->n);

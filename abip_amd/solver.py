@@ -154,6 +154,7 @@ class Solver:
         self.L.abip_hip_profile_read(self.w, C.byref(p), 1 if reset else 0)
         return dict(ms={k: p.ms[i] for i, k in enumerate(K_CLASSES)},
                     launches={k: p.launches[i] for i, k in enumerate(K_CLASSES)},
+                    noop_ms=p.noop_ms, noop_launches=p.noop_launches,
                     admm_iters=p.admm_iters, cg_iters=p.cg_iters, kkt_solves=p.kkt_solves)
 
     def close(self) -> None:

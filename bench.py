@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- ADMM iterations/s of the MI355X-native ABIP-LP hot path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W [--workload c4|c2|c3] [--to-tol]
+
+One "step" = one inner ADMM iteration of the real solver trajectory (KKT solve incl. all its PCG
+iterations, barrier prox, dual update, averages, stopping test; outer-iteration work -- residuals,
+mu update, Barzilai-Borwein search -- runs when the trajectory reaches it and is inside the timed region).
+The problem is resident in HBM before the timed region starts (abip_init + abip_hip_solve_begin).
+
+Workloads (BASELINE.json configs; no Netlib/Mittelmann files exist offline, so C2/C3 are seeded
+structure-matched surrogates, labelled as such):
+    c4  synthetic random sparse LP m=200k n=500k nnz~5M, PCG back-end        (default: the roofline config
+        and the only LP config that partitions over GPUs)
+    c2  25fv47-class block-staircase LP (816 x 1879, nnz~1e4), direct LDL' back-end
+    c3  pds-class multi-commodity network LP, PCG back-end
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+
+def make_workload(name: str):
+    from abip_amd import problems
+    if name == "c4":
+        A, b, c = problems.lp_random_sparse(m=200_000, n=500_000, per_col=16)
+        return A, b, c, "indirect", "synthetic random sparse LP m=200000 n=500000 nnz~5.0e6 (BASELINE configs[3]), PCG"
+    if name == "c2":
+        A, b, c = problems.lp_staircase()
+        return A, b, c, "direct", "synth-25fv47-like block-staircase LP 816x1879 nnz~1.0e4 (BASELINE configs[1] surrogate), direct LDL'"
+    if name == "c3":
+        A, b, c = problems.lp_multicommodity(nodes=1200, arcs=4400, commodities=10)
+        return A, b, c, "indirect", "synth-pds-like multi-commodity network LP (BASELINE configs[2] surrogate), PCG"
+    raise SystemExit(f"unknown workload {name}")
+
+
+def b_spmv(R, C, nnz):
+    """Algorithmic bytes of one CSR SpMV: values+indices, row pointers, x read, y read-modify-write."""
+    return 12 * nnz + 4 * (R + 1) + 8 * C + 16 * R
+
+
+def cpu_baseline(A, b, c, linsys, budget_s=20.0):
+    """The reference itself (oracle/_ref, kind 'reference') or our C restatement (kind 'port'), one host thread,
+    on a bounded prefix of the same trajectory."""
+    from oracle import pyoracle as po
+    kind = "reference" if po.have_ref() else "port"
+    which = "ref" if kind == "reference" else "oracle"
+    # probe with a few iterations, then size the sample to the budget
+    T = 4
+    t0 = time.time()
+    r = po.solve(which, A, b, c, linsys=linsys, eps=1e-6, max_admm_iters=T)
+    probe = max(r.info["solve_time"] / 1e3, 1e-6)
+    per_it = probe / max(r.info["admm_iter"], 1)
+    T2 = int(min(max(budget_s / per_it, 8), 20000))
+    if T2 > 2 * T and (time.time() - t0) < budget_s:
+        r = po.solve(which, A, b, c, linsys=linsys, eps=1e-6, max_admm_iters=T2)
+    secs = r.info["solve_time"] / 1e3
+    its = r.info["admm_iter"]
+    return dict(value=its / secs, unit="ADMM iterations/s", cores=1, kind=kind,
+                sample=f"first {its} ADMM iterations of the same LP and settings (max_admm_iters={max(T, T2)}), {secs:.2f} s, single thread, gcc -O2")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3"])
+    ap.add_argument("--to-tol", action="store_true", help="also run a full solve to eps=1e-6 and report wall-clock")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libabip_hip has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    steps = args.steps if args.steps is not None else {"c4": 200, "c2": 2000, "c3": 500}[args.workload]
+    warmup = args.warmup if args.warmup is not None else {"c4": 20, "c2": 200, "c3": 50}[args.workload]
+
+    from abip_amd import Solver
+    A, b, c, linsys, desc = make_workload(args.workload)
+    m, n = A.shape
+    nnz = A.nnz
+
+    S = Solver(A, b, c, linsys=linsys, eps=1e-6, verbose=0)
+    S.begin()
+    fin, done_w = S.step(warmup)
+    S.sync()
+    dom = ("spmv_At", "spmv_A") if linsys == "indirect" else ("sptrsv",)
+    S.profile_enable(dom)
+    S.profile_read(reset=True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    fin, done = S.step(steps)
+    S.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = S.profile_read(reset=True)
+    S.profile_enable(())
+    if done != steps:
+        # the solve terminated inside the timed window: the number is still exact for `done` steps
+        steps_eff = done
+    else:
+        steps_eff = steps
+    # N > 1: independent replicas of the same LP (row-block sharding of the PCG path is the next milestone)
+    value = world * steps_eff / elapsed
+
+    roof = None
+    if linsys == "indirect":
+        cand = {"spmv_At": (b_spmv(n, m, nnz), "k_cg_spmv_At (tmp = A'(z + beta p), CSC gather over n rows)"),
+                "spmv_A": (b_spmv(m, n, nnz), "k_cg_spmv_A (Gp = A tmp + rho p, CSR gather over m rows)")}
+        name = max(cand, key=lambda k: prof["ms"][k])
+        nl = max(prof["launches"][name], 1)
+        avg_ms = prof["ms"][name] / nl
+        ach = cand[name][0] / (avg_ms * 1e-3) / 1e9
+        roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+                    kernel=cand[name][1], avg_launch_us=avg_ms * 1e3, launches=nl, algorithmic_bytes_per_launch=cand[name][0])
+    else:
+        lnnz = int(S.scalar("lnnz")); N = m + n
+        bytes_solve = 2 * (12 * lnnz + 4 * (N + 1) + 16 * N) + 24 * N + 2 * 20 * N   # SURVEY.md 8(d) B_solve_direct
+        nl = max(prof["launches"]["sptrsv"], 1)
+        avg_ms = prof["ms"]["sptrsv"] / nl
+        ach = bytes_solve / (avg_ms * 1e-3) / 1e9
+        roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+                    kernel="k_ldl_solve_small (perm, L, D, L', perm' in one workgroup)", avg_launch_us=avg_ms * 1e3, launches=nl,
+                    algorithmic_bytes_per_launch=bytes_solve, lnnz=lnnz)
+
+    extra = dict(cg_iters_per_step=prof["cg_iters"] / max(prof["admm_iters"], 1), noop_launches=prof["noop_launches"],
+                 m=m, n=n, nnz=int(nnz))
+    if linsys == "indirect":
+        cg = extra["cg_iters_per_step"]
+        l = m + n + 1
+        b_cg = b_spmv(n, m, nnz) + b_spmv(m, n, nnz) + 8 * (21 * m + n)
+        b_vec = 8 * (37 * l + 8 * m + 19 * n)
+        b_iter = cg * b_cg + 4 * b_spmv(m, n, nnz) + b_vec            # SURVEY.md 8(d) "Indirect"
+        extra["effective_GBs_whole_iteration"] = b_iter * (steps_eff / elapsed) / 1e9
+    S.close()
+
+    tt = None
+    if args.to_tol and rank == 0:
+        S2 = Solver(A, b, c, linsys=linsys, eps=1e-6, verbose=0)
+        t1 = time.perf_counter()
+        info = S2.solve()
+        tt = dict(seconds=time.perf_counter() - t1, setup_s=info["setup_time"] / 1e3, solve_s=info["solve_time"] / 1e3,
+                  status=info["status"], admm_iter=info["admm_iter"], ipm_iter=info["ipm_iter"],
+                  res_pri=info["res_pri"], res_dual=info["res_dual"], rel_gap=info["rel_gap"])
+        S2.close()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(A, b, c, linsys)
+
+    if rank == 0:
+        out = {
+            "metric": "ADMM iterations/s", "value": value, "unit": "ADMM iterations/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * elapsed / max(steps_eff, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "linsys": linsys, "eps": 1e-6,
+                       "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (replicas only)"},
+            "roofline": roof, "cpu_baseline": cpu, "time_to_tol": tt, "extra": extra,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

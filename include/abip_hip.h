@@ -54,16 +54,19 @@ abip_float abip_hip_get_scalar(ABIPWork *w, const char *name);
 
 /* --- measurement ------------------------------------------------------------ */
 /* Kernel classes timed with hipEvents on the solver's own stream. */
-#define ABIP_HIP_K_SPMV_AT 0   /* tmp = A' p   (CSC gather, n rows)  -- PCG inner product 1 */
-#define ABIP_HIP_K_SPMV_A 1    /* Gp = A tmp + rho p (CSR gather, m rows) -- PCG inner product 2 */
-#define ABIP_HIP_K_CG_VEC 2    /* x,r,z update + 2 reductions */
+#define ABIP_HIP_K_SPMV_AT 0   /* k_cg_spmv_At: tmp = A'(z + beta p)  (CSC gather, n rows) -- PCG SpMV 1 */
+#define ABIP_HIP_K_SPMV_A 1    /* k_cg_spmv_A : Gp = A tmp + rho p    (CSR gather, m rows) -- PCG SpMV 2 */
+#define ABIP_HIP_K_CG_VEC 2    /* k_cg_update : x,r,z update + 2 reductions */
 #define ABIP_HIP_K_SPTRSV 3    /* permuted L / D / L' solve (direct back-end) */
-#define ABIP_HIP_K_VEC 4       /* fused rhs / barrier prox / dual / averages passes */
+#define ABIP_HIP_K_VEC 4       /* fused rhs / barrier prox / dual / averages passes, finalize */
 #define ABIP_HIP_K_QNORM 5     /* residual SpMV pair + reductions */
-#define ABIP_HIP_K_CLASSES 6
+#define ABIP_HIP_K_CG_EDGE 6   /* PCG set-up and back-substitution SpMVs (k_cg_init_At/_A, k_post_At) */
+#define ABIP_HIP_K_CLASSES 7
 typedef struct {
-  double ms[ABIP_HIP_K_CLASSES];     /* summed device time per class, milliseconds */
-  long launches[ABIP_HIP_K_CLASSES]; /* launches per class */
+  double ms[ABIP_HIP_K_CLASSES];     /* summed device time per class, milliseconds (launches that did work) */
+  long launches[ABIP_HIP_K_CLASSES]; /* launches per class that did work */
+  double noop_ms;                    /* time of PCG launches enqueued past convergence (they return at their gate) */
+  long noop_launches;
   long admm_iters;                   /* inner iterations covered */
   long cg_iters;                     /* CG iterations covered */
   long kkt_solves;                   /* linear solves covered */

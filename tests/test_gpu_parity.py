@@ -1,0 +1,214 @@
+"""GPU (-m gpu): the HIP path through the C ABI against (i) the committed outputs of the real reference
+(tests/golden), (ii) the CPU oracle on the same seeded inputs, (iii) size-independent properties at the full
+BASELINE size.
+
+Tolerances (fp64 everywhere; the device sums in a different order than the CPU):
+  * SpMV / KKT-solve unit checks: 1e-13 relative (direct), CG tolerance for the PCG back-end;
+  * per-iteration iterates vs the oracle: 1e-9 relative;
+  * final (x, y, s): max(1e-6, eps/10) relative when the run makes the same number of iterations as the reference
+    (1e-6 at the eps=1e-6 the north star names), else 50*eps (one flipped stopping decision moves the exit point by a
+    few iterations; both answers then agree to the accuracy that was asked for)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from _golden import TINY_VARIANTS, info_of, load, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    import __graft_entry__ as g
+    g.build()
+    import abip_amd
+    return abip_amd
+
+
+def kkt_matrix(Asc, rho):
+    m, n = Asc.shape
+    return sp.bmat([[rho * sp.identity(m), Asc], [Asc.T, -sp.identity(n)]], format="csc")
+
+
+# ---------------------------------------------------------------------------------------------- unit kernels
+@pytest.mark.parametrize("name", ["lp_afiro_like", "lp_staircase", "lp_multicommodity_small"])
+@pytest.mark.parametrize("linsys", ["indirect", "direct"])
+def test_spmv_and_kkt_solve(gpu, name, linsys):
+    z, A, b, c = load(name)
+    rng = np.random.default_rng(1)
+    with gpu.Solver(A, b, c, linsys=linsys, verbose=0) as S:
+        Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
+        x, y = rng.standard_normal(S.n), rng.standard_normal(S.m)
+        assert rel(S.accum_by_A(x, y), y + Asc @ x) < 1e-14
+        assert rel(S.accum_by_Atrans(y, x), x + Asc.T @ y) < 1e-14
+        K = kkt_matrix(Asc, 1e-3)
+        rhs = rng.standard_normal(S.m + S.n)
+        sol, its = S.kkt_solve(rhs, None, -1)
+        if linsys == "direct":
+            assert its == 0 and rel(K @ sol, rhs) < 1e-11
+        else:
+            assert its > 0 and rel(K @ sol, rhs) < 1e-6          # cg_tol = 1e-9*||b_y|| floored at 1e-7 (indirect.c:406-409)
+            sol2, its2 = S.kkt_solve(rhs, sol[: S.m], -1)         # warm start at the solution: nothing left to do
+            assert its2 <= 2
+
+
+def test_spmv_long_rows_and_ragged_blocks(gpu):
+    """Rows longer than one LDS chunk (1024 non-zeros), empty rows of A' (empty columns are rejected upstream only with a
+    warning) and 1-entry rows exercise every branch of the CSR-stream kernel."""
+    rng = np.random.default_rng(3)
+    m, n = 40, 6000
+    dense_rows = sp.random(3, n, density=0.6, random_state=rng, format="csr")          # ~3600 nnz per row
+    rest = sp.random(m - 3, n, density=0.002, random_state=rng, format="csr")
+    A = sp.vstack([dense_rows, rest]).tocsc()
+    A = sp.hstack([A, sp.identity(m, format="csc")], format="csc")
+    b = A @ rng.random(A.shape[1]); c = rng.random(A.shape[1]) + 0.1
+    with gpu.Solver(A, b, c, linsys="indirect", verbose=0) as S:
+        Asc = sp.csc_matrix((S.vector("Ax"), sp.csc_matrix(A).indices, sp.csc_matrix(A).indptr), shape=A.shape)
+        x, y = rng.standard_normal(S.n), rng.standard_normal(S.m)
+        assert rel(S.accum_by_A(x, np.zeros(S.m)), Asc @ x) < 1e-13
+        assert rel(S.accum_by_Atrans(y, np.zeros(S.n)), Asc.T @ y) < 1e-13
+
+
+# ---------------------------------------------------------------------------------------------- trajectories
+@pytest.mark.parametrize("name", ["lp_afiro_like", "lp_random_sparse_small", "lp_multicommodity_small"])
+@pytest.mark.parametrize("linsys", ["indirect", "direct"])
+def test_iterates_follow_the_oracle(gpu, oracle_built, name, linsys):
+    po = oracle_built
+    z, A, b, c = load(name)
+    T = 25
+    o = po.solve("oracle", A, b, c, linsys=linsys, eps=1e-9, trace=T, max_admm_iters=100000)
+    with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-9) as S:
+        S.begin()
+        assert rel(S.vector("g"), o.work["g"]) < 1e-10 and abs(S.scalar("g_th") - o.work["g_th"]) < 1e-10 * abs(o.work["g_th"])
+        for t in range(min(T, len(o.trace))):
+            fin, done = S.step(1)
+            assert done == 1 and not fin
+            for col, nm in enumerate(("u", "v", "u_t")):
+                assert rel(S.vector(nm), o.trace[t, col]) < 1e-9, (name, linsys, t + 1, nm)
+
+
+# ---------------------------------------------------------------------------------------------- full solves
+def _check_against_golden(S, info, z, tag, eps):
+    g = info_of(z, tag)
+    assert info["status_val"] == g["status_val"]
+    assert info["ipm_iter"] == g["ipm_iter"]
+    same = info["admm_iter"] == g["admm_iter"]
+    if not same:
+        assert abs(info["admm_iter"] - g["admm_iter"]) <= 0.03 * g["admm_iter"] + 2
+    tol = max(1e-6, 0.1 * eps) if same else 50 * eps
+    for k in "xys":
+        assert rel(getattr(S, k), z[f"{tag}_{k}"]) < tol, (tag, k, info["admm_iter"], g["admm_iter"])
+    assert abs(info["pobj"] - g["pobj"]) <= tol * (1 + abs(g["pobj"]))
+    assert abs(info["dobj"] - g["dobj"]) <= tol * (1 + abs(g["dobj"]))
+    for k in ("res_pri", "res_dual", "rel_gap"):
+        assert info[k] < eps
+
+
+@pytest.mark.parametrize("name,eps_list", [("lp_afiro_like", (1e-3, 1e-6)), ("lp_random_sparse_small", (1e-3, 1e-6)),
+                                           ("lp_multicommodity_small", (1e-4,)), ("lp_staircase", (1e-3, 1e-6))])
+@pytest.mark.parametrize("linsys", ["indirect", "direct"])
+def test_final_solution_matches_reference_fixture(gpu, name, eps_list, linsys):
+    z, A, b, c = load(name)
+    for eps in eps_list:
+        with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=eps) as S:
+            info = S.solve()
+            _check_against_golden(S, info, z, f"{linsys}_{eps:g}", eps)
+
+
+@pytest.mark.parametrize("variant", sorted(TINY_VARIANTS))
+@pytest.mark.parametrize("linsys", ["indirect", "direct"])
+def test_non_default_switches_match_reference_fixture(gpu, variant, linsys):
+    z, A, b, c = load("lp_tiny_" + variant)
+    with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-4, **TINY_VARIANTS[variant]) as S:
+        info = S.solve()
+        _check_against_golden(S, info, z, f"{linsys}_0.0001", 1e-4)
+
+
+def test_matlab_surface_end_to_end(gpu):
+    z, A, b, c = load("lp_afiro_like")
+    for pcg, tag in ((0, "direct_1e-06"), (1, "indirect_1e-06")):
+        p = gpu.abip_get_params()
+        p.update(verbose=0, pcg=pcg, tol=1e-6)
+        x, y, s, info = gpu.abip(dict(A=A, b=b, c=c), {"l": A.shape[1]}, p)
+        assert info["status"] == "Solved" and info["solver"] == "abip-lp"
+        assert rel(x, z[tag + "_x"]) < 1e-6 and rel(y, z[tag + "_y"]) < 1e-6 and rel(s, z[tag + "_s"]) < 1e-6
+        assert abs(info["pobj"] - float(c @ x)) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------- edge cases
+def test_status_codes_on_infeasible_and_unbounded(gpu, oracle_built):
+    po = oracle_built
+    cases = {
+        "infeasible": (sp.csc_matrix(np.array([[1.0, 1.0, 0.0], [0.0, 1.0, 1.0]])), np.array([-1.0, 2.0]), np.array([1.0, 1.0, 1.0])),
+        "unbounded": (sp.csc_matrix(np.array([[1.0, -1.0, 0.0], [0.0, 1.0, -1.0]])), np.array([0.0, 0.0]), np.array([-1.0, 0.0, 0.0])),
+    }
+    for nm, (A, b, c) in cases.items():
+        for linsys in ("direct", "indirect"):
+            o = po.solve("oracle", A, b, c, linsys=linsys, eps=1e-5, max_admm_iters=20000)
+            with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-5, max_admm_iters=20000) as S:
+                info = S.solve()
+            assert info["status_val"] == o.info["status_val"], (nm, linsys, info["status"], o.info["status"])
+            assert info["status"] == o.info["status"]
+
+
+def test_iteration_limits_and_inaccurate_status(gpu, oracle_built):
+    po = oracle_built
+    z, A, b, c = load("lp_random_sparse_small")
+    for linsys in ("indirect", "direct"):
+        o = po.solve("oracle", A, b, c, linsys=linsys, eps=1e-9, max_admm_iters=60)
+        with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-9, max_admm_iters=60) as S:
+            info = S.solve()
+            assert info["status"] == o.info["status"] == "Solved/Inaccurate"
+            assert info["admm_iter"] == o.info["admm_iter"] and info["ipm_iter"] == o.info["ipm_iter"]
+            assert rel(S.x, o.x) < 1e-8 and rel(S.y, o.y) < 1e-8 and rel(S.s, o.s) < 1e-8
+
+
+def test_invalid_input_is_rejected_like_the_reference(gpu):
+    A = sp.csc_matrix(np.ones((3, 2)))                       # m > n  (abip.c:1661-1665)
+    with pytest.raises(RuntimeError):
+        gpu.Solver(A, np.ones(3), np.ones(2), verbose=0)
+    A = sp.identity(3, format="csc")
+    with pytest.raises(RuntimeError):
+        gpu.Solver(A, np.ones(3), np.ones(3), verbose=0, alpha=2.5)   # alpha must be in (0,2)
+
+
+def test_warm_start_quirk_matches_oracle(gpu, oracle_built):
+    """warm_start_vars overwrites the guess with sqrt(mu/beta) (abip.c:328-347): same iterates as the reference anyway."""
+    po = oracle_built
+    z, A, b, c = load("lp_afiro_like")
+    warm = (z["indirect_1e-06_x"], z["indirect_1e-06_y"], z["indirect_1e-06_s"])
+    o = po.solve("oracle", A, b, c, linsys="indirect", eps=1e-5, warm=warm, warm_start=1)
+    with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-5, warm_start=1) as S:
+        S.x[:], S.y[:], S.s[:] = warm
+        info = S.solve()
+        assert info["admm_iter"] == o.info["admm_iter"] and rel(S.x, o.x) < 1e-7
+
+
+# ---------------------------------------------------------------------------------------------- full size (C4)
+def test_full_size_properties(gpu):
+    """BASELINE configs[3] shape (m=200k, n=500k, nnz~5M): adjoint identity <Ax, y> = <x, A'y>, linearity, a KKT solve
+    whose residual is checked with the device SpMVs themselves, and monotone decrease of the barrier parameter."""
+    from abip_amd import problems
+    A, b, c = problems.lp_random_sparse()
+    rng = np.random.default_rng(7)
+    with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-6) as S:
+        m, n = S.m, S.n
+        x1, x2, y = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(m)
+        Ax1 = S.accum_by_A(x1, np.zeros(m)); Ax2 = S.accum_by_A(x2, np.zeros(m)); Aty = S.accum_by_Atrans(y, np.zeros(n))
+        assert abs(Ax1 @ y - x1 @ Aty) <= 1e-10 * (np.linalg.norm(Ax1) * np.linalg.norm(y))
+        assert rel(S.accum_by_A(2.0 * x1 - 3.0 * x2, np.zeros(m)), 2.0 * Ax1 - 3.0 * Ax2) < 1e-13
+        rhs = rng.standard_normal(m + n)
+        sol, its = S.kkt_solve(rhs, None, -1)
+        ry = 1e-3 * sol[:m] + S.accum_by_A(sol[m:], np.zeros(m)) - rhs[:m]
+        rx = S.accum_by_Atrans(sol[:m], np.zeros(n)) - sol[m:] - rhs[m:]
+        assert its > 0 and np.sqrt(ry @ ry + rx @ rx) / np.linalg.norm(rhs) < 1e-6
+        S.begin()
+        mus = []
+        for _ in range(6):
+            S.step(5)
+            mus.append(S.scalar("mu"))
+        assert all(b2 <= a2 for a2, b2 in zip(mus, mus[1:])) and mus[-1] < 1.0
+        info = S.end()
+        assert np.isfinite(info["res_pri"]) and np.isfinite(info["res_dual"])
