@@ -19,14 +19,15 @@ namespace abip {
 constexpr int BS = 256;        // threads per block
 constexpr int WAVES = BS / 64; // wavefronts per block
 constexpr int CHUNK = 1024;    // non-zeros staged through LDS per row block (4 per thread)
-constexpr int MAXNB = 1024;    // upper bound on the persistent grid == partials per slot
+constexpr int MAXNB = 2048;    // upper bound on the persistent grid == partials per slot
 
 // CSR view (A' is the CSC of A read as CSR; A is the explicit transpose, indirect.c:81-139).
 struct Csr {
   const int *ptr;    // nrows+1
   const int *idx;    // nnz
   const double *val; // nnz
-  const int *rb;     // row-block boundaries, nrb+1 (host-built: <= CHUNK nnz per block, or one long row)
+  const int4 *rbd;   // row-block descriptors {first row, last row + 1, first nnz, last nnz + 1} (host-built:
+                     // <= CHUNK non-zeros and <= CHUNK rows per block, or exactly one longer row)
   int nrb;
   int nrows;
 };
@@ -100,12 +101,25 @@ __device__ __forceinline__ void write_partials(double *part, const int (&slots)[
 }
 
 // Re-reduce the nb per-block partials of NS slots; all threads of all blocks get identical totals.
+// All MAXNB/BS loads of a thread are issued before the first add: a rolled loop would serialise them into that
+// many dependent L2 round trips (measured: ~8 us of a 40 us kernel).
 template <int NS>
 __device__ __forceinline__ void read_partials(const double *part, const int (&slots)[NS], int nb, double (&out)[NS], double *sm) {
+  constexpr int PER = MAXNB / BS;
+  double t[NS][PER];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = threadIdx.x + u * BS;
+      t[s][u] = (i < nb) ? part[slots[s] * MAXNB + i] : 0.0;
+    }
+  }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     double acc = 0.0;
-    for (int i = threadIdx.x; i < nb; i += BS) acc += part[slots[s] * MAXNB + i];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) acc += t[s][u];
     out[s] = acc;
   }
   block_sum<NS>(out, sm);
@@ -118,21 +132,42 @@ __device__ __forceinline__ int pow2_floor(int x) { return x <= 1 ? 1 : 1 << (31 
 // then groups of `lpr` lanes reduce one row each from LDS and one lane per row runs the
 // row epilogue.  A block holding a single row longer than CHUNK is reduced by the whole
 // workgroup instead.  prod(col, a, out[NV]) forms the products; rowf(row, acc[NV]) consumes a row.
+//
+// Latency hiding (the kernel is a chain of dependent memory round trips, not a bandwidth stream, unless
+// enough of them overlap): the row-block descriptor {r0, r1, k0, k1} is ONE 16-byte load; the block's row
+// pointers are staged into LDS by the same round trip that fetches values and indices; and the NEXT
+// block's descriptor, values and indices are requested before the current block's LDS reduction starts, so
+// only the gather itself sits on the critical path of an iteration.
 template <int NV, class ProdF, class RowF>
-__device__ __forceinline__ void spmv_stream(const Csr M, double *lds /* NV*CHUNK */, double *sm /* NV*WAVES */, ProdF prod, RowF rowf) {
-  for (int b = blockIdx.x; b < M.nrb; b += gridDim.x) {
-    const int r0 = M.rb[b], r1 = M.rb[b + 1];
-    const int k0 = M.ptr[r0], k1 = M.ptr[r1];
-    const int nn = k1 - k0;
-    if (nn <= CHUNK) {
-      double a[4];
-      int c[4];
+__device__ __forceinline__ void spmv_stream(const Csr M, double *lds /* NV*CHUNK */, int *lptr /* CHUNK+1 */, double *sm /* NV*WAVES */,
+                                            ProdF prod, RowF rowf) {
+  int b = blockIdx.x;
+  if (b >= M.nrb) return;
+  int4 d = M.rbd[b];
+  double a[4];
+  int c[4];
+  auto fetch = [&](const int4 &dd, double(&aa)[4], int(&cc)[4]) {
+    const int nn = dd.w - dd.z;
+    if (nn > CHUNK) return;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = threadIdx.x + u * BS;
-        a[u] = 0.0; c[u] = 0;
-        if (k < nn) { a[u] = M.val[k0 + k]; c[u] = M.idx[k0 + k]; }
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int k = threadIdx.x + u * BS;
+      aa[u] = 0.0; cc[u] = 0;
+      if (k < nn) { aa[u] = M.val[dd.z + k]; cc[u] = M.idx[dd.z + k]; }
+    }
+  };
+  fetch(d, a, c);
+  for (;;) {
+    const int bn = b + gridDim.x;
+    const bool has_next = bn < M.nrb;
+    int4 dn = d;
+    if (has_next) dn = M.rbd[bn];
+    const int r0 = d.x, k0 = d.z, k1 = d.w;
+    const int nn = k1 - k0, R = d.y - d.x;
+    double an[4];
+    int cn[4];
+    if (nn <= CHUNK) {
+      for (int t = threadIdx.x; t <= R; t += BS) lptr[t] = M.ptr[r0 + t] - k0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int k = threadIdx.x + u * BS;
@@ -144,7 +179,7 @@ __device__ __forceinline__ void spmv_stream(const Csr M, double *lds /* NV*CHUNK
         }
       }
       __syncthreads();
-      const int R = r1 - r0;
+      if (has_next) fetch(dn, an, cn);
       int lpr = pow2_floor(BS / (R > 0 ? R : 1));
       if (lpr > 64) lpr = 64;
       const int ngrp = BS / lpr, grp = threadIdx.x / lpr, q = threadIdx.x % lpr;
@@ -154,7 +189,7 @@ __device__ __forceinline__ void spmv_stream(const Csr M, double *lds /* NV*CHUNK
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[v] = 0.0;
         if (r < R) {
-          const int s = M.ptr[r0 + r] - k0, e = M.ptr[r0 + r + 1] - k0;
+          const int s = lptr[r], e = lptr[r + 1];
           for (int k = s + q; k < e; k += lpr) {
 #pragma unroll
             for (int v = 0; v < NV; ++v) acc[v] += lds[v * CHUNK + k];
@@ -177,10 +212,15 @@ __device__ __forceinline__ void spmv_stream(const Csr M, double *lds /* NV*CHUNK
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[v] += pr[v];
       }
+      if (has_next) fetch(dn, an, cn);
       block_sum<NV>(acc, sm);
       if (threadIdx.x == 0) rowf(r0, acc);
       __syncthreads();
     }
+    if (!has_next) break;
+    b = bn; d = dn;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = an[u]; c[u] = cn[u]; }
   }
 }
 

@@ -92,9 +92,10 @@ __global__ __launch_bounds__(BS) void k_cg_init_At(Csr At /* rows = columns of A
                                                    double *__restrict__ tmp, const Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
   __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
   spmv_stream<1>(
-      At, lds, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * s[c]; },
+      At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * s[c]; },
       [&](int row, double(&acc)[1]) { tmp[row] = acc[0]; });
 }
 
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rh
                                                   double *part, int nb, Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
   __shared__ double lds[2 * CHUNK];
+  __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[2 * WAVES];
   double bn[1];
   const int rs[1] = {S_BN};
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rh
   double acc2[2] = {0.0, 0.0};
   if (s) {
     spmv_stream<2>(
-        A, lds, sm, [&](int c, double a, double(&pr)[2]) { pr[0] = a * bx[c]; pr[1] = a * tmp[c]; },
+        A, lds, lptr, sm, [&](int c, double a, double(&pr)[2]) { pr[0] = a * bx[c]; pr[1] = a * tmp[c]; },
         [&](int i, double(&acc)[2]) {
           const double si = s[i];
           const double b = rhs[i] + acc[0];
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rh
         });
   } else {
     spmv_stream<1>(
-        A, lds, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * bx[c]; },
+        A, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * bx[c]; },
         [&](int i, double(&acc)[1]) {
           const double ri = rhs[i] + acc[0];
           const double zi = ri * Minv[i];
@@ -158,12 +160,15 @@ __device__ __forceinline__ bool cg_converged(Ctl *ctl, const double *part, int n
   return done;
 }
 
-// tmp = A' p_new with p_new = z + beta p formed on the fly (indirect.c:386-387 folded into 216)
-__global__ __launch_bounds__(BS) void k_cg_spmv_At(Csr At, const double *__restrict__ z, const double *__restrict__ p,
+// tmp = A' p_new with p_new = z + beta p (indirect.c:386-387 folded into 216).  Gathering two m-vectors per non-zero
+// costs a second pass through the texture path, so the identity A'(z + beta p) = A'z + beta (A'p) is used instead:
+// tmp still holds A'p of the previous iteration (it is rebuilt from scratch, beta = 0, at every solve).
+__global__ __launch_bounds__(BS) void k_cg_spmv_At(Csr At, const double *__restrict__ z,
                                                    double *__restrict__ tmp, int max_its, double *part, int nb, Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
   if (ctl->cg_done) return;
   __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[2 * WAVES];
   int it; double zr;
   if (cg_converged(ctl, part, nb, max_its, sm, it, zr)) {
@@ -173,9 +178,15 @@ __global__ __launch_bounds__(BS) void k_cg_spmv_At(Csr At, const double *__restr
   const int par = it & 1;
   const double beta = (it == 0) ? 0.0 : zr / ctl->zr_hist[par ^ 1];
   if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->it_cur = it; ctl->beta_cur = beta; ctl->zr_cur = zr; ctl->zr_hist[par] = zr; }
-  spmv_stream<1>(
-      At, lds, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * (z[c] + beta * p[c]); },
-      [&](int row, double(&acc)[1]) { tmp[row] = acc[0]; });
+  if (it == 0) {
+    spmv_stream<1>(
+        At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * z[c]; },
+        [&](int row, double(&acc)[1]) { tmp[row] = acc[0]; });
+  } else {
+    spmv_stream<1>(
+        At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * z[c]; },
+        [&](int row, double(&acc)[1]) { tmp[row] = acc[0] + beta * tmp[row]; });
+  }
 }
 
 // p <- z + beta p ; Gp = A tmp + rho p ; S_PG <- p'Gp            (indirect.c:214-219, 371)
@@ -184,11 +195,12 @@ __global__ __launch_bounds__(BS) void k_cg_spmv_A(Csr A, const double *__restric
   ABIP_GATE_HALT(ctl);
   if (ctl->cg_done) return;
   __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
   const double beta = ctl->beta_cur;
   double acc1[1] = {0.0};
   spmv_stream<1>(
-      A, lds, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * tmp[c]; },
+      A, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * tmp[c]; },
       [&](int i, double(&acc)[1]) {
         const double pn = z[i] + beta * p[i];
         const double gp = acc[0] + rho * pn;
@@ -222,6 +234,10 @@ __global__ __launch_bounds__(BS) void k_cg_update(double *__restrict__ x, double
   const int par = (it + 1) & 1;
   const int ws[2] = {S_RR0 + par, S_ZR0 + par};
   write_partials<2>(part, ws, acc, sm);
+  // this kernel runs on a smaller grid than the SpMVs (dispatching NB workgroups costs more than its work): the
+  // partial entries of the workgroups that do not exist are zeroed so that consumers can keep summing nb entries
+  if (threadIdx.x == 0)
+    for (int e = blockIdx.x + gridDim.x; e < nb; e += gridDim.x) { part[ws[0] * MAXNB + e] = 0.0; part[ws[1] * MAXNB + e] = 0.0; }
   if (blockIdx.x == 0 && threadIdx.x == 0) ctl->cg_it = it + 1;
 }
 
@@ -232,6 +248,7 @@ __global__ __launch_bounds__(BS) void k_post_At(Csr At, double *__restrict__ rhs
                                                 int max_its, double *part, int nb, Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
   __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[2 * WAVES];
   if (!ctl->cg_done) {
     int it; double zr;
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(BS) void k_post_At(Csr At, double *__restrict__ rhs
   const double *hx = h + d.MP;
   double acc1[1] = {0.0};
   spmv_stream<1>(
-      At, lds, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * rhs[c]; },
+      At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * rhs[c]; },
       [&](int j, double(&acc)[1]) {
         const double v = acc[0] - bx[j];
         bx[j] = v;
@@ -394,12 +411,13 @@ __global__ __launch_bounds__(BS) void k_q_A(Csr A, const double *__restrict__ uu
   ABIP_GATE_HALT(ctl);
   if (!ctl->cg_done) return;
   __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[3 * WAVES];
   const double *x = uu + d.MP;
   const double tau = uu[d.MP + d.n];
   double acc3[3] = {0.0, 0.0, 0.0};
   spmv_stream<1>(
-      A, lds, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
+      A, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
       [&](int i, double(&acc)[1]) {
         const double pri = acc[0], e = pri - b[i] * tau;
         double sc = wD ? wD[i] : 1.0;
@@ -415,12 +433,13 @@ __global__ __launch_bounds__(BS) void k_q_At(Csr At, const double *__restrict__ 
   ABIP_GATE_HALT(ctl);
   if (!ctl->cg_done) return;
   __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[3 * WAVES];
   const double *s = vv + d.MP;
   const double tau = uu[d.MP + d.n];
   double acc3[3] = {0.0, 0.0, 0.0};
   spmv_stream<1>(
-      At, lds, sm, [&](int cidx, double a, double(&pr)[1]) { pr[0] = a * uu[cidx]; },
+      At, lds, lptr, sm, [&](int cidx, double a, double(&pr)[1]) { pr[0] = a * uu[cidx]; },
       [&](int j, double(&acc)[1]) {
         const double drj = acc[0] + s[j], e = drj - c[j] * tau;
         double sc = wE ? wE[j] : 1.0;
@@ -434,13 +453,22 @@ __global__ __launch_bounds__(BS) void k_q_At(Csr At, const double *__restrict__ 
 // One block: fold the listed slots into ctl->out[slot] and append the tau/kappa entries the host needs.
 struct FinArgs { int nslots; int slots[40]; const double *u, *v, *ua, *va; };
 __global__ __launch_bounds__(BS) void k_finalize(FinArgs f, Dims d, const double *part, int nb, Ctl *ctl) {
-  __shared__ double sm[WAVES];
-  for (int s = 0; s < f.nslots; ++s) {
+  // one wavefront per slot, all loads of a lane in flight at once, no workgroup barrier
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int PER = MAXNB / 64;
+  for (int s = wave; s < f.nslots; s += WAVES) {
     const int slot = f.slots[s];
-    double v[1] = {0.0};
-    for (int i = threadIdx.x; i < nb; i += BS) v[0] += part[slot * MAXNB + i];
-    block_sum<1>(v, sm);
-    if (threadIdx.x == 0) ctl->out[slot] = v[0];
+    double t[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = lane + u * 64;
+      t[u] = (i < nb) ? part[slot * MAXNB + i] : 0.0;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) acc += t[u];
+    acc = wave_sum(acc);
+    if (lane == 0) ctl->out[slot] = acc;
   }
   if (threadIdx.x == 0) {
     const int q = d.MP + d.n;
@@ -560,9 +588,10 @@ __global__ __launch_bounds__(BS) void k_adapt_vprev(double *vp, const double *up
 // plain y += A x for the unit-level ABI and the direct back-end's accumulations
 __global__ __launch_bounds__(BS) void k_spmv_acc(Csr M, const double *__restrict__ x, double *__restrict__ y) {
   __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
   spmv_stream<1>(
-      M, lds, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
+      M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
       [&](int row, double(&acc)[1]) { y[row] += acc[0]; });
 }
 

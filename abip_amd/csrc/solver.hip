@@ -63,16 +63,18 @@ struct DBuf { // device buffer
 };
 
 struct DevCsr {
-  DBuf<int> ptr, idx, rb;
+  DBuf<int> ptr, idx, rbd; // rbd: 4 ints per row block, read as int4
   DBuf<double> val;
   int nrows = 0, nrb = 0;
   int upload(const host::HostCsr &h, hipStream_t s) {
     nrows = h.nrows; nrb = (int)h.rb.size() - 1;
-    if (ptr.upload(h.ptr, s) || idx.upload(h.idx, s) || val.upload(h.val, s) || rb.upload(h.rb, s)) return -1;
+    std::vector<int> d4((size_t)4 * std::max(nrb, 1), 0);
+    for (int q = 0; q < nrb; ++q) { d4[4 * q] = h.rb[q]; d4[4 * q + 1] = h.rb[q + 1]; d4[4 * q + 2] = h.ptr[h.rb[q]]; d4[4 * q + 3] = h.ptr[h.rb[q + 1]]; }
+    if (ptr.upload(h.ptr, s) || idx.upload(h.idx, s) || val.upload(h.val, s) || rbd.upload(d4, s)) return -1;
     return 0;
   }
-  Csr view() const { return Csr{ptr.p, idx.p, val.p, rb.p, nrb, nrows}; }
-  void release() { ptr.release(); idx.release(); rb.release(); val.release(); }
+  Csr view() const { return Csr{ptr.p, idx.p, val.p, (const int4 *)rbd.p, nrb, nrows}; }
+  void release() { ptr.release(); idx.release(); rbd.release(); val.release(); }
 };
 
 struct DevTri {
@@ -228,11 +230,11 @@ void enqueue_cg_chunk(W *w, double *rhs, int its) {
   const int max_its = (int)w->m; // indirect.c:418
   for (int q = 0; q < its; ++q) {
     w->ev_tag = w->cg_enq++;
-    launch(w, ABIP_HIP_K_SPMV_AT, k_cg_spmv_At, w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, (const double *)w->cg_p.p, w->cg_tmp.p,
+    launch(w, ABIP_HIP_K_SPMV_AT, k_cg_spmv_At, w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, w->cg_tmp.p,
            max_its, w->part.p, w->NB, w->ctl.p);
     launch(w, ABIP_HIP_K_SPMV_A, k_cg_spmv_A, w->NB, BS, w->dA.view(), (const double *)w->cg_tmp.p, (const double *)w->cg_z.p, w->cg_p.p,
            w->cg_Gp.p, w->stgs->rho_y, w->part.p, (const Ctl *)w->ctl.p);
-    launch(w, ABIP_HIP_K_CG_VEC, k_cg_update, w->NB, BS, rhs, w->cg_r.p, w->cg_z.p, (const double *)w->cg_p.p, (const double *)w->cg_Gp.p,
+    launch(w, ABIP_HIP_K_CG_VEC, k_cg_update, std::max(1, std::min(w->NB, (int)((w->m + 2 * BS - 1) / (2 * BS)))), BS, rhs, w->cg_r.p, w->cg_z.p, (const double *)w->cg_p.p, (const double *)w->cg_Gp.p,
            (const double *)w->cg_M.p, (int)w->m, w->part.p, w->NB, w->ctl.p);
   }
   w->ev_tag = -1;
@@ -829,10 +831,7 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
   w->MP = (int)(((m + 31) / 32) * 32);
   w->LV = w->MP + (int)n + 1;
   w->LV = ((w->LV + 31) / 32) * 32;
-  {
-    const long work = std::max<long>(std::max<long>(m, n), (long)d->A->p[n] / 4);
-    w->NB = (int)std::max<long>(1, std::min<long>(MAXNB, (work + BS - 1) / BS));
-  }
+  w->NB = 1; // fixed below, once the row blocks are known
   auto fail = [&](const char *msg) -> ABIPWork * { printf("ERROR: %s\n", msg); free_work(w); return nullptr; };
   if (hipStreamCreate(&w->stream) != hipSuccess) return fail("hipStreamCreate failed");
   if (w->stgs->normalize) host::normalize_A(w->A, w->stgs, w->D, w->E, &w->mean_norm_row_A, &w->mean_norm_col_A);
@@ -841,6 +840,12 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
   host::csc_as_csr(w->A, hAt); host::build_row_blocks(hAt, CHUNK);
   host::transpose_to_csr(w->A, hA); host::build_row_blocks(hA, CHUNK);
   if (w->dAt.upload(hAt, w->stream) || w->dA.upload(hA, w->stream)) return fail("device allocation failure (matrix)");
+  { // persistent grid: every kernel uses the same NB (== partials per slot).  Sized so that the SpMV kernels give each
+    // workgroup the same whole number of row blocks (no tail), at most MAXNB (8 workgroups per CU on 256 CUs).
+    const long nrb = std::max<long>(std::max<long>(w->dAt.nrb, w->dA.nrb), (std::max<long>(m, n) + 4 * BS - 1) / (4 * BS));
+    const long per = (nrb + MAXNB - 1) / MAXNB;
+    w->NB = (int)std::max<long>(1, (nrb + per - 1) / per);
+  }
   DBuf<double> *lvecs[] = {&w->u, &w->v, &w->ut, &w->u_avg, &w->v_avg, &w->u_sum, &w->v_sum, &w->u_avgc, &w->v_avgc, &w->h, &w->g,
                            &w->a_up, &w->a_vp, &w->a_ut, &w->a_u, &w->a_v, &w->a_utn, &w->a_un, &w->a_vn};
   for (auto *b : lvecs) {
