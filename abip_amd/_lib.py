@@ -65,7 +65,11 @@ EXPORTS = (
     "abip_hip_device_info", "abip_hip_solve_begin", "abip_hip_step", "abip_hip_solve_end",
     "abip_hip_accum_by_A", "abip_hip_accum_by_Atrans", "abip_hip_kkt_solve", "abip_hip_get_vector",
     "abip_hip_get_scalar", "abip_hip_profile_enable", "abip_hip_profile_read", "abip_hip_sync",
+    "abip_hip_dist_get_unique_id", "abip_hip_dist_init_rccl", "abip_hip_dist_init_callback", "abip_hip_dist_finalize",
+    "abip_hip_dist_partition", "abip_hip_dist_rows",
 )
+
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_long)
 
 _lib = None
 
@@ -118,5 +122,16 @@ def load() -> C.CDLL:
     L.abip_hip_profile_read.argtypes = [W, C.POINTER(AbipHipProfile), C.c_int]
     L.abip_hip_sync.restype = None
     L.abip_hip_sync.argtypes = [W]
+    L.abip_hip_dist_get_unique_id.restype = C.c_int
+    L.abip_hip_dist_get_unique_id.argtypes = [C.c_void_p]
+    L.abip_hip_dist_init_rccl.restype = C.c_int
+    L.abip_hip_dist_init_rccl.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    L.abip_hip_dist_init_callback.restype = C.c_int
+    L.abip_hip_dist_init_callback.argtypes = [C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
+    L.abip_hip_dist_finalize.restype = None
+    L.abip_hip_dist_partition.restype = C.c_int
+    L.abip_hip_dist_partition.argtypes = [C.POINTER(ABIPMatrix), C.c_int, PI]
+    L.abip_hip_dist_rows.restype = None
+    L.abip_hip_dist_rows.argtypes = [W, PI, PI]
     _lib = L
     return L

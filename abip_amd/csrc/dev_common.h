@@ -125,6 +125,18 @@ __device__ __forceinline__ void read_partials(const double *part, const int (&sl
   block_sum<NS>(out, sm);
 }
 
+// Consumers take their scalars either from the partials (single GPU) or, when the rows of A are sharded over several
+// GPUs, from the table `gs` that k_fold filled and the all-reduce summed over the ranks.
+template <int NS>
+__device__ __forceinline__ void get_scalars(const double *part, const int (&slots)[NS], int nb, double (&out)[NS], double *sm, const double *gs) {
+  if (gs) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) out[s] = gs[slots[s]];
+  } else {
+    read_partials<NS>(part, slots, nb, out, sm);
+  }
+}
+
 __device__ __forceinline__ int pow2_floor(int x) { return x <= 1 ? 1 : 1 << (31 - __clz(x)); }
 
 // CSR-stream SpMV skeleton.  For every row block: all 256 threads stream the block's

@@ -27,12 +27,12 @@ struct Dims { int m, n, MP; }; // MP = offset of the x block inside an l-vector;
 // depend on tau; k_rhs adds the tau term analytically: (w - t h)'g = w'g - t g_th)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BS) void k_dot_wg(const double *__restrict__ u, const double *__restrict__ v,
-                                               const double *__restrict__ g, double rho, Dims d, double *part) {
+                                               const double *__restrict__ g, double rho, Dims d, double *part, double xw) {
   __shared__ double sm[WAVES];
   double acc[1] = {0.0};
   const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
   for (int i = t0; i < d.m; i += stride) acc[0] += rho * (u[i] + v[i]) * g[i];
-  for (int j = t0; j < d.n; j += stride) acc[0] += (u[d.MP + j] + v[d.MP + j]) * g[d.MP + j];
+  for (int j = t0; j < d.n; j += stride) acc[0] += xw * ((u[d.MP + j] + v[d.MP + j]) * g[d.MP + j]);
   const int slots[1] = {S_WG};
   write_partials<1>(part, slots, acc, sm);
 }
@@ -52,12 +52,12 @@ __global__ __launch_bounds__(BS) void k_norm_y(const double *__restrict__ x, Dim
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BS) void k_rhs(const double *__restrict__ u, const double *__restrict__ v, double *__restrict__ ut,
                                             const double *__restrict__ h, double rho, double g_th, Dims d,
-                                            double *part, int nb, const Ctl *ctl) {
+                                            double *part, int nb, const Ctl *ctl, const double *gs) {
   ABIP_GATE_HALT(ctl);
   __shared__ double sm[WAVES];
   double wg[1];
   const int rs[1] = {S_WG};
-  read_partials<1>(part, rs, nb, wg, sm);
+  get_scalars<1>(part, rs, nb, wg, sm, gs);
   const int tail = d.MP + d.n;
   const double tsum = u[tail] + v[tail];
   const double coef = (wg[0] - tsum * g_th) / (g_th + 1.0);
@@ -103,14 +103,14 @@ __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rh
                                                   const double *__restrict__ tmp, const double *__restrict__ s,
                                                   const double *__restrict__ Minv, double *__restrict__ r, double *__restrict__ z,
                                                   double *__restrict__ p, double rho, double tol_factor, Dims d,
-                                                  double *part, int nb, Ctl *ctl) {
+                                                  double *part, int nb, Ctl *ctl, const double *gs) {
   ABIP_GATE_HALT(ctl);
   __shared__ double lds[2 * CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[2 * WAVES];
   double bn[1];
   const int rs[1] = {S_BN};
-  read_partials<1>(part, rs, nb, bn, sm);
+  get_scalars<1>(part, rs, nb, bn, sm, gs);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     double tol = sqrt(bn[0]) * tol_factor; // indirect.c:406-409
     tol = fmax(tol, 1e-7);
@@ -147,12 +147,13 @@ __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rh
 
 // Convergence test shared by the first SpMV of an iteration and by the post-solve kernel.
 // Every block evaluates it on the same partials, so all blocks agree (idempotent flag write).
-__device__ __forceinline__ bool cg_converged(Ctl *ctl, const double *part, int nb, int max_its, double *sm, int &it, double &zr) {
+__device__ __forceinline__ bool cg_converged(Ctl *ctl, const double *part, int nb, int max_its, double *sm, int &it, double &zr,
+                                             const double *gs = nullptr) {
   it = ctl->cg_it;
   const int par = it & 1;
   double v[2];
   const int rs[2] = {S_RR0 + par, S_ZR0 + par};
-  read_partials<2>(part, rs, nb, v, sm);
+  get_scalars<2>(part, rs, nb, v, sm, gs);
   zr = v[1];
   const double nr = sqrt(v[0]), tol = ctl->cg_tol;
   bool done = (it == 0) ? (nr < fmin(tol, 1e-18)) : (nr < tol); // indirect.c:359, 375
@@ -214,13 +215,13 @@ __global__ __launch_bounds__(BS) void k_cg_spmv_A(Csr A, const double *__restric
 // x += alpha p ; r -= alpha Gp ; z = M r ; S_RR, S_ZR (next parity)          (indirect.c:371-385)
 __global__ __launch_bounds__(BS) void k_cg_update(double *__restrict__ x, double *__restrict__ r, double *__restrict__ z,
                                                   const double *__restrict__ p, const double *__restrict__ Gp,
-                                                  const double *__restrict__ Minv, int m, double *part, int nb, Ctl *ctl) {
+                                                  const double *__restrict__ Minv, int m, double *part, int nb, Ctl *ctl, const double *gs) {
   ABIP_GATE_HALT(ctl);
   if (ctl->cg_done) return;
   __shared__ double sm[2 * WAVES];
   double pg[1];
   const int rs[1] = {S_PG};
-  read_partials<1>(part, rs, nb, pg, sm);
+  get_scalars<1>(part, rs, nb, pg, sm, gs);
   const int it = ctl->it_cur;
   const double alpha = ctl->zr_cur / pg[0];
   double acc[2] = {0.0, 0.0};
@@ -290,6 +291,8 @@ struct UpdArgs {
   double *u_avg, *v_avg, *u_sum, *v_sum, *u_avgc, *v_avgc;
   const double *g, *b, *c;
   double alpha, mu_over_beta, rho, dom;
+  double xw;       // weight of the replicated (x, tau) entries in the reductions: 1 on a single GPU / rank 0, 0 on the other ranks
+  const double *gs; // all-reduced scalars (multi-GPU) or null
   int half_update; // abip.c:2143-2149
   int fuse_avg;    // 1: also do compute_avg + the statistics (no restart this iteration)
   int avg_stats;   // 1: (j+1)%10==0 -> statistics of the averaged iterate too (abip.c:2000)
@@ -312,12 +315,12 @@ __device__ __forceinline__ void avg_and_stats_x(const UpdArgs &a, int q /* MP + 
   a.u_sum[q] = us; a.v_sum[q] = vs;
   const double ua = us / a.dom, va = vs / a.dom;
   a.u_avgc[q] = ua; a.v_avgc[q] = va;
-  st.nu += un * un; st.nv += vn * vn;
-  if (a.avg_stats) { st.nua += ua * ua; st.nva += va * va; }
+  st.nu += a.xw * (un * un); st.nv += a.xw * (vn * vn);
+  if (a.avg_stats) { st.nua += a.xw * (ua * ua); st.nva += a.xw * (va * va); }
   if (!tail) {
-    st.wg += (un + vn) * a.g[q];
-    st.cx += a.c[j] * un;
-    if (a.avg_stats) st.cxa += a.c[j] * ua;
+    st.wg += a.xw * ((un + vn) * a.g[q]);
+    st.cx += a.xw * (a.c[j] * un);
+    if (a.avg_stats) st.cxa += a.xw * (a.c[j] * ua);
   }
 }
 __device__ __forceinline__ void prox_x(const UpdArgs &a, int q, double utq, double &un, double &vn) {
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(BS) void k_admm_update(UpdArgs a, Dims d, double *p
   __shared__ double sm[9 * WAVES];
   double dh[1];
   const int rs[1] = {S_DH};
-  read_partials<1>(part, rs, nb, dh, sm);
+  get_scalars<1>(part, rs, nb, dh, sm, a.gs);
   Stat st = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
   for (int i = t0; i < d.m; i += stride) {
@@ -451,13 +454,14 @@ __global__ __launch_bounds__(BS) void k_q_At(Csr At, const double *__restrict__ 
 }
 
 // One block: fold the listed slots into ctl->out[slot] and append the tau/kappa entries the host needs.
-struct FinArgs { int nslots; int slots[40]; const double *u, *v, *ua, *va; };
+struct FinArgs { int nslots; int slots[40]; const double *u, *v, *ua, *va; const double *gs; /* non-null: take the already all-reduced values */ };
 __global__ __launch_bounds__(BS) void k_finalize(FinArgs f, Dims d, const double *part, int nb, Ctl *ctl) {
   // one wavefront per slot, all loads of a lane in flight at once, no workgroup barrier
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int PER = MAXNB / 64;
   for (int s = wave; s < f.nslots; s += WAVES) {
     const int slot = f.slots[s];
+    if (f.gs) { if (lane == 0) ctl->out[slot] = f.gs[slot]; continue; }
     double t[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
@@ -522,12 +526,12 @@ __global__ void k_min_fold(const double *part, int nb, Ctl *ctl) { // single thr
 __global__ __launch_bounds__(BS) void k_neg_x(double *g, Dims d) {
   for (int j = blockIdx.x * BS + threadIdx.x; j < d.n; j += gridDim.x * BS) g[d.MP + j] = -g[d.MP + j];
 }
-__global__ __launch_bounds__(BS) void k_dot_full(const double *a, const double *b, Dims d, int slot, double *part) { // over l-1 entries
+__global__ __launch_bounds__(BS) void k_dot_full(const double *a, const double *b, Dims d, int slot, double *part, double xw) { // over l-1 entries
   __shared__ double sm[WAVES];
   double acc[1] = {0.0};
   const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
   for (int i = t0; i < d.m; i += stride) acc[0] += a[i] * b[i];
-  for (int j = t0; j < d.n; j += stride) acc[0] += a[d.MP + j] * b[d.MP + j];
+  for (int j = t0; j < d.n; j += stride) acc[0] += xw * (a[d.MP + j] * b[d.MP + j]);
   const int ws[1] = {slot};
   write_partials<1>(part, ws, acc, sm);
 }
@@ -546,11 +550,11 @@ __global__ __launch_bounds__(BS) void k_clip_v(double *v, Dims d) {
 // one ADMM step on scratch vectors: (ut, u_prev, v_prev) -> (u, v) with penalty beta_prev
 __global__ __launch_bounds__(BS) void k_adapt_step(const double *ut_in, double *ut_tail_fix, const double *__restrict__ up,
                                                    const double *__restrict__ vp, double *__restrict__ u, double *__restrict__ v,
-                                                   double alpha, double mu_over_beta, Dims d, const double *part, int nb) {
+                                                   double alpha, double mu_over_beta, Dims d, const double *part, int nb, const double *gs) {
   __shared__ double sm[WAVES];
   double dh[1];
   const int rs[1] = {S_DH};
-  read_partials<1>(part, rs, nb, dh, sm);
+  get_scalars<1>(part, rs, nb, dh, sm, gs);
   const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
   for (int i = t0; i < d.m; i += stride) u[i] = ut_in[i] - vp[i]; // adaptive.c:101-104 (v[0:m) is left untouched, :118-121)
   for (int j = t0; j <= d.n; j += stride) {
@@ -566,16 +570,18 @@ __global__ __launch_bounds__(BS) void k_adapt_step(const double *ut_in, double *
 }
 // the five inner products of the difference vectors, formed on the fly (adaptive.c:154-174)
 __global__ __launch_bounds__(BS) void k_adapt_dots(const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ un,
-                                                   const double *__restrict__ vn, const double *__restrict__ vp, double alpha, Dims d, double *part) {
+                                                   const double *__restrict__ vn, const double *__restrict__ vp, double alpha, Dims d, double *part,
+                                                   double xw) {
   __shared__ double sm[5 * WAVES];
   double a[5] = {0, 0, 0, 0, 0};
   const int len = d.MP + d.n + 1;
   for (int i = blockIdx.x * BS + threadIdx.x; i < len; i += gridDim.x * BS) {
     if (i >= d.m && i < d.MP) continue; // padding
+    const double wgt = (i < d.m) ? 1.0 : xw;
     const double dut = 2.0 * v[i] + un[i] - u[i] - vn[i] - vp[i];
     const double du = u[i] - un[i];
     const double dv = (un[i] - u[i]) * (alpha - 1.0) + vn[i] - v[i];
-    a[0] += dut * dut; a[1] += dut * dv; a[2] += du * du; a[3] += dv * dv; a[4] += du * dv;
+    a[0] += wgt * (dut * dut); a[1] += wgt * (dut * dv); a[2] += wgt * (du * du); a[3] += wgt * (dv * dv); a[4] += wgt * (du * dv);
   }
   const int ws[5] = {S_A0, S_A1, S_A2, S_A3, S_A4};
   write_partials<5>(part, ws, a, sm);
@@ -583,6 +589,95 @@ __global__ __launch_bounds__(BS) void k_adapt_dots(const double *__restrict__ u,
 // v_prev[x,tau] = (mu/beta)/u_prev  (adaptive.c:238-241); y block copied by the caller
 __global__ __launch_bounds__(BS) void k_adapt_vprev(double *vp, const double *up, double mu_over_beta, Dims d) {
   for (int j = blockIdx.x * BS + threadIdx.x; j <= d.n; j += gridDim.x * BS) vp[d.MP + j] = mu_over_beta / up[d.MP + j];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU (rows of A sharded over ranks).  m-space is local, n-space replicated; a rank's
+// A_g' y_g is a PARTIAL n-vector that the host all-reduces (RCCL) together with the packed scalars in `gs`.
+// ---------------------------------------------------------------------------------------------
+// partials -> local scalars gs[slot] (one wavefront per slot); the all-reduce then sums gs over the ranks
+struct FoldArgs { int nslots; int slots[40]; };
+__global__ __launch_bounds__(BS) void k_fold(FoldArgs f, const double *part, int nb, double *gs) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int PER = MAXNB / 64;
+  for (int s = wave; s < f.nslots; s += WAVES) {
+    const int slot = f.slots[s];
+    double t[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = lane + u * 64;
+      t[u] = (i < nb) ? part[slot * MAXNB + i] : 0.0;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) acc += t[u];
+    acc = wave_sum(acc);
+    if (lane == 0) gs[slot] = acc;
+  }
+}
+// out = M x (overwrites), gated: mode 0 always, 1 while the PCG runs, 2 once it has converged
+__global__ __launch_bounds__(BS) void k_spmv_set(Csr M, const double *__restrict__ x, double *__restrict__ out, int mode, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (mode == 1 && ctl->cg_done) return;
+  if (mode == 2 && !ctl->cg_done) return;
+  __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
+  __shared__ double sm[WAVES];
+  spmv_stream<1>(
+      M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
+      [&](int row, double(&acc)[1]) { out[row] = acc[0]; });
+}
+// After the all-reduce of [A_g'z_g | rr | zr]: the convergence decision and beta (identical on every rank) and, when
+// `vec`, tmp = T + beta*tmp  (k_cg_spmv_At's second half).  vec == 0: decision only (end of a chunk).
+__global__ __launch_bounds__(BS) void k_dist_cg_step(const double *__restrict__ T, double *__restrict__ tmp, int n, int max_its, int vec,
+                                                     const double *gs, Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (ctl->cg_done) return;
+  int it; double zr;
+  if (cg_converged(ctl, nullptr, 0, max_its, nullptr, it, zr, gs)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->cg_done = 1;
+    return;
+  }
+  if (!vec) return;
+  const int par = it & 1;
+  const double beta = (it == 0) ? 0.0 : zr / ctl->zr_hist[par ^ 1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->it_cur = it; ctl->beta_cur = beta; ctl->zr_cur = zr; ctl->zr_hist[par] = zr; }
+  for (int j = blockIdx.x * BS + threadIdx.x; j < n; j += gridDim.x * BS) tmp[j] = (it == 0) ? T[j] : T[j] + beta * tmp[j];
+}
+// rhs_x <- T - rhs_x with T = A'rhs_y all-reduced; S_DH partial (x part weighted: replicated)      (indirect.c:419-420, abip.c:560)
+__global__ __launch_bounds__(BS) void k_dist_post(const double *__restrict__ T, double *__restrict__ rhs, const double *__restrict__ h, Dims d,
+                                                  double xw, double *part, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (!ctl->cg_done) return;
+  __shared__ double sm[WAVES];
+  double acc[1] = {0.0};
+  const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
+  for (int j = t0; j < d.n; j += stride) {
+    const double v = T[j] - rhs[d.MP + j];
+    rhs[d.MP + j] = v;
+    acc[0] += xw * (v * h[d.MP + j]);
+  }
+  for (int i = t0; i < d.m; i += stride) acc[0] += rhs[i] * h[i];
+  const int ws[1] = {S_DH};
+  write_partials<1>(part, ws, acc, sm);
+}
+// dual residual sums from T = A'y all-reduced (k_q_At without the SpMV)
+__global__ __launch_bounds__(BS) void k_dist_q(const double *__restrict__ T, const double *__restrict__ uu, const double *__restrict__ vv,
+                                               const double *__restrict__ c, const double *__restrict__ wE, Dims d, int slot0, double xw,
+                                               double *part, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (!ctl->cg_done) return;
+  __shared__ double sm[3 * WAVES];
+  const double tau = uu[d.MP + d.n];
+  double acc3[3] = {0.0, 0.0, 0.0};
+  for (int j = blockIdx.x * BS + threadIdx.x; j < d.n; j += gridDim.x * BS) {
+    const double drj = T[j] + vv[d.MP + j], e = drj - c[j] * tau;
+    double sc = wE ? wE[j] : 1.0;
+    sc = sc * sc;
+    acc3[0] += xw * (e * e); acc3[1] += xw * ((e * e) * sc); acc3[2] += xw * ((drj * drj) * sc);
+  }
+  const int ws[3] = {slot0, slot0 + 1, slot0 + 2};
+  write_partials<3>(part, ws, acc3, sm);
 }
 
 // plain y += A x for the unit-level ABI and the direct back-end's accumulations

@@ -9,6 +9,7 @@
 // Inside the PCG loop nothing comes back to the host: convergence is decided on the device and the remaining
 // kernels of an enqueued chunk turn into no-ops (dev_kernels.h, cg_converged).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -39,6 +40,41 @@ using namespace abip;
 namespace {
 
 int g_linsys = -1; // -1: not chosen yet -> environment / default
+
+// ---- multi-GPU context (one process per GPU; set before abip_init) --------------------------------------
+// RCCL is bound with dlopen so that the library neither needs it for single-GPU use nor clashes with the copy a host
+// program (e.g. PyTorch) may already have loaded under the same soname.
+typedef void *rcclComm_t;
+struct Uid128 { char b[128]; }; // ncclUniqueId
+struct RcclApi {
+  void *handle = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(rcclComm_t *, int, Uid128, int) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+  int (*CommDestroy)(rcclComm_t) = nullptr;
+};
+struct DistCtx {
+  int kind = 0; // 0 none, 1 RCCL, 2 host callback (tests)
+  int rank = 0, world = 1;
+  rcclComm_t comm = nullptr;
+  abip_hip_allreduce_fn fn = nullptr;
+  void *fn_ctx = nullptr;
+  RcclApi api;
+};
+DistCtx g_dist;
+
+bool load_rccl(RcclApi &a) {
+  if (a.handle) return true;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char *nm : names) { a.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (a.handle) break; }
+  if (!a.handle) { fprintf(stderr, "abip_hip: cannot load librccl (%s)\n", dlerror()); return false; }
+  a.GetUniqueId = (int (*)(void *))dlsym(a.handle, "ncclGetUniqueId");
+  a.CommInitRank = (int (*)(rcclComm_t *, int, Uid128, int))dlsym(a.handle, "ncclCommInitRank");
+  a.AllReduce = (int (*)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t))dlsym(a.handle, "ncclAllReduce");
+  a.CommDestroy = (int (*)(rcclComm_t))dlsym(a.handle, "ncclCommDestroy");
+  if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy) { fprintf(stderr, "abip_hip: librccl lacks a required symbol\n"); return false; }
+  return true;
+}
 
 int chosen_linsys() {
   if (g_linsys >= 0) return g_linsys;
@@ -156,6 +192,18 @@ struct ABIP_WORK {
   std::vector<double> sol_x, sol_y, sol_s;
   ABIPInfo last_info;
   bool have_solution = false;
+  // ---- multi-GPU (rows [row0, row0+m) of the global problem live on this rank) ------------------
+  bool dist = false;
+  int rank = 0, world = 1;
+  abip_int m_glob = 0, row0 = 0;
+  double xwt = 1.0;         // weight of replicated (x, tau) terms in reductions: 1 on rank 0, else 0
+  DBuf<double> T;           // all-reduce buffer: [n-vector | S_COUNT scalars]
+  double *gs = nullptr;     // = T.p + n_pad when dist, else null
+  size_t n_pad = 0;
+  std::vector<double> hstage; // host staging for the callback backend
+  bool vy_zero = true;      // v[0:m) == 0 (cold start, no half_update): A'u_y == A'u_t,y, one all-reduce less per iteration
+  ABIPMatrix Aloc{};        // this rank's row block in CSC (owned)
+  std::vector<double> Aloc_x; std::vector<abip_int> Aloc_i, Aloc_p;
   // ---- profiling -----------------------------------------------------------------------------
   unsigned prof_mask = 0;
   struct Ev { hipEvent_t a, b; int cls; int tag; };
@@ -212,6 +260,33 @@ int sync_ctl(W *w) { // the once-per-iteration control read
 inline Dims dims(const W *w) { return Dims{(int)w->m, (int)w->n, w->MP}; }
 
 // ------------------------------------------------------------------------------------------------
+// multi-GPU: in-place sum over the ranks of `count` doubles at device pointer `buf`, ordered on the solver's stream
+// ------------------------------------------------------------------------------------------------
+int allreduce_dev(W *w, double *buf, size_t count) {
+  if (!w->dist) return 0;
+  if (g_dist.kind == 1) {
+    const int rc = g_dist.api.AllReduce(buf, buf, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, g_dist.comm, w->stream);
+    if (rc != 0) { fprintf(stderr, "abip_hip: ncclAllReduce failed (%d)\n", rc); return -1; }
+    return 0;
+  }
+  // host-staged callback (test backend): D2H, reduce on the host through the caller's collective, H2D
+  w->hstage.resize(count);
+  HIP_OK(hipMemcpyAsync(w->hstage.data(), buf, sizeof(double) * count, hipMemcpyDeviceToHost, w->stream));
+  HIP_OK(hipStreamSynchronize(w->stream));
+  g_dist.fn(g_dist.fn_ctx, w->hstage.data(), (long)count);
+  HIP_OK(hipMemcpyAsync(buf, w->hstage.data(), sizeof(double) * count, hipMemcpyHostToDevice, w->stream));
+  HIP_OK(hipStreamSynchronize(w->stream));
+  return 0;
+}
+void enqueue_fold(W *w, std::initializer_list<int> slots) {
+  FoldArgs f; f.nslots = 0;
+  for (int sl : slots) f.slots[f.nslots++] = sl;
+  launch(w, ABIP_HIP_K_VEC, k_fold, 1, BS, f, (const double *)w->part.p, w->NB, w->gs);
+}
+inline int allreduce_scalars(W *w) { return allreduce_dev(w, w->gs, (size_t)S_COUNT); }
+inline int allreduce_vec_and_scalars(W *w) { return allreduce_dev(w, w->T.p, w->n_pad + S_COUNT); }
+
+// ------------------------------------------------------------------------------------------------
 // KKT solve on an l-vector already holding the rhs.  S_BN must hold ||rhs_y||^2 (indirect).
 // enqueue-only pieces + a synchronising driver
 // ------------------------------------------------------------------------------------------------
@@ -219,28 +294,66 @@ double cg_tol_factor(const W *w, abip_int iter) { // indirect.c:406-407
   return iter < 0 ? 1e-9 : 1e-1 / std::pow((double)iter + 1, w->stgs->cg_rate);
 }
 
-void enqueue_cg_begin(W *w, double *rhs, const double *warm, abip_int iter) {
+// PCG pieces.  Single GPU: everything stays on the device (dev_kernels.h).  Multi-GPU (w->dist): the rank's A_g' x_g is
+// a partial n-vector in T[0:n); it is all-reduced together with the packed scalars in T[n:] (one collective), and the
+// second half of each step runs on the summed data.  Per CG iteration: 1 vector+scalar all-reduce, 1 scalar all-reduce.
+int enqueue_cg_begin(W *w, double *rhs, const double *warm, abip_int iter) {
   const Dims d = dims(w);
   w->cg_enq = 0;
-  if (warm) launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_At, w->NB, BS, w->dAt.view(), warm, w->cg_tmp.p, (const Ctl *)w->ctl.p);
-  launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_A, w->NB, BS, w->dA.view(), rhs, (const double *)w->cg_tmp.p, warm, (const double *)w->cg_M.p,
-         w->cg_r.p, w->cg_z.p, w->cg_p.p, w->stgs->rho_y, cg_tol_factor(w, iter), d, w->part.p, w->NB, w->ctl.p);
+  const Ctl *ctl = w->ctl.p;
+  if (!w->dist) {
+    if (warm) launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_At, w->NB, BS, w->dAt.view(), warm, w->cg_tmp.p, ctl);
+    launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_A, w->NB, BS, w->dA.view(), rhs, (const double *)w->cg_tmp.p, warm, (const double *)w->cg_M.p,
+           w->cg_r.p, w->cg_z.p, w->cg_p.p, w->stgs->rho_y, cg_tol_factor(w, iter), d, w->part.p, w->NB, w->ctl.p, (const double *)nullptr);
+    return 0;
+  }
+  enqueue_fold(w, {S_BN});
+  if (warm) {
+    launch(w, ABIP_HIP_K_CG_EDGE, k_spmv_set, w->NB, BS, w->dAt.view(), warm, w->T.p, 0, ctl);
+    if (allreduce_vec_and_scalars(w)) return -1;
+  } else if (allreduce_scalars(w)) return -1;
+  launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_A, w->NB, BS, w->dA.view(), rhs, (const double *)w->T.p, warm, (const double *)w->cg_M.p,
+         w->cg_r.p, w->cg_z.p, w->cg_p.p, w->stgs->rho_y, cg_tol_factor(w, iter), d, w->part.p, w->NB, w->ctl.p, (const double *)w->gs);
+  return 0;
 }
-void enqueue_cg_chunk(W *w, double *rhs, int its) {
-  const int max_its = (int)w->m; // indirect.c:418
+int enqueue_cg_chunk(W *w, double *rhs, int its) {
+  const int max_its = (int)w->m_glob; // indirect.c:418: at most m iterations
+  const int gvec = std::max(1, std::min(w->NB, (int)((w->m + 2 * BS - 1) / (2 * BS))));
   for (int q = 0; q < its; ++q) {
     w->ev_tag = w->cg_enq++;
-    launch(w, ABIP_HIP_K_SPMV_AT, k_cg_spmv_At, w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, w->cg_tmp.p,
-           max_its, w->part.p, w->NB, w->ctl.p);
+    if (!w->dist) {
+      launch(w, ABIP_HIP_K_SPMV_AT, k_cg_spmv_At, w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, w->cg_tmp.p,
+             max_its, w->part.p, w->NB, w->ctl.p);
+    } else {
+      enqueue_fold(w, {S_RR0, S_RR1, S_ZR0, S_ZR1});
+      launch(w, ABIP_HIP_K_SPMV_AT, k_spmv_set, w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, w->T.p, 1, (const Ctl *)w->ctl.p);
+      if (allreduce_vec_and_scalars(w)) return -1;
+      launch(w, ABIP_HIP_K_CG_VEC, k_dist_cg_step, w->NB, BS, (const double *)w->T.p, w->cg_tmp.p, (int)w->n, max_its, 1, (const double *)w->gs, w->ctl.p);
+    }
     launch(w, ABIP_HIP_K_SPMV_A, k_cg_spmv_A, w->NB, BS, w->dA.view(), (const double *)w->cg_tmp.p, (const double *)w->cg_z.p, w->cg_p.p,
            w->cg_Gp.p, w->stgs->rho_y, w->part.p, (const Ctl *)w->ctl.p);
-    launch(w, ABIP_HIP_K_CG_VEC, k_cg_update, std::max(1, std::min(w->NB, (int)((w->m + 2 * BS - 1) / (2 * BS)))), BS, rhs, w->cg_r.p, w->cg_z.p, (const double *)w->cg_p.p, (const double *)w->cg_Gp.p,
-           (const double *)w->cg_M.p, (int)w->m, w->part.p, w->NB, w->ctl.p);
+    if (w->dist) { enqueue_fold(w, {S_PG}); if (allreduce_scalars(w)) return -1; }
+    launch(w, ABIP_HIP_K_CG_VEC, k_cg_update, gvec, BS, rhs, w->cg_r.p, w->cg_z.p, (const double *)w->cg_p.p, (const double *)w->cg_Gp.p,
+           (const double *)w->cg_M.p, (int)w->m, w->part.p, w->NB, w->ctl.p, (const double *)w->gs);
   }
   w->ev_tag = -1;
+  return 0;
 }
-void enqueue_cg_post(W *w, double *rhs) {
-  launch(w, ABIP_HIP_K_CG_EDGE, k_post_At, w->NB, BS, w->dAt.view(), rhs, (const double *)w->h.p, dims(w), (int)w->m, w->part.p, w->NB, w->ctl.p);
+int enqueue_cg_post(W *w, double *rhs) {
+  if (!w->dist) {
+    launch(w, ABIP_HIP_K_CG_EDGE, k_post_At, w->NB, BS, w->dAt.view(), rhs, (const double *)w->h.p, dims(w), (int)w->m_glob, w->part.p, w->NB, w->ctl.p);
+    return 0;
+  }
+  // late convergence decision on the summed ||r||^2, then (only if converged) the back-substitution A'y
+  enqueue_fold(w, {S_RR0, S_RR1, S_ZR0, S_ZR1});
+  if (allreduce_scalars(w)) return -1;
+  launch(w, ABIP_HIP_K_CG_VEC, k_dist_cg_step, 1, BS, (const double *)w->T.p, w->cg_tmp.p, (int)w->n, (int)w->m_glob, 0, (const double *)w->gs, w->ctl.p);
+  launch(w, ABIP_HIP_K_CG_EDGE, k_spmv_set, w->NB, BS, w->dAt.view(), (const double *)rhs, w->T.p, 2, (const Ctl *)w->ctl.p);
+  if (allreduce_vec_and_scalars(w)) return -1;
+  launch(w, ABIP_HIP_K_CG_EDGE, k_dist_post, w->NB, BS, (const double *)w->T.p, rhs, (const double *)w->h.p, dims(w), w->xwt, w->part.p, (const Ctl *)w->ctl.p);
+  enqueue_fold(w, {S_DH});
+  if (allreduce_scalars(w)) return -1;
+  return 0;
 }
 void enqueue_direct(W *w, double *rhs) {
   const int N = (int)(w->m + w->n);
@@ -269,7 +382,12 @@ void enqueue_direct(W *w, double *rhs) {
   launch(w, ABIP_HIP_K_VEC, k_post_dot, w->NB, BS, (const double *)rhs, (const double *)w->h.p, dims(w), w->part.p, ctl);
 }
 
-int next_chunk(const W *w) { return std::max(2, std::min((int)w->m, w->last_cg_its + (w->last_cg_its >> 2) + 2)); }
+// CG iterations to enqueue blind.  Single GPU: generous (a launch past convergence costs ~3.6 us).  Multi-GPU: tight --
+// a collective past convergence cannot be gated on the device, so over-enqueueing costs real all-reduces.
+int next_chunk(const W *w) {
+  if (w->dist) return std::max(1, std::min((int)w->m_glob, w->last_cg_its - 1));
+  return std::max(2, std::min((int)w->m_glob, w->last_cg_its + (w->last_cg_its >> 2) + 2));
+}
 
 // Solve K z = rhs in place and leave S_DH = z[0:l-1)'h; synchronises with the host (used outside the hot loop:
 // the set-up solve for g and the BB look-ahead).  Returns CG iterations, <0 on error.
@@ -281,14 +399,14 @@ int kkt_solve_sync(W *w, double *rhs, const double *warm, abip_int iter) {
     if (sync_ctl(w)) return -1;
     return 0;
   }
-  enqueue_cg_begin(w, rhs, warm, iter);
+  if (enqueue_cg_begin(w, rhs, warm, iter)) return -1;
   int chunk = next_chunk(w);
   for (;;) {
-    enqueue_cg_chunk(w, rhs, chunk);
-    enqueue_cg_post(w, rhs);
+    if (enqueue_cg_chunk(w, rhs, chunk)) return -1;
+    if (enqueue_cg_post(w, rhs)) return -1;
     if (sync_ctl(w)) return -1;
     if (w->hctl->cg_done) break;
-    chunk = std::max(4, chunk);
+    chunk = w->dist ? 2 : std::max(4, chunk);
   }
   const int its = w->hctl->cg_it;
   w->last_cg_its = its;
@@ -333,25 +451,49 @@ abip_int has_converged(const W *w, abip_int ipm_iter, abip_int admm_iter) { // a
 // ------------------------------------------------------------------------------------------------
 // statistics pass on the current iterate(s): the two residual SpMVs + finalise + control read
 // ------------------------------------------------------------------------------------------------
-void enqueue_q_and_finalize(W *w, bool avg_stats) {
+int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty) {
   const Dims d = dims(w);
   const Ctl *ctl = w->ctl.p;
   const double *wD = w->stgs->normalize ? w->wD.p : nullptr, *wE = w->stgs->normalize ? w->wE.p : nullptr;
-  launch(w, ABIP_HIP_K_QNORM, k_q_A, w->NB, BS, w->dA.view(), (const double *)w->u.p, (const double *)w->b.p, wD, d, (int)S_QP, w->part.p, ctl);
-  launch(w, ABIP_HIP_K_QNORM, k_q_At, w->NB, BS, w->dAt.view(), (const double *)w->u.p, (const double *)w->v.p, (const double *)w->c.p, wE, d, (int)S_QD, w->part.p, ctl);
   FinArgs f;
   int ns = 0;
   const int base[] = {S_NU, S_NV, S_CX, S_BY, S_QP, S_RP, S_NAX, S_QD, S_RD, S_NATY};
+  const int extra[] = {S_NUA, S_NVA, S_CXA, S_BYA, S_QPA, S_RPA, S_NAXA, S_QDA, S_RDA, S_NATYA};
   for (int s : base) f.slots[ns++] = s;
+  launch(w, ABIP_HIP_K_QNORM, k_q_A, w->NB, BS, w->dA.view(), (const double *)w->u.p, (const double *)w->b.p, wD, d, (int)S_QP, w->part.p, ctl);
+  if (!w->dist) {
+    launch(w, ABIP_HIP_K_QNORM, k_q_At, w->NB, BS, w->dAt.view(), (const double *)w->u.p, (const double *)w->v.p, (const double *)w->c.p, wE, d, (int)S_QD, w->part.p, ctl);
+  } else {
+    if (!T_holds_Aty) { // A'u_y differs from the A'u_t,y the back-substitution left in T (v_y != 0): one more partial + all-reduce
+      launch(w, ABIP_HIP_K_QNORM, k_spmv_set, w->NB, BS, w->dAt.view(), (const double *)w->u.p, w->T.p, 2, ctl);
+      if (allreduce_vec_and_scalars(w)) return -1;
+    }
+    launch(w, ABIP_HIP_K_QNORM, k_dist_q, w->NB, BS, (const double *)w->T.p, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->c.p, wE, d,
+           (int)S_QD, w->xwt, w->part.p, ctl);
+  }
   if (avg_stats) {
     launch(w, ABIP_HIP_K_QNORM, k_q_A, w->NB, BS, w->dA.view(), (const double *)w->u_avgc.p, (const double *)w->b.p, wD, d, (int)S_QPA, w->part.p, ctl);
-    launch(w, ABIP_HIP_K_QNORM, k_q_At, w->NB, BS, w->dAt.view(), (const double *)w->u_avgc.p, (const double *)w->v_avgc.p, (const double *)w->c.p, wE, d, (int)S_QDA, w->part.p, ctl);
-    const int extra[] = {S_NUA, S_NVA, S_CXA, S_BYA, S_QPA, S_RPA, S_NAXA, S_QDA, S_RDA, S_NATYA};
+    if (!w->dist) {
+      launch(w, ABIP_HIP_K_QNORM, k_q_At, w->NB, BS, w->dAt.view(), (const double *)w->u_avgc.p, (const double *)w->v_avgc.p, (const double *)w->c.p, wE, d, (int)S_QDA, w->part.p, ctl);
+    } else {
+      launch(w, ABIP_HIP_K_QNORM, k_spmv_set, w->NB, BS, w->dAt.view(), (const double *)w->u_avgc.p, w->T.p, 2, ctl);
+      if (allreduce_vec_and_scalars(w)) return -1;
+      launch(w, ABIP_HIP_K_QNORM, k_dist_q, w->NB, BS, (const double *)w->T.p, (const double *)w->u_avgc.p, (const double *)w->v_avgc.p, (const double *)w->c.p, wE, d,
+             (int)S_QDA, w->xwt, w->part.p, ctl);
+    }
     for (int s : extra) f.slots[ns++] = s;
   }
   f.nslots = ns;
-  f.u = w->u.p; f.v = w->v.p; f.ua = w->u_avgc.p; f.va = w->v_avgc.p;
+  f.u = w->u.p; f.v = w->v.p; f.ua = w->u_avgc.p; f.va = w->v_avgc.p; f.gs = w->gs;
+  if (w->dist) {
+    FoldArgs fo; fo.nslots = ns;
+    for (int q = 0; q < ns; ++q) fo.slots[q] = f.slots[q];
+    fo.slots[fo.nslots++] = S_WG; // the next k_rhs needs it summed over the ranks as well
+    launch(w, ABIP_HIP_K_VEC, k_fold, 1, BS, fo, (const double *)w->part.p, w->NB, w->gs);
+    if (allreduce_scalars(w)) return -1;
+  }
   launch(w, ABIP_HIP_K_VEC, k_finalize, 1, BS, f, d, (const double *)w->part.p, w->NB, w->ctl.p);
+  return 0;
 }
 
 UpdArgs upd_args(W *w, bool fuse_avg, bool avg_stats) {
@@ -360,6 +502,7 @@ UpdArgs upd_args(W *w, bool fuse_avg, bool avg_stats) {
   a.u_avg = w->u_avg.p; a.v_avg = w->v_avg.p; a.u_sum = w->u_sum.p; a.v_sum = w->v_sum.p; a.u_avgc = w->u_avgc.p; a.v_avgc = w->v_avgc.p;
   a.g = w->g.p; a.b = w->b.p; a.c = w->c.p;
   a.alpha = w->stgs->alpha; a.mu_over_beta = w->mu / w->beta; a.rho = w->stgs->rho_y; a.dom = (double)(w->j + 1);
+  a.xw = w->xwt; a.gs = w->gs;
   a.half_update = (int)w->stgs->half_update; a.fuse_avg = fuse_avg ? 1 : 0; a.avg_stats = avg_stats ? 1 : 0;
   return a;
 }
@@ -371,35 +514,40 @@ int admm_iteration(W *w, double *metric_out) {
   const Dims d = dims(w);
   const Ctl *ctl = w->ctl.p;
   ABIPSettings *st = w->stgs;
-  if (!w->wg_valid) launch(w, ABIP_HIP_K_VEC, k_dot_wg, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->g.p, st->rho_y, d, w->part.p);
+  if (!w->wg_valid) {
+    launch(w, ABIP_HIP_K_VEC, k_dot_wg, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->g.p, st->rho_y, d, w->part.p, w->xwt);
+    if (w->dist) { enqueue_fold(w, {S_WG}); if (allreduce_scalars(w)) return -1; }
+  }
   launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, w->ut.p, (const double *)w->h.p, st->rho_y, w->g_th, d,
-         w->part.p, w->NB, ctl);
+         w->part.p, w->NB, ctl, (const double *)w->gs);
   const bool avg_stats = ((w->j + 1) % 10 == 0);                                                   // abip.c:2000
   const bool restart = !(w->k < st->restart_thresh || (w->j + 1 - w->fre_old) % st->restart_fre != 0); // abip.c:608-609
+  int err = 0;
   auto tail = [&]() {
     launch(w, ABIP_HIP_K_VEC, k_admm_update, w->NB, BS, upd_args(w, !restart, avg_stats), d, w->part.p, w->NB, ctl);
     if (restart) {
       launch(w, ABIP_HIP_K_VEC, k_restart_apply, w->NB, BS, w->u.p, w->v.p, w->u_avg.p, w->v_avg.p, (double)st->restart_fre, w->LV);
       launch(w, ABIP_HIP_K_VEC, k_avg_stats, w->NB, BS, upd_args(w, true, avg_stats), d, w->part.p, ctl);
     }
-    enqueue_q_and_finalize(w, avg_stats);
+    // T still holds A'u_t,y from the back-substitution; it equals A'u_y iff v_y == 0 and (u, v) were not replaced by the restart mean
+    if (enqueue_q_and_finalize(w, avg_stats, w->vy_zero && !restart)) err = -1;
   };
   w->tot_solves++;
   w->prof.kkt_solves++;
   if (w->linsys == ABIP_HIP_LINSYS_DIRECT) {
     enqueue_direct(w, w->ut.p);
     tail();
-    if (sync_ctl(w)) return -1;
+    if (err || sync_ctl(w)) return -1;
   } else {
-    enqueue_cg_begin(w, w->ut.p, w->u.p, w->k); // warm start = current u[0:m), abip.c:559
+    if (enqueue_cg_begin(w, w->ut.p, w->u.p, w->k)) return -1; // warm start = current u[0:m), abip.c:559
     int chunk = next_chunk(w);
     for (;;) {
-      enqueue_cg_chunk(w, w->ut.p, chunk);
-      enqueue_cg_post(w, w->ut.p);
+      if (enqueue_cg_chunk(w, w->ut.p, chunk)) return -1;
+      if (enqueue_cg_post(w, w->ut.p)) return -1;
       tail();
-      if (sync_ctl(w)) return -1;
+      if (err || sync_ctl(w)) return -1;
       if (w->hctl->cg_done) break;
-      chunk = std::max(4, chunk); // not converged inside the chunk: everything behind it was a no-op; go on
+      chunk = w->dist ? 2 : std::max(4, chunk); // not converged inside the chunk: everything behind it was a no-op; go on
     }
     w->last_cg_its = w->hctl->cg_it;
     w->tot_cg_its += w->hctl->cg_it;
@@ -477,6 +625,7 @@ int update_barrier_dynamic(W *w) { // LOQO, abip.c:930-977
   launch(w, ABIP_HIP_K_VEC, k_xs, w->NB, BS, uu, vv, dims(w), w->part.p);
   launch(w, ABIP_HIP_K_VEC, k_min_fold, 1, 1, (const double *)w->part.p, w->NB, w->ctl.p);
   FinArgs f; f.nslots = 1; f.slots[0] = S_XS; f.u = w->u.p; f.v = w->v.p; f.ua = w->u_avgc.p; f.va = w->v_avgc.p;
+  f.gs = nullptr; // (x, tau) are replicated: every rank computes the same sum and minimum, nothing to exchange
   launch(w, ABIP_HIP_K_VEC, k_finalize, 1, BS, f, dims(w), (const double *)w->part.p, w->NB, w->ctl.p);
   if (sync_ctl(w)) return -2;
   double xs = w->hctl->out[S_XS];
@@ -503,8 +652,10 @@ void reinitialize_vars(W *w, int indx) { // abip.c:996-1075
 // ------------------------------------------------------------------------------------------------
 int lin_projection(W *w, double *ut, const double *u, const double *v, abip_int iter) { // abip.c:552-560 on scratch vectors
   const Dims d = dims(w);
-  launch(w, ABIP_HIP_K_VEC, k_dot_wg, w->NB, BS, u, v, (const double *)w->g.p, w->stgs->rho_y, d, w->part.p);
-  launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, u, v, ut, (const double *)w->h.p, w->stgs->rho_y, w->g_th, d, w->part.p, w->NB, (const Ctl *)w->ctl.p);
+  launch(w, ABIP_HIP_K_VEC, k_dot_wg, w->NB, BS, u, v, (const double *)w->g.p, w->stgs->rho_y, d, w->part.p, w->xwt);
+  if (w->dist) { enqueue_fold(w, {S_WG}); if (allreduce_scalars(w)) return -1; }
+  launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, u, v, ut, (const double *)w->h.p, w->stgs->rho_y, w->g_th, d, w->part.p, w->NB, (const Ctl *)w->ctl.p,
+         (const double *)w->gs);
   return kkt_solve_sync(w, ut, u, iter) < 0 ? -1 : 0; // S_DH is left for k_adapt_step
 }
 int adaptive_search(W *w, abip_int iter) {
@@ -517,16 +668,17 @@ int adaptive_search(W *w, abip_int iter) {
   for (abip_int it = 0; it < st->adaptive_lookback; ++it) {
     if (lin_projection(w, w->a_ut.p, w->a_up.p, w->a_vp.p, iter)) return -1;
     launch(w, ABIP_HIP_K_VEC, k_adapt_step, w->NB, BS, (const double *)w->a_ut.p, w->a_ut.p, (const double *)w->a_up.p, (const double *)w->a_vp.p,
-           w->a_u.p, w->a_v.p, st->alpha, w->mu / beta_prev, d, (const double *)w->part.p, w->NB);
+           w->a_u.p, w->a_v.p, st->alpha, w->mu / beta_prev, d, (const double *)w->part.p, w->NB, (const double *)w->gs);
     if (lin_projection(w, w->a_utn.p, w->a_u.p, w->a_v.p, iter)) return -1;
     launch(w, ABIP_HIP_K_VEC, k_adapt_step, w->NB, BS, (const double *)w->a_utn.p, w->a_utn.p, (const double *)w->a_u.p, (const double *)w->a_v.p,
-           w->a_un.p, w->a_vn.p, st->alpha, w->mu / beta_prev, d, (const double *)w->part.p, w->NB);
+           w->a_un.p, w->a_vn.p, st->alpha, w->mu / beta_prev, d, (const double *)w->part.p, w->NB, (const double *)w->gs);
     launch(w, ABIP_HIP_K_VEC, k_adapt_dots, w->NB, BS, (const double *)w->a_u.p, (const double *)w->a_v.p, (const double *)w->a_un.p,
-           (const double *)w->a_vn.p, (const double *)w->a_vp.p, st->alpha, d, w->part.p);
+           (const double *)w->a_vn.p, (const double *)w->a_vp.p, st->alpha, d, w->part.p, w->xwt);
+    if (w->dist) { enqueue_fold(w, {S_A0, S_A1, S_A2, S_A3, S_A4}); if (allreduce_scalars(w)) return -1; }
     FinArgs f; f.nslots = 5;
     const int sl[5] = {S_A0, S_A1, S_A2, S_A3, S_A4};
     for (int q = 0; q < 5; ++q) f.slots[q] = sl[q];
-    f.u = w->u.p; f.v = w->v.p; f.ua = nullptr; f.va = nullptr;
+    f.u = w->u.p; f.v = w->v.p; f.ua = nullptr; f.va = nullptr; f.gs = w->gs;
     launch(w, ABIP_HIP_K_VEC, k_finalize, 1, BS, f, d, (const double *)w->part.p, w->NB, w->ctl.p);
     if (sync_ctl(w)) return -1;
     const double utut = w->hctl->out[S_A0], utv = w->hctl->out[S_A1], uu = w->hctl->out[S_A2], vv = w->hctl->out[S_A3], uv = w->hctl->out[S_A4];
@@ -563,6 +715,32 @@ bool st_solved(abip_int s) { return s == ABIP_SOLVED || s == ABIP_SOLVED_INACCUR
 bool st_infeas(abip_int s) { return s == ABIP_INFEASIBLE || s == ABIP_INFEASIBLE_INACCURATE; }
 bool st_unbdd(abip_int s) { return s == ABIP_UNBOUNDED || s == ABIP_UNBOUNDED_INACCURATE; }
 
+// multi-GPU helpers off the hot path: sum a few host scalars over the ranks; assemble the full y from the row blocks
+int allreduce_host(W *w, double *vals, int cnt) {
+  if (!w->dist) return 0;
+  DBuf<double> tmp;
+  if (tmp.alloc(cnt)) return -1;
+  HIP_OK(hipMemcpyAsync(tmp.p, vals, sizeof(double) * cnt, hipMemcpyHostToDevice, w->stream));
+  if (allreduce_dev(w, tmp.p, cnt)) return -1;
+  HIP_OK(hipMemcpyAsync(vals, tmp.p, sizeof(double) * cnt, hipMemcpyDeviceToHost, w->stream));
+  HIP_OK(hipStreamSynchronize(w->stream));
+  tmp.release();
+  return 0;
+}
+int gather_rows(W *w, const double *local /* m */, std::vector<double> &full /* m_glob */) {
+  full.assign(w->m_glob, 0.0);
+  std::copy(local, local + w->m, full.begin() + w->row0);
+  if (!w->dist) return 0;
+  DBuf<double> tmp;
+  if (tmp.alloc(w->m_glob)) return -1;
+  HIP_OK(hipMemcpyAsync(tmp.p, full.data(), sizeof(double) * w->m_glob, hipMemcpyHostToDevice, w->stream));
+  if (allreduce_dev(w, tmp.p, w->m_glob)) return -1;
+  HIP_OK(hipMemcpyAsync(full.data(), tmp.p, sizeof(double) * w->m_glob, hipMemcpyDeviceToHost, w->stream));
+  HIP_OK(hipStreamSynchronize(w->stream));
+  tmp.release();
+  return 0;
+}
+
 int ensure_stats(W *w) { // make ctl.out describe the CURRENT iterate and the averaged one (off the hot path:
                          // only after an out-of-band change of (u, v) such as the half-update clip, or for a mid-run snapshot)
   if (w->stats_valid && (!w->stgs->avg_criterion || w->avg_stats_valid)) return 0;
@@ -575,12 +753,13 @@ int ensure_stats(W *w) { // make ctl.out describe the CURRENT iterate and the av
   const int zero = 0, one = 1;
   HIP_OK(hipMemcpyAsync(&w->ctl.p->halt, &zero, sizeof(int), hipMemcpyHostToDevice, w->stream));
   HIP_OK(hipMemcpyAsync(&w->ctl.p->cg_done, &one, sizeof(int), hipMemcpyHostToDevice, w->stream));
-  enqueue_q_and_finalize(w, true);
+  if (enqueue_q_and_finalize(w, true, false)) return -1;
   if (sync_ctl(w)) return -1;
   double *o = w->hctl->out;
   double by = 0, cx = 0, bya = 0, cxa = 0;
   for (abip_int i = 0; i < w->m; ++i) { by += hb[i] * hu[i]; bya += hb[i] * hua[i]; }
   for (abip_int j = 0; j < w->n; ++j) { cx += hc[j] * hu[w->MP + j]; cxa += hc[j] * hua[w->MP + j]; }
+  { double yy[2] = {by, bya}; if (allreduce_host(w, yy, 2)) return -1; by = yy[0]; bya = yy[1]; } // y is sharded, x replicated
   o[S_BY] = by; o[S_CX] = cx; o[S_BYA] = bya; o[S_CXA] = cxa;
   w->stats_valid = true; w->avg_stats_valid = true;
   w->r.last_admm_iter = -1;
@@ -594,14 +773,14 @@ void fail_fill(W *w, ABIPInfo *info, abip_int status_val, const char *ststr) { /
     strcpy(info->status, ststr);
   }
   if (w) {
-    w->sol_x.assign(w->n, NAN); w->sol_y.assign(w->m, NAN); w->sol_s.assign(w->n, NAN);
+    w->sol_x.assign(w->n, NAN); w->sol_y.assign(w->m_glob, NAN); w->sol_s.assign(w->n, NAN);
     w->have_solution = true;
     if (info) w->last_info = *info;
   }
 }
 
 int finish_solution(W *w, ABIPInfo *info, abip_int ipm_iter, abip_int admm_iter) {
-  const abip_int m = w->m, n = w->n, l = m + n + 1;
+  const abip_int m = w->m, n = w->n, l = w->m_glob + n + 1;
   ABIPSettings *st = w->stgs;
   if (ensure_stats(w)) return -1;
   calc_residuals(w, ipm_iter, admm_iter);
@@ -612,12 +791,14 @@ int finish_solution(W *w, ABIPInfo *info, abip_int ipm_iter, abip_int admm_iter)
   HIP_OK(hipMemcpyAsync(hv.data(), avg ? w->v_avgc.p : w->v.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream));
   HIP_OK(hipStreamSynchronize(w->stream));
   w->sol_x.assign(hu.begin() + w->MP, hu.begin() + w->MP + n);
-  w->sol_y.assign(hu.begin(), hu.begin() + m);
+  if (gather_rows(w, hu.data(), w->sol_y)) return -1;
   w->sol_s.assign(hv.begin() + w->MP, hv.begin() + w->MP + n);
   int kind; // 0 solved, 1 indeterminate, 2 infeasible, 3 unbounded
   if (info->status_val == ABIP_UNFINISHED) {
-    double nrm2 = 0;
-    for (abip_int i = 0; i < m; ++i) nrm2 += hu[i] * hu[i];
+    double nrm2 = 0, ny = 0;
+    for (abip_int i = 0; i < m; ++i) ny += hu[i] * hu[i];
+    if (allreduce_host(w, &ny, 1)) return -1;
+    nrm2 = ny;
     for (abip_int j = 0; j <= n; ++j) nrm2 += hu[w->MP + j] * hu[w->MP + j];
     if (r.tau > 1e-9 && r.tau > r.kap) kind = 0;
     else if (std::sqrt(nrm2) < 1e-9 * std::sqrt((double)l)) kind = 1;
@@ -648,7 +829,7 @@ int finish_solution(W *w, ABIPInfo *info, abip_int ipm_iter, abip_int admm_iter)
   }
   if (st->normalize) { // un_normalize_sol, normalize.c:133-158
     for (abip_int j = 0; j < n; ++j) w->sol_x[j] /= (w->E[j] * w->sc_b);
-    for (abip_int i = 0; i < m; ++i) w->sol_y[i] /= (w->D[i] * w->sc_c);
+    for (abip_int i = 0; i < w->m_glob; ++i) w->sol_y[i] /= (w->D[i] * w->sc_c);
     for (abip_int j = 0; j < n; ++j) w->sol_s[j] *= w->E[j] / (w->sc_c * st->scale);
   }
   info->ipm_iter = ipm_iter + 1; info->admm_iter = admm_iter + 1; // get_info, abip.c:1296-1340
@@ -732,7 +913,7 @@ void free_work(W *w) {
                           &w->wD, &w->wE, &w->cg_p, &w->cg_r, &w->cg_Gp, &w->cg_z, &w->cg_M, &w->cg_tmp, &w->a_up, &w->a_vp, &w->a_ut, &w->a_u,
                           &w->a_v, &w->a_utn, &w->a_un, &w->a_vn, &w->part, &w->Dg, &w->xw};
   for (auto *b : bufs) b->release();
-  w->ctl.release(); w->Pmap.release(); w->triF.release(); w->triB.release();
+  w->ctl.release(); w->Pmap.release(); w->triF.release(); w->triB.release(); w->T.release();
   if (w->hctl) (void)hipHostFree(w->hctl);
   for (auto &e : w->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (w->stream) (void)hipStreamDestroy(w->stream);
@@ -826,19 +1007,50 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
   W *w = new W();
   w->linsys = chosen_linsys();
   if (d->stgs->verbose) print_init_header(d, w->linsys);
-  w->stgs = d->stgs; w->m = d->m; w->n = d->n; w->A = d->A; w->sp = d->sp;
-  const abip_int m = d->m, n = d->n;
+  w->stgs = d->stgs; w->n = d->n; w->A = d->A; w->sp = d->sp;
+  w->m_glob = d->m; w->m = d->m; w->row0 = 0;
+  const abip_int n = d->n;
+  auto fail = [&](const char *msg) -> ABIPWork * { printf("ERROR: %s\n", msg); free_work(w); return nullptr; };
+  if (hipStreamCreate(&w->stream) != hipSuccess) return fail("hipStreamCreate failed");
+  if (w->stgs->normalize) host::normalize_A(w->A, w->stgs, w->D, w->E, &w->mean_norm_row_A, &w->mean_norm_col_A);
+  // multi-GPU: the PCG back-end keeps only this rank's block of rows (the direct back-end does not shard: replicas)
+  w->dist = (g_dist.kind != 0) && (w->linsys == ABIP_HIP_LINSYS_INDIRECT);
+  const ABIPMatrix *Ause = w->A;
+  if (w->dist) {
+    w->rank = g_dist.rank; w->world = g_dist.world; w->xwt = (w->rank == 0) ? 1.0 : 0.0;
+    const abip_int mg = d->m, nnz = w->A->p[n];
+    if (mg < w->world) return fail("fewer rows than ranks");
+    std::vector<abip_int> bounds(w->world + 1);
+    if (abip_hip_dist_partition(w->A, w->world, bounds.data()) != 0) return fail("row partition failed");
+    const abip_int r0 = bounds[w->rank], r1 = bounds[w->rank + 1];
+    (void)nnz;
+    w->row0 = r0; w->m = r1 - r0;
+    w->Aloc_p.assign(n + 1, 0);
+    for (abip_int j = 0; j < n; ++j) {
+      abip_int c = 0;
+      for (abip_int q = w->A->p[j]; q < w->A->p[j + 1]; ++q) c += (w->A->i[q] >= r0 && w->A->i[q] < r1);
+      w->Aloc_p[j + 1] = w->Aloc_p[j] + c;
+    }
+    w->Aloc_i.resize(std::max<abip_int>(w->Aloc_p[n], 1)); w->Aloc_x.resize(std::max<abip_int>(w->Aloc_p[n], 1));
+    for (abip_int j = 0, t = 0; j < n; ++j)
+      for (abip_int q = w->A->p[j]; q < w->A->p[j + 1]; ++q)
+        if (w->A->i[q] >= r0 && w->A->i[q] < r1) { w->Aloc_i[t] = w->A->i[q] - r0; w->Aloc_x[t] = w->A->x[q]; ++t; }
+    w->Aloc.x = w->Aloc_x.data(); w->Aloc.i = w->Aloc_i.data(); w->Aloc.p = w->Aloc_p.data(); w->Aloc.m = w->m; w->Aloc.n = n;
+    Ause = &w->Aloc;
+    w->n_pad = ((size_t)n + 31) / 32 * 32; // scalars start 256-byte aligned behind the n-vector
+    if (w->T.alloc(w->n_pad + S_COUNT)) return fail("work memory allocation failure");
+    if (hipMemsetAsync(w->T.p, 0, sizeof(double) * (w->n_pad + S_COUNT), w->stream) != hipSuccess) return fail("memset failure");
+    w->gs = w->T.p + w->n_pad;
+  }
+  const abip_int m = w->m; // rows on this device
   w->MP = (int)(((m + 31) / 32) * 32);
   w->LV = w->MP + (int)n + 1;
   w->LV = ((w->LV + 31) / 32) * 32;
   w->NB = 1; // fixed below, once the row blocks are known
-  auto fail = [&](const char *msg) -> ABIPWork * { printf("ERROR: %s\n", msg); free_work(w); return nullptr; };
-  if (hipStreamCreate(&w->stream) != hipSuccess) return fail("hipStreamCreate failed");
-  if (w->stgs->normalize) host::normalize_A(w->A, w->stgs, w->D, w->E, &w->mean_norm_row_A, &w->mean_norm_col_A);
   // device images of the (scaled) matrix
   host::HostCsr hAt, hA;
-  host::csc_as_csr(w->A, hAt); host::build_row_blocks(hAt, CHUNK);
-  host::transpose_to_csr(w->A, hA); host::build_row_blocks(hA, CHUNK);
+  host::csc_as_csr(Ause, hAt); host::build_row_blocks(hAt, CHUNK);
+  host::transpose_to_csr(Ause, hA); host::build_row_blocks(hA, CHUNK);
   if (w->dAt.upload(hAt, w->stream) || w->dA.upload(hA, w->stream)) return fail("device allocation failure (matrix)");
   { // persistent grid: every kernel uses the same NB (== partials per slot).  Sized so that the SpMV kernels give each
     // workgroup the same whole number of row blocks (no tail), at most MAXNB (8 workgroups per CU on 256 CUs).
@@ -860,7 +1072,7 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
   memset(w->hctl, 0, sizeof(Ctl));
   if (w->linsys == ABIP_HIP_LINSYS_INDIRECT) { // init_lin_sys_work, indirect.c:282-318
     std::vector<double> Minv;
-    host::jacobi_preconditioner(w->A, Minv);
+    host::jacobi_preconditioner(Ause, Minv);
     if (w->cg_M.upload(Minv, w->stream) || w->cg_p.alloc(m) || w->cg_r.alloc(m) || w->cg_Gp.alloc(m) || w->cg_z.alloc(m) || w->cg_tmp.alloc(n))
       return fail("init_lin_sys_work failure");
     if (hipMemsetAsync(w->cg_tmp.p, 0, sizeof(double) * n, w->stream) != hipSuccess) return fail("memset failure");
@@ -869,7 +1081,7 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
     if (host::factor_kkt(w->A, w->stgs->rho_y, F) < 0) return fail("init_lin_sys_work failure");
     w->lnnz = F.lnnz;
     std::vector<int> pmap(F.N);
-    for (int q = 0; q < F.N; ++q) pmap[q] = F.P[q] < m ? F.P[q] : w->MP + (F.P[q] - (int)m);
+    for (int q = 0; q < F.N; ++q) pmap[q] = F.P[q] < (int)m ? F.P[q] : w->MP + (F.P[q] - (int)m);
     if (w->Pmap.upload(pmap, w->stream) || w->Dg.upload(F.D, w->stream) || w->xw.alloc(F.N) || w->triF.upload(F.fwd, w->stream) ||
         w->triB.upload(F.bwd, w->stream))
       return fail("init_lin_sys_work failure");
@@ -887,31 +1099,31 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
 abip_int abip_hip_solve_begin(ABIPWork *w, const ABIPData *d, const ABIPSolution *sol, ABIPInfo *info) { // update_work, abip.c:1843-1927
   if (!w || !d || !info || !d->b || !d->c) { printf("ERROR: ABIP_NULL input\n"); return ABIP_FAILED; }
   ABIPSettings *st = w->stgs;
-  const abip_int m = w->m, n = w->n;
+  const abip_int m = w->m, n = w->n, mg = w->m_glob, r0 = w->row0; // m: rows on this device, mg: rows of the problem
   w->t_solve0 = now_ms(); w->cpu0 = (double)clock();
   info->status_val = ABIP_UNFINISHED; w->status = 0;
   w->r = Resid();
-  std::vector<double> hb(d->b, d->b + m), hc(d->c, d->c + n);
+  std::vector<double> hb(d->b, d->b + mg), hc(d->c, d->c + n);
   auto nrm = [](const std::vector<double> &v) { double s = 0; for (double x : v) s += x * x; return std::sqrt(s); };
   w->nm_b = nrm(hb); w->nm_c = nrm(hc);
   if (st->normalize) { // normalize_b_c, normalize.c:11-40
     for (abip_int j = 0; j < n; ++j) hc[j] /= w->E[j];
     w->sc_c = w->mean_norm_row_A / std::max(nrm(hc), 1e-3);
-    for (abip_int i = 0; i < m; ++i) hb[i] /= w->D[i];
+    for (abip_int i = 0; i < mg; ++i) hb[i] /= w->D[i];
     w->sc_b = w->mean_norm_col_A / std::max(nrm(hb), 1e-3);
     for (abip_int j = 0; j < n; ++j) hc[j] *= w->sc_c * st->scale;
-    for (abip_int i = 0; i < m; ++i) hb[i] *= w->sc_b * st->scale;
+    for (abip_int i = 0; i < mg; ++i) hb[i] *= w->sc_b * st->scale;
   } else { w->sc_b = 1; w->sc_c = 1; }
   const double mx = std::max(w->sp, st->sparsity_ratio), mn = std::min(w->sp, st->sparsity_ratio); // abip.c:1886-1900
   if (mx > 0.4 || (mn > 0.1 && mn < 0.2)) { w->sigma = 0.3; w->gamma = 2.0; }
   else if (mn > 0.2) { w->sigma = 0.5; w->gamma = 3.0; }
   else { w->sigma = 0.8; w->gamma = 3.0; }
   w->final_check = 0; w->double_check = 0; w->mu = 1.0; w->beta = 1.0;
-  HIP_OK(hipMemcpyAsync(w->b.p, hb.data(), sizeof(double) * m, hipMemcpyHostToDevice, w->stream));
+  HIP_OK(hipMemcpyAsync(w->b.p, hb.data() + r0, sizeof(double) * m, hipMemcpyHostToDevice, w->stream));
   HIP_OK(hipMemcpyAsync(w->c.p, hc.data(), sizeof(double) * n, hipMemcpyHostToDevice, w->stream));
   if (st->normalize) { // weights of the un-scaled residual norms, abip.c:409,445
     std::vector<double> wD(m), wE(n);
-    for (abip_int i = 0; i < m; ++i) wD[i] = w->D[i] / (w->sc_b * st->scale);
+    for (abip_int i = 0; i < m; ++i) wD[i] = w->D[r0 + i] / (w->sc_b * st->scale);
     for (abip_int j = 0; j < n; ++j) wE[j] = w->E[j] / (w->sc_c * st->scale);
     HIP_OK(hipMemcpyAsync(w->wD.p, wD.data(), sizeof(double) * m, hipMemcpyHostToDevice, w->stream));
     HIP_OK(hipMemcpyAsync(w->wE.p, wE.data(), sizeof(double) * n, hipMemcpyHostToDevice, w->stream));
@@ -921,13 +1133,15 @@ abip_int abip_hip_solve_begin(ABIPWork *w, const ABIPData *d, const ABIPSolution
   {
     std::vector<double> uy(m, 0.0), ux(n), vy(m, 0.0), vx(n);
     double ut = std::sqrt(w->mu / w->beta), vt = ut;
+    w->vy_zero = !st->half_update;
     if (st->warm_start && sol && sol->x && sol->y && sol->s) { // warm_start_vars, abip.c:307-357 (quirk kept: the loop overwrites the guess)
-      for (abip_int i = 0; i < m; ++i) { const double y = sol->y[i]; uy[i] = (y != y) ? 0.0 : std::sqrt(w->mu / w->beta); vy[i] = std::sqrt(w->mu / w->beta); }
+      w->vy_zero = false;
+      for (abip_int i = 0; i < m; ++i) { const double y = sol->y[r0 + i]; uy[i] = (y != y) ? 0.0 : std::sqrt(w->mu / w->beta); vy[i] = std::sqrt(w->mu / w->beta); }
       for (abip_int j = 0; j < n; ++j) { ux[j] = std::sqrt(w->mu / w->beta); const double s = sol->s[j]; vx[j] = (s != s) ? 0.0 : std::sqrt(w->mu / w->beta); }
       ut = std::sqrt(w->mu / w->beta); vt = std::sqrt(w->mu / w->beta);
       if (st->normalize) { // normalize_warm_start, normalize.c:101-128
         for (abip_int j = 0; j < n; ++j) ux[j] *= (w->E[j] * w->sc_b);
-        for (abip_int i = 0; i < m; ++i) uy[i] *= (w->D[i] * w->sc_c);
+        for (abip_int i = 0; i < m; ++i) uy[i] *= (w->D[r0 + i] * w->sc_c);
         for (abip_int j = 0; j < n; ++j) vx[j] /= (w->E[j] / (w->sc_c * st->scale));
       }
     } else { // cold_start_vars, abip.c:361-381
@@ -939,13 +1153,14 @@ abip_int abip_hip_solve_begin(ABIPWork *w, const ABIPData *d, const ABIPSolution
   // h = (-b, c); g = K^-1 h with the x block negated; g_th = h'g   (abip.c:1917-1924)
   {
     std::vector<double> hy(m);
-    for (abip_int i = 0; i < m; ++i) hy[i] = -hb[i];
+    for (abip_int i = 0; i < m; ++i) hy[i] = -hb[r0 + i];
     if (upload_lvec(w, w->h, hy.data(), hc.data(), 0.0) || upload_lvec(w, w->g, hy.data(), hc.data(), 0.0)) return ABIP_FAILED;
     launch(w, ABIP_HIP_K_VEC, k_norm_y, w->NB, BS, (const double *)w->g.p, dims(w), w->part.p);
     if (kkt_solve_sync(w, w->g.p, nullptr, -1) < 0) return ABIP_FAILED;
     launch(w, ABIP_HIP_K_VEC, k_neg_x, w->NB, BS, w->g.p, dims(w));
-    launch(w, ABIP_HIP_K_VEC, k_dot_full, w->NB, BS, (const double *)w->h.p, (const double *)w->g.p, dims(w), (int)S_T0, w->part.p);
-    FinArgs f; f.nslots = 1; f.slots[0] = S_T0; f.u = w->u.p; f.v = w->v.p; f.ua = nullptr; f.va = nullptr;
+    launch(w, ABIP_HIP_K_VEC, k_dot_full, w->NB, BS, (const double *)w->h.p, (const double *)w->g.p, dims(w), (int)S_T0, w->part.p, w->xwt);
+    if (w->dist) { enqueue_fold(w, {S_T0}); if (allreduce_scalars(w)) return ABIP_FAILED; }
+    FinArgs f; f.nslots = 1; f.slots[0] = S_T0; f.u = w->u.p; f.v = w->v.p; f.ua = nullptr; f.va = nullptr; f.gs = w->gs;
     launch(w, ABIP_HIP_K_VEC, k_finalize, 1, BS, f, dims(w), (const double *)w->part.p, w->NB, w->ctl.p);
     if (sync_ctl(w)) return ABIP_FAILED;
     w->g_th = w->hctl->out[S_T0];
@@ -1021,7 +1236,9 @@ abip_int abip_hip_step(ABIPWork *w, abip_int max_admm_steps, abip_int *steps_don
       case PH_OUTER_END: {
         if (steps > 0 && steps >= max_admm_steps) return done(0); // hand back right after the last requested iteration
         const double elapsed = ((double)clock() - w->cpu0) / CLOCKS_PER_SEC; // abip.c:2217-2221
-        if (elapsed > st->max_time) { printf("Timelimit reached. \n"); st->max_admm_iters = (abip_int)(w->k * 1.05); }
+        double over = elapsed > st->max_time ? 1.0 : 0.0;
+        if (w->dist && allreduce_host(w, &over, 1)) return hard_fail("collective failure"); // every rank must take the same branch
+        if (over > 0) { printf("Timelimit reached. \n"); st->max_admm_iters = (abip_int)(w->k * 1.05); }
         if (w->mu < st->eps) w->final_check = 1;
         if (!w->stats_valid) { if (ensure_stats(w)) return hard_fail("device error in calc_residuals"); }
         calc_residuals(w, w->i, w->k);
@@ -1073,11 +1290,11 @@ abip_int abip_hip_solve_end(ABIPWork *w, ABIPSolution *sol, ABIPInfo *info) {
     info->setup_time = setup;
   }
   if (!sol->x) sol->x = (abip_float *)malloc(sizeof(abip_float) * w->n);
-  if (!sol->y) sol->y = (abip_float *)malloc(sizeof(abip_float) * w->m);
+  if (!sol->y) sol->y = (abip_float *)malloc(sizeof(abip_float) * w->m_glob);
   if (!sol->s) sol->s = (abip_float *)malloc(sizeof(abip_float) * w->n);
   if (!sol->x || !sol->y || !sol->s) return ABIP_FAILED;
   memcpy(sol->x, w->sol_x.data(), sizeof(double) * w->n);
-  memcpy(sol->y, w->sol_y.data(), sizeof(double) * w->m);
+  memcpy(sol->y, w->sol_y.data(), sizeof(double) * w->m_glob);
   memcpy(sol->s, w->sol_s.data(), sizeof(double) * w->n);
   return info->status_val;
 }
@@ -1125,7 +1342,7 @@ abip_int abip_main(const ABIPData *d, ABIPSolution *sol, ABIPInfo *info) { // ab
 }
 
 // ---- unit-level device access --------------------------------------------------------------------
-abip_int abip_hip_accum_by_A(ABIPWork *w, const abip_float *x, abip_float *y) {
+abip_int abip_hip_accum_by_A(ABIPWork *w, const abip_float *x, abip_float *y) { // on a sharded solve: this rank's rows
   if (!w || !x || !y) return -1;
   DBuf<double> dx, dy;
   if (dx.alloc(w->n) || dy.alloc(w->m)) return -1;
@@ -1153,6 +1370,7 @@ abip_int abip_hip_accum_by_Atrans(ABIPWork *w, const abip_float *x, abip_float *
 }
 abip_int abip_hip_kkt_solve(ABIPWork *w, abip_float *rhs, const abip_float *warm, abip_int iter) {
   if (!w || !rhs) return -1;
+  // sharded: rhs / warm are this rank's [y rows | x] pieces; every rank must call
   // a_ut holds the rhs, a_u the warm start (scratch vectors of the BB search; not live outside it)
   if (upload_lvec(w, w->a_ut, rhs, rhs + w->m, 0.0)) return -1;
   if (warm && upload_lvec(w, w->a_u, warm, nullptr, 0.0)) return -1;
@@ -1204,6 +1422,51 @@ abip_float abip_hip_get_scalar(ABIPWork *w, const char *name) {
   RET("nb", w->NB) RET("small_solve", w->small_solve ? 1 : 0)
 #undef RET
   return NAN;
+}
+
+int abip_hip_dist_partition(const ABIPMatrix *A, int world, abip_int *bounds) { // pure host code
+  if (!A || !bounds || world < 1 || A->m < world) return -1;
+  const abip_int mg = A->m, nnz = A->p[A->n];
+  std::vector<abip_int> rcnt(mg + 1, 0);
+  for (abip_int q = 0; q < nnz; ++q) rcnt[A->i[q] + 1]++;
+  for (abip_int i = 0; i < mg; ++i) rcnt[i + 1] += rcnt[i];
+  bounds[0] = 0; bounds[world] = mg;
+  for (int g = 1; g < world; ++g) { // first row of rank g: balance non-zeros (+1 per row), keep >= 1 row per rank
+    const double target = (double)(nnz + mg) * g / world;
+    abip_int lo = 0, hi = mg;
+    while (lo < hi) { const abip_int mid = (lo + hi) / 2; if ((double)(rcnt[mid] + mid) < target) lo = mid + 1; else hi = mid; }
+    bounds[g] = std::min<abip_int>(std::max<abip_int>(lo, bounds[g - 1] + 1), mg - (world - g));
+  }
+  return 0;
+}
+int abip_hip_dist_get_unique_id(void *out128) {
+  if (!out128 || !load_rccl(g_dist.api)) return -1;
+  return g_dist.api.GetUniqueId(out128) == 0 ? 0 : -2;
+}
+int abip_hip_dist_init_rccl(int rank, int world, const void *unique_id128) {
+  if (world < 1 || rank < 0 || rank >= world || !unique_id128) return -1;
+  if (!load_rccl(g_dist.api)) return -2;
+  Uid128 id;
+  memcpy(id.b, unique_id128, 128);
+  rcclComm_t comm = nullptr;
+  const int rc = g_dist.api.CommInitRank(&comm, world, id, rank);
+  if (rc != 0 || !comm) { fprintf(stderr, "abip_hip: ncclCommInitRank failed (%d)\n", rc); return -3; }
+  g_dist.kind = 1; g_dist.rank = rank; g_dist.world = world; g_dist.comm = comm;
+  return 0;
+}
+int abip_hip_dist_init_callback(int rank, int world, abip_hip_allreduce_fn fn, void *ctx) {
+  if (world < 1 || rank < 0 || rank >= world || !fn) return -1;
+  g_dist.kind = 2; g_dist.rank = rank; g_dist.world = world; g_dist.fn = fn; g_dist.fn_ctx = ctx;
+  return 0;
+}
+void abip_hip_dist_finalize(void) {
+  if (g_dist.kind == 1 && g_dist.comm) g_dist.api.CommDestroy(g_dist.comm);
+  g_dist.kind = 0; g_dist.rank = 0; g_dist.world = 1; g_dist.comm = nullptr; g_dist.fn = nullptr; g_dist.fn_ctx = nullptr;
+}
+void abip_hip_dist_rows(ABIPWork *w, abip_int *row0, abip_int *row1) {
+  if (!w) return;
+  if (row0) *row0 = w->row0;
+  if (row1) *row1 = w->row0 + w->m;
 }
 
 void abip_hip_profile_enable(ABIPWork *w, unsigned mask) { if (w) w->prof_mask = mask; }

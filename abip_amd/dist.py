@@ -1,0 +1,76 @@
+"""Multi-GPU set-up for the sharded PCG path (include/abip_hip.h, "multi-GPU"): one process per GPU.
+
+    dist.init_rccl(rank, world, broadcast)   # production: RCCL over xGMI; `broadcast(bytes_or_None) -> bytes` moves the id
+    dist.init_torch(process_group=None)      # the same, using torch.distributed for the 128-byte id exchange
+    dist.init_callback(rank, world, allreduce)  # tests: host-staged sum through any collective (e.g. gloo)
+    dist.finalize()
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+
+_keepalive = []
+
+
+def partition(A, world: int) -> np.ndarray:
+    """Row bounds of the sharded path (pure host code; also what abip_init uses)."""
+    L = _lib.load()
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    Ax = np.ascontiguousarray(A.data, dtype=np.float64)
+    Ai = np.ascontiguousarray(A.indices, dtype=np.int64)
+    Ap = np.ascontiguousarray(A.indptr, dtype=np.int64)
+    mat = _lib.ABIPMatrix(Ax.ctypes.data_as(_lib.PF), Ai.ctypes.data_as(_lib.PI), Ap.ctypes.data_as(_lib.PI), A.shape[0], A.shape[1])
+    out = np.zeros(world + 1, dtype=np.int64)
+    if L.abip_hip_dist_partition(C.byref(mat), world, out.ctypes.data_as(_lib.PI)) != 0:
+        raise ValueError("cannot partition: fewer rows than ranks")
+    return out
+
+
+def init_rccl(rank: int, world: int, broadcast) -> None:
+    L = _lib.load()
+    buf = C.create_string_buffer(128)
+    if rank == 0 and L.abip_hip_dist_get_unique_id(buf) != 0:
+        raise RuntimeError("ncclGetUniqueId failed (librccl not loadable?)")
+    uid = broadcast(buf.raw if rank == 0 else None)
+    idbuf = C.create_string_buffer(bytes(uid), 128)
+    rc = L.abip_hip_dist_init_rccl(rank, world, idbuf)
+    if rc != 0:
+        raise RuntimeError(f"abip_hip_dist_init_rccl failed ({rc})")
+
+
+def init_torch(process_group=None) -> None:
+    """RCCL communicator for the solver, bootstrapped over an existing torch.distributed process group."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+
+    def bcast(payload):
+        box = [payload]
+        dist.broadcast_object_list(box, src=0, group=process_group)
+        return box[0]
+
+    init_rccl(rank, world, bcast)
+
+
+def init_callback(rank: int, world: int, allreduce) -> None:
+    """`allreduce(np.ndarray)` must sum the array in place over all ranks (host memory)."""
+    L = _lib.load()
+
+    def _cb(_ctx, ptr, count):
+        arr = np.ctypeslib.as_array(ptr, shape=(count,))
+        allreduce(arr)
+
+    fn = _lib.ALLREDUCE_FN(_cb)
+    _keepalive.append(fn)
+    if L.abip_hip_dist_init_callback(rank, world, fn, None) != 0:
+        raise RuntimeError("abip_hip_dist_init_callback failed")
+
+
+def finalize() -> None:
+    _lib.load().abip_hip_dist_finalize()
+    _keepalive.clear()

@@ -52,6 +52,25 @@ abip_int abip_hip_get_vector(ABIPWork *w, const char *name, abip_float *out, abi
 /* Scalars: "mu","beta","sigma","gamma","g_th","sc_b","sc_c","nm_b","nm_c","tot_cg_its","lnnz","levels_fwd","levels_bwd","admm_iter","ipm_iter". */
 abip_float abip_hip_get_scalar(ABIPWork *w, const char *name);
 
+/* --- multi-GPU (one process per GPU) ---------------------------
+ * The PCG back-end shards A by contiguous row blocks (balanced by non-zeros) over `world` ranks: m-space vectors are
+ * local, n-space vectors replicated; each rank's A_g' y_g is all-reduced together with the packed reduction scalars.
+ * Call ONE of the two init functions on every rank before abip_init; abip_init then takes the FULL problem on every
+ * rank (the scaling of A needs all of it) and keeps only its row block on the GPU.  abip_solve returns the full
+ * (x, y, s) on every rank.  The direct back-end does not shard: with it every rank is an independent replica.
+ *   RCCL:     rank 0 calls abip_hip_dist_get_unique_id, the host program broadcasts the 128 bytes (MPI,
+ *             torch.distributed, ...), every rank calls abip_hip_dist_init_rccl after selecting its device.
+ *   callback: host-staged sum through a caller-supplied collective (tests; any number of ranks may share one GPU). */
+typedef void (*abip_hip_allreduce_fn)(void *ctx, double *host_buf, long count); /* in-place sum over all ranks */
+int abip_hip_dist_get_unique_id(void *out128);
+int abip_hip_dist_init_rccl(int rank, int world, const void *unique_id128);
+int abip_hip_dist_init_callback(int rank, int world, abip_hip_allreduce_fn fn, void *ctx);
+void abip_hip_dist_finalize(void);
+/* Row ranges the sharded path uses: bounds[g] .. bounds[g+1] are rank g's rows (world+1 entries out).  Pure host code. */
+int abip_hip_dist_partition(const ABIPMatrix *A, int world, abip_int *bounds);
+/* this rank's row range [row0, row1) of the last abip_init (0, m on a single GPU) */
+void abip_hip_dist_rows(ABIPWork *w, abip_int *row0, abip_int *row1);
+
 /* --- measurement ------------------------------------------------------------ */
 /* Kernel classes timed with hipEvents on the solver's own stream. */
 #define ABIP_HIP_K_SPMV_AT 0   /* k_cg_spmv_At: tmp = A'(z + beta p)  (CSC gather, n rows) -- PCG SpMV 1 */

@@ -1,0 +1,54 @@
+"""Worker for the multi-rank tests (launched by torch.distributed.run; not collected by pytest).
+
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 --master-port P tests/dist_worker.py MODE FIXTURE EPS
+
+MODE = gloo-callback : every rank uses cuda:0 and the host-staged collective over gloo (runs on a 1-GPU box)
+MODE = rccl          : one GPU per rank, RCCL communicator bootstrapped over torch.distributed
+Rank 0 prints a JSON line with the result."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    mode, fixture, eps = sys.argv[1], sys.argv[2], float(sys.argv[3])
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    from _golden import load
+    from abip_amd import Solver
+    from abip_amd import dist as adist
+    z, A, b, c = load(fixture)
+    if mode == "gloo-callback":
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        adist.init_callback(rank, world, lambda arr: dist.all_reduce(torch.from_numpy(arr)))
+    else:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        adist.init_torch()
+    with Solver(A, b, c, linsys="indirect", verbose=0, eps=eps) as S:
+        info = S.solve()
+        out = dict(rank=rank, world=world, status=info["status"], admm_iter=info["admm_iter"], ipm_iter=info["ipm_iter"], pobj=info["pobj"],
+                   dobj=info["dobj"], cg=S.scalar("tot_cg_its"), x=S.x.tolist(), y=S.y.tolist(), s=S.s.tolist())
+    # every rank must hold the same full solution
+    t = torch.tensor([out["pobj"], float(out["admm_iter"]), float(np.sum(S.y)), float(np.sum(S.x))], dtype=torch.float64)
+    if mode != "gloo-callback":
+        t = t.cuda()
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    out["consistent"] = bool(all(torch.equal(g, gathered[0]) for g in gathered))
+    if rank == 0:
+        print("RESULT " + json.dumps(out), flush=True)
+    adist.finalize()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+"""CPU, gloo, world_size 2: the collectives of the row-sharded PCG path on a numpy model --
+row blocks from the product's own partitioner (abip_hip_dist_partition), local A_g'y_g partials all-reduced, m-space
+dots all-reduced, n-space replicated -- must reproduce the unsharded solve of K z = rhs, iteration for iteration."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def pcg_kkt(A_rows, rhs_y, rhs_x, rho, tol, allreduce, m_glob):
+    """indirect.c:393-434 / 321-391 on a row block: returns (y_block, x, iterations)."""
+    M = 1.0 / np.asarray(A_rows.multiply(A_rows).sum(axis=1)).ravel()
+    b = rhs_y + A_rows @ rhs_x
+
+    def G(p):
+        t = A_rows.T @ p
+        allreduce(t)                       # A'p = sum_g A_g' p_g
+        return A_rows @ t + rho * p
+
+    x = np.zeros_like(b); r = b.copy(); z = M * r; p = z.copy()
+    s = np.array([z @ r]); allreduce(s); ipzr = s[0]
+    its = 0
+    for its in range(1, m_glob + 1):
+        Gp = G(p)
+        s = np.array([p @ Gp]); allreduce(s)
+        alpha = ipzr / s[0]
+        x += alpha * p; r -= alpha * Gp
+        s = np.array([r @ r]); allreduce(s)
+        if np.sqrt(s[0]) < tol:
+            break
+        z = M * r
+        s = np.array([z @ r]); allreduce(s)
+        p = z + (s[0] / ipzr) * p
+        ipzr = s[0]
+    t = A_rows.T @ x
+    allreduce(t)
+    return x, t - rhs_x, its
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from abip_amd import dist as adist, problems
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    A, b, c = problems.lp_random_sparse(m=180, n=420, per_col=5, seed=21)
+    A = sp.csr_matrix(A)
+    bounds = adist.partition(A, world)
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    rng = np.random.default_rng(5)
+    rhs = rng.standard_normal(A.shape[0] + A.shape[1])
+    ar = lambda arr: dist.all_reduce(torch.from_numpy(arr))
+    y_blk, x, its = pcg_kkt(A[r0:r1], rhs[r0:r1], rhs[A.shape[0]:], 1e-3, 1e-10, ar, A.shape[0])
+    y_full = np.zeros(A.shape[0]); y_full[r0:r1] = y_blk; ar(y_full)
+    if rank == 0:
+        q.put((bounds.tolist(), y_full, x, its))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_sharded_pcg_equals_unsharded(world):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    from abip_amd import problems
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29871
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    bounds, y, x, its = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    A, b, c = problems.lp_random_sparse(m=180, n=420, per_col=5, seed=21)
+    A = sp.csr_matrix(A)
+    m, n = A.shape
+    assert bounds[0] == 0 and bounds[-1] == m and all(b2 > b1 for b1, b2 in zip(bounds, bounds[1:]))
+    nnz_blk = [A[bounds[g]:bounds[g + 1]].nnz for g in range(world)]
+    assert max(nnz_blk) <= 1.25 * (A.nnz / world) + 16          # balanced by non-zeros
+    rng = np.random.default_rng(5)
+    rhs = rng.standard_normal(m + n)
+    K = sp.bmat([[1e-3 * sp.identity(m), A], [A.T, -sp.identity(n)]], format="csc")
+    ref = spla.spsolve(K, rhs)
+    assert np.linalg.norm(np.concatenate([y, x]) - ref) / np.linalg.norm(ref) < 1e-7
+    y1, x1, its1 = pcg_kkt(A, rhs[:m], rhs[m:], 1e-3, 1e-10, lambda arr: None, m)     # one "rank", no communication
+    assert its == its1
+    assert np.linalg.norm(y - y1) / np.linalg.norm(y1) < 1e-10 and np.linalg.norm(x - x1) / np.linalg.norm(x1) < 1e-10
+
+
+def test_partition_edge_cases():
+    sys.path.insert(0, ROOT)
+    from abip_amd import dist as adist
+    A = sp.identity(5, format="csc")
+    assert adist.partition(A, 5).tolist() == [0, 1, 2, 3, 4, 5]
+    assert adist.partition(A, 1).tolist() == [0, 5]
+    with pytest.raises(ValueError):
+        adist.partition(A, 6)
+    # one dense row must not starve the other ranks of rows
+    B = sp.vstack([sp.csr_matrix(np.ones((1, 50))), sp.random(9, 50, density=0.05, random_state=1)]).tocsc()
+    bd = adist.partition(B, 4).tolist()
+    assert bd[0] == 0 and bd[-1] == 10 and all(b2 > b1 for b1, b2 in zip(bd, bd[1:]))
