@@ -150,7 +150,12 @@ def main():
         nl = max(prof["launches"][name], 1)
         avg_ms = prof["ms"][name] / nl
         ach = cand[name][0] / (avg_ms * 1e-3) / 1e9
-        roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+        traffic, tsrc = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # PMC counters need rocprofv3: measured in separate passes, committed
+        if args.workload == "c4" and world == 1 and os.path.exists(pmc):
+            rec = json.load(open(pmc)).get("k_cg_" + name, {})
+            traffic, tsrc = rec.get("traffic_bytes"), "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=tsrc,
                     kernel=cand[name][1], avg_launch_us=avg_ms * 1e3, launches=nl, algorithmic_bytes_per_launch=cand[name][0])
     else:
         lnnz = int(S.scalar("lnnz")); N = m + n
