@@ -1,0 +1,120 @@
+/*
+ * abip_qcp.h -- C ABI of the conic (ABIP-QCP) path of libabip_hip.so.
+ *
+ *   min 1/2 x'Qx + c'x   s.t.  Ax = b,  x in K = SOC^q x RSOC^rq x R^f x {0}^z x R^l_+
+ *
+ * Layout-compatible with the reference's QCP structs (src/abip-qcp/include/abip.h:63-158; the QCP sources are
+ * built WITHOUT -DDLONG, so abip_int is a 32-bit int there -- the mex casts mwIndex arrays, abip_qcp_mex.c:186-188)
+ * and entry point `abip(d, sol, info, K)` (src/abip-qcp/include/abip.h:235-241, source/abip.c:1335-1371).
+ * Because that name and the LP structs' names collide with include/abip.h in one translation unit, this header
+ * uses a qcp_ prefix for the types and exports the entry point as abip_qcp(); INTEGRATION.md shows the one-line
+ * `#define` a maintainer adds to compile the reference's abip_qcp_mex.c against it.
+ *
+ * Only the generic QCP formulation (enum QCP, prob_type 2) with the QDLDL-class direct solver (linsys_solver 1)
+ * is served: the reference's PCG for this formulation is unreachable through abip() and
+ * its MKL / LAPACKE / CSparse-Cholesky back-ends are out of scope.  Other values are rejected with ABIP_FAILED.
+ */
+#ifndef ABIP_HIP_QCP_H
+#define ABIP_HIP_QCP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int qcp_int;
+typedef double qcp_float;
+
+typedef struct { /* struct ABIP_A_DATA_MATRIX, src/abip-qcp/include/amatrix.h */
+  qcp_float *x;
+  qcp_int *i;
+  qcp_int *p;
+  qcp_int m, n;
+} QCPMatrix;
+
+typedef struct { /* struct ABIP_CONE, abip.h:67-76; columns of A must come in this order */
+  qcp_int *q;     /* second-order cones (t, x): t >= ||x||        */
+  qcp_int qsize;
+  qcp_int *rq;    /* rotated cones (t1, t2, x): 2 t1 t2 >= ||x||^2 */
+  qcp_int rqsize;
+  qcp_int f;      /* free     */
+  qcp_int z;      /* zero     */
+  qcp_int l;      /* x >= 0   */
+} QCPCone;
+
+typedef struct { /* struct ABIP_SETTINGS, abip.h:93-131 */
+  qcp_int normalize;
+  qcp_int scale_E;
+  qcp_int scale_bc;
+  qcp_float scale;
+  qcp_float rho_x;
+  qcp_float rho_y;
+  qcp_float rho_tau;
+
+  qcp_int max_ipm_iters;
+  qcp_int max_admm_iters;
+  qcp_float eps;
+  qcp_float eps_p;
+  qcp_float eps_d;
+  qcp_float eps_g;
+  qcp_float eps_inf;
+  qcp_float eps_unb;
+
+  qcp_float err_dif;
+  qcp_float alpha;
+  qcp_float cg_rate;
+
+  qcp_int use_indirect;
+  qcp_int inner_check_period;
+  qcp_int outer_check_period;
+
+  qcp_int verbose;
+  qcp_int linsys_solver; /* 1 = QDLDL-class direct (the only one served) */
+  qcp_int prob_type;     /* 2 = generic QCP (what the mex sets, abip_qcp_mex.c:436) */
+  qcp_float time_limit;  /* seconds */
+  qcp_float psi;
+
+  qcp_int origin_scaling;
+  qcp_int ruiz_scaling;
+  qcp_int pc_scaling;
+} QCPSettings;
+
+typedef struct { /* struct ABIP_PROBLEM_DATA, abip.h:79-91 */
+  qcp_int m;
+  qcp_int n;
+  QCPMatrix *A;
+  QCPMatrix *Q; /* full symmetric storage, may be NULL */
+  qcp_float *b;
+  qcp_float *c;
+  qcp_float lambda;
+  QCPSettings *stgs;
+} QCPData;
+
+typedef struct { qcp_float *x, *y, *s; } QCPSolution; /* abip.h:133-138 */
+
+typedef struct { /* struct ABIP_INFO, abip.h:140-158 */
+  char status[32];
+  qcp_int status_val;
+  qcp_int ipm_iter;
+  qcp_int admm_iter;
+  qcp_float pobj;
+  qcp_float dobj;
+  qcp_float res_pri;
+  qcp_float res_dual;
+  qcp_float rel_gap;
+  qcp_float res_infeas;
+  qcp_float res_unbdd;
+  qcp_float setup_time; /* ms */
+  qcp_float solve_time; /* ms */
+  qcp_float avg_linsys_time;
+  qcp_float avg_cg_iters;
+} QCPInfo;
+
+/* abip(d, sol, info, K) of the reference (source/abip.c:1335-1371).  sol->x/y/s are malloc'ed when NULL. */
+qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K);
+/* ABIP(set_default_settings), source/util.c:203-255 (prob_type is left at the mex's value 2 = QCP). */
+void abip_qcp_set_default_settings(QCPData *d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

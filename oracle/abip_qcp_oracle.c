@@ -1,0 +1,531 @@
+/*
+ * abip_qcp_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the generic conic path of leavesgrp/ABIP v2.0.0 (src/abip-qcp, problem type QCP,
+ * linsys_solver = 1): scaling, KKT assembly, projection, cone barrier sub-problems, dual update, inner stopping
+ * test, residuals, barrier adjustment, solution extraction.  Each routine cites the reference lines it follows.
+ *
+ * Parity status: PARTIALLY PINNED.  The reference's QCP sources include five MKL headers unconditionally
+ * (source/abip.c:13-14, include/cones.h:11-12, include/linsys.h:14-18), so they cannot be compiled here without
+ * writing stand-ins for them, which the rules of this build forbid: there is no oracle/_ref for QCP.  What pins
+ * this restatement instead (tests/test_qcp_oracle.py):
+ *   (1) the reference's own output on the fully literal toy problem of test/test_abip_install.m:32-43, recorded
+ *       by the survey from a run of the real code (ipm 10, admm 91, pobj -0.984063813,
+ *       dobj -0.984063938, x to 6 digits);
+ *   (2) the cross-solver check the reference's test performs (test_abip_install.m:24-27): an LP solved through
+ *       this conic path must reach the optimum the pinned LP oracle / the LP reference fixtures reach;
+ *   (3) KKT conditions of the returned (x, y, s) on seeded SOCP / QP instances (a property, not a pin).
+ * The ordering of the KKT factorisation is our own minimum-degree code instead of AMD (orc_ldl.h).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's shared object.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "../include/abip_qcp.h"
+#include "orc_ldl.h"
+
+typedef qcp_int I;
+typedef qcp_float F;
+typedef long L;
+
+#define MAXF(a, b) (((a) > (b)) ? (a) : (b))
+#define MINF(a, b) (((a) < (b)) ? (a) : (b))
+#define ABSF(x) (((x) < 0) ? -(x) : (x))
+#define MIN_SCALE (1e-3) /* qcp_config.c:2 */
+#define MAX_SCALE (1e3)  /* qcp_config.c:3 */
+#define EPS_TOL (1E-18)
+#define SAFEDIV_POS(X, Y) ((Y) < EPS_TOL ? ((X) / EPS_TOL) : (X) / (Y))
+
+#define ST_SOLVED 1
+#define ST_SOLVED_INACC 2
+#define ST_UNBOUNDED (-1)
+#define ST_INFEASIBLE (-2)
+#define ST_FAILED (-4)
+#define ST_UNB_INACC (-6)
+#define ST_INF_INACC (-7)
+
+/* ---- linalg.c ---------------------------------------------------------------------------------------- */
+static F v_dot(const F *x, const F *y, L n) { F s = 0; for (L i = 0; i < n; ++i) s += x[i] * y[i]; return s; }
+static F v_nrm2sq(const F *x, L n) { F s = 0; for (L i = 0; i < n; ++i) s += x[i] * x[i]; return s; }
+static F v_nrm2(const F *x, L n) { return sqrt(v_nrm2sq(x, n)); }
+static F v_nrminf(const F *a, L n) { F mx = 0; for (L i = 0; i < n; ++i) { F t = ABSF(a[i]); if (t >= mx) mx = t; } return mx; }
+static F v_mean(const F *x, L n) { F y = 0; for (L i = 0; i < n; ++i) y += x[i]; return y / n; } /* linalg.c:19-31 */
+static void sp_accum_A(const QCPMatrix *A, const F *x, F *y) { /* y += A x, linsys.c:242-262 */
+  for (I j = 0; j < A->n; ++j) { F xj = x[j]; for (I p = A->p[j]; p < A->p[j + 1]; ++p) y[A->i[p]] += A->x[p] * xj; }
+}
+static void sp_accum_At(const QCPMatrix *A, const F *x, F *y) { /* y += A' x, linsys.c:191-225 */
+  for (I j = 0; j < A->n; ++j) { F yj = y[j]; for (I p = A->p[j]; p < A->p[j + 1]; ++p) yj += A->x[p] * x[A->i[p]]; y[j] = yj; }
+}
+
+/* ---- work ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  I m, n;
+  const QCPSettings *stgs;
+  QCPMatrix A, Q; int hasQ;
+  F *b, *c, *D, *E, *rho_dr;
+  F sc_b, sc_c;
+  int sparsity;
+  /* KKT factor */
+  long N; long *P, *Lp, *Li; F *Lx, *Dg, *bp;
+  /* iterates (struct ABIP_WORK, abip.h:160-180) */
+  F mu, beta, *u, *v, *v_origin, *u_t, *rel_ut, *r, a, nm_inf_b, nm_inf_c;
+} QW;
+
+typedef struct {
+  I last_ipm_iter, last_admm_iter;
+  F res_pri, res_dual, rel_gap, res_infeas, res_unbdd, pobj, dobj, tau, kap, res_dif, error_ratio, Ax_b_norm, Qx_ATy_c_s_norm;
+} QR;
+
+static void copy_mat(QCPMatrix *dst, const QCPMatrix *src) {
+  const I nnz = src->p[src->n];
+  dst->m = src->m; dst->n = src->n;
+  dst->x = (F *)malloc(sizeof(F) * (nnz > 0 ? nnz : 1)); dst->i = (I *)malloc(sizeof(I) * (nnz > 0 ? nnz : 1)); dst->p = (I *)malloc(sizeof(I) * (src->n + 1));
+  memcpy(dst->x, src->x, sizeof(F) * nnz); memcpy(dst->i, src->i, sizeof(I) * nnz); memcpy(dst->p, src->p, sizeof(I) * (src->n + 1));
+}
+
+/* cone-wise averaging of the column scale (qcp_config.c:194-212 and its repeats) */
+static void cone_average(F *E, const QCPCone *k) {
+  I count = 0;
+  if (k->q) for (I i = 0; i < k->qsize; ++i) { F me = v_mean(&E[count], k->q[i]); for (I j = 0; j < k->q[i]; ++j) E[j + count] = me; count += k->q[i]; }
+  if (k->rq) for (I i = 0; i < k->rqsize; ++i) { F me = v_mean(&E[count], k->rq[i]); for (I j = 0; j < k->rq[i]; ++j) E[j + count] = me; count += k->rq[i]; }
+}
+/* apply one (D, E) pass to A and Q and fold it into D_hat, E_hat (qcp_config.c:214-262 and its repeats) */
+static void apply_pass(QW *w, F *D, F *E, F min_row, F max_row, F min_col, F max_col) {
+  const I m = w->m, n = w->n; QCPMatrix *A = &w->A, *Q = &w->Q;
+  for (I i = 0; i < m; ++i) { if (D[i] < min_row) D[i] = 1; else if (D[i] > max_row) D[i] = max_row; }
+  for (I i = 0; i < n; ++i) {
+    if (E[i] < min_col) E[i] = 1; else if (E[i] > max_col) E[i] = max_col;
+    for (I j = A->p[i]; j < A->p[i + 1]; ++j) A->x[j] /= E[i];
+  }
+  if (w->hasQ) {
+    for (I i = 0; i < n; ++i) for (I j = Q->p[i]; j < Q->p[i + 1]; ++j) Q->x[j] /= E[i];
+    for (I i = 0; i < Q->p[n]; ++i) Q->x[i] /= E[Q->i[i]];
+  }
+  for (I i = 0; i < A->p[n]; ++i) A->x[i] /= D[A->i[i]];
+  for (I i = 0; i < n; ++i) w->E[i] *= E[i];
+  for (I i = 0; i < m; ++i) w->D[i] *= D[i];
+}
+
+static void scaling_qcp_data(QW *w, const QCPData *d, const QCPCone *k) { /* qcp_config.c:91-491 */
+  const I m = w->m, n = w->n; QCPMatrix *A = &w->A, *Q = &w->Q;
+  const F min_row = MIN_SCALE * sqrt((F)n), max_row = MAX_SCALE * sqrt((F)n), min_col = MIN_SCALE * sqrt((F)m), max_col = MAX_SCALE * sqrt((F)m);
+  memcpy(w->b, d->b, sizeof(F) * m); memcpy(w->c, d->c, sizeof(F) * n);
+  for (I i = 0; i < n; ++i) w->E[i] = 1;
+  for (I i = 0; i < m; ++i) w->D[i] = 1;
+  F *E = (F *)calloc(n, sizeof(F)), *E1 = (F *)calloc(n, sizeof(F)), *E2 = (F *)calloc(n, sizeof(F)), *D = (F *)calloc(m, sizeof(F));
+  if (w->stgs->ruiz_scaling) { /* :158-264 */
+    for (int it = 0; it < 10; ++it) {
+      memset(E, 0, sizeof(F) * n); memset(E1, 0, sizeof(F) * n); memset(E2, 0, sizeof(F) * n); memset(D, 0, sizeof(F) * m);
+      for (I j = 0; j < n; ++j) E1[j] = (A->p[j] == A->p[j + 1]) ? 0 : sqrt(v_nrminf(&A->x[A->p[j]], A->p[j + 1] - A->p[j]));
+      if (w->hasQ) for (I j = 0; j < n; ++j) E2[j] = (Q->p[j] == Q->p[j + 1]) ? 0 : sqrt(v_nrminf(&Q->x[Q->p[j]], Q->p[j + 1] - Q->p[j]));
+      for (I i = 0; i < n; ++i) E[i] = E1[i] < E2[i] ? E2[i] : E1[i];
+      cone_average(E, k);
+      for (I i = 0; i < A->p[n]; ++i) if (D[A->i[i]] < ABSF(A->x[i])) D[A->i[i]] = ABSF(A->x[i]);
+      for (I i = 0; i < m; ++i) D[i] = sqrt(D[i]);
+      apply_pass(w, D, E, min_row, max_row, min_col, max_col);
+    }
+  }
+  if (w->stgs->origin_scaling) { /* :266-363 */
+    memset(E, 0, sizeof(F) * n); memset(E1, 0, sizeof(F) * n); memset(E2, 0, sizeof(F) * n); memset(D, 0, sizeof(F) * m);
+    for (I i = 0; i < n; ++i) { for (I j = A->p[i]; j < A->p[i + 1]; ++j) E1[i] += A->x[j] * A->x[j]; E1[i] = sqrt(E1[i]); }
+    if (w->hasQ) for (I i = 0; i < n; ++i) { for (I j = Q->p[i]; j < Q->p[i + 1]; ++j) E2[i] += Q->x[j] * Q->x[j]; E2[i] = sqrt(E2[i]); }
+    for (I i = 0; i < n; ++i) E[i] = sqrt(E1[i] < E2[i] ? E2[i] : E1[i]);
+    cone_average(E, k);
+    for (I i = 0; i < A->p[n]; ++i) D[A->i[i]] += A->x[i] * A->x[i];
+    for (I i = 0; i < m; ++i) D[i] = sqrt(sqrt(D[i]));
+    apply_pass(w, D, E, min_row, max_row, min_col, max_col);
+  }
+  if (w->stgs->pc_scaling) { /* :365-460 with alpha_pc = 1 */
+    memset(E, 0, sizeof(F) * n); memset(E1, 0, sizeof(F) * n); memset(E2, 0, sizeof(F) * n); memset(D, 0, sizeof(F) * m);
+    for (I i = 0; i < n; ++i) { for (I j = A->p[i]; j < A->p[i + 1]; ++j) E1[i] += pow(ABSF(A->x[j]), 1.0); E1[i] = sqrt(pow(E1[i], 1.0)); }
+    if (w->hasQ) for (I i = 0; i < n; ++i) { for (I j = Q->p[i]; j < Q->p[i + 1]; ++j) E2[i] += pow(ABSF(Q->x[j]), 1.0); E2[i] = sqrt(pow(E2[i], 1.0)); }
+    for (I i = 0; i < n; ++i) E[i] = E1[i] < E2[i] ? E2[i] : E1[i];
+    cone_average(E, k);
+    for (I i = 0; i < A->p[n]; ++i) D[A->i[i]] += pow(ABSF(A->x[i]), 1.0);
+    for (I i = 0; i < m; ++i) D[i] = sqrt(pow(D[i], 1.0));
+    apply_pass(w, D, E, min_row, max_row, min_col, max_col);
+  }
+  F sc = sqrt(sqrt(v_nrm2sq(w->c, n) + v_nrm2sq(w->b, m))); /* :462-463 (before the division by D_hat / E_hat) */
+  for (I i = 0; i < m; ++i) w->b[i] /= w->D[i];
+  for (I i = 0; i < n; ++i) w->c[i] /= w->E[i];
+  if (sc < MIN_SCALE) sc = 1; else if (sc > MAX_SCALE) sc = MAX_SCALE;
+  w->sc_b = 1 / sc; w->sc_c = 1 / sc;
+  for (I i = 0; i < m; ++i) w->b[i] *= w->sc_b * w->stgs->scale;
+  for (I i = 0; i < n; ++i) w->c[i] *= w->sc_c * w->stgs->scale;
+  free(E); free(E1); free(E2); free(D);
+}
+
+/* K = [[-rho_y I, -A], [., Q_upper + rho_x I]] upper triangle (qcp_config.c:699-748), factorised with orc_ldl.h */
+static int init_kkt(QW *w) {
+  const I m = w->m, n = w->n; const QCPMatrix *A = &w->A, *Q = &w->Q;
+  const long N = (long)m + n, cap = (long)m + A->p[n] + (w->hasQ ? Q->p[n] : 0) + n;
+  long *Kp = (long *)malloc(sizeof(long) * (N + 1)), *Ki = (long *)malloc(sizeof(long) * cap); F *Kx = (F *)malloc(sizeof(F) * cap);
+  long kk = 0;
+  for (I i = 0; i < m; ++i) { Kp[i] = kk; Ki[kk] = i; Kx[kk] = -w->rho_dr[i]; ++kk; }
+  for (I i = 0; i < n; ++i) {
+    Kp[m + i] = kk;
+    for (I j = A->p[i]; j < A->p[i + 1]; ++j) { Ki[kk] = A->i[j]; Kx[kk] = -A->x[j]; ++kk; }
+    if (!w->hasQ || Q->p[i] == Q->p[i + 1]) { Ki[kk] = m + i; Kx[kk] = w->rho_dr[m + i]; ++kk; }
+    else for (I j = Q->p[i]; j < Q->p[i + 1]; ++j) {
+      F t;
+      if (Q->i[j] > i) continue;                       /* strictly lower entries are zeroed and dropped (:732-745) */
+      t = (Q->i[j] == i) ? Q->x[j] + w->rho_dr[m + i] : Q->x[j];
+      if (t == 0) continue;                            /* cs_dropzeros */
+      Ki[kk] = m + Q->i[j]; Kx[kk] = t; ++kk;
+    }
+  }
+  Kp[N] = kk;
+  w->N = N;
+  const int rc = orc_ldl_factor(N, Kp, Ki, Kx, &w->P, &w->Lp, &w->Li, &w->Lx, &w->Dg);
+  w->bp = (F *)malloc(sizeof(F) * N);
+  free(Kp); free(Ki); free(Kx);
+  return rc;
+}
+static void solve_qcp_linsys(QW *w, F *b) { /* qcp_config.c:868-876: negate the first m entries, then K^-1 */
+  for (I i = 0; i < w->m; ++i) b[i] *= -1;
+  orc_ldl_solve(w->N, w->P, w->Lp, w->Li, w->Lx, w->Dg, b, w->bp);
+}
+
+/* ---- cones.c:130-288 ------------------------------------------------------------------------------------ */
+static void orthant_prox(F *x, const F *t, F lambda, I n) { /* :279-288 */
+  for (I i = 0; i < n; ++i) {
+    if (t[i] >= 0) x[i] = (t[i] + sqrt(t[i] * t[i] + 4 * lambda)) / 2;
+    else x[i] = 2 * lambda / (-t[i] * (1 + sqrt(1 + 4 * lambda / pow(t[i], 2))));
+  }
+}
+static void soc_prox(F *x, const F *tmp, F lambda, I n) { /* :130-161 */
+  const F a = tmp[0], tol = 1e-9; const F *b = &tmp[1];
+  const F bsq = v_nrm2sq(b, n - 1);
+  if (ABSF(a) <= tol) {
+    x[0] = sqrt(2 * lambda + bsq / 4);
+    for (I i = 0; i < n - 1; ++i) x[1 + i] = b[i] * 0.5;
+  } else {
+    const F r = 16 * a * a / (8 * lambda - a * a + bsq + sqrt(pow((8 * lambda - a * a + bsq), 2) + 32 * a * a * lambda));
+    const F s1 = (r - sqrt(r * (r + 8))) / 2, s2 = (r + sqrt(r * (r + 8))) / 2;
+    const F s = a > 0 ? s2 : s1;
+    x[0] = (s + 2) * a / s;
+    const F sc = (s + 2) / (s + 4);
+    for (I i = 0; i < n - 1; ++i) x[1 + i] = b[i] * sc;
+  }
+}
+static void rsoc_prox(F *x, const F *tmp, F lambda, I n) { /* :169-248 */
+  const I nx = n - 2; const F ze = tmp[0], zn = tmp[1]; const F *zx = &tmp[2];
+  const F xsq = v_nrm2sq(zx, nx);
+  if (ze + zn == 0) {
+    x[1] = (-ze + sqrt(ze * ze + 4 * lambda + xsq)) / 2;
+    x[0] = x[0] + ze; /* sic: reads the previous x[0] (:183) */
+    for (I i = 0; i < nx; ++i) x[2 + i] = zx[i] * 0.5;
+  } else {
+    F w_, s; const F dd = 2 * ze * zn - xsq;
+    if (dd < 0) {
+      const F q = -dd / (2 * lambda);
+      w_ = (2 * pow(ze + zn, 2) / lambda) / q / (1 + 4 / q + sqrt(1 + (4 * (ze * ze + zn * zn + xsq) / lambda + 16) / q / q));
+    } else {
+      const F q = dd / (2 * lambda);
+      w_ = q * (1 - 4 / q + sqrt(1 + (4 * (ze * ze + zn * zn + xsq) / lambda + 16) / q / q)) / 2;
+    }
+    if (ze + zn > 0) {
+      s = (w_ + sqrt(w_ * (w_ + 4))) / 2;
+      x[0] = (ze * pow(s + 1, 2) + zn * (s + 1)) / (s * (s + 2));
+      x[1] = (zn * pow(s + 1, 2) + ze * (s + 1)) / (s * (s + 2));
+      for (I i = 0; i < nx; ++i) x[2 + i] = zx[i] * ((s + 1) / (s + 2));
+    } else if (w_ > 10) {
+      s = 2 / (w_ + 2 + sqrt(w_ * (w_ + 4)));
+      x[0] = (ze * pow(s, 2) + zn * s) / ((s - 1) * (s + 1));
+      x[1] = (zn * pow(s, 2) + ze * s) / ((s - 1) * (s + 1));
+      for (I i = 0; i < nx; ++i) x[2 + i] = zx[i] * (s / (s + 1));
+    } else {
+      s = (w_ - sqrt(w_ * (w_ + 4))) / 2;
+      x[0] = (ze * pow(s + 1, 2) + zn * (s + 1)) / (s * (s + 2));
+      x[1] = (zn * pow(s + 1, 2) + ze * (s + 1)) / (s * (s + 2));
+      for (I i = 0; i < nx; ++i) x[2 + i] = zx[i] * ((s + 1) / (s + 2));
+    }
+  }
+}
+
+/* ---- abip.c ------------------------------------------------------------------------------------------------ */
+static void projection(QW *w, I iter) { /* abip.c:186-255 (the direct branch) */
+  const I m = w->m, n = w->n; const long mn = (long)m + n;
+  F *mu = (F *)malloc(sizeof(F) * mn), *p = (F *)malloc(sizeof(F) * mn), *tem = (F *)malloc(sizeof(F) * mn), *Qp = (F *)calloc(n, sizeof(F));
+  for (long i = 0; i < mn; ++i) mu[i] = (w->u[i] + w->v[i]) * w->rho_dr[i];
+  const F eta = w->rho_dr[mn] * (w->u[mn] + w->v[mn]);
+  memcpy(p, mu, sizeof(F) * mn);
+  solve_qcp_linsys(w, p);
+  for (long i = 0; i < mn; ++i) tem[i] = p[i] * w->rho_dr[i];
+  const F bq = v_dot(w->r, mu, mn) - 2 * v_dot(w->r, tem, mn) - eta;
+  if (w->hasQ) sp_accum_A(&w->Q, &p[m], Qp);
+  const F cq = -v_dot(&p[m], Qp, n);
+  const F a = w->a;
+  w->u_t[mn] = (iter > 0) ? (-bq + sqrt(MAXF(0, bq * bq - 4 * a * cq))) / (2 * a) : 1;
+  for (long i = 0; i < mn; ++i) w->u_t[i] = p[i] + (-w->u_t[mn]) * w->r[i];
+  free(mu); free(p); free(tem); free(Qp);
+}
+static void solve_barrier_subproblem(QW *w, const QCPCone *c) { /* abip.c:326-413 */
+  const I m = w->m, n = w->n; const long l = (long)m + n + 1;
+  const F lambda = w->mu / w->beta, al = w->stgs->alpha;
+  for (long i = 0; i < l; ++i) w->rel_ut[i] = w->u_t[i] * al + (1 - al) * w->u[i] - w->v[i]; /* :336-342 (scale, axpy, axpy) */
+  const F *tmp = w->rel_ut;
+  const F tl = tmp[l - 1];
+  const F tau = (tl + sqrt(tl * tl + 4 * lambda / w->rho_dr[l - 1])) / 2;
+  memcpy(w->u, tmp, sizeof(F) * m);
+  w->u[l - 1] = tau;
+  I count = 0;
+  if (c->qsize && c->q) for (I i = 0; i < c->qsize; ++i) {
+    if (c->q[i] == 0) continue;
+    if (c->q[i] == 1) orthant_prox(&w->u[m + count], &tmp[m + count], lambda / w->rho_dr[m + count], 1);
+    else soc_prox(&w->u[m + count], &tmp[m + count], lambda / w->rho_dr[m + count], c->q[i]);
+    count += c->q[i];
+  }
+  if (c->rqsize && c->rq) for (I i = 0; i < c->rqsize; ++i) {
+    if (c->rq[i] < 3) continue; /* sic: count is not advanced (:379-381) */
+    rsoc_prox(&w->u[m + count], &tmp[m + count], lambda / w->rho_dr[m + count], c->rq[i]);
+    count += c->rq[i];
+  }
+  if (c->f) { for (I i = 0; i < c->f; ++i) w->u[m + count + i] = tmp[m + count + i]; count += c->f; }
+  if (c->z) { for (I i = 0; i < c->z; ++i) w->u[m + count + i] = 0; count += c->z; }
+  if (c->l) { orthant_prox(&w->u[m + count], &tmp[m + count], lambda / w->rho_dr[m + count], c->l); count += c->l; }
+}
+static F inner_conv_check(QW *w) { /* qcp_config.c:518-557 */
+  const I m = w->m, n = w->n; const long mn = (long)m + n;
+  F *Qu = (F *)malloc(sizeof(F) * (mn + 1)), *Mu = (F *)calloc(mn, sizeof(F));
+  sp_accum_A(&w->A, &w->u[m], Mu);
+  sp_accum_At(&w->A, w->u, &Mu[m]);
+  for (I j = 0; j < n; ++j) Mu[m + j] *= -1;
+  if (w->hasQ) sp_accum_A(&w->Q, &w->u[m], &Mu[m]);
+  memcpy(Qu, Mu, sizeof(F) * mn);
+  for (I i = 0; i < m; ++i) Qu[i] += -w->u[mn] * w->b[i];
+  for (I j = 0; j < n; ++j) Qu[m + j] += w->u[mn] * w->c[j];
+  Qu[mn] = -v_dot(w->u, Mu, mn) / w->u[mn] + v_dot(w->u, w->b, m) - v_dot(&w->u[m], w->c, n);
+  F num = 0;
+  for (long i = 0; i <= mn; ++i) { F t = Qu[i] - w->v_origin[i]; num += t * t; }
+  const F err = sqrt(num) / (1 + v_nrm2(Qu, mn + 1) + v_nrm2(w->v_origin, mn + 1));
+  free(Qu); free(Mu);
+  return err;
+}
+static void calc_residuals(QW *w, QR *r, I ipm_iter, I admm_iter) { /* qcp_config.c:562-691 */
+  const I n = w->n, m = w->m;
+  if (admm_iter && r->last_admm_iter == admm_iter) return;
+  r->last_ipm_iter = ipm_iter; r->last_admm_iter = admm_iter;
+  F *y = (F *)malloc(sizeof(F) * m), *x = (F *)malloc(sizeof(F) * n), *s = (F *)malloc(sizeof(F) * n);
+  r->tau = ABSF(w->u[n + m]);
+  r->kap = ABSF(w->v_origin[n + m]) / (w->stgs->normalize ? (w->stgs->scale * w->sc_c * w->sc_b) : 1);
+  for (I i = 0; i < m; ++i) y[i] = w->u[i] * (1 / r->tau);
+  for (I j = 0; j < n; ++j) { x[j] = w->u[m + j] * (1 / r->tau); s[j] = w->v_origin[m + j] * (1 / r->tau); }
+  F *Ax = (F *)calloc(m, sizeof(F)), *Ax_b = (F *)malloc(sizeof(F) * m);
+  sp_accum_A(&w->A, x, Ax);
+  for (I i = 0; i < m; ++i) Ax_b[i] = Ax[i] - w->b[i];
+  r->Ax_b_norm = v_nrminf(Ax_b, m);
+  for (I i = 0; i < m; ++i) { Ax[i] *= w->D[i]; Ax_b[i] *= w->D[i]; }
+  const F this_pr = v_nrminf(Ax_b, m) / (w->sc_b + MAXF(v_nrminf(Ax, m), w->sc_b * w->nm_inf_b));
+  F *Qx = (F *)calloc(n, sizeof(F)), *ATy = (F *)calloc(n, sizeof(F)), *R = (F *)malloc(sizeof(F) * n);
+  F xQx_2 = 0;
+  if (w->hasQ) { sp_accum_A(&w->Q, x, Qx); xQx_2 = v_dot(x, Qx, n) / (2 * w->sc_b * w->sc_c); }
+  sp_accum_At(&w->A, y, ATy);
+  for (I j = 0; j < n; ++j) R[j] = Qx[j] - ATy[j] + w->c[j] - s[j];
+  r->Qx_ATy_c_s_norm = v_nrminf(R, n);
+  for (I j = 0; j < n; ++j) { Qx[j] *= w->E[j]; ATy[j] *= w->E[j]; R[j] *= w->E[j]; s[j] *= w->E[j]; }
+  const F this_dr = v_nrminf(R, n) / (w->sc_c + MAXF(w->sc_c * w->nm_inf_c, v_nrminf(Qx, n)));
+  const F cTx = v_dot(w->c, x, n) / (w->sc_b * w->sc_c), bTy = v_dot(w->b, y, m) / (w->sc_b * w->sc_c);
+  const F this_gap = ABSF(2 * xQx_2 + cTx - bTy) / (1 + MAXF(2 * xQx_2, MAXF(ABSF(cTx), ABSF(bTy))));
+  r->pobj = xQx_2 + cTx; r->dobj = -xQx_2 + bTy;
+  r->res_dif = MAXF(MAXF(ABSF(this_pr - r->res_pri), ABSF(this_dr - r->res_dual)), ABSF(this_gap - r->rel_gap));
+  r->res_pri = this_pr; r->res_dual = this_dr; r->rel_gap = this_gap;
+  r->error_ratio = MAXF(r->res_pri / w->stgs->eps_p, MAXF(r->res_dual / w->stgs->eps_d, r->rel_gap / w->stgs->eps_g));
+  const F ctu = v_dot(w->c, &w->u[m], n), btu = v_dot(w->b, w->u, m);
+  if (ctu < 0) {
+    for (I j = 0; j < n; ++j) Qx[j] *= r->tau;
+    for (I i = 0; i < m; ++i) Ax[i] *= r->tau;
+    r->res_unbdd = MAXF(v_nrm2(Qx, n), v_nrm2(Ax, m)) / (-ctu);
+  } else r->res_unbdd = INFINITY;
+  if (btu > 0) {
+    for (I j = 0; j < n; ++j) ATy[j] = ATy[j] * r->tau + s[j] * r->tau;
+    r->res_infeas = v_nrm2(ATy, n) / btu;
+  } else r->res_infeas = INFINITY;
+  free(y); free(x); free(s); free(Ax); free(Ax_b); free(Qx); free(ATy); free(R);
+}
+static I has_converged(const QW *w, const QR *r, I ipm_iter, I admm_iter) { /* abip.c:750-777 */
+  const QCPSettings *st = w->stgs;
+  if (r->res_pri < st->eps_p && r->res_dual < st->eps_d && r->rel_gap < st->eps_g) return ST_SOLVED;
+  if (r->res_dif < st->err_dif * MAXF(MAXF(st->eps_p, st->eps_d), st->eps_g)) return ST_SOLVED_INACC;
+  if (r->res_unbdd < st->eps_unb && ipm_iter > 0 && admm_iter > 0) return ST_UNBOUNDED;
+  if (r->res_infeas < st->eps_inf && ipm_iter > 0 && admm_iter > 0) return ST_INFEASIBLE;
+  return 0;
+}
+static F adjust_barrier(QW *w, const QR *r) { /* abip.c:994-1071 */
+  const QCPSettings *st = w->stgs;
+  F sigma = 0.8, gamma;
+  const F ratio = w->mu / MINF(MINF(st->eps_p, st->eps_d), st->eps_g);
+  if (ratio > 50 && ratio <= 100) gamma = 1.5;
+  else if (ratio > 10 && ratio <= 50) gamma = 1.3;
+  else if (ratio > 5 && ratio <= 10) gamma = 1.2;
+  else if (ratio > 1 && ratio <= 5) gamma = 1.1;
+  else if (ratio > 0.5 && ratio <= 1) gamma = 1;
+  else if (ratio > 0.05 && ratio <= 0.5) gamma = 0.9;
+  else if (ratio > 0.005 && ratio <= 0.05) gamma = 0.8;
+  else if (ratio > 0.0005 && ratio <= 0.005) gamma = 0.7;
+  else if (ratio > 0.00005 && ratio <= 0.0005) gamma = 0.6;
+  else gamma = 0.5;
+  const F mr = r->error_ratio;
+  if (mr > 22) gamma *= 4.4;
+  else if (mr > 18 && mr <= 22) gamma *= 4.2;
+  else if (mr > 15 && mr <= 18) gamma *= 4;
+  else if (mr > 12 && mr <= 15) gamma *= 3.8;
+  else if (mr > 8 && mr <= 12) gamma *= 3.6;
+  else if (mr > 6 && mr <= 8) { sigma = 0.81; gamma *= 3.4; }
+  else if (mr > 4 && mr <= 6) { sigma = 0.82; gamma *= 3.4; }
+  else if (mr > 3 && mr <= 4) { sigma = 0.83; gamma *= 3.2; }
+  else if (mr > 2 && mr <= 3) { sigma = 0.85; gamma *= 2.8; }
+  else if (mr > 1.5 && mr <= 2) { sigma = 0.85; gamma *= 2.6; }
+  else if (mr < 1.5) { sigma = 0.85; gamma *= 2.4; }
+  sigma *= 0.2;
+  w->mu = sigma * w->mu;
+  return gamma * pow(w->mu, st->psi);
+}
+static void get_solution(QW *w, QCPSolution *sol, QCPInfo *info, const QR *r, I ipm_iter, I admm_iter) { /* abip.c:559-587 */
+  const I m = w->m, n = w->n;
+  if (!sol->x) sol->x = (F *)malloc(sizeof(F) * n);
+  if (!sol->y) sol->y = (F *)malloc(sizeof(F) * m);
+  if (!sol->s) sol->s = (F *)malloc(sizeof(F) * n);
+  memcpy(sol->x, &w->u[m], sizeof(F) * n); memcpy(sol->y, w->u, sizeof(F) * m); memcpy(sol->s, &w->v[m], sizeof(F) * n);
+  const I sv = info->status_val;
+  if (sv == 0 || sv == ST_SOLVED || sv == ST_SOLVED_INACC) { /* solved(), abip.c:427-443 */
+    const F sc = SAFEDIV_POS(1.0, r->tau);
+    for (I j = 0; j < n; ++j) { sol->x[j] *= sc; sol->s[j] *= sc; }
+    for (I i = 0; i < m; ++i) sol->y[i] *= sc;
+    if (sv == 0 || sv == 2) { strcpy(info->status, "Solved/Inaccurate"); info->status_val = ST_SOLVED_INACC; }
+    else { strcpy(info->status, "Solved"); info->status_val = ST_SOLVED; }
+  } else if (sv == ST_INFEASIBLE || sv == ST_INF_INACC) { /* abip.c:480-495 */
+    const F bty = r->dobj * r->tau;
+    for (I i = 0; i < m; ++i) sol->y[i] *= 1 / bty;
+    for (I j = 0; j < n; ++j) { sol->s[j] *= 1 / bty; sol->x[j] = NAN; }
+    strcpy(info->status, "Infeasible"); info->status_val = ST_INFEASIBLE;
+  } else { /* abip.c:497-512 */
+    const F ctx = r->pobj * r->tau;
+    for (I j = 0; j < n; ++j) { sol->x[j] *= -1 / ctx; sol->s[j] = NAN; }
+    for (I i = 0; i < m; ++i) sol->y[i] = NAN;
+    strcpy(info->status, "Unbounded"); info->status_val = ST_UNBOUNDED;
+  }
+  if (w->stgs->normalize) { /* un_scaling_qcp_sol, qcp_config.c:496-513 */
+    for (I j = 0; j < n; ++j) sol->x[j] /= (w->E[j] * w->sc_b);
+    for (I i = 0; i < m; ++i) sol->y[i] /= (w->D[i] * w->sc_c);
+    for (I j = 0; j < n; ++j) sol->s[j] *= w->E[j] / (w->sc_c * w->stgs->scale);
+  }
+  info->ipm_iter = ipm_iter + 1; info->admm_iter = admm_iter; /* get_info, abip.c:526-557 */
+  info->res_infeas = r->res_infeas; info->res_unbdd = r->res_unbdd;
+  if (info->status_val == ST_SOLVED || info->status_val == ST_SOLVED_INACC) {
+    info->rel_gap = r->rel_gap; info->res_pri = r->res_pri; info->res_dual = r->res_dual; info->pobj = r->pobj; info->dobj = r->dobj;
+  } else if (info->status_val == ST_UNBOUNDED) { info->rel_gap = info->res_pri = info->res_dual = NAN; info->pobj = info->dobj = -INFINITY; }
+  else { info->rel_gap = info->res_pri = info->res_dual = NAN; info->pobj = info->dobj = INFINITY; }
+}
+
+void orc_qcp_set_default_settings(QCPData *d) { /* util.c:203-255 */
+  QCPSettings *s = d->stgs;
+  const double nz = d->A ? d->A->p[d->n] : 0, sparsity = nz / ((double)d->m * d->n);
+  s->normalize = 1; s->scale_E = 1; s->scale_bc = 1; s->max_ipm_iters = 500; s->max_admm_iters = 10000000;
+  s->eps = s->eps_p = s->eps_d = s->eps_g = s->eps_inf = s->eps_unb = 1e-3; s->alpha = 1.8; s->cg_rate = 2.0;
+  s->use_indirect = 0; s->scale = 1.0; s->rho_y = 1e-6; s->rho_x = 1; s->rho_tau = 1; s->verbose = 1; s->err_dif = 0;
+  s->inner_check_period = 500; s->outer_check_period = 1;
+  s->linsys_solver = ((double)d->m * d->n > 1e12) ? 3 : (sparsity > 0.4 ? 5 : 1);
+  s->prob_type = 2; /* the mex overrides the default 3 with the enum value QCP = 2 (abip_qcp_mex.c:436) */
+  s->time_limit = INFINITY; s->psi = 1; s->origin_scaling = 1; s->ruiz_scaling = 1; s->pc_scaling = 0;
+}
+
+static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec / 1e6; }
+
+/* optional trace of (u, v, u_t) after each of the first T inner iterations */
+static F *g_trace = 0; static I g_trace_T = 0, g_trace_n = 0;
+void orc_qcp_set_trace(I T, F *buf) { g_trace = buf; g_trace_T = T; g_trace_n = 0; }
+I orc_qcp_trace_count(void) { return g_trace_n; }
+
+qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) { /* abip(), abip.c:1335-1371 */
+  if (!d || !sol || !info || !K || !d->A || !d->b || !d->c || d->stgs->linsys_solver != 1 || d->stgs->prob_type != 2) {
+    if (info) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); }
+    return ST_FAILED;
+  }
+  const double t_init = now_ms();
+  QW W; memset(&W, 0, sizeof(W)); QW *w = &W;
+  const I m = d->m, n = d->n; const long l = (long)m + n + 1;
+  w->m = m; w->n = n; w->stgs = d->stgs; w->hasQ = d->Q != 0;
+  { /* validate, abip.c:779-832 + cones.c:37-81 */
+    long dims = K->l + K->z + K->f;
+    for (I i = 0; K->q && i < K->qsize; ++i) dims += K->q[i];
+    for (I i = 0; K->rq && i < K->rqsize; ++i) dims += K->rq[i];
+    const QCPSettings *s = d->stgs;
+    if (n <= 0 || m > n || dims != n || s->max_ipm_iters <= 0 || s->max_admm_iters <= 0 || s->eps_p <= 0 || s->eps_d <= 0 || s->eps_g <= 0 ||
+        s->eps_inf <= 0 || s->eps_unb <= 0 || s->alpha <= 0 || s->alpha >= 2 || s->rho_y <= 0) {
+      info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED;
+    }
+  }
+  w->sparsity = ((d->A->p[n] / (m * n)) < 0.05); /* integer division, qcp_config.c:22 */
+  w->rho_dr = (F *)malloc(sizeof(F) * l);
+  for (long i = 0; i < l; ++i) w->rho_dr[i] = i < m ? d->stgs->rho_y : (i < m + n ? d->stgs->rho_x : d->stgs->rho_tau);
+  copy_mat(&w->A, d->A); if (w->hasQ) copy_mat(&w->Q, d->Q);
+  w->b = (F *)malloc(sizeof(F) * m); w->c = (F *)malloc(sizeof(F) * n); w->D = (F *)malloc(sizeof(F) * m); w->E = (F *)malloc(sizeof(F) * n);
+  w->mu = 1.0; w->beta = 1.0;
+  w->u = (F *)calloc(l, sizeof(F)); w->v = (F *)calloc(l, sizeof(F)); w->v_origin = (F *)calloc(l, sizeof(F)); w->u_t = (F *)calloc(l, sizeof(F));
+  w->rel_ut = (F *)calloc(l, sizeof(F)); w->r = (F *)calloc(l, sizeof(F));
+  w->nm_inf_b = v_nrminf(d->b, m); w->nm_inf_c = v_nrminf(d->c, n);
+  scaling_qcp_data(w, d, K);
+  if (init_kkt(w) < 0) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED; }
+  info->setup_time = now_ms() - t_init;
+  const double t0 = now_ms();
+  QR R; memset(&R, 0, sizeof(R)); QR *r = &R;
+  info->status_val = 0;
+  r->last_ipm_iter = -1; r->last_admm_iter = -1; r->res_pri = r->res_dual = r->rel_gap = r->error_ratio = 1e8;
+  F tol_inner = 4 * pow(w->mu, d->stgs->psi);
+  { /* update_work, abip.c:912-992 */
+    F *x = &w->u[m]; I count = 0;
+    for (I i = 0; K->q && i < K->qsize; ++i) { if (K->q[i] == 0) continue; memset(&x[count], 0, sizeof(F) * K->q[i]); x[count] = 1; count += K->q[i]; }
+    for (I i = 0; K->rq && i < K->rqsize; ++i) { if (K->rq[i] < 3) continue; memset(&x[count], 0, sizeof(F) * K->rq[i]); x[count] = 1; x[count + 1] = 1; count += K->rq[i]; }
+    for (I i = 0; i < K->f + K->z; ++i) x[count + i] = 0;
+    count += K->f + K->z;
+    for (I i = 0; i < K->l; ++i) x[count + i] = 1;
+    w->u[m + n] = 1.0;
+    memcpy(w->v, w->u, sizeof(F) * l);
+    /* pre_calculate, abip.c:886-910 */
+    for (I i = 0; i < m; ++i) w->r[i] = -w->b[i];
+    memcpy(&w->r[m], w->c, sizeof(F) * n);
+    solve_qcp_linsys(w, w->r);
+    F acc = 0; for (long i = 0; i < (long)m + n; ++i) acc += (w->r[i] * w->rho_dr[i]) * w->r[i];
+    w->a = w->rho_dr[m + n] + acc;
+  }
+  I i, j = 0, k = 0;
+  const QCPSettings *st = d->stgs;
+  for (i = 0; i < st->max_ipm_iters; ++i) {
+    for (j = 0; j < st->max_admm_iters; ++j) {
+      projection(w, k);
+      solve_barrier_subproblem(w, K);
+      for (long q = 0; q < l; ++q) w->v[q] = w->u[q] - w->rel_ut[q]; /* update_dual_vars, abip.c:314-324 */
+      for (long q = 0; q < l; ++q) w->v_origin[q] = w->v[q] * w->rho_dr[q];
+      if (g_trace && g_trace_n < g_trace_T) { F *dst = g_trace + 3 * l * g_trace_n; memcpy(dst, w->u, sizeof(F) * l); memcpy(dst + l, w->v, sizeof(F) * l); memcpy(dst + 2 * l, w->u_t, sizeof(F) * l); g_trace_n++; }
+      k += 1;
+      const F err_inner = inner_conv_check(w);
+      if (err_inner < tol_inner) break;
+      if ((j + 1) % st->inner_check_period == 0 || r->error_ratio <= 8) {
+        calc_residuals(w, r, i, k);
+        if ((info->status_val = has_converged(w, r, i, k)) != 0 || (double)k + 1 >= (double)st->max_admm_iters * st->max_ipm_iters || i + 1 >= st->max_ipm_iters) {
+          get_solution(w, sol, info, r, i, k); info->solve_time = now_ms() - t0; goto done;
+        }
+      }
+    }
+    if (w->sparsity || (i + 1) % st->outer_check_period == 0) {
+      calc_residuals(w, r, i, k);
+      if ((info->status_val = has_converged(w, r, i, k)) != 0 || (double)k + 1 >= (double)st->max_admm_iters * st->max_ipm_iters || i + 1 >= st->max_ipm_iters) {
+        get_solution(w, sol, info, r, i, k); info->solve_time = now_ms() - t0; goto done;
+      }
+    }
+    tol_inner = adjust_barrier(w, r);
+  }
+done:
+  info->avg_linsys_time = 0; info->avg_cg_iters = 0;
+  free(w->rho_dr); free(w->A.x); free(w->A.i); free(w->A.p);
+  if (w->hasQ) { free(w->Q.x); free(w->Q.i); free(w->Q.p); }
+  free(w->b); free(w->c); free(w->D); free(w->E); free(w->u); free(w->v); free(w->v_origin); free(w->u_t); free(w->rel_ut); free(w->r);
+  free(w->P); free(w->Lp); free(w->Li); free(w->Lx); free(w->Dg); free(w->bp);
+  return info->status_val;
+}
