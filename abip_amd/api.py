@@ -175,5 +175,6 @@ def abip(data, K, params=None):  # scripts/matlab/abip.m:1-29
         params = abip_get_params()
     params = abip_check_params(params)
     if _has(K, "f") or _has(K, "q") or _has(K, "rq") or params["solver"] == 1:
-        raise NotImplementedError("the QCP path (abip_qcpsolve, src/abip-qcp) is not built yet; see DESIGN.md")
+        from .qcp import abip_qcpsolve
+        return abip_qcpsolve(data, K, params)      # conic path (src/abip-qcp), generic QCP formulation
     return abip_lpsolve(data, K, params)

@@ -39,7 +39,7 @@ __device__ __forceinline__ void tri_level(const Tri &T, double *x, int a, int b,
 }
 
 // whole solve in one workgroup
-__global__ __launch_bounds__(TBS) void k_ldl_solve_small(Tri F, Tri B, const int *__restrict__ Pmap, const double *__restrict__ D,
+static __global__ __launch_bounds__(TBS) void k_ldl_solve_small(Tri F, Tri B, const int *__restrict__ Pmap, const double *__restrict__ D,
                                                          double *b /* l-vector */, double *x /* work, N */, int N, const Ctl *ctl) {
   if (ctl->halt) return;
   const int tid = threadIdx.x;
@@ -59,25 +59,25 @@ __global__ __launch_bounds__(TBS) void k_ldl_solve_small(Tri F, Tri B, const int
 }
 
 // segmented variant for systems too large for one workgroup
-__global__ __launch_bounds__(BS) void k_perm_in(const int *__restrict__ Pmap, const double *__restrict__ b, double *__restrict__ x, int N, const Ctl *ctl) {
+static __global__ __launch_bounds__(BS) void k_perm_in(const int *__restrict__ Pmap, const double *__restrict__ b, double *__restrict__ x, int N, const Ctl *ctl) {
   if (ctl->halt) return;
   for (int j = blockIdx.x * BS + threadIdx.x; j < N; j += gridDim.x * BS) x[j] = b[Pmap[j]];
 }
-__global__ __launch_bounds__(BS) void k_perm_out(const int *__restrict__ Pmap, double *__restrict__ b, const double *__restrict__ x, int N, const Ctl *ctl) {
+static __global__ __launch_bounds__(BS) void k_perm_out(const int *__restrict__ Pmap, double *__restrict__ b, const double *__restrict__ x, int N, const Ctl *ctl) {
   if (ctl->halt) return;
   for (int j = blockIdx.x * BS + threadIdx.x; j < N; j += gridDim.x * BS) b[Pmap[j]] = x[j];
 }
-__global__ __launch_bounds__(BS) void k_dscale(double *__restrict__ x, const double *__restrict__ D, int N, const Ctl *ctl) {
+static __global__ __launch_bounds__(BS) void k_dscale(double *__restrict__ x, const double *__restrict__ D, int N, const Ctl *ctl) {
   if (ctl->halt) return;
   for (int j = blockIdx.x * BS + threadIdx.x; j < N; j += gridDim.x * BS) x[j] /= D[j];
 }
 // one wide level over a grid
-__global__ __launch_bounds__(BS) void k_tri_wide(Tri T, double *x, int lev, const Ctl *ctl) {
+static __global__ __launch_bounds__(BS) void k_tri_wide(Tri T, double *x, int lev, const Ctl *ctl) {
   if (ctl->halt) return;
   tri_level(T, x, T.lev_ptr[lev], T.lev_ptr[lev + 1], T.lev_g[lev], blockIdx.x * BS + threadIdx.x, gridDim.x * BS);
 }
 // a run of thin levels [l0, l1) in one workgroup
-__global__ __launch_bounds__(TBS) void k_tri_thin(Tri T, double *x, int l0, int l1, const Ctl *ctl) {
+static __global__ __launch_bounds__(TBS) void k_tri_thin(Tri T, double *x, int l0, int l1, const Ctl *ctl) {
   if (ctl->halt) return;
   for (int l = l0; l < l1; ++l) {
     tri_level(T, x, T.lev_ptr[l], T.lev_ptr[l + 1], T.lev_g[l], threadIdx.x, TBS);

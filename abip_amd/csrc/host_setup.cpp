@@ -279,7 +279,6 @@ void level_sets(int N, TriHost &T, bool backward) {
 int factor_kkt(const ABIPMatrix *A, double rho_y, LdlHost &out) {
   const int m = (int)A->m, n = (int)A->n, N = m + n;
   const long nnzA = (long)A->p[n];
-  out.N = N;
   // upper triangle of K by columns (direct.c:49-104)
   std::vector<int> Kp(N + 1), Ki(N + nnzA);
   std::vector<double> Kx(N + nnzA);
@@ -291,6 +290,12 @@ int factor_kkt(const ABIPMatrix *A, double rho_y, LdlHost &out) {
     Ki[kk] = m + j; Kx[kk] = -1.0; ++kk;
   }
   Kp[N] = (int)kk;
+  return factor_upper(N, Kp, Ki, Kx, out);
+}
+
+int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, const std::vector<double> &Kx, LdlHost &out) {
+  out.N = N;
+  const long kk = Kp[N];
   // symmetric adjacency (no diagonal)
   std::vector<int> Gp(N + 1, 0);
   for (int j = 0; j < N; ++j) for (int q = Kp[j]; q < Kp[j + 1]; ++q) if (Ki[q] != j) { Gp[Ki[q] + 1]++; Gp[j + 1]++; }

@@ -46,6 +46,8 @@ struct LdlHost {
   TriHost fwd, bwd;
 };
 int factor_kkt(const ABIPMatrix *A, double rho_y, LdlHost &out);
+// the same for any symmetric quasi-definite matrix given by its upper triangle in CSC form (QCP KKT, qcp_config.c:699-748)
+int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, const std::vector<double> &Kx, LdlHost &out);
 
 } // namespace host
 } // namespace abip

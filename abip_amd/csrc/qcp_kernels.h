@@ -1,0 +1,321 @@
+// qcp_kernels.h -- HIP kernels of the conic (ABIP-QCP) inner iteration (reference: src/abip-qcp/source/abip.c:1130-1157):
+//
+//   kq_rhs           mu = rho o (u+v); rhs = (-mu_y, mu_x); partial r'mu                  abip.c:198-202,222 ; qcp_config.c:873
+//   (LDL' solve)     dev_sptrsv.h on the QCP KKT matrix                                   linsys.c:309-316, qdldl.c:236-281
+//   kq_dots, kq_Qp   partial r'(rho o p), p_x'Q p_x                                       abip.c:226-239
+//   kq_ut_prox       tau~ from the scalar quadratic; u_t = p - tau~ r; over-relaxed point; y, tau, orthant/free/zero
+//                    blocks of the barrier sub-problem                                    abip.c:241-248, 336-353, 390-409 ; cones.c:255-288
+//   kq_cones         SOC / rotated-SOC barrier prox, one wavefront per cone               cones.c:130-248
+//   kq_dual          v = u - rel_ut ; v_origin = rho o v                                  abip.c:314-324, 1143-1144
+//   kq_inner_*       Mu = (A x ; -A'y + Q x) and the sums of the inner stopping test      qcp_config.c:518-557
+//   kq_resid         inf-norm residuals, objectives, certificates from the stored A x, A'y, Q x   qcp_config.c:562-691
+//   kq_finalize      partials -> scalars (sum or max)
+#pragma once
+#include "dev_common.h"
+
+namespace abip {
+
+struct QDims { int m, n, MP; };
+
+enum QSlot : int { // reuse of the partials table; *_MAX slots are reduced with max
+  Q_T0 = 0, Q_T1, Q_PG,                       // r'mu, r'(rho o p), p_x'Qp
+  Q_D1, Q_D2, Q_D3, Q_E1, Q_E2, Q_E3,         // inner test: u'Mu, u_y'b, u_x'c, |Qu - v_o|^2, |Qu|^2, |v_o|^2 (tau entry added by the host)
+  Q_S0, Q_S1, Q_S2, Q_S3, Q_S4, Q_S5,         // |D o Ax|^2, b'u_y, c'u_x, u_x'Qx, |E o Qx|^2, |E o (A'y + v_o)|^2
+  Q_M0, Q_M1, Q_M2, Q_M3, Q_M4, Q_M5,         // max slots: |Ax/t-b|, D|Ax/t-b|, D|Ax/t|, |R|, E|R|, E|Qx/t|
+  Q_COUNT
+};
+__host__ __device__ inline bool qslot_is_max(int s) { return s >= Q_M0 && s <= Q_M5; }
+
+struct QCtl { double out[32]; double tau_t; int pad[2]; };
+
+__device__ __forceinline__ double wave_max(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_down(x, off, 64));
+  return x;
+}
+template <int NS>
+__device__ __forceinline__ void write_partials_max(double *part, const int (&slots)[NS], double (&v)[NS], double *sm) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) v[s] = wave_max(v[s]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sm[s * WAVES + wave] = v[s];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      double t = sm[s * WAVES];
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) t = fmax(t, sm[s * WAVES + w]);
+      part[slots[s] * MAXNB + blockIdx.x] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BS) void kq_rhs(const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ r,
+                                             double *__restrict__ p, double rho_y, double rho_x, QDims d, double *part) {
+  __shared__ double sm[WAVES];
+  double acc[1] = {0.0};
+  const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
+  for (int i = t0; i < d.m; i += stride) { const double mu = (u[i] + v[i]) * rho_y; p[i] = -mu; acc[0] += r[i] * mu; }
+  for (int j = t0; j < d.n; j += stride) { const int q = d.MP + j; const double mu = (u[q] + v[q]) * rho_x; p[q] = mu; acc[0] += r[q] * mu; }
+  const int ws[1] = {Q_T0};
+  write_partials<1>(part, ws, acc, sm);
+}
+__global__ __launch_bounds__(BS) void kq_dots(const double *__restrict__ r, const double *__restrict__ p, double rho_y, double rho_x, QDims d, double *part) {
+  __shared__ double sm[WAVES];
+  double acc[1] = {0.0};
+  const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
+  for (int i = t0; i < d.m; i += stride) acc[0] += r[i] * (p[i] * rho_y);
+  for (int j = t0; j < d.n; j += stride) acc[0] += r[d.MP + j] * (p[d.MP + j] * rho_x);
+  const int ws[1] = {Q_T1};
+  write_partials<1>(part, ws, acc, sm);
+}
+__global__ __launch_bounds__(BS) void kq_Qp(Csr Q, const double *__restrict__ p, QDims d, double *part) {
+  __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
+  __shared__ double sm[WAVES];
+  const double *px = p + d.MP;
+  double acc1[1] = {0.0};
+  spmv_stream<1>(
+      Q, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * px[c]; },
+      [&](int i, double(&acc)[1]) { acc1[0] += px[i] * acc[0]; });
+  const int ws[1] = {Q_PG};
+  write_partials<1>(part, ws, acc1, sm);
+}
+
+// x-entry kinds (host-built from the cone description, abip.c:358-409)
+enum : int { XK_ORTHANT = 0, XK_FREE = 1, XK_ZERO = 2, XK_CONE = 3, XK_NONE = 4 };
+
+__device__ __forceinline__ double orthant_prox(double t, double lambda) { // cones.c:279-288
+  if (t >= 0) return (t + sqrt(t * t + 4 * lambda)) / 2;
+  return 2 * lambda / (-t * (1 + sqrt(1 + 4 * lambda / (t * t))));
+}
+
+struct QProxArgs {
+  double *u, *v, *ut, *rel;
+  const double *p, *r;
+  const int *xkind;
+  double alpha, lambda, rho_x, rho_tau, a_quad;
+  int iter_pos; // iter > 0
+  int hasQ;
+};
+__global__ __launch_bounds__(BS) void kq_ut_prox(QProxArgs a, QDims d, const double *part, int nb, QCtl *ctl) {
+  __shared__ double sm[3 * WAVES];
+  double s3[3];
+  const int rs[3] = {Q_T0, Q_T1, Q_PG};
+  read_partials<3>(part, rs, nb, s3, sm);
+  const int tail = d.MP + d.n;
+  const double eta = a.rho_tau * (a.u[tail] + a.v[tail]);
+  const double bq = s3[0] - 2 * s3[1] - eta;               // abip.c:229-230
+  const double cq = a.hasQ ? -s3[2] : -0.0;                 // abip.c:239
+  const double tt = a.iter_pos ? (-bq + sqrt(fmax(0.0, bq * bq - 4 * a.a_quad * cq))) / (2 * a.a_quad) : 1.0; // abip.c:241-245
+  const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
+  for (int i = t0; i < d.m; i += stride) {
+    const double uti = a.p[i] + (-tt) * a.r[i];             // abip.c:247-248
+    const double rl = uti * a.alpha + (1 - a.alpha) * a.u[i] - a.v[i]; // abip.c:336-342
+    a.ut[i] = uti; a.rel[i] = rl; a.u[i] = rl;              // abip.c:352
+  }
+  const double lam_x = a.lambda / a.rho_x;
+  for (int j = t0; j < d.n; j += stride) {
+    const int q = d.MP + j;
+    const double uti = a.p[q] + (-tt) * a.r[q];
+    const double rl = uti * a.alpha + (1 - a.alpha) * a.u[q] - a.v[q];
+    a.ut[q] = uti; a.rel[q] = rl;
+    const int kd = a.xkind[j];
+    if (kd == XK_ORTHANT) a.u[q] = orthant_prox(rl, lam_x);
+    else if (kd == XK_FREE) a.u[q] = rl;
+    else if (kd == XK_ZERO) a.u[q] = 0.0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const double rl = tt * a.alpha + (1 - a.alpha) * a.u[tail] - a.v[tail];
+    a.ut[tail] = tt; a.rel[tail] = rl;
+    a.u[tail] = (rl + sqrt(rl * rl + 4 * a.lambda / a.rho_tau)) / 2; // abip.c:348-350
+    ctl->tau_t = tt;
+  }
+}
+
+// one wavefront per SOC / RSOC cone: ||tail||^2 by a wave reduction, closed form on lane 0, scaled copy by all lanes
+struct QCones { const int *off, *len, *kind; int n; }; // kind 0 SOC, 1 RSOC
+__global__ __launch_bounds__(BS) void kq_cones(QCones C, double *__restrict__ u, const double *__restrict__ rel, double lambda, int MP) {
+  const int wave = (blockIdx.x * BS + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= C.n) return;
+  const int off = MP + C.off[wave], len = C.len[wave], kind = C.kind[wave];
+  const int h = (kind == 0) ? 1 : 2; // head entries
+  double sq = 0.0;
+  for (int k = h + lane; k < len; k += 64) { const double t = rel[off + k]; sq += t * t; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  double x0 = 0, x1 = 0, sc = 0;
+  if (kind == 0) { // cones.c:130-161
+    const double a = rel[off];
+    if (fabs(a) <= 1e-9) { x0 = sqrt(2 * lambda + sq / 4); sc = 0.5; }
+    else {
+      const double w8 = 8 * lambda - a * a + sq;
+      const double rr = 16 * a * a / (w8 + sqrt(w8 * w8 + 32 * a * a * lambda));
+      const double s1 = (rr - sqrt(rr * (rr + 8))) / 2, s2 = (rr + sqrt(rr * (rr + 8))) / 2;
+      const double s = a > 0 ? s2 : s1;
+      x0 = (s + 2) * a / s; sc = (s + 2) / (s + 4);
+    }
+    if (lane == 0) u[off] = x0;
+  } else { // cones.c:169-248
+    const double ze = rel[off], zn = rel[off + 1];
+    if (ze + zn == 0) {
+      x1 = (-ze + sqrt(ze * ze + 4 * lambda + sq)) / 2;
+      x0 = u[off] + ze; // sic (cones.c:183)
+      sc = 0.5;
+    } else {
+      double w, s;
+      const double dd = 2 * ze * zn - sq;
+      if (dd < 0) { const double q = -dd / (2 * lambda); w = (2 * (ze + zn) * (ze + zn) / lambda) / q / (1 + 4 / q + sqrt(1 + (4 * (ze * ze + zn * zn + sq) / lambda + 16) / q / q)); }
+      else { const double q = dd / (2 * lambda); w = q * (1 - 4 / q + sqrt(1 + (4 * (ze * ze + zn * zn + sq) / lambda + 16) / q / q)) / 2; }
+      if (ze + zn > 0) {
+        s = (w + sqrt(w * (w + 4))) / 2;
+        x0 = (ze * (s + 1) * (s + 1) + zn * (s + 1)) / (s * (s + 2)); x1 = (zn * (s + 1) * (s + 1) + ze * (s + 1)) / (s * (s + 2)); sc = (s + 1) / (s + 2);
+      } else if (w > 10) {
+        s = 2 / (w + 2 + sqrt(w * (w + 4)));
+        x0 = (ze * s * s + zn * s) / ((s - 1) * (s + 1)); x1 = (zn * s * s + ze * s) / ((s - 1) * (s + 1)); sc = s / (s + 1);
+      } else {
+        s = (w - sqrt(w * (w + 4))) / 2;
+        x0 = (ze * (s + 1) * (s + 1) + zn * (s + 1)) / (s * (s + 2)); x1 = (zn * (s + 1) * (s + 1) + ze * (s + 1)) / (s * (s + 2)); sc = (s + 1) / (s + 2);
+      }
+    }
+    if (lane == 0) { u[off] = x0; u[off + 1] = x1; }
+  }
+  for (int k = h + lane; k < len; k += 64) u[off + k] = rel[off + k] * sc;
+}
+
+__global__ __launch_bounds__(BS) void kq_dual(const double *__restrict__ u, const double *__restrict__ rel, double *__restrict__ v, double *__restrict__ vo,
+                                              double rho_y, double rho_x, double rho_tau, QDims d) {
+  const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
+  for (int i = t0; i < d.m; i += stride) { const double t = u[i] - rel[i]; v[i] = t; vo[i] = t * rho_y; }
+  for (int j = t0; j <= d.n; j += stride) { const int q = d.MP + j; const double t = u[q] - rel[q]; v[q] = t; vo[q] = t * (j == d.n ? rho_tau : rho_x); }
+}
+
+// ---- inner stopping test (qcp_config.c:518-557); the tau entry of Qu is completed by the host from the sums ----
+__global__ __launch_bounds__(BS) void kq_inner_A(Csr A, const double *__restrict__ u, const double *__restrict__ vo, const double *__restrict__ b,
+                                                 double *__restrict__ Ax, QDims d, double *part) {
+  __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
+  __shared__ double sm[5 * WAVES];
+  const double *x = u + d.MP;
+  const double tau = u[d.MP + d.n];
+  double a5[5] = {0, 0, 0, 0, 0};
+  spmv_stream<1>(
+      A, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
+      [&](int i, double(&acc)[1]) {
+        const double mu = acc[0], qu = mu + (-tau) * b[i], dv = qu - vo[i];
+        Ax[i] = mu;
+        a5[0] += u[i] * mu; a5[1] += u[i] * b[i]; a5[2] += dv * dv; a5[3] += qu * qu; a5[4] += vo[i] * vo[i];
+      });
+  const int ws[5] = {Q_D1, Q_D2, Q_E1, Q_E2, Q_E3};
+  write_partials<5>(part, ws, a5, sm);
+}
+// rows of A' (and of Q): with Q the A'y product is only stored and kq_inner_Q finishes the row
+__global__ __launch_bounds__(BS) void kq_inner_At(Csr At, const double *__restrict__ u, const double *__restrict__ vo, const double *__restrict__ c,
+                                                  double *__restrict__ ATy, double *__restrict__ Qx, int finish, QDims d, double *part) {
+  __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
+  __shared__ double sm[5 * WAVES];
+  const double tau = u[d.MP + d.n];
+  double a5[5] = {0, 0, 0, 0, 0};
+  spmv_stream<1>(
+      At, lds, lptr, sm, [&](int cc, double a, double(&pr)[1]) { pr[0] = a * u[cc]; },
+      [&](int j, double(&acc)[1]) {
+        ATy[j] = acc[0];
+        if (finish) {
+          const int q = d.MP + j;
+          const double mu = -acc[0], qu = mu + tau * c[j], dv = qu - vo[q];
+          Qx[j] = 0.0;
+          a5[0] += u[q] * mu; a5[1] += u[q] * c[j]; a5[2] += dv * dv; a5[3] += qu * qu; a5[4] += vo[q] * vo[q];
+        }
+      });
+  if (finish) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { const double t = vo[d.MP + d.n]; a5[4] += t * t; }
+    const int ws[5] = {Q_D1 + 0, Q_D3, Q_E1, Q_E2, Q_E3};
+    // the y rows already own slots D1, E1..E3: use the second half of the table (offset Q_COUNT) for the x rows
+    double *part2 = part + (size_t)Q_COUNT * MAXNB;
+    write_partials<5>(part2, ws, a5, sm);
+  }
+}
+__global__ __launch_bounds__(BS) void kq_inner_Q(Csr Q, const double *__restrict__ u, const double *__restrict__ vo, const double *__restrict__ c,
+                                                 const double *__restrict__ ATy, double *__restrict__ Qx, QDims d, double *part) {
+  __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
+  __shared__ double sm[5 * WAVES];
+  const double *x = u + d.MP;
+  const double tau = u[d.MP + d.n];
+  double a5[5] = {0, 0, 0, 0, 0};
+  spmv_stream<1>(
+      Q, lds, lptr, sm, [&](int cc, double a, double(&pr)[1]) { pr[0] = a * x[cc]; },
+      [&](int j, double(&acc)[1]) {
+        const int q = d.MP + j;
+        Qx[j] = acc[0];
+        const double mu = -ATy[j] + acc[0], qu = mu + tau * c[j], dv = qu - vo[q];
+        a5[0] += u[q] * mu; a5[1] += u[q] * c[j]; a5[2] += dv * dv; a5[3] += qu * qu; a5[4] += vo[q] * vo[q];
+      });
+  if (blockIdx.x == 0 && threadIdx.x == 0) { const double t = vo[d.MP + d.n]; a5[4] += t * t; }
+  const int ws[5] = {Q_D1 + 0, Q_D3, Q_E1, Q_E2, Q_E3};
+  double *part2 = part + (size_t)Q_COUNT * MAXNB;
+  write_partials<5>(part2, ws, a5, sm);
+}
+
+// ---- residuals (qcp_config.c:562-691) from the stored products; x = u_x / tau etc. folded into the formulas ----
+__global__ __launch_bounds__(BS) void kq_resid(const double *__restrict__ u, const double *__restrict__ vo, const double *__restrict__ b,
+                                               const double *__restrict__ c, const double *__restrict__ Dv, const double *__restrict__ Ev,
+                                               const double *__restrict__ Ax, const double *__restrict__ ATy, const double *__restrict__ Qx,
+                                               QDims d, double *part) {
+  __shared__ double sm[6 * WAVES];
+  const double tau = fabs(u[d.MP + d.n]), it = 1 / tau;
+  double s6[6] = {0, 0, 0, 0, 0, 0}, m6[6] = {0, 0, 0, 0, 0, 0};
+  const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
+  for (int i = t0; i < d.m; i += stride) {
+    const double ax = Ax[i] * it, e = ax - b[i], Di = Dv[i];
+    m6[0] = fmax(m6[0], fabs(e)); m6[1] = fmax(m6[1], fabs(e * Di)); m6[2] = fmax(m6[2], fabs(ax * Di));
+    const double dax = Di * Ax[i];
+    s6[0] += dax * dax; s6[1] += b[i] * u[i];
+  }
+  for (int j = t0; j < d.n; j += stride) {
+    const int q = d.MP + j;
+    const double qx = Qx[j] * it, aty = ATy[j] * it, s = vo[q] * it, Ej = Ev[j];
+    const double R = qx - aty + c[j] - s;
+    m6[3] = fmax(m6[3], fabs(R)); m6[4] = fmax(m6[4], fabs(R * Ej)); m6[5] = fmax(m6[5], fabs(qx * Ej));
+    const double eq = Ej * Qx[j], ea = Ej * (ATy[j] + vo[q]);
+    s6[2] += c[j] * u[q]; s6[3] += u[q] * Qx[j]; s6[4] += eq * eq; s6[5] += ea * ea;
+  }
+  const int ws[6] = {Q_S0, Q_S1, Q_S2, Q_S3, Q_S4, Q_S5};
+  write_partials<6>(part, ws, s6, sm);
+  const int wm[6] = {Q_M0, Q_M1, Q_M2, Q_M3, Q_M4, Q_M5};
+  __syncthreads();
+  write_partials_max<6>(part, wm, m6, sm);
+}
+
+// one block: partials (both halves of the table) -> ctl->out
+struct QFin { int nslots; int slots[24]; int second_half[24]; };
+__global__ __launch_bounds__(BS) void kq_finalize(QFin f, const double *part, int nb, QCtl *ctl) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int PER = MAXNB / 64;
+  for (int s = wave; s < f.nslots; s += WAVES) {
+    const int slot = f.slots[s];
+    const bool mx = qslot_is_max(slot);
+    double acc = 0.0;
+    for (int half = 0; half <= f.second_half[s]; ++half) {
+      const double *pp = part + ((size_t)half * Q_COUNT + slot) * MAXNB;
+      double t[PER];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) { const int i = lane + u * 64; t[u] = (i < nb) ? pp[i] : 0.0; }
+      double a2 = 0.0;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) a2 = mx ? fmax(a2, t[u]) : a2 + t[u];
+      a2 = mx ? wave_max(a2) : wave_sum(a2);
+      acc = mx ? fmax(acc, a2) : acc + a2;
+    }
+    if (lane == 0) ctl->out[slot] = acc;
+  }
+}
+
+} // namespace abip

@@ -1,0 +1,531 @@
+// qcp_solver.hip -- the conic (ABIP-QCP) path of libabip_hip.so: abip_qcp() == abip(d, sol, info, K) of the reference
+// (src/abip-qcp/source/abip.c:1335-1371) for the generic QCP formulation with the QDLDL-class direct solver.
+// Host: scaling (qcp_config.c:91-491), KKT assembly (699-748) + LDL' (host_setup.cpp), the loop of abip.c:1129-1246 with its
+// scalar decisions.  Device: everything per iteration (qcp_kernels.h, dev_sptrsv.h); one control read per inner iteration.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/abip_qcp.h"
+#include "dev_host_util.h"
+#include "qcp_kernels.h"
+
+using namespace abip;
+using namespace abip::hostutil;
+
+namespace {
+
+constexpr double kMinScale = 1e-3, kMaxScale = 1e3; // qcp_config.c:2-3
+constexpr double EPS_TOL = 1E-18;
+inline double safediv_pos(double x, double y) { return y < EPS_TOL ? x / EPS_TOL : x / y; }
+
+struct HMat { int m = 0, n = 0; std::vector<int> p, i; std::vector<double> x; };
+void copy_in(HMat &dst, const QCPMatrix *src) {
+  dst.m = src->m; dst.n = src->n;
+  const int nnz = src->p[src->n];
+  dst.p.assign(src->p, src->p + src->n + 1); dst.i.assign(src->i, src->i + nnz); dst.x.assign(src->x, src->x + nnz);
+}
+double vnrminf(const double *a, long n) { double mx = 0; for (long k = 0; k < n; ++k) { const double t = std::fabs(a[k]); if (t >= mx) mx = t; } return mx; }
+
+struct QResid { // struct ABIP_RESIDUALS, abip.h:182-207
+  int last_ipm_iter = -1, last_admm_iter = -1;
+  double res_pri = 1e8, res_dual = 1e8, rel_gap = 1e8, res_infeas = 0, res_unbdd = 0, pobj = 0, dobj = 0, tau = 0, kap = 0, res_dif = 0,
+         error_ratio = 1e8, Ax_b_norm = 0, Qx_ATy_c_s_norm = 0;
+};
+
+struct QWk {
+  int m = 0, n = 0, MP = 0, LV = 0, NB = 1;
+  const QCPSettings *st = nullptr;
+  bool hasQ = false;
+  int sparsity = 0;
+  HMat A, Q;
+  std::vector<double> D, E, b, c;
+  double sc_b = 1, sc_c = 1, nm_inf_b = 0, nm_inf_c = 0, a_quad = 0, mu = 1, beta = 1;
+  hipStream_t stream = nullptr;
+  DevCsr dA, dAt, dQ;
+  DBuf<double> u, v, vo, ut, rel, r, p, bd, cd, Dd, Ed, Ax, ATy, Qx, part, xw, Dg;
+  DBuf<int> xkind, c_off, c_len, c_kind, Pmap;
+  DBuf<QCtl> ctl;
+  QCtl *hctl = nullptr;
+  DevTri triF, triB;
+  std::vector<Segment> segF, segB;
+  bool small_solve = false;
+  int ncones = 0;
+  Ctl *lp_ctl = nullptr; // dev_sptrsv kernels are gated on an LP-style control block (halt flag): a zeroed one
+};
+
+#define QLAUNCH(w, kern, grid, block, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (w)->stream, __VA_ARGS__)
+
+void release(QWk *w) {
+  w->dA.release(); w->dAt.release(); w->dQ.release();
+  DBuf<double> *bufs[] = {&w->u, &w->v, &w->vo, &w->ut, &w->rel, &w->r, &w->p, &w->bd, &w->cd, &w->Dd, &w->Ed, &w->Ax, &w->ATy, &w->Qx, &w->part, &w->xw, &w->Dg};
+  for (auto *b : bufs) b->release();
+  w->xkind.release(); w->c_off.release(); w->c_len.release(); w->c_kind.release(); w->Pmap.release(); w->ctl.release();
+  w->triF.release(); w->triB.release();
+  if (w->lp_ctl) (void)hipFree(w->lp_ctl);
+  if (w->hctl) (void)hipHostFree(w->hctl);
+  if (w->stream) (void)hipStreamDestroy(w->stream);
+}
+
+// ---- scaling, qcp_config.c:91-491 -----------------------------------------------------------------------------
+void cone_average(std::vector<double> &E, const QCPCone *k) { // :194-212
+  int count = 0;
+  auto avg = [&](int len) { double y = 0; for (int j = 0; j < len; ++j) y += E[count + j]; y /= len; for (int j = 0; j < len; ++j) E[count + j] = y; count += len; };
+  if (k->q) for (int i = 0; i < k->qsize; ++i) avg(k->q[i]);
+  if (k->rq) for (int i = 0; i < k->rqsize; ++i) avg(k->rq[i]);
+}
+void apply_pass(QWk *w, std::vector<double> &Dp, std::vector<double> &Ep) { // :214-262
+  const int m = w->m, n = w->n;
+  const double min_row = kMinScale * std::sqrt((double)n), max_row = kMaxScale * std::sqrt((double)n);
+  const double min_col = kMinScale * std::sqrt((double)m), max_col = kMaxScale * std::sqrt((double)m);
+  HMat &A = w->A, &Q = w->Q;
+  for (int i = 0; i < m; ++i) { if (Dp[i] < min_row) Dp[i] = 1; else if (Dp[i] > max_row) Dp[i] = max_row; }
+  for (int i = 0; i < n; ++i) {
+    if (Ep[i] < min_col) Ep[i] = 1; else if (Ep[i] > max_col) Ep[i] = max_col;
+    for (int j = A.p[i]; j < A.p[i + 1]; ++j) A.x[j] /= Ep[i];
+  }
+  if (w->hasQ) {
+    for (int i = 0; i < n; ++i) for (int j = Q.p[i]; j < Q.p[i + 1]; ++j) Q.x[j] /= Ep[i];
+    for (int q = 0; q < Q.p[n]; ++q) Q.x[q] /= Ep[Q.i[q]];
+  }
+  for (int q = 0; q < A.p[n]; ++q) A.x[q] /= Dp[A.i[q]];
+  for (int i = 0; i < n; ++i) w->E[i] *= Ep[i];
+  for (int i = 0; i < m; ++i) w->D[i] *= Dp[i];
+}
+void scale_data(QWk *w, const QCPData *d, const QCPCone *k) {
+  const int m = w->m, n = w->n;
+  HMat &A = w->A, &Q = w->Q;
+  w->b.assign(d->b, d->b + m); w->c.assign(d->c, d->c + n);
+  w->D.assign(m, 1.0); w->E.assign(n, 1.0);
+  std::vector<double> Ep(n), E1(n), E2(n), Dp(m);
+  auto col_inf = [](const HMat &M, int j) { double mx = 0; for (int q = M.p[j]; q < M.p[j + 1]; ++q) { const double t = std::fabs(M.x[q]); if (t >= mx) mx = t; } return mx; };
+  if (w->st->ruiz_scaling) {
+    for (int it = 0; it < 10; ++it) {
+      std::fill(E2.begin(), E2.end(), 0.0); std::fill(Dp.begin(), Dp.end(), 0.0);
+      for (int j = 0; j < n; ++j) E1[j] = (A.p[j] == A.p[j + 1]) ? 0 : std::sqrt(col_inf(A, j));
+      if (w->hasQ) for (int j = 0; j < n; ++j) E2[j] = (Q.p[j] == Q.p[j + 1]) ? 0 : std::sqrt(col_inf(Q, j));
+      for (int j = 0; j < n; ++j) Ep[j] = E1[j] < E2[j] ? E2[j] : E1[j];
+      cone_average(Ep, k);
+      for (int q = 0; q < A.p[n]; ++q) if (Dp[A.i[q]] < std::fabs(A.x[q])) Dp[A.i[q]] = std::fabs(A.x[q]);
+      for (int i = 0; i < m; ++i) Dp[i] = std::sqrt(Dp[i]);
+      apply_pass(w, Dp, Ep);
+    }
+  }
+  if (w->st->origin_scaling) {
+    std::fill(E1.begin(), E1.end(), 0.0); std::fill(E2.begin(), E2.end(), 0.0); std::fill(Dp.begin(), Dp.end(), 0.0);
+    for (int j = 0; j < n; ++j) { for (int q = A.p[j]; q < A.p[j + 1]; ++q) E1[j] += A.x[q] * A.x[q]; E1[j] = std::sqrt(E1[j]); }
+    if (w->hasQ) for (int j = 0; j < n; ++j) { for (int q = Q.p[j]; q < Q.p[j + 1]; ++q) E2[j] += Q.x[q] * Q.x[q]; E2[j] = std::sqrt(E2[j]); }
+    for (int j = 0; j < n; ++j) Ep[j] = std::sqrt(E1[j] < E2[j] ? E2[j] : E1[j]);
+    cone_average(Ep, k);
+    for (int q = 0; q < A.p[n]; ++q) Dp[A.i[q]] += A.x[q] * A.x[q];
+    for (int i = 0; i < m; ++i) Dp[i] = std::sqrt(std::sqrt(Dp[i]));
+    apply_pass(w, Dp, Ep);
+  }
+  if (w->st->pc_scaling) {
+    std::fill(E1.begin(), E1.end(), 0.0); std::fill(E2.begin(), E2.end(), 0.0); std::fill(Dp.begin(), Dp.end(), 0.0);
+    for (int j = 0; j < n; ++j) { for (int q = A.p[j]; q < A.p[j + 1]; ++q) E1[j] += std::fabs(A.x[q]); E1[j] = std::sqrt(E1[j]); }
+    if (w->hasQ) for (int j = 0; j < n; ++j) { for (int q = Q.p[j]; q < Q.p[j + 1]; ++q) E2[j] += std::fabs(Q.x[q]); E2[j] = std::sqrt(E2[j]); }
+    for (int j = 0; j < n; ++j) Ep[j] = E1[j] < E2[j] ? E2[j] : E1[j];
+    cone_average(Ep, k);
+    for (int q = 0; q < A.p[n]; ++q) Dp[A.i[q]] += std::fabs(A.x[q]);
+    for (int i = 0; i < m; ++i) Dp[i] = std::sqrt(Dp[i]);
+    apply_pass(w, Dp, Ep);
+  }
+  double ss = 0;
+  for (double t : w->c) ss += t * t;
+  double sb = 0;
+  for (double t : w->b) sb += t * t;
+  double sc = std::sqrt(std::sqrt(ss + sb)); // :462-463
+  for (int i = 0; i < m; ++i) w->b[i] /= w->D[i];
+  for (int j = 0; j < n; ++j) w->c[j] /= w->E[j];
+  if (sc < kMinScale) sc = 1; else if (sc > kMaxScale) sc = kMaxScale;
+  w->sc_b = 1 / sc; w->sc_c = 1 / sc;
+  for (int i = 0; i < m; ++i) w->b[i] *= w->sc_b * w->st->scale;
+  for (int j = 0; j < n; ++j) w->c[j] *= w->sc_c * w->st->scale;
+}
+
+void hcsr_from(const HMat &M, host::HostCsr &out, bool transpose_to_rows) {
+  // transpose_to_rows = false: CSC read as CSR of M' (ncols rows); true: explicit CSR of M (nrows rows)
+  const int nnz = M.p[M.n];
+  if (!transpose_to_rows) {
+    out.nrows = M.n; out.ncols = M.m; out.ptr = M.p; out.idx = M.i; out.val = M.x;
+  } else {
+    out.nrows = M.m; out.ncols = M.n; out.ptr.assign(M.m + 1, 0); out.idx.resize(nnz); out.val.resize(nnz);
+    for (int q = 0; q < nnz; ++q) out.ptr[M.i[q] + 1]++;
+    for (int i = 0; i < M.m; ++i) out.ptr[i + 1] += out.ptr[i];
+    std::vector<int> pos(out.ptr.begin(), out.ptr.end() - 1);
+    for (int j = 0; j < M.n; ++j) for (int q = M.p[j]; q < M.p[j + 1]; ++q) { const int dst = pos[M.i[q]]++; out.idx[dst] = j; out.val[dst] = M.x[q]; }
+  }
+  host::build_row_blocks(out, CHUNK);
+}
+
+void enqueue_solve(QWk *w, double *rhs) { // _ldl_solve, linsys.c:309-316
+  const int N = w->m + w->n;
+  const Ctl *ctl = w->lp_ctl;
+  if (w->small_solve) {
+    QLAUNCH(w, k_ldl_solve_small, 1, TBS, w->triF.view(), w->triB.view(), (const int *)w->Pmap.p, (const double *)w->Dg.p, rhs, w->xw.p, N, ctl);
+    return;
+  }
+  const int gN = std::max(1, std::min(w->NB, (N + BS - 1) / BS));
+  QLAUNCH(w, k_perm_in, gN, BS, (const int *)w->Pmap.p, (const double *)rhs, w->xw.p, N, ctl);
+  auto run = [&](const DevTri &T, const std::vector<Segment> &segs) {
+    for (const Segment &s : segs) {
+      if (s.wide) {
+        const int rows = T.h_lev_ptr[s.l0 + 1] - T.h_lev_ptr[s.l0];
+        QLAUNCH(w, k_tri_wide, std::max(1, std::min(MAXNB, (rows * 8 + BS - 1) / BS)), BS, T.view(), w->xw.p, s.l0, ctl);
+      } else QLAUNCH(w, k_tri_thin, 1, TBS, T.view(), w->xw.p, s.l0, s.l1, ctl);
+    }
+  };
+  run(w->triF, w->segF);
+  QLAUNCH(w, k_dscale, gN, BS, w->xw.p, (const double *)w->Dg.p, N, ctl);
+  run(w->triB, w->segB);
+  QLAUNCH(w, k_perm_out, gN, BS, (const int *)w->Pmap.p, rhs, (const double *)w->xw.p, N, ctl);
+}
+
+int read_ctl(QWk *w) {
+  HIP_OK(hipMemcpyAsync(w->hctl, w->ctl.p, sizeof(QCtl), hipMemcpyDeviceToHost, w->stream));
+  HIP_OK(hipStreamSynchronize(w->stream));
+  return 0;
+}
+void finalize(QWk *w, std::initializer_list<int> slots, std::initializer_list<int> both_halves) {
+  QFin f; f.nslots = 0;
+  for (int s : slots) { f.slots[f.nslots] = s; f.second_half[f.nslots] = 0; for (int bsl : both_halves) if (bsl == s) f.second_half[f.nslots] = 1; ++f.nslots; }
+  QLAUNCH(w, kq_finalize, 1, BS, f, (const double *)w->part.p, w->NB, w->ctl.p);
+}
+
+double adjust_barrier(QWk *w, const QResid &r) { // abip.c:994-1071
+  const QCPSettings *st = w->st;
+  double sigma = 0.8, gamma;
+  const double ratio = w->mu / std::min(std::min(st->eps_p, st->eps_d), st->eps_g);
+  if (ratio > 50 && ratio <= 100) gamma = 1.5;
+  else if (ratio > 10 && ratio <= 50) gamma = 1.3;
+  else if (ratio > 5 && ratio <= 10) gamma = 1.2;
+  else if (ratio > 1 && ratio <= 5) gamma = 1.1;
+  else if (ratio > 0.5 && ratio <= 1) gamma = 1;
+  else if (ratio > 0.05 && ratio <= 0.5) gamma = 0.9;
+  else if (ratio > 0.005 && ratio <= 0.05) gamma = 0.8;
+  else if (ratio > 0.0005 && ratio <= 0.005) gamma = 0.7;
+  else if (ratio > 0.00005 && ratio <= 0.0005) gamma = 0.6;
+  else gamma = 0.5;
+  const double mr = r.error_ratio;
+  if (mr > 22) gamma *= 4.4;
+  else if (mr > 18 && mr <= 22) gamma *= 4.2;
+  else if (mr > 15 && mr <= 18) gamma *= 4;
+  else if (mr > 12 && mr <= 15) gamma *= 3.8;
+  else if (mr > 8 && mr <= 12) gamma *= 3.6;
+  else if (mr > 6 && mr <= 8) { sigma = 0.81; gamma *= 3.4; }
+  else if (mr > 4 && mr <= 6) { sigma = 0.82; gamma *= 3.4; }
+  else if (mr > 3 && mr <= 4) { sigma = 0.83; gamma *= 3.2; }
+  else if (mr > 2 && mr <= 3) { sigma = 0.85; gamma *= 2.8; }
+  else if (mr > 1.5 && mr <= 2) { sigma = 0.85; gamma *= 2.6; }
+  else if (mr < 1.5) { sigma = 0.85; gamma *= 2.4; }
+  sigma *= 0.2;
+  w->mu = sigma * w->mu;
+  return gamma * std::pow(w->mu, st->psi);
+}
+
+int has_converged(const QWk *w, const QResid &r, int ipm_iter, int admm_iter) { // abip.c:750-777
+  const QCPSettings *st = w->st;
+  if (r.res_pri < st->eps_p && r.res_dual < st->eps_d && r.rel_gap < st->eps_g) return 1;
+  if (r.res_dif < st->err_dif * std::max(std::max(st->eps_p, st->eps_d), st->eps_g)) return 2;
+  if (r.res_unbdd < st->eps_unb && ipm_iter > 0 && admm_iter > 0) return -1;
+  if (r.res_infeas < st->eps_inf && ipm_iter > 0 && admm_iter > 0) return -2;
+  return 0;
+}
+
+int calc_residuals(QWk *w, QResid &r, int ipm_iter, int admm_iter) { // qcp_config.c:562-691 (sums from kq_resid)
+  if (admm_iter && r.last_admm_iter == admm_iter) return 0;
+  r.last_ipm_iter = ipm_iter; r.last_admm_iter = admm_iter;
+  const QDims d{w->m, w->n, w->MP};
+  QLAUNCH(w, kq_resid, w->NB, BS, (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->bd.p, (const double *)w->cd.p,
+          (const double *)w->Dd.p, (const double *)w->Ed.p, (const double *)w->Ax.p, (const double *)w->ATy.p, (const double *)w->Qx.p, d, w->part.p);
+  finalize(w, {Q_S0, Q_S1, Q_S2, Q_S3, Q_S4, Q_S5, Q_M0, Q_M1, Q_M2, Q_M3, Q_M4, Q_M5}, {});
+  double tails[2];
+  HIP_OK(hipMemcpyAsync(&tails[0], w->u.p + w->MP + w->n, sizeof(double), hipMemcpyDeviceToHost, w->stream));
+  HIP_OK(hipMemcpyAsync(&tails[1], w->vo.p + w->MP + w->n, sizeof(double), hipMemcpyDeviceToHost, w->stream));
+  if (read_ctl(w)) return -1;
+  const double *o = w->hctl->out;
+  const QCPSettings *st = w->st;
+  r.tau = std::fabs(tails[0]);
+  r.kap = std::fabs(tails[1]) / (st->normalize ? (st->scale * w->sc_c * w->sc_b) : 1);
+  r.Ax_b_norm = o[Q_M0];
+  const double this_pr = o[Q_M1] / (w->sc_b + std::max(o[Q_M2], w->sc_b * w->nm_inf_b));
+  const double xQx_2 = w->hasQ ? (o[Q_S3] / (r.tau * r.tau)) / (2 * w->sc_b * w->sc_c) : 0.0;
+  r.Qx_ATy_c_s_norm = o[Q_M3];
+  const double this_dr = o[Q_M4] / (w->sc_c + std::max(w->sc_c * w->nm_inf_c, o[Q_M5]));
+  const double cTx = (o[Q_S2] / r.tau) / (w->sc_b * w->sc_c), bTy = (o[Q_S1] / r.tau) / (w->sc_b * w->sc_c);
+  const double this_gap = std::fabs(2 * xQx_2 + cTx - bTy) / (1 + std::max(2 * xQx_2, std::max(std::fabs(cTx), std::fabs(bTy))));
+  r.pobj = xQx_2 + cTx; r.dobj = -xQx_2 + bTy;
+  r.res_dif = std::max(std::max(std::fabs(this_pr - r.res_pri), std::fabs(this_dr - r.res_dual)), std::fabs(this_gap - r.rel_gap));
+  r.res_pri = this_pr; r.res_dual = this_dr; r.rel_gap = this_gap;
+  r.error_ratio = std::max(r.res_pri / st->eps_p, std::max(r.res_dual / st->eps_d, r.rel_gap / st->eps_g));
+  const double ctu = o[Q_S2], btu = o[Q_S1];
+  r.res_unbdd = ctu < 0 ? std::max(std::sqrt(o[Q_S4]), std::sqrt(o[Q_S0])) / (-ctu) : INFINITY;
+  r.res_infeas = btu > 0 ? std::sqrt(o[Q_S5]) / btu : INFINITY;
+  return 0;
+}
+
+qcp_int fail(QCPInfo *info, const char *msg) {
+  if (info) { info->status_val = -4; strcpy(info->status, "Failure"); info->ipm_iter = -1; info->admm_iter = -1; info->pobj = info->dobj = NAN; }
+  printf("Failure:%s\n", msg);
+  return -4;
+}
+
+} // namespace
+
+extern "C" {
+
+void abip_qcp_set_default_settings(QCPData *d) { // util.c:203-255
+  QCPSettings *s = d->stgs;
+  const double nz = d->A ? d->A->p[d->n] : 0, sparsity = nz / ((double)d->m * d->n);
+  s->normalize = 1; s->scale_E = 1; s->scale_bc = 1; s->max_ipm_iters = 500; s->max_admm_iters = 10000000;
+  s->eps = s->eps_p = s->eps_d = s->eps_g = s->eps_inf = s->eps_unb = 1e-3; s->alpha = 1.8; s->cg_rate = 2.0;
+  s->use_indirect = 0; s->scale = 1.0; s->rho_y = 1e-6; s->rho_x = 1; s->rho_tau = 1; s->verbose = 1; s->err_dif = 0;
+  s->inner_check_period = 500; s->outer_check_period = 1;
+  s->linsys_solver = ((double)d->m * d->n > 1e12) ? 3 : (sparsity > 0.4 ? 5 : 1);
+  s->prob_type = 2; // what the mex gateway sets before calling abip() (abip_qcp_mex.c:436)
+  s->time_limit = INFINITY; s->psi = 1; s->origin_scaling = 1; s->ruiz_scaling = 1; s->pc_scaling = 0;
+}
+
+qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) {
+  if (!d || !sol || !info || !K) return fail(info, "ABIP_NULL input");
+  if (!d->A || !d->b || !d->c) return fail(info, "the device path needs A, b and c");
+  if (d->stgs->prob_type != 2) return fail(info, "only the generic QCP formulation (prob_type 2) is served");
+  if (d->stgs->linsys_solver != 1) return fail(info, "only linsys_solver = 1 (QDLDL-class direct) is served");
+  const QCPSettings *st = d->stgs;
+  const int m = d->m, n = d->n;
+  { // validate, abip.c:779-832 ; cones.c:37-81
+    long dims = (long)K->l + K->z + K->f;
+    for (int i = 0; K->q && i < K->qsize; ++i) dims += K->q[i];
+    for (int i = 0; K->rq && i < K->rqsize; ++i) dims += K->rq[i];
+    if (n <= 0) { printf("n must be greater than 0; n = %li\n", (long)n); return fail(info, "could not initialize work"); }
+    if (m > n) { printf("WARN: m larger than n, problem likely degenerate\n"); return fail(info, "could not initialize work"); }
+    if (dims != n) { printf("cone dimensions %li not equal to num rows in A = n = %li\n", dims, (long)n); return fail(info, "could not initialize work"); }
+    if (st->max_ipm_iters <= 0 || st->max_admm_iters <= 0 || st->eps_p <= 0 || st->eps_d <= 0 || st->eps_g <= 0 || st->eps_inf <= 0 ||
+        st->eps_unb <= 0 || st->alpha <= 0 || st->alpha >= 2 || st->rho_y <= 0)
+      return fail(info, "could not initialize work");
+  }
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) { printf("ERROR: no usable HIP device: libabip_hip has no CPU fallback\n"); return fail(info, "could not initialize work"); }
+  const double t_init = now_ms();
+  QWk W; QWk *w = &W;
+  w->m = m; w->n = n; w->st = st; w->hasQ = d->Q != nullptr;
+  w->sparsity = ((d->A->p[n] / (m * n)) < 0.05); // integer division, qcp_config.c:22
+  copy_in(w->A, d->A);
+  if (w->hasQ) copy_in(w->Q, d->Q);
+  w->nm_inf_b = vnrminf(d->b, m); w->nm_inf_c = vnrminf(d->c, n);
+  scale_data(w, d, K);
+  w->MP = ((m + 31) / 32) * 32;
+  w->LV = ((w->MP + n + 1 + 31) / 32) * 32;
+  auto bail = [&](const char *msg) { release(w); return fail(info, msg); };
+  if (hipStreamCreate(&w->stream) != hipSuccess) return bail("hipStreamCreate failed");
+  { // matrices
+    host::HostCsr hAt, hA, hQ;
+    hcsr_from(w->A, hAt, false); hcsr_from(w->A, hA, true);
+    if (w->dAt.upload(hAt, w->stream) || w->dA.upload(hA, w->stream)) return bail("device allocation failure");
+    long nrb = std::max<long>(std::max<long>(w->dAt.nrb, w->dA.nrb), (std::max(m, n) + 4 * BS - 1) / (4 * BS));
+    if (w->hasQ) { hcsr_from(w->Q, hQ, false); if (w->dQ.upload(hQ, w->stream)) return bail("device allocation failure"); nrb = std::max<long>(nrb, w->dQ.nrb); }
+    const long per = (nrb + MAXNB - 1) / MAXNB;
+    w->NB = (int)std::max<long>(1, (nrb + per - 1) / per);
+  }
+  { // KKT upper triangle (qcp_config.c:699-748) -> LDL' -> level-scheduled device factors
+    const int N = m + n;
+    const double rho_y = st->rho_y, rho_x = st->rho_x;
+    std::vector<int> Kp(N + 1), Ki; std::vector<double> Kx;
+    Ki.reserve(N + w->A.p[n] + (w->hasQ ? w->Q.p[n] : 0)); Kx.reserve(Ki.capacity());
+    for (int i = 0; i < m; ++i) { Kp[i] = (int)Ki.size(); Ki.push_back(i); Kx.push_back(-rho_y); }
+    for (int i = 0; i < n; ++i) {
+      Kp[m + i] = (int)Ki.size();
+      for (int j = w->A.p[i]; j < w->A.p[i + 1]; ++j) { Ki.push_back(w->A.i[j]); Kx.push_back(-w->A.x[j]); }
+      if (!w->hasQ || w->Q.p[i] == w->Q.p[i + 1]) { Ki.push_back(m + i); Kx.push_back(rho_x); }
+      else for (int j = w->Q.p[i]; j < w->Q.p[i + 1]; ++j) {
+        if (w->Q.i[j] > i) continue;
+        const double t = (w->Q.i[j] == i) ? w->Q.x[j] + rho_x : w->Q.x[j];
+        if (t == 0) continue; // cs_dropzeros
+        Ki.push_back(m + w->Q.i[j]); Kx.push_back(t);
+      }
+    }
+    Kp[N] = (int)Ki.size();
+    host::LdlHost F;
+    if (host::factor_upper(N, Kp, Ki, Kx, F) < 0) { printf("\nerror in LDL factorization\n"); return bail("init_lin_sys_work failure"); }
+    std::vector<int> pmap(N);
+    for (int q = 0; q < N; ++q) pmap[q] = F.P[q] < m ? F.P[q] : w->MP + (F.P[q] - m);
+    if (w->Pmap.upload(pmap, w->stream) || w->Dg.upload(F.D, w->stream) || w->xw.alloc(N) || w->triF.upload(F.fwd, w->stream) || w->triB.upload(F.bwd, w->stream))
+      return bail("init_lin_sys_work failure");
+    w->segF = plan_segments(F.fwd.lev_ptr); w->segB = plan_segments(F.bwd.lev_ptr);
+    w->small_solve = (w->segF.size() <= 1 && w->segB.size() <= 1 && (w->segF.empty() || !w->segF[0].wide) && (w->segB.empty() || !w->segB[0].wide) && N <= 65536);
+    if (hipMalloc((void **)&w->lp_ctl, sizeof(Ctl)) != hipSuccess || hipMemsetAsync(w->lp_ctl, 0, sizeof(Ctl), w->stream) != hipSuccess) return bail("allocation failure");
+  }
+  DBuf<double> *lv[] = {&w->u, &w->v, &w->vo, &w->ut, &w->rel, &w->r, &w->p};
+  for (auto *b : lv) { if (b->alloc(w->LV)) return bail("work memory allocation failure"); if (hipMemsetAsync(b->p, 0, sizeof(double) * w->LV, w->stream) != hipSuccess) return bail("memset failure"); }
+  if (w->bd.upload(w->b, w->stream) || w->cd.upload(w->c, w->stream) || w->Dd.upload(w->D, w->stream) || w->Ed.upload(w->E, w->stream) || w->Ax.alloc(m) ||
+      w->ATy.alloc(n) || w->Qx.alloc(n) || w->part.alloc((size_t)2 * Q_COUNT * MAXNB) || w->ctl.alloc(1))
+    return bail("work memory allocation failure");
+  if (hipMemsetAsync(w->part.p, 0, sizeof(double) * 2 * Q_COUNT * MAXNB, w->stream) != hipSuccess || hipMemsetAsync(w->Qx.p, 0, sizeof(double) * n, w->stream) != hipSuccess ||
+      hipMemsetAsync(w->ctl.p, 0, sizeof(QCtl), w->stream) != hipSuccess || hipHostMalloc((void **)&w->hctl, sizeof(QCtl), hipHostMallocDefault) != hipSuccess)
+    return bail("work memory allocation failure");
+  // cone layout (abip.c:355-409, same `count` walk) and the start point (update_work, abip.c:912-985)
+  std::vector<int> xkind(n, XK_NONE), c_off, c_len, c_kind;
+  std::vector<double> hu(w->LV, 0.0);
+  {
+    int count = 0;
+    double *x = hu.data() + w->MP;
+    for (int i = 0; K->q && i < K->qsize; ++i) {
+      const int len = K->q[i];
+      if (len == 0) continue;
+      if (len == 1) xkind[count] = XK_ORTHANT;
+      else { for (int t = 0; t < len; ++t) xkind[count + t] = XK_CONE; c_off.push_back(count); c_len.push_back(len); c_kind.push_back(0); }
+      for (int t = 0; t < len; ++t) x[count + t] = 0;
+      x[count] = 1;
+      count += len;
+    }
+    for (int i = 0; K->rq && i < K->rqsize; ++i) {
+      const int len = K->rq[i];
+      if (len < 3) continue; // sic: count is not advanced (abip.c:379-381, 944-946)
+      for (int t = 0; t < len; ++t) { xkind[count + t] = XK_CONE; x[count + t] = 0; }
+      c_off.push_back(count); c_len.push_back(len); c_kind.push_back(1);
+      x[count] = 1; x[count + 1] = 1;
+      count += len;
+    }
+    for (int t = 0; t < K->f && count + t < n; ++t) { xkind[count + t] = XK_FREE; x[count + t] = 0; }
+    count += K->f;
+    for (int t = 0; t < K->z && count + t < n; ++t) { xkind[count + t] = XK_ZERO; x[count + t] = 0; }
+    count += K->z;
+    for (int t = 0; t < K->l && count + t < n; ++t) { xkind[count + t] = XK_ORTHANT; x[count + t] = 1; }
+    hu[w->MP + n] = 1.0;
+  }
+  w->ncones = (int)c_off.size();
+  if (w->xkind.upload(xkind, w->stream) || w->c_off.upload(c_off, w->stream) || w->c_len.upload(c_len, w->stream) || w->c_kind.upload(c_kind, w->stream))
+    return bail("work memory allocation failure");
+  if (hipMemcpyAsync(w->u.p, hu.data(), sizeof(double) * w->LV, hipMemcpyHostToDevice, w->stream) != hipSuccess ||
+      hipMemcpyAsync(w->v.p, hu.data(), sizeof(double) * w->LV, hipMemcpyHostToDevice, w->stream) != hipSuccess)
+    return bail("upload failure");
+  // pre_calculate, abip.c:886-910: r = K^-1 (b ; c)  [the solve negates the first block of (-b ; c)] ; a = rho_tau + r' (rho o r)
+  {
+    std::vector<double> hr(w->LV, 0.0);
+    for (int i = 0; i < m; ++i) hr[i] = w->b[i]; // -(-b)
+    for (int j = 0; j < n; ++j) hr[w->MP + j] = w->c[j];
+    if (hipMemcpyAsync(w->r.p, hr.data(), sizeof(double) * w->LV, hipMemcpyHostToDevice, w->stream) != hipSuccess) return bail("upload failure");
+    enqueue_solve(w, w->r.p);
+    if (hipMemcpyAsync(hr.data(), w->r.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess)
+      return bail("device failure in pre_calculate");
+    double acc = 0;
+    for (int i = 0; i < m; ++i) acc += (hr[i] * st->rho_y) * hr[i];
+    for (int j = 0; j < n; ++j) acc += (hr[w->MP + j] * st->rho_x) * hr[w->MP + j];
+    w->a_quad = st->rho_tau + acc;
+  }
+  info->setup_time = now_ms() - t_init;
+  const double t0 = now_ms();
+  const double time_limit_left = 1e3 * st->time_limit - info->setup_time;
+
+  QResid r;
+  info->status_val = 0;
+  double tol_inner = 4 * std::pow(w->mu, st->psi);
+  const QDims dm{m, n, w->MP};
+  int i = 0, j = 0, k = 0;
+  bool finished = false;
+  auto get_solution = [&](int ipm_iter, int admm_iter) -> int { // abip.c:559-587
+    std::vector<double> hu2(w->LV), hv2(w->LV);
+    if (hipMemcpyAsync(hu2.data(), w->u.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+        hipMemcpyAsync(hv2.data(), w->v.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess)
+      return -1;
+    if (!sol->x) sol->x = (qcp_float *)malloc(sizeof(qcp_float) * n);
+    if (!sol->y) sol->y = (qcp_float *)malloc(sizeof(qcp_float) * m);
+    if (!sol->s) sol->s = (qcp_float *)malloc(sizeof(qcp_float) * n);
+    for (int q = 0; q < n; ++q) { sol->x[q] = hu2[w->MP + q]; sol->s[q] = hv2[w->MP + q]; }
+    for (int q = 0; q < m; ++q) sol->y[q] = hu2[q];
+    const int sv = info->status_val;
+    if (sv == 0 || sv == 1 || sv == 2) {
+      const double sc = safediv_pos(1.0, r.tau);
+      for (int q = 0; q < n; ++q) { sol->x[q] *= sc; sol->s[q] *= sc; }
+      for (int q = 0; q < m; ++q) sol->y[q] *= sc;
+      if (sv == 0 || sv == 2) { strcpy(info->status, "Solved/Inaccurate"); info->status_val = 2; } else { strcpy(info->status, "Solved"); info->status_val = 1; }
+    } else if (sv == -2 || sv == -7) {
+      const double bty = r.dobj * r.tau;
+      for (int q = 0; q < m; ++q) sol->y[q] *= 1 / bty;
+      for (int q = 0; q < n; ++q) { sol->s[q] *= 1 / bty; sol->x[q] = NAN; }
+      strcpy(info->status, "Infeasible"); info->status_val = -2;
+    } else {
+      const double ctx = r.pobj * r.tau;
+      for (int q = 0; q < n; ++q) { sol->x[q] *= -1 / ctx; sol->s[q] = NAN; }
+      for (int q = 0; q < m; ++q) sol->y[q] = NAN;
+      strcpy(info->status, "Unbounded"); info->status_val = -1;
+    }
+    if (st->normalize) { // un_scaling_qcp_sol, qcp_config.c:496-513
+      for (int q = 0; q < n; ++q) sol->x[q] /= (w->E[q] * w->sc_b);
+      for (int q = 0; q < m; ++q) sol->y[q] /= (w->D[q] * w->sc_c);
+      for (int q = 0; q < n; ++q) sol->s[q] *= w->E[q] / (w->sc_c * st->scale);
+    }
+    info->ipm_iter = ipm_iter + 1; info->admm_iter = admm_iter;
+    info->res_infeas = r.res_infeas; info->res_unbdd = r.res_unbdd;
+    if (info->status_val == 1 || info->status_val == 2) { info->rel_gap = r.rel_gap; info->res_pri = r.res_pri; info->res_dual = r.res_dual; info->pobj = r.pobj; info->dobj = r.dobj; }
+    else if (info->status_val == -1) { info->rel_gap = info->res_pri = info->res_dual = NAN; info->pobj = info->dobj = -INFINITY; }
+    else { info->rel_gap = info->res_pri = info->res_dual = NAN; info->pobj = info->dobj = INFINITY; }
+    info->solve_time = now_ms() - t0;
+    return 0;
+  };
+  auto stop_now = [&](int ii) { return (double)k + 1 >= (double)st->max_admm_iters * st->max_ipm_iters || ii + 1 >= st->max_ipm_iters || (now_ms() - t0) > time_limit_left; };
+
+  for (i = 0; i < st->max_ipm_iters && !finished; ++i) {
+    for (j = 0; j < st->max_admm_iters; ++j) {
+      // projection, abip.c:186-255
+      QLAUNCH(w, kq_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->r.p, w->p.p, st->rho_y, st->rho_x, dm, w->part.p);
+      enqueue_solve(w, w->p.p);
+      QLAUNCH(w, kq_dots, w->NB, BS, (const double *)w->r.p, (const double *)w->p.p, st->rho_y, st->rho_x, dm, w->part.p);
+      if (w->hasQ) QLAUNCH(w, kq_Qp, w->NB, BS, w->dQ.view(), (const double *)w->p.p, dm, w->part.p);
+      QProxArgs pa;
+      pa.u = w->u.p; pa.v = w->v.p; pa.ut = w->ut.p; pa.rel = w->rel.p; pa.p = w->p.p; pa.r = w->r.p; pa.xkind = w->xkind.p;
+      pa.alpha = st->alpha; pa.lambda = w->mu / w->beta; pa.rho_x = st->rho_x; pa.rho_tau = st->rho_tau; pa.a_quad = w->a_quad; pa.iter_pos = k > 0; pa.hasQ = w->hasQ;
+      QLAUNCH(w, kq_ut_prox, w->NB, BS, pa, dm, (const double *)w->part.p, w->NB, w->ctl.p);
+      if (w->ncones) {
+        QCones C{w->c_off.p, w->c_len.p, w->c_kind.p, w->ncones};
+        QLAUNCH(w, kq_cones, (w->ncones + WAVES - 1) / WAVES, BS, C, w->u.p, (const double *)w->rel.p, (w->mu / w->beta) / st->rho_x, w->MP);
+      }
+      QLAUNCH(w, kq_dual, w->NB, BS, (const double *)w->u.p, (const double *)w->rel.p, w->v.p, w->vo.p, st->rho_y, st->rho_x, st->rho_tau, dm);
+      k += 1;
+      // inner stopping test, qcp_config.c:518-557
+      QLAUNCH(w, kq_inner_A, w->NB, BS, w->dA.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->bd.p, w->Ax.p, dm, w->part.p);
+      QLAUNCH(w, kq_inner_At, w->NB, BS, w->dAt.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->cd.p, w->ATy.p, w->Qx.p, w->hasQ ? 0 : 1, dm, w->part.p);
+      if (w->hasQ) QLAUNCH(w, kq_inner_Q, w->NB, BS, w->dQ.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->cd.p, (const double *)w->ATy.p, w->Qx.p, dm, w->part.p);
+      finalize(w, {Q_D1, Q_D2, Q_D3, Q_E1, Q_E2, Q_E3}, {Q_D1, Q_D3, Q_E1, Q_E2, Q_E3});
+      double tails[2];
+      if (hipMemcpyAsync(&tails[0], w->u.p + w->MP + n, sizeof(double), hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+          hipMemcpyAsync(&tails[1], w->vo.p + w->MP + n, sizeof(double), hipMemcpyDeviceToHost, w->stream) != hipSuccess || read_ctl(w))
+        return bail("device error in the inner iteration");
+      const double *o = w->hctl->out;
+      const double tau = tails[0], vot = tails[1];
+      const double qut = -o[Q_D1] / tau + o[Q_D2] - o[Q_D3];
+      const double e1 = o[Q_E1] + (qut - vot) * (qut - vot), e2 = o[Q_E2] + qut * qut, e3 = o[Q_E3];
+      const double err_inner = std::sqrt(e1) / (1 + std::sqrt(e2) + std::sqrt(e3));
+      if (err_inner < tol_inner || (now_ms() - t0) > time_limit_left) break;
+      if ((j + 1) % st->inner_check_period == 0 || r.error_ratio <= 8) {
+        if (calc_residuals(w, r, i, k)) return bail("device error in calc_residuals");
+        if ((info->status_val = has_converged(w, r, i, k)) != 0 || stop_now(i)) {
+          if (get_solution(i, k)) return bail("device error in get_solution");
+          finished = true;
+          break;
+        }
+      }
+    }
+    if (finished) break;
+    if (w->sparsity || (i + 1) % st->outer_check_period == 0) {
+      if (calc_residuals(w, r, i, k)) return bail("device error in calc_residuals");
+      if ((info->status_val = has_converged(w, r, i, k)) != 0 || stop_now(i)) {
+        if (get_solution(i, k)) return bail("device error in get_solution");
+        finished = true;
+        break;
+      }
+    }
+    tol_inner = adjust_barrier(w, r);
+  }
+  info->avg_linsys_time = 0; info->avg_cg_iters = 0;
+  release(w);
+  return info->status_val;
+}
+
+} // extern "C"

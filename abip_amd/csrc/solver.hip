@@ -25,17 +25,10 @@
 #include "dev_kernels.h"
 #include "dev_sptrsv.h"
 #include "host_setup.h"
+#include "dev_host_util.h"
 
 using namespace abip;
-
-#define HIP_OK(expr)                                                                                  \
-  do {                                                                                                \
-    hipError_t e_ = (expr);                                                                           \
-    if (e_ != hipSuccess) {                                                                           \
-      fprintf(stderr, "abip_hip: HIP error %s at %s:%d (%s)\n", hipGetErrorString(e_), __FILE__, __LINE__, #expr); \
-      return -1;                                                                                      \
-    }                                                                                                 \
-  } while (0)
+using namespace abip::hostutil;
 
 namespace {
 
@@ -82,53 +75,6 @@ int chosen_linsys() {
   if (e && (!strcmp(e, "indirect") || !strcmp(e, "pcg") || !strcmp(e, "1"))) return ABIP_HIP_LINSYS_INDIRECT;
   return ABIP_HIP_LINSYS_DIRECT;
 }
-
-double now_ms() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec / 1e6; }
-
-template <class T>
-struct DBuf { // device buffer
-  T *p = nullptr;
-  size_t n = 0;
-  int alloc(size_t cnt) { n = cnt; if (!cnt) cnt = 1; HIP_OK(hipMalloc((void **)&p, cnt * sizeof(T))); return 0; }
-  int upload(const std::vector<T> &h, hipStream_t s) {
-    if (alloc(h.size())) return -1;
-    if (!h.empty()) HIP_OK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
-    return 0;
-  }
-  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-};
-
-struct DevCsr {
-  DBuf<int> ptr, idx, rbd; // rbd: 4 ints per row block, read as int4
-  DBuf<double> val;
-  int nrows = 0, nrb = 0;
-  int upload(const host::HostCsr &h, hipStream_t s) {
-    nrows = h.nrows; nrb = (int)h.rb.size() - 1;
-    std::vector<int> d4((size_t)4 * std::max(nrb, 1), 0);
-    for (int q = 0; q < nrb; ++q) { d4[4 * q] = h.rb[q]; d4[4 * q + 1] = h.rb[q + 1]; d4[4 * q + 2] = h.ptr[h.rb[q]]; d4[4 * q + 3] = h.ptr[h.rb[q + 1]]; }
-    if (ptr.upload(h.ptr, s) || idx.upload(h.idx, s) || val.upload(h.val, s) || rbd.upload(d4, s)) return -1;
-    return 0;
-  }
-  Csr view() const { return Csr{ptr.p, idx.p, val.p, (const int4 *)rbd.p, nrb, nrows}; }
-  void release() { ptr.release(); idx.release(); rbd.release(); val.release(); }
-};
-
-struct DevTri {
-  DBuf<int> ptr, idx, lev_ptr, lev_rows, lev_g;
-  DBuf<double> val;
-  int nlev = 0;
-  std::vector<int> h_lev_ptr; // host copy for launch planning
-  int upload(const host::TriHost &h, hipStream_t s) {
-    nlev = (int)h.lev_ptr.size() - 1; h_lev_ptr = h.lev_ptr;
-    if (ptr.upload(h.ptr, s) || idx.upload(h.idx, s) || val.upload(h.val, s) || lev_ptr.upload(h.lev_ptr, s) ||
-        lev_rows.upload(h.lev_rows, s) || lev_g.upload(h.lev_g, s)) return -1;
-    return 0;
-  }
-  Tri view() const { return Tri{ptr.p, idx.p, val.p, lev_ptr.p, lev_rows.p, lev_g.p, nlev}; }
-  void release() { ptr.release(); idx.release(); val.release(); lev_ptr.release(); lev_rows.release(); lev_g.release(); }
-};
-
-struct Segment { bool wide; int l0, l1; };
 
 struct Resid { // ABIPResiduals, include/abip.h:178-195
   abip_int last_ipm_iter = -1, last_admm_iter = -1;
@@ -918,18 +864,6 @@ void free_work(W *w) {
   for (auto &e : w->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (w->stream) (void)hipStreamDestroy(w->stream);
   delete w;
-}
-
-std::vector<Segment> plan_segments(const std::vector<int> &lev_ptr) {
-  std::vector<Segment> segs;
-  const int nlev = (int)lev_ptr.size() - 1;
-  int l = 0;
-  while (l < nlev) {
-    const int rows = lev_ptr[l + 1] - lev_ptr[l];
-    if (rows >= 2048) { segs.push_back(Segment{true, l, l + 1}); ++l; }
-    else { int e = l; while (e < nlev && lev_ptr[e + 1] - lev_ptr[e] < 2048) ++e; segs.push_back(Segment{false, l, e}); l = e; }
-  }
-  return segs;
 }
 
 int upload_lvec(W *w, DBuf<double> &dst, const double *y, const double *x, double tail) { // host [y|x|tau] pieces -> padded device layout

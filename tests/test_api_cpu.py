@@ -48,8 +48,6 @@ def test_cone_dispatch_and_input_errors():
     data = dict(A=A, b=np.ones(2), c=np.ones(2))
     with pytest.raises(ValueError, match="Invalid conic format for LP"):
         api.abip_lpsolve(data, {}, api.abip_get_params())
-    with pytest.raises(NotImplementedError):
-        api.abip(data, {"q": [2]})
     with pytest.raises(ValueError, match="sparse format"):
         api.abip_direct(dict(A=np.eye(2), b=np.ones(2), c=np.ones(2)), {})
     with pytest.raises(ValueError, match="must contain a vector 'b'"):

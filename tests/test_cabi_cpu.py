@@ -20,7 +20,7 @@ def lib():
 
 def declared_symbols():
     names = set()
-    for h in ("abip.h", "abip_hip.h"):
+    for h in ("abip.h", "abip_hip.h", "abip_qcp.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         for mm in re.finditer(r"\b(abip_[a-z_A-Z0-9]+)\s*\(", src):
