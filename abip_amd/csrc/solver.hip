@@ -332,7 +332,7 @@ void enqueue_direct(W *w, double *rhs) {
 // a collective past convergence cannot be gated on the device, so over-enqueueing costs real all-reduces.
 int next_chunk(const W *w) {
   if (w->dist) return std::max(1, std::min((int)w->m_glob, w->last_cg_its - 1));
-  return std::max(2, std::min((int)w->m_glob, w->last_cg_its + (w->last_cg_its >> 2) + 2));
+  return std::max(2, std::min((int)w->m_glob, w->last_cg_its + std::max(2, w->last_cg_its >> 3)));
 }
 
 // Solve K z = rhs in place and leave S_DH = z[0:l-1)'h; synchronises with the host (used outside the hot loop:

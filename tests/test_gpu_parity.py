@@ -199,11 +199,11 @@ def test_warm_start_quirk_matches_oracle(gpu, oracle_built):
     po = oracle_built
     z, A, b, c = load("lp_afiro_like")
     warm = (z["indirect_1e-06_x"], z["indirect_1e-06_y"], z["indirect_1e-06_s"])
-    o = po.solve("oracle", A, b, c, linsys="indirect", eps=1e-5, warm=warm, warm_start=1)
-    with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-5, warm_start=1) as S:
+    o = po.solve("oracle", A, b, c, linsys="indirect", eps=1e-5, warm=warm, warm_start=1, max_admm_iters=400)
+    with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-5, warm_start=1, max_admm_iters=400) as S:
         S.x[:], S.y[:], S.s[:] = warm
         info = S.solve()
-        assert info["admm_iter"] == o.info["admm_iter"] and rel(S.x, o.x) < 1e-7
+        assert info["admm_iter"] == o.info["admm_iter"] and info["status"] == o.info["status"] and rel(S.x, o.x) < 1e-7
 
 
 # ---------------------------------------------------------------------------------------------- full size (C4)
