@@ -1,0 +1,298 @@
+// dev_ldl.h -- the direct KKT back-end on the device: sparse head + dense tail.
+//
+//   P K P' = L D L',   L = [[L11, 0], [L21, L22]]      (reference: LDL_numeric / _ldl_solve, linsys/direct.c:172-270)
+//
+// The host (host_setup.cpp: factor_upper) factors the sparse head (L11, L21, D1) with the reference's up-looking algorithm and
+// hands over S = K22 - L21 D1 L21', the Schur complement onto the last T pivots.  With a fill-reducing ordering that trailing
+// block is (nearly) dense and, level-scheduled, would be T one-row levels -- the sequential part of the solve.  Here S is
+// factored densely on the device (blocked right-looking LDL', 64x64 blocks, no pivoting: K is quasi-definite), W = inv(L22) is
+// formed once, and every solve applies the tail as two dense triangular mat-vecs:
+//
+//   forward :  levels over [L11; L21]           (gather form, dev_sptrsv.h)   z1, w = b2 - L21 z1
+//              t  = D2^-1 (W w)                 k_tail_mv, one wavefront per row, HBM/Infinity-Cache stream of W
+//   backward:  x2 = W' t                        k_tail_mv on the stored transpose
+//              levels over the head columns     x1 = D1^-1 z1 - L11'.. - L21' x2
+//
+// Set-up kernels are plain LDS-tiled fp64 FMA code (MI355X's fp64 MFMA rate equals its vector rate; set-up is not the hot path).
+#pragma once
+#include <cmath>
+
+#include "dev_host_util.h"
+#include "dev_sptrsv.h"
+#include "host_setup.h"
+
+namespace abip {
+
+constexpr int DB = 64;  // dense block edge
+constexpr int DH = 32;  // K-slice staged through LDS per step
+
+// acc[a][b] += sum_q A[ty*4+a][q] * (TRANSB ? B[tx*4+b][q] : B[q][tx*4+b]),  q in [0, DH)
+template <bool TRANSB>
+__device__ __forceinline__ void tile_mac(double (&acc)[4][4], const double (*As)[DH + 1], const double *Bs, int ty, int tx) {
+#pragma unroll 4
+  for (int q = 0; q < DH; ++q) {
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = As[ty * 4 + i][q];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = TRANSB ? Bs[(tx * 4 + i) * (DH + 1) + q] : Bs[q * (DB + 1) + tx * 4 + i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+  }
+}
+
+// 64 x DH slice (columns [q0, q0+DH)) of a row-major 64x64 tile -> LDS [64][DH+1]
+__device__ __forceinline__ void load_rows_slice(double (*dst)[DH + 1], const double *src, long ld, int q0, int tid) {
+  for (int e = tid; e < DB * DH; e += 256) { const int r = e / DH, q = e % DH; dst[r][q] = src[(long)r * ld + q0 + q]; }
+}
+// DH x 64 slice (rows [q0, q0+DH)) -> LDS [DH][DB+1]
+__device__ __forceinline__ void load_cols_slice(double *dst, const double *src, long ld, int q0, int tid) {
+  for (int e = tid; e < DH * DB; e += 256) { const int q = e / DB, c = e % DB; dst[q * (DB + 1) + c] = src[(long)(q0 + q) * ld + c]; }
+}
+
+// (1) factor the diagonal block at (k0, k0) in place; pivots -> Dt[k0..], inverse of its unit-lower factor -> Linv (64x64)
+static __global__ __launch_bounds__(256) void k_dldl_diag(double *S, int ld, int k0, double *Dt, double *Linv, int *fail) {
+  __shared__ double a[DB][DB + 1];
+  const int tid = threadIdx.x, r = tid >> 2, c4 = tid & 3;
+  for (int e = tid; e < DB * DB; e += 256) a[e / DB][e % DB] = S[(long)(k0 + e / DB) * ld + k0 + e % DB];
+  // right-looking; column c keeps l_rc d_c until the end, so no entry is read and written in the same step
+  for (int c = 0; c < DB - 1; ++c) {
+    __syncthreads();
+    if (r > c) {
+      const double lr = a[r][c] / a[c][c];
+      for (int cc = c + 1 + ((c4 - (c + 1)) & 3); cc <= r; cc += 4) a[r][cc] -= lr * a[cc][c];
+    }
+  }
+  __syncthreads();
+  if (tid < DB) { const double d = a[tid][tid]; Dt[k0 + tid] = d; if (d == 0.0 || !isfinite(d)) *fail = 1; }
+  for (int e = tid; e < DB * DB; e += 256) { const int i = e / DB, j = e % DB; if (i > j) a[i][j] /= a[j][j]; }
+  __syncthreads();
+  for (int e = tid; e < DB * DB; e += 256) { const int i = e / DB, j = e % DB; if (i > j) S[(long)(k0 + i) * ld + k0 + j] = a[i][j]; }
+  // column j of inv(L): x_j = 1, x_i = -sum_{c=j}^{i-1} L_ic x_c, kept in the unused upper triangle as a[j][i]
+  if (tid < DB) {
+    const int j = tid;
+    for (int i = j + 1; i < DB; ++i) { double s = a[i][j]; for (int c = j + 1; c < i; ++c) s += a[i][c] * a[j][c]; a[j][i] = -s; }
+  }
+  __syncthreads();
+  for (int e = tid; e < DB * DB; e += 256) { const int i = e / DB, j = e % DB; Linv[e] = i > j ? a[j][i] : (i == j ? 1.0 : 0.0); }
+}
+
+// (2) panel below the diagonal block: P = S[i, k] inv(Lkk)' (= L[i,k] Dk) -> LD; L[i,k] = P / Dk -> S
+static __global__ __launch_bounds__(256) void k_dldl_panel(double *S, int ld, int k0, const double *Dt, const double *Linv, double *LD) {
+  __shared__ double As[DB][DH + 1], Bs[DB * (DH + 1)];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const long i0 = k0 + DB + (long)blockIdx.x * DB;
+  double acc[4][4] = {};
+  for (int q0 = 0; q0 < DB; q0 += DH) {
+    __syncthreads();
+    load_rows_slice(As, S + i0 * ld + k0, ld, q0, tid);
+    load_rows_slice((double(*)[DH + 1])Bs, Linv, DB, q0, tid); // Linv[c][q], used transposed
+    __syncthreads();
+    tile_mac<true>(acc, As, Bs, ty, tx);
+  }
+  __syncthreads();
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const int r = ty * 4 + i, c = tx * 4 + j;
+      LD[(i0 + r) * DB + c] = acc[i][j];
+      S[(i0 + r) * ld + k0 + c] = acc[i][j] / Dt[k0 + c];
+    }
+}
+
+// (3) trailing update: S[i, j] -= LD[i] * L[j, k]'   for tile pairs i >= j > k
+static __global__ __launch_bounds__(256) void k_dldl_update(double *S, int ld, int k0, const double *LD) {
+  __shared__ double As[DB][DH + 1], Bs[DB * (DH + 1)];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  int bi = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((long)(bi + 1) * (bi + 2) / 2 <= (long)blockIdx.x) ++bi;
+  while ((long)bi * (bi + 1) / 2 > (long)blockIdx.x) --bi;
+  const int bj = blockIdx.x - bi * (bi + 1) / 2;
+  const long i0 = k0 + DB + (long)bi * DB, j0 = k0 + DB + (long)bj * DB;
+  double acc[4][4] = {};
+  for (int q0 = 0; q0 < DB; q0 += DH) {
+    __syncthreads();
+    load_rows_slice(As, LD + i0 * DB, DB, q0, tid);
+    load_rows_slice((double(*)[DH + 1])Bs, S + j0 * ld + k0, ld, q0, tid);
+    __syncthreads();
+    tile_mac<true>(acc, As, Bs, ty, tx);
+  }
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) S[(i0 + ty * 4 + i) * ld + j0 + tx * 4 + j] -= acc[i][j];
+}
+
+// (4) block row kb of W = inv(L22):  W[kb, j] = -inv(L_kb,kb) * sum_{i=j}^{kb-1} L[kb, i] W[i, j],  W[kb, kb] = inv(L_kb,kb)
+static __global__ __launch_bounds__(256) void k_dtri_inv_row(const double *L, int ld, int kb, const double *Linv_all, double *W) {
+  constexpr int NA = DB * (DH + 1), NC = DB * (DB + 1);
+  __shared__ double sm[NA + NC];
+  double(*As)[DH + 1] = (double(*)[DH + 1])sm;
+  double *Bs = sm + NA;                              // accumulation phase: DH x (DB+1) slice of W[i, j]
+  double(*Cs)[DB + 1] = (double(*)[DB + 1])(sm + NA); // afterwards: the accumulated 64x64 product
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int j = blockIdx.x;
+  const double *Lk = Linv_all + (long)kb * DB * DB;
+  double *out = W + (long)kb * DB * ld + (long)j * DB;
+  if (j == kb) { for (int e = tid; e < DB * DB; e += 256) out[(long)(e / DB) * ld + e % DB] = Lk[e]; return; }
+  double acc[4][4] = {};
+  for (int i = j; i < kb; ++i) {
+    const double *A = L + (long)kb * DB * ld + (long)i * DB;       // L[kb, i]
+    const double *B = W + (long)i * DB * ld + (long)j * DB;        // W[i, j] (block rows < kb are final)
+    for (int q0 = 0; q0 < DB; q0 += DH) {
+      __syncthreads();
+      load_rows_slice(As, A, ld, q0, tid);
+      load_cols_slice(Bs, B, ld, q0, tid);
+      __syncthreads();
+      tile_mac<false>(acc, As, Bs, ty, tx);
+    }
+  }
+  __syncthreads();
+  for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) Cs[ty * 4 + a][tx * 4 + b] = acc[a][b];
+  double res[4][4] = {};
+  for (int q0 = 0; q0 < DB; q0 += DH) {
+    __syncthreads();
+    load_rows_slice(As, Lk, DB, q0, tid);
+    __syncthreads();
+#pragma unroll 4
+    for (int q = 0; q < DH; ++q) {
+      double a[4], b[4];
+      for (int x = 0; x < 4; ++x) { a[x] = As[ty * 4 + x][q]; b[x] = Cs[q0 + q][tx * 4 + x]; }
+      for (int x = 0; x < 4; ++x) for (int y = 0; y < 4; ++y) res[x][y] += a[x] * b[y];
+    }
+  }
+  for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) out[(long)(ty * 4 + a) * ld + tx * 4 + b] = -res[a][b];
+}
+
+// (5) Wt = W' (lower triangle of W -> upper triangle of Wt), 64x64 tiles
+static __global__ __launch_bounds__(256) void k_dtranspose_lower(const double *W, double *Wt, int ld) {
+  __shared__ double t[DB][DB + 1];
+  const int bi = blockIdx.y, bj = blockIdx.x, tid = threadIdx.x;
+  if (bj > bi) return;
+  for (int e = tid; e < DB * DB; e += 256) t[e / DB][e % DB] = W[((long)bi * DB + e / DB) * ld + (long)bj * DB + e % DB];
+  __syncthreads();
+  for (int e = tid; e < DB * DB; e += 256) Wt[((long)bj * DB + e / DB) * ld + (long)bi * DB + e % DB] = t[e % DB][e / DB];
+}
+
+// ---- solve time ---------------------------------------------------------------------------------------------------------
+// out[r] = (sum_c M[r, c] v[c]) / (dsc ? dsc[r] : 1),  c in [0, r] (lower) or [r, T) (upper); one wavefront per row,
+// rows dealt round-robin so that the triangle's long and short rows mix in every workgroup
+static __global__ __launch_bounds__(BS) void k_tail_mv(const double *__restrict__ M, int ld, int T, int upper, const double *__restrict__ v,
+                                                       double *__restrict__ out, const double *__restrict__ dsc, const Ctl *ctl) {
+  if (ctl->halt) return;
+  const int lane = threadIdx.x & 63, wave = blockIdx.x * (BS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (BS / 64);
+  for (int r = wave; r < T; r += nw) {
+    const int lo = upper ? r : 0, hi = upper ? T : r + 1;
+    const double *row = M + (long)r * ld;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int c = (lo & ~63) + lane;
+    if (c >= lo && c < hi) a0 = row[c] * v[c];
+    c += 64;
+    for (; c + 192 < hi; c += 256) {
+      a0 += row[c] * v[c]; a1 += row[c + 64] * v[c + 64]; a2 += row[c + 128] * v[c + 128]; a3 += row[c + 192] * v[c + 192];
+    }
+    for (; c < hi; c += 64) a0 += row[c] * v[c];
+    double s = (a0 + a1) + (a2 + a3);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) out[r] = dsc ? s / dsc[r] : s;
+  }
+}
+
+// small systems: [perm, forward levels] and [head D^-1, backward levels, perm'] each in one workgroup
+static __global__ __launch_bounds__(TBS) void k_ldl_fwd_small(Tri F, const int *__restrict__ Pmap, const double *__restrict__ b, double *x, int N, const Ctl *ctl) {
+  if (ctl->halt) return;
+  const int tid = threadIdx.x;
+  for (int j = tid; j < N; j += TBS) x[j] = b[Pmap[j]];
+  __syncthreads();
+  for (int l = 0; l < F.nlev; ++l) { tri_level(F, x, F.lev_ptr[l], F.lev_ptr[l + 1], F.lev_g[l], tid, TBS); __syncthreads(); }
+}
+static __global__ __launch_bounds__(TBS) void k_ldl_bwd_small(Tri B, const int *__restrict__ Pmap, const double *__restrict__ D, double *b, double *x, int t0, int N, const Ctl *ctl) {
+  if (ctl->halt) return;
+  const int tid = threadIdx.x;
+  for (int j = tid; j < t0; j += TBS) x[j] /= D[j];
+  __syncthreads();
+  for (int l = 0; l < B.nlev; ++l) { tri_level(B, x, B.lev_ptr[l], B.lev_ptr[l + 1], B.lev_g[l], tid, TBS); __syncthreads(); }
+  for (int j = tid; j < N; j += TBS) b[Pmap[j]] = x[j];
+}
+
+namespace hostutil {
+
+struct DevLdl {
+  DevTri F, B;
+  DBuf<int> Pmap, flag;
+  DBuf<double> D, xw, W, Wt, tmp;
+  std::vector<Segment> segF, segB;
+  bool small = false;
+  int N = 0, t0 = 0, T = 0;
+  long lnnz = 0;
+
+  // pmap[k] = position in the caller's rhs vector of pivot k.  Returns 0, or -1 (allocation / zero pivot).
+  int setup(const host::LdlHost &H, const std::vector<int> &pmap, hipStream_t s) {
+    N = H.N; t0 = H.t0; T = H.T; lnnz = H.lnnz;
+    if (Pmap.upload(pmap, s) || D.upload(H.D, s) || xw.alloc(N) || F.upload(H.fwd, s) || B.upload(H.bwd, s)) return -1;
+    segF = plan_segments(H.fwd.lev_ptr); segB = plan_segments(H.bwd.lev_ptr);
+    small = (segF.size() <= 1 && segB.size() <= 1 && (segF.empty() || !segF[0].wide) && (segB.empty() || !segB[0].wide) && N <= 65536);
+    if (T == 0) return 0;
+    const int nt = T / DB;
+    DBuf<double> Linv, LD;
+    const std::vector<int> zero(1, 0);
+    if (Wt.upload(H.S, s) || W.alloc((size_t)T * T) || tmp.alloc(T) || Linv.alloc((size_t)nt * DB * DB) || LD.alloc((size_t)T * DB) || flag.upload(zero, s)) return -1;
+    if (hipMemsetAsync(W.p, 0, sizeof(double) * (size_t)T * T, s) != hipSuccess) return -1;
+    double *S = Wt.p, *Dt = D.p + t0;
+    for (int kb = 0; kb < nt; ++kb) {
+      const int k0 = kb * DB, rem = nt - kb - 1;
+      hipLaunchKernelGGL(k_dldl_diag, dim3(1), dim3(256), 0, s, S, T, k0, Dt, Linv.p + (size_t)kb * DB * DB, flag.p);
+      if (rem > 0) {
+        hipLaunchKernelGGL(k_dldl_panel, dim3(rem), dim3(256), 0, s, S, T, k0, (const double *)Dt, (const double *)(Linv.p + (size_t)kb * DB * DB), LD.p);
+        hipLaunchKernelGGL(k_dldl_update, dim3(rem * (rem + 1) / 2), dim3(256), 0, s, S, T, k0, (const double *)LD.p);
+      }
+    }
+    for (int kb = 0; kb < nt; ++kb) hipLaunchKernelGGL(k_dtri_inv_row, dim3(kb + 1), dim3(256), 0, s, (const double *)S, T, kb, (const double *)Linv.p, W.p);
+    // L22 is no longer needed: its buffer takes the transpose
+    hipLaunchKernelGGL(k_dtranspose_lower, dim3(nt, nt), dim3(256), 0, s, (const double *)W.p, Wt.p, T);
+    int bad = 0;
+    if (hipMemcpyAsync(&bad, flag.p, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) return -1;
+    Linv.release(); LD.release();
+    return bad ? -1 : 0;
+  }
+
+  // enqueue rhs <- K^-1 rhs; `launch(kernel, grid, block, args...)` is the caller's launcher (profiling classes differ)
+  template <class LaunchFn>
+  void enqueue(LaunchFn &&launch, double *rhs, const Ctl *ctl, int NB) const {
+    auto tail = [&]() {
+      if (T == 0) return;
+      const int grid = std::max(1, std::min(MAXNB, (T + BS / 64 - 1) / (BS / 64)));
+      launch(k_tail_mv, grid, BS, (const double *)W.p, T, T, 0, (const double *)(xw.p + t0), tmp.p, (const double *)(D.p + t0), ctl);
+      launch(k_tail_mv, grid, BS, (const double *)Wt.p, T, T, 1, (const double *)tmp.p, xw.p + t0, (const double *)nullptr, ctl);
+    };
+    if (small && T == 0) {
+      launch(k_ldl_solve_small, 1, TBS, F.view(), B.view(), (const int *)Pmap.p, (const double *)D.p, rhs, xw.p, N, ctl);
+      return;
+    }
+    if (small) {
+      launch(k_ldl_fwd_small, 1, TBS, F.view(), (const int *)Pmap.p, (const double *)rhs, xw.p, N, ctl);
+      tail();
+      launch(k_ldl_bwd_small, 1, TBS, B.view(), (const int *)Pmap.p, (const double *)D.p, rhs, xw.p, t0, N, ctl);
+      return;
+    }
+    const int gN = std::max(1, std::min(NB, (N + BS - 1) / BS));
+    launch(k_perm_in, gN, BS, (const int *)Pmap.p, (const double *)rhs, xw.p, N, ctl);
+    auto run = [&](const DevTri &Tr, const std::vector<Segment> &segs) {
+      for (const Segment &sg : segs) {
+        if (sg.wide) {
+          const int rows = Tr.h_lev_ptr[sg.l0 + 1] - Tr.h_lev_ptr[sg.l0];
+          launch(k_tri_wide, std::max(1, std::min(MAXNB, (rows * 8 + BS - 1) / BS)), BS, Tr.view(), xw.p, sg.l0, ctl);
+        } else launch(k_tri_thin, 1, TBS, Tr.view(), xw.p, sg.l0, sg.l1, ctl);
+      }
+    };
+    run(F, segF);
+    tail();
+    launch(k_dscale, gN, BS, xw.p, (const double *)D.p, t0, ctl);
+    run(B, segB);
+    launch(k_perm_out, gN, BS, (const int *)Pmap.p, rhs, (const double *)xw.p, N, ctl);
+  }
+
+  void release() { F.release(); B.release(); Pmap.release(); flag.release(); D.release(); xw.release(); W.release(); Wt.release(); tmp.release(); }
+};
+
+} // namespace hostutil
+} // namespace abip

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -246,6 +247,15 @@ void min_degree(int N, const std::vector<int> &Gp, const std::vector<int> &Gi, s
 
 inline int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
+// ABIP_HIP_TAIL: -1 / unset = choose by density, 0 = no dense tail, T > 0 = force (rounded down to a multiple of 64)
+int g_tail_request = -2;
+int tail_request() {
+  if (g_tail_request != -2) return g_tail_request;
+  const char *e = getenv("ABIP_HIP_TAIL");
+  return e ? atoi(e) : -1;
+}
+int tail_cap() { const char *e = getenv("ABIP_HIP_TAIL_MAX"); return e ? atoi(e) : 12288; }
+
 void level_sets(int N, TriHost &T, bool backward) {
   std::vector<int> lev(N, 0);
   int maxlev = 0;
@@ -275,6 +285,8 @@ void level_sets(int N, TriHost &T, bool backward) {
 }
 
 } // namespace
+
+void set_tail_request(int t) { g_tail_request = t; }
 
 int factor_kkt(const ABIPMatrix *A, double rho_y, LdlHost &out) {
   const int m = (int)A->m, n = (int)A->n, N = m + n;
@@ -326,14 +338,41 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
     flag[j] = j;
     for (int q = Cp[j]; q < Cp[j + 1]; ++q) { int r = Ci[q]; while (r < j && flag[r] != j) { lnz[r]++; flag[r] = j; r = parent[r]; } }
   }
-  std::vector<int> Lp(N + 1, 0);
+  std::vector<long> Lp(N + 1, 0);
   for (int j = 0; j < N; ++j) Lp[j + 1] = Lp[j] + lnz[j];
-  const long Lnnz = Lp[N];
-  out.lnnz = Lnnz;
-  std::vector<int> Li(std::max<long>(Lnnz, 1));
-  std::vector<double> Lx(std::max<long>(Lnnz, 1));
+  out.lnnz = Lp[N];
+
+  // ---- head / dense-tail split -----------------------------------------------------------------------------------
+  // With a fill-reducing ordering the last pivots form a (nearly) dense trailing block whose rows are one level each:
+  // the sequential part of a level-scheduled solve.  Columns >= t0 are therefore not kept as a sparse factor: the host
+  // computes only the Schur complement S onto them (sparse arithmetic), the device factors S densely and applies
+  // inv(L22) as two dense triangular mat-vecs (dev_ldl.h).  Candidate sizes come from the column counts alone
+  // (column j >= N-T has all its lnz[j] entries inside the trailing block).
+  int T = 0;
+  {
+    const int Tmax = std::min(N - 1, tail_cap());
+    const int req = tail_request();
+    if (req > 0) T = std::min(req, Tmax) / 64 * 64;
+    else if (req < 0 && N >= 256) {
+      long tn = 0;
+      int best = 0;
+      for (int t = 1; t <= Tmax; ++t) {
+        tn += lnz[N - t];
+        if (t % 64 == 0 && (double)tn >= 0.25 * 0.5 * (double)t * (t - 1)) best = t;
+      }
+      T = best;
+    }
+  }
+  const int t0 = N - T;
+  out.t0 = t0; out.T = T;
+  if (T > 0) out.S.assign((size_t)T * T, 0.0);
+
+  // numeric, up-looking: row k of L by a sparse triangular solve against the leading block.  For a tail row only the head
+  // columns take part; what is left in Y on the tail positions is row k of S.
+  const long Lhead = Lp[t0];
+  std::vector<int> Li(std::max<long>(Lhead, 1));
+  std::vector<double> Lx(std::max<long>(Lhead, 1));
   out.D.assign(N, 0.0);
-  // numeric: row k of L by a sparse triangular solve against the leading block (up-looking)
   std::vector<double> Y(N, 0.0);
   std::vector<int> stack(N), pat(N), fill(N, 0);
   std::fill(flag.begin(), flag.end(), -1);
@@ -350,25 +389,34 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
     }
     for (; top < N; ++top) {
       const int c = stack[top];
+      if (c >= t0) continue;       // tail column: its contribution is applied on the device
       const double yc = Y[c];
       Y[c] = 0.0;
-      const int e = Lp[c] + fill[c];
-      for (int q = Lp[c]; q < e; ++q) Y[Li[q]] -= Lx[q] * yc;
+      const long e = Lp[c] + fill[c];
+      for (long q = Lp[c]; q < e; ++q) Y[Li[q]] -= Lx[q] * yc;
       const double lkc = yc / out.D[c];
       dk -= lkc * yc;
       Li[e] = k; Lx[e] = lkc; fill[c]++;
     }
+    if (k >= t0) {
+      double *Srow = out.S.data() + (size_t)(k - t0) * T;
+      for (int r = t0; r < k; ++r) { Srow[r - t0] = Y[r]; Y[r] = 0.0; }
+      Srow[k - t0] = dk;
+      continue;
+    }
     out.D[k] = dk;
     if (dk == 0.0) return -1;
   }
-  // backward form = CSC of L as built; forward form = CSR of L
-  out.bwd.ptr = Lp; out.bwd.idx.assign(Li.begin(), Li.begin() + Lnnz); out.bwd.val.assign(Lx.begin(), Lx.begin() + Lnnz);
+  // backward form = CSC of the head columns of L (all rows); forward form = CSR of [L11; L21]
+  out.bwd.ptr.assign(N + 1, 0);
+  for (int j = 0; j <= N; ++j) out.bwd.ptr[j] = (int)Lp[std::min(j, t0)];
+  out.bwd.idx.assign(Li.begin(), Li.begin() + Lhead); out.bwd.val.assign(Lx.begin(), Lx.begin() + Lhead);
   out.fwd.ptr.assign(N + 1, 0);
-  for (long q = 0; q < Lnnz; ++q) out.fwd.ptr[Li[q] + 1]++;
+  for (long q = 0; q < Lhead; ++q) out.fwd.ptr[Li[q] + 1]++;
   for (int i = 0; i < N; ++i) out.fwd.ptr[i + 1] += out.fwd.ptr[i];
-  out.fwd.idx.resize(Lnnz); out.fwd.val.resize(Lnnz);
+  out.fwd.idx.resize(Lhead); out.fwd.val.resize(Lhead);
   std::vector<int> rpos(out.fwd.ptr.begin(), out.fwd.ptr.end() - 1);
-  for (int j = 0; j < N; ++j) for (int q = Lp[j]; q < Lp[j + 1]; ++q) { const int dst = rpos[Li[q]]++; out.fwd.idx[dst] = j; out.fwd.val[dst] = Lx[q]; }
+  for (int j = 0; j < t0; ++j) for (long q = Lp[j]; q < Lp[j + 1]; ++q) { const int dst = rpos[Li[q]]++; out.fwd.idx[dst] = j; out.fwd.val[dst] = Lx[q]; }
   level_sets(N, out.fwd, false);
   level_sets(N, out.bwd, true);
   return 0;

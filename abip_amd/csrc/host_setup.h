@@ -40,11 +40,15 @@ struct TriHost {
 };
 struct LdlHost {
   int N = 0;
-  long lnnz = 0;
+  long lnnz = 0;         // strictly-lower non-zeros of the complete factor (head + tail), as LDL_symbolic counts them
   std::vector<int> P;    // P[k] = original KKT index of pivot k
-  std::vector<double> D;
-  TriHost fwd, bwd;
+  std::vector<double> D; // pivots of the head [0, t0); the tail's come from the device factorisation
+  TriHost fwd, bwd;      // sparse part: columns < t0 of L (rows of the tail included)
+  int t0 = 0, T = 0;     // head size, dense-tail size (T % 64 == 0, t0 + T = N)
+  std::vector<double> S; // T x T row-major, lower triangle: Schur complement of the head onto the tail
 };
+// override the tail choice (tests): -2 = environment / automatic, -1 automatic, 0 none, T > 0 forced
+void set_tail_request(int t);
 int factor_kkt(const ABIPMatrix *A, double rho_y, LdlHost &out);
 // the same for any symmetric quasi-definite matrix given by its upper triangle in CSC form (QCP KKT, qcp_config.c:699-748)
 int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, const std::vector<double> &Kx, LdlHost &out);

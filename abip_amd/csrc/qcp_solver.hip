@@ -13,6 +13,7 @@
 
 #include "../../include/abip_qcp.h"
 #include "dev_host_util.h"
+#include "dev_ldl.h"
 #include "qcp_kernels.h"
 
 using namespace abip;
@@ -48,13 +49,11 @@ struct QWk {
   double sc_b = 1, sc_c = 1, nm_inf_b = 0, nm_inf_c = 0, a_quad = 0, mu = 1, beta = 1;
   hipStream_t stream = nullptr;
   DevCsr dA, dAt, dQ;
-  DBuf<double> u, v, vo, ut, rel, r, p, bd, cd, Dd, Ed, Ax, ATy, Qx, part, xw, Dg;
-  DBuf<int> xkind, c_off, c_len, c_kind, Pmap;
+  DBuf<double> u, v, vo, ut, rel, r, p, bd, cd, Dd, Ed, Ax, ATy, Qx, part;
+  DBuf<int> xkind, c_off, c_len, c_kind;
   DBuf<QCtl> ctl;
   QCtl *hctl = nullptr;
-  DevTri triF, triB;
-  std::vector<Segment> segF, segB;
-  bool small_solve = false;
+  DevLdl ldl;
   int ncones = 0;
   Ctl *lp_ctl = nullptr; // dev_sptrsv kernels are gated on an LP-style control block (halt flag): a zeroed one
 };
@@ -63,10 +62,10 @@ struct QWk {
 
 void release(QWk *w) {
   w->dA.release(); w->dAt.release(); w->dQ.release();
-  DBuf<double> *bufs[] = {&w->u, &w->v, &w->vo, &w->ut, &w->rel, &w->r, &w->p, &w->bd, &w->cd, &w->Dd, &w->Ed, &w->Ax, &w->ATy, &w->Qx, &w->part, &w->xw, &w->Dg};
+  DBuf<double> *bufs[] = {&w->u, &w->v, &w->vo, &w->ut, &w->rel, &w->r, &w->p, &w->bd, &w->cd, &w->Dd, &w->Ed, &w->Ax, &w->ATy, &w->Qx, &w->part};
   for (auto *b : bufs) b->release();
-  w->xkind.release(); w->c_off.release(); w->c_len.release(); w->c_kind.release(); w->Pmap.release(); w->ctl.release();
-  w->triF.release(); w->triB.release();
+  w->xkind.release(); w->c_off.release(); w->c_len.release(); w->c_kind.release(); w->ctl.release();
+  w->ldl.release();
   if (w->lp_ctl) (void)hipFree(w->lp_ctl);
   if (w->hctl) (void)hipHostFree(w->hctl);
   if (w->stream) (void)hipStreamDestroy(w->stream);
@@ -165,26 +164,7 @@ void hcsr_from(const HMat &M, host::HostCsr &out, bool transpose_to_rows) {
 }
 
 void enqueue_solve(QWk *w, double *rhs) { // _ldl_solve, linsys.c:309-316
-  const int N = w->m + w->n;
-  const Ctl *ctl = w->lp_ctl;
-  if (w->small_solve) {
-    QLAUNCH(w, k_ldl_solve_small, 1, TBS, w->triF.view(), w->triB.view(), (const int *)w->Pmap.p, (const double *)w->Dg.p, rhs, w->xw.p, N, ctl);
-    return;
-  }
-  const int gN = std::max(1, std::min(w->NB, (N + BS - 1) / BS));
-  QLAUNCH(w, k_perm_in, gN, BS, (const int *)w->Pmap.p, (const double *)rhs, w->xw.p, N, ctl);
-  auto run = [&](const DevTri &T, const std::vector<Segment> &segs) {
-    for (const Segment &s : segs) {
-      if (s.wide) {
-        const int rows = T.h_lev_ptr[s.l0 + 1] - T.h_lev_ptr[s.l0];
-        QLAUNCH(w, k_tri_wide, std::max(1, std::min(MAXNB, (rows * 8 + BS - 1) / BS)), BS, T.view(), w->xw.p, s.l0, ctl);
-      } else QLAUNCH(w, k_tri_thin, 1, TBS, T.view(), w->xw.p, s.l0, s.l1, ctl);
-    }
-  };
-  run(w->triF, w->segF);
-  QLAUNCH(w, k_dscale, gN, BS, w->xw.p, (const double *)w->Dg.p, N, ctl);
-  run(w->triB, w->segB);
-  QLAUNCH(w, k_perm_out, gN, BS, (const int *)w->Pmap.p, rhs, (const double *)w->xw.p, N, ctl);
+  w->ldl.enqueue([&](auto kern, int grid, int block, auto... a) { QLAUNCH(w, kern, grid, block, a...); }, rhs, w->lp_ctl, w->NB);
 }
 
 int read_ctl(QWk *w) {
@@ -355,10 +335,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     if (host::factor_upper(N, Kp, Ki, Kx, F) < 0) { printf("\nerror in LDL factorization\n"); return bail("init_lin_sys_work failure"); }
     std::vector<int> pmap(N);
     for (int q = 0; q < N; ++q) pmap[q] = F.P[q] < m ? F.P[q] : w->MP + (F.P[q] - m);
-    if (w->Pmap.upload(pmap, w->stream) || w->Dg.upload(F.D, w->stream) || w->xw.alloc(N) || w->triF.upload(F.fwd, w->stream) || w->triB.upload(F.bwd, w->stream))
-      return bail("init_lin_sys_work failure");
-    w->segF = plan_segments(F.fwd.lev_ptr); w->segB = plan_segments(F.bwd.lev_ptr);
-    w->small_solve = (w->segF.size() <= 1 && w->segB.size() <= 1 && (w->segF.empty() || !w->segF[0].wide) && (w->segB.empty() || !w->segB[0].wide) && N <= 65536);
+    if (w->ldl.setup(F, pmap, w->stream)) { printf("\nerror in LDL factorization\n"); return bail("init_lin_sys_work failure"); }
     if (hipMalloc((void **)&w->lp_ctl, sizeof(Ctl)) != hipSuccess || hipMemsetAsync(w->lp_ctl, 0, sizeof(Ctl), w->stream) != hipSuccess) return bail("allocation failure");
   }
   DBuf<double> *lv[] = {&w->u, &w->v, &w->vo, &w->ut, &w->rel, &w->r, &w->p};

@@ -23,7 +23,7 @@
 #include "../../include/abip.h"
 #include "../../include/abip_hip.h"
 #include "dev_kernels.h"
-#include "dev_sptrsv.h"
+#include "dev_ldl.h"
 #include "host_setup.h"
 #include "dev_host_util.h"
 
@@ -118,11 +118,7 @@ struct ABIP_WORK {
   DBuf<Ctl> ctl;
   Ctl *hctl = nullptr; // pinned mirror
   // direct
-  DBuf<int> Pmap; DBuf<double> Dg, xw;
-  DevTri triF, triB;
-  std::vector<Segment> segF, segB;
-  bool small_solve = false;
-  long lnnz = 0;
+  DevLdl ldl;
   // ---- loop state (locals of ABIP(solve)) ------------------------------------------------
   Phase phase = PH_IDLE;
   abip_int i = 0, j = 0, k = 0, inner_stopper = 0;
@@ -302,29 +298,8 @@ int enqueue_cg_post(W *w, double *rhs) {
   return 0;
 }
 void enqueue_direct(W *w, double *rhs) {
-  const int N = (int)(w->m + w->n);
   const Ctl *ctl = w->ctl.p;
-  if (w->small_solve) {
-    launch(w, ABIP_HIP_K_SPTRSV, k_ldl_solve_small, 1, TBS, w->triF.view(), w->triB.view(), (const int *)w->Pmap.p, (const double *)w->Dg.p, rhs, w->xw.p, N, ctl);
-  } else {
-    const int gN = std::min(w->NB, (N + BS - 1) / BS);
-    launch(w, ABIP_HIP_K_SPTRSV, k_perm_in, gN, BS, (const int *)w->Pmap.p, (const double *)rhs, w->xw.p, N, ctl);
-    auto run = [&](const DevTri &T, const std::vector<Segment> &segs) {
-      for (const Segment &s : segs) {
-        if (s.wide) {
-          const int rows = T.h_lev_ptr[s.l0 + 1] - T.h_lev_ptr[s.l0];
-          const int grid = std::max(1, std::min(MAXNB, (rows * 8 + BS - 1) / BS));
-          launch(w, ABIP_HIP_K_SPTRSV, k_tri_wide, grid, BS, T.view(), w->xw.p, s.l0, ctl);
-        } else {
-          launch(w, ABIP_HIP_K_SPTRSV, k_tri_thin, 1, TBS, T.view(), w->xw.p, s.l0, s.l1, ctl);
-        }
-      }
-    };
-    run(w->triF, w->segF);
-    launch(w, ABIP_HIP_K_SPTRSV, k_dscale, gN, BS, w->xw.p, (const double *)w->Dg.p, N, ctl);
-    run(w->triB, w->segB);
-    launch(w, ABIP_HIP_K_SPTRSV, k_perm_out, gN, BS, (const int *)w->Pmap.p, rhs, (const double *)w->xw.p, N, ctl);
-  }
+  w->ldl.enqueue([&](auto kern, int grid, int block, auto... a) { launch(w, ABIP_HIP_K_SPTRSV, kern, grid, block, a...); }, rhs, ctl, w->NB);
   launch(w, ABIP_HIP_K_VEC, k_post_dot, w->NB, BS, (const double *)rhs, (const double *)w->h.p, dims(w), w->part.p, ctl);
 }
 
@@ -837,7 +812,7 @@ void print_footer(const W *w, const ABIPInfo *info) {
   if (info->admm_iter + 1 >= w->stgs->max_admm_iters) printf("Hit max_admm_iters, solution may be inaccurate\n");
   printf("Timing: Solve time: %1.2es\n", info->solve_time / 1e3);
   if (w->linsys == ABIP_HIP_LINSYS_INDIRECT) printf("\tLin-sys: avg # CG iterations: %2.2f\n", (double)w->tot_cg_its / (info->admm_iter + 1));
-  else printf("\tLin-sys: nnz in L factor: %li\n", (long)(w->lnnz + w->m + w->n));
+  else printf("\tLin-sys: nnz in L factor: %li\n", (long)(w->ldl.lnnz + w->m + w->n));
   print_line('-');
   if (st_infeas(info->status_val)) { printf("Certificate of primal infeasibility:\n|A'y + s|_2 * |b|_2 = %.4e\n", info->res_infeas); }
   else if (st_unbdd(info->status_val)) { printf("Certificate of dual infeasibility:\n|Ax|_2 * |c|_2 = %.4e\n", info->res_unbdd); }
@@ -857,9 +832,9 @@ void free_work(W *w) {
   w->dAt.release(); w->dA.release();
   DBuf<double> *bufs[] = {&w->u, &w->v, &w->ut, &w->u_avg, &w->v_avg, &w->u_sum, &w->v_sum, &w->u_avgc, &w->v_avgc, &w->h, &w->g, &w->b, &w->c,
                           &w->wD, &w->wE, &w->cg_p, &w->cg_r, &w->cg_Gp, &w->cg_z, &w->cg_M, &w->cg_tmp, &w->a_up, &w->a_vp, &w->a_ut, &w->a_u,
-                          &w->a_v, &w->a_utn, &w->a_un, &w->a_vn, &w->part, &w->Dg, &w->xw};
+                          &w->a_v, &w->a_utn, &w->a_un, &w->a_vn, &w->part};
   for (auto *b : bufs) b->release();
-  w->ctl.release(); w->Pmap.release(); w->triF.release(); w->triB.release(); w->T.release();
+  w->ctl.release(); w->ldl.release(); w->T.release();
   if (w->hctl) (void)hipHostFree(w->hctl);
   for (auto &e : w->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (w->stream) (void)hipStreamDestroy(w->stream);
@@ -1013,14 +988,9 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
   } else { // init_lin_sys_work / factorize, direct.c:218-303
     host::LdlHost F;
     if (host::factor_kkt(w->A, w->stgs->rho_y, F) < 0) return fail("init_lin_sys_work failure");
-    w->lnnz = F.lnnz;
     std::vector<int> pmap(F.N);
     for (int q = 0; q < F.N; ++q) pmap[q] = F.P[q] < (int)m ? F.P[q] : w->MP + (F.P[q] - (int)m);
-    if (w->Pmap.upload(pmap, w->stream) || w->Dg.upload(F.D, w->stream) || w->xw.alloc(F.N) || w->triF.upload(F.fwd, w->stream) ||
-        w->triB.upload(F.bwd, w->stream))
-      return fail("init_lin_sys_work failure");
-    w->segF = plan_segments(F.fwd.lev_ptr); w->segB = plan_segments(F.bwd.lev_ptr);
-    w->small_solve = (w->segF.size() <= 1 && w->segB.size() <= 1 && (w->segF.empty() || !w->segF[0].wide) && (w->segB.empty() || !w->segB[0].wide) && F.N <= 65536);
+    if (w->ldl.setup(F, pmap, w->stream)) return fail("init_lin_sys_work failure");
     const int one = 1; // the post-solve kernels are gated on cg_done: permanently set for the direct back-end
     if (hipMemcpyAsync(&w->ctl.p->cg_done, &one, sizeof(int), hipMemcpyHostToDevice, w->stream) != hipSuccess) return fail("memcpy failure");
   }
@@ -1352,8 +1322,8 @@ abip_float abip_hip_get_scalar(ABIPWork *w, const char *name) {
 #define RET(nm, val) if (!strcmp(name, nm)) return (abip_float)(val);
   RET("mu", w->mu) RET("beta", w->beta) RET("sigma", w->sigma) RET("gamma", w->gamma) RET("g_th", w->g_th)
   RET("sc_b", w->sc_b) RET("sc_c", w->sc_c) RET("nm_b", w->nm_b) RET("nm_c", w->nm_c) RET("tot_cg_its", w->tot_cg_its)
-  RET("lnnz", w->lnnz) RET("levels_fwd", w->triF.nlev) RET("levels_bwd", w->triB.nlev) RET("admm_iter", w->k) RET("ipm_iter", w->i)
-  RET("nb", w->NB) RET("small_solve", w->small_solve ? 1 : 0)
+  RET("lnnz", w->ldl.lnnz) RET("levels_fwd", w->ldl.F.nlev) RET("levels_bwd", w->ldl.B.nlev) RET("tail", w->ldl.T) RET("admm_iter", w->k) RET("ipm_iter", w->i)
+  RET("nb", w->NB) RET("small_solve", w->ldl.small ? 1 : 0)
 #undef RET
   return NAN;
 }

@@ -53,6 +53,47 @@ def test_spmv_and_kkt_solve(gpu, name, linsys):
             assert its2 <= 2
 
 
+@pytest.mark.parametrize("tail", ["0", "64", "128", "512", "auto"])
+def test_direct_solve_dense_tail(gpu, oracle_built, tail, monkeypatch):
+    """Head/tail split of the factor (dev_ldl.h): the same K^-1 rhs whatever part of L is applied as a dense inverse, and the
+    same ADMM trajectory.  `0` = pure level-scheduled solve, `auto` = trailing block chosen by density."""
+    if tail == "auto":
+        monkeypatch.delenv("ABIP_HIP_TAIL", raising=False)
+    else:
+        monkeypatch.setenv("ABIP_HIP_TAIL", tail)
+    z, A, b, c = load("lp_staircase")
+    rng = np.random.default_rng(7)
+    with gpu.Solver(A, b, c, linsys="direct", verbose=0, max_admm_iters=400) as S:
+        T = int(S.scalar("tail"))
+        assert T == (768 if tail == "auto" else int(tail)), T
+        assert S.scalar("levels_fwd") <= {0: 464, 64: 401, 128: 400, 512: 109, 768: 8}[T]   # the one-row levels of the tail are gone
+        Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
+        K = kkt_matrix(Asc, 1e-3)
+        for _ in range(3):
+            rhs = rng.standard_normal(S.m + S.n)
+            sol, its = S.kkt_solve(rhs, None, -1)
+            assert its == 0 and rel(K @ sol, rhs) < 1e-11
+        info = S.solve()
+    ref = oracle_built.solve("oracle", A, b, c, linsys="direct", verbose=0, max_admm_iters=400)
+    assert info["admm_iter"] == ref.info["admm_iter"] and info["ipm_iter"] == ref.info["ipm_iter"]
+    assert abs(info["pobj"] - ref.info["pobj"]) <= 1e-8 * (1 + abs(ref.info["pobj"]))
+
+
+def test_direct_solve_wide_head_with_tail(gpu):
+    """A factor whose head levels are wider than one workgroup (segmented path) and whose tail is several thousand pivots."""
+    from abip_amd import problems
+    A, b, c = problems.lp_random_sparse(m=2000, n=10000, per_col=4)[:3]
+    A = sp.csc_matrix(A); A.sort_indices()
+    rng = np.random.default_rng(8)
+    with gpu.Solver(A, b, c, linsys="direct", verbose=0) as S:
+        assert S.scalar("tail") >= 1024 and S.scalar("small_solve") == 0
+        Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
+        K = kkt_matrix(Asc, 1e-3)
+        rhs = rng.standard_normal(S.m + S.n)
+        sol, its = S.kkt_solve(rhs, None, -1)
+        assert rel(K @ sol, rhs) < 1e-10
+
+
 def test_spmv_long_rows_and_ragged_blocks(gpu):
     """Rows longer than one LDS chunk (1024 non-zeros), empty rows of A' (empty columns are rejected upstream only with a
     warning) and 1-entry rows exercise every branch of the CSR-stream kernel."""
