@@ -62,6 +62,10 @@ struct Ctl {
   double zr_hist[2];
   double cg_tol;
   double out[96];  // finalised reductions, index = Slot
+  // inner-loop exit test, evaluated by k_finalize (iterate_Q_norm_resd, abip.c:2027-2050, and the comparison of abip.c:2173)
+  double metric;   // min(sqrt(Qres)/norm, sqrt(Qres_avg)/norm_avg)
+  int avg_crit;    // 1: the averaged iterate gave the smaller value
+  int it_count;    // ADMM iterations completed since abip_init (never reset)
 };
 
 __device__ __forceinline__ double wave_sum(double x) {

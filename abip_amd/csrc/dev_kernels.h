@@ -454,9 +454,16 @@ __global__ __launch_bounds__(BS) void k_q_At(Csr At, const double *__restrict__ 
 }
 
 // One block: fold the listed slots into ctl->out[slot] and append the tau/kappa entries the host needs.
-struct FinArgs { int nslots; int slots[40]; const double *u, *v, *ua, *va; const double *gs; /* non-null: take the already all-reduced values */ };
+struct FinArgs {
+  int nslots; int slots[40]; const double *u, *v, *ua, *va; const double *gs; /* non-null: take the already all-reduced values */
+  // decide = 1 (the finalize that closes an ADMM iteration): evaluate the inner-loop exit test on the device and raise ctl->halt
+  // when it holds, so that iterations enqueued behind this one fall through; the kernel itself is then gated on halt too
+  int decide = 0, avg_stats = 0;
+  double thr = 0.0, sentinel = 0.0; // gamma * mu; Qres_avg when no averaged statistics were taken (= max_admm_iters, abip.c:1957)
+};
 __global__ __launch_bounds__(BS) void k_finalize(FinArgs f, Dims d, const double *part, int nb, Ctl *ctl) {
-  // one wavefront per slot, all loads of a lane in flight at once, no workgroup barrier
+  // one wavefront per slot, all loads of a lane in flight at once
+  if (f.decide && (ctl->halt || !ctl->cg_done)) return; // cg_done: permanently set for the direct back-end
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int PER = MAXNB / 64;
   for (int s = wave; s < f.nslots; s += WAVES) {
@@ -478,6 +485,27 @@ __global__ __launch_bounds__(BS) void k_finalize(FinArgs f, Dims d, const double
     const int q = d.MP + d.n;
     ctl->out[80] = f.u[q]; ctl->out[81] = f.v[q];
     ctl->out[82] = f.ua ? f.ua[q] : 0.0; ctl->out[83] = f.va ? f.va[q] : 0.0;
+  }
+  if (!f.decide) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double *o = ctl->out;
+    double Qres = o[S_QP] + o[S_QD];
+    const double gap = o[S_BY] - o[S_CX] - o[81];
+    Qres += gap * gap;
+    const double norm = 1 + sqrt(o[S_NU] + o[S_NV]);
+    double Qres_avg = f.sentinel, norm_avg = 1;
+    if (f.avg_stats) {
+      Qres_avg = o[S_QPA] + o[S_QDA];
+      const double gap_a = o[S_BYA] - o[S_CXA] - o[83];
+      Qres_avg += gap_a * gap_a;
+      norm_avg = 1 + sqrt(o[S_NUA] + o[S_NVA]);
+    }
+    const double ma = sqrt(Qres_avg) / norm_avg, mc = sqrt(Qres) / norm;
+    const int ac = ma < mc ? 1 : 0;
+    const double metric = ac ? ma : mc;
+    ctl->metric = metric; ctl->avg_crit = ac; ctl->it_count = ctl->it_count + 1;
+    if (metric < f.thr) ctl->halt = 1;
   }
 }
 

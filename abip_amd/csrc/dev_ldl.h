@@ -197,20 +197,76 @@ static __global__ __launch_bounds__(BS) void k_tail_mv(const double *__restrict_
   }
 }
 
-// small systems: [perm, forward levels] and [head D^-1, backward levels, perm'] each in one workgroup
-static __global__ __launch_bounds__(TBS) void k_ldl_fwd_small(Tri F, const int *__restrict__ Pmap, const double *__restrict__ b, double *x, int N, const Ctl *ctl) {
-  if (ctl->halt) return;
-  const int tid = threadIdx.x;
-  for (int j = tid; j < N; j += TBS) x[j] = b[Pmap[j]];
-  __syncthreads();
-  for (int l = 0; l < F.nlev; ++l) { tri_level(F, x, F.lev_ptr[l], F.lev_ptr[l + 1], F.lev_g[l], tid, TBS); __syncthreads(); }
+// ---- small systems: the sparse part of the solve in ONE 1024-thread workgroup ---------------------------------------------------
+// A level costs one workgroup barrier plus the latency of whatever it loads after the barrier.  Only the gathers x[idx] depend
+// on the previous level, so (i) x lives in LDS when it fits (N <= XL_MAX), (ii) the level table is copied to LDS up front and
+// (iii) the row extents and first matrix entry of level l+1 are fetched while level l is being reduced.
+constexpr int MAXLEV_LDS = 1024;
+constexpr int XL_MAX = 16384;
+
+struct RowPre { int row, s, e, i0; double v0; };
+__device__ __forceinline__ RowPre row_pre(const Tri &T, int a, int b, int g, int tid) {
+  RowPre p; p.row = -1; p.s = 0; p.e = 0; p.i0 = 0; p.v0 = 0.0;
+  const int r = a + tid / g;
+  if (r < b) {
+    p.row = T.lev_rows[r]; p.s = T.ptr[r] + tid % g; p.e = T.ptr[r + 1];
+    if (p.s < p.e) { p.v0 = T.val[p.s]; p.i0 = T.idx[p.s]; }
+  }
+  return p;
 }
-static __global__ __launch_bounds__(TBS) void k_ldl_bwd_small(Tri B, const int *__restrict__ Pmap, const double *__restrict__ D, double *b, double *x, int t0, int N, const Ctl *ctl) {
+
+__device__ __forceinline__ void run_levels(const Tri &T, double *x, int *s_lp, int *s_lg, int tid) {
+  if (T.nlev == 0) return;
+  const bool meta = T.nlev <= MAXLEV_LDS;
+  if (meta) {
+    for (int l = tid; l <= T.nlev; l += TBS) s_lp[l] = T.lev_ptr[l];
+    for (int l = tid; l < T.nlev; l += TBS) s_lg[l] = T.lev_g[l];
+    __syncthreads();
+  }
+  auto lp = [&](int l) { return meta ? s_lp[l] : T.lev_ptr[l]; };
+  auto lg = [&](int l) { return meta ? s_lg[l] : T.lev_g[l]; };
+  int a = lp(0), b = lp(1), g = lg(0);
+  RowPre cur = row_pre(T, a, b, g, tid);
+  for (int l = 0; l < T.nlev; ++l) {
+    int nb = b, ng = 1;
+    RowPre nxt = cur;
+    if (l + 1 < T.nlev) { nb = lp(l + 2); ng = lg(l + 1); nxt = row_pre(T, b, nb, ng, tid); }
+    {
+      double acc = 0.0;
+      if (cur.s < cur.e) {
+        acc = cur.v0 * x[cur.i0];
+        for (int k = cur.s + g; k < cur.e; k += g) acc += T.val[k] * x[T.idx[k]];
+      }
+      for (int off = g >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      if (cur.row >= 0 && tid % g == 0) x[cur.row] -= acc;
+    }
+    const int ngrp = TBS / g;
+    if (a + ngrp < b) tri_level(T, x, a + ngrp, b, g, tid, TBS); // rows beyond the first 1024/g of a wide level
+    __syncthreads();
+    a = b; b = nb; g = ng; cur = nxt;
+  }
+}
+
+// FWD: x = P b, L-solve over the sparse rows.  BWD: head D^-1, L'-solve over the head columns, b = P' x.  Both when there is no tail.
+template <bool XL, bool FWD, bool BWD>
+static __global__ __launch_bounds__(TBS) void k_ldl_small(Tri F, Tri B, const int *__restrict__ Pmap, const double *__restrict__ D, double *b, double *xg,
+                                                          int t0, int N, const Ctl *ctl) {
   if (ctl->halt) return;
+  extern __shared__ double x_lds[];
+  __shared__ int s_lp[MAXLEV_LDS + 1], s_lg[MAXLEV_LDS];
+  double *x = XL ? x_lds : xg;
   const int tid = threadIdx.x;
-  for (int j = tid; j < t0; j += TBS) x[j] /= D[j];
+  if (FWD) {
+    for (int j = tid; j < N; j += TBS) x[j] = b[Pmap[j]];
+    __syncthreads();
+    run_levels(F, x, s_lp, s_lg, tid);
+    if (!BWD) { if (XL) for (int j = tid; j < N; j += TBS) xg[j] = x[j]; return; }
+    for (int j = tid; j < t0; j += TBS) x[j] /= D[j];
+  } else {
+    for (int j = tid; j < N; j += TBS) { const double v = xg[j]; x[j] = j < t0 ? v / D[j] : v; }
+  }
   __syncthreads();
-  for (int l = 0; l < B.nlev; ++l) { tri_level(B, x, B.lev_ptr[l], B.lev_ptr[l + 1], B.lev_g[l], tid, TBS); __syncthreads(); }
+  run_levels(B, x, s_lp, s_lg, tid);
   for (int j = tid; j < N; j += TBS) b[Pmap[j]] = x[j];
 }
 
@@ -221,7 +277,7 @@ struct DevLdl {
   DBuf<int> Pmap, flag;
   DBuf<double> D, xw, W, Wt, tmp;
   std::vector<Segment> segF, segB;
-  bool small = false;
+  bool small = false, xl = false; // one-workgroup sparse part; x in LDS
   int N = 0, t0 = 0, T = 0;
   long lnnz = 0;
 
@@ -231,6 +287,13 @@ struct DevLdl {
     if (Pmap.upload(pmap, s) || D.upload(H.D, s) || xw.alloc(N) || F.upload(H.fwd, s) || B.upload(H.bwd, s)) return -1;
     segF = plan_segments(H.fwd.lev_ptr); segB = plan_segments(H.bwd.lev_ptr);
     small = (segF.size() <= 1 && segB.size() <= 1 && (segF.empty() || !segF[0].wide) && (segB.empty() || !segB[0].wide) && N <= 65536);
+    xl = small && N <= XL_MAX;
+    if (xl) { // more than 64 KB of dynamic LDS has to be asked for
+      const int bytes = (int)(sizeof(double) * (size_t)N);
+      if (hipFuncSetAttribute((const void *)k_ldl_small<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+          hipFuncSetAttribute((const void *)k_ldl_small<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+          hipFuncSetAttribute((const void *)k_ldl_small<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) xl = false;
+    }
     if (T == 0) return 0;
     const int nt = T / DB;
     DBuf<double> Linv, LD;
@@ -255,40 +318,45 @@ struct DevLdl {
     return bad ? -1 : 0;
   }
 
-  // enqueue rhs <- K^-1 rhs; `launch(kernel, grid, block, args...)` is the caller's launcher (profiling classes differ)
+  // enqueue rhs <- K^-1 rhs; `launch(kernel, grid, block, lds_bytes, args...)` is the caller's launcher (profiling classes differ)
   template <class LaunchFn>
   void enqueue(LaunchFn &&launch, double *rhs, const Ctl *ctl, int NB) const {
     auto tail = [&]() {
       if (T == 0) return;
       const int grid = std::max(1, std::min(MAXNB, (T + BS / 64 - 1) / (BS / 64)));
-      launch(k_tail_mv, grid, BS, (const double *)W.p, T, T, 0, (const double *)(xw.p + t0), tmp.p, (const double *)(D.p + t0), ctl);
-      launch(k_tail_mv, grid, BS, (const double *)Wt.p, T, T, 1, (const double *)tmp.p, xw.p + t0, (const double *)nullptr, ctl);
+      launch(k_tail_mv, grid, BS, (size_t)0, (const double *)W.p, T, T, 0, (const double *)(xw.p + t0), tmp.p, (const double *)(D.p + t0), ctl);
+      launch(k_tail_mv, grid, BS, (size_t)0, (const double *)Wt.p, T, T, 1, (const double *)tmp.p, xw.p + t0, (const double *)nullptr, ctl);
     };
-    if (small && T == 0) {
-      launch(k_ldl_solve_small, 1, TBS, F.view(), B.view(), (const int *)Pmap.p, (const double *)D.p, rhs, xw.p, N, ctl);
-      return;
-    }
     if (small) {
-      launch(k_ldl_fwd_small, 1, TBS, F.view(), (const int *)Pmap.p, (const double *)rhs, xw.p, N, ctl);
+      const size_t sh = xl ? sizeof(double) * (size_t)N : 0;
+      const int *pm = Pmap.p; const double *dd = D.p;
+      if (T == 0) {
+        if (xl) launch(k_ldl_small<true, true, true>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl);
+        else launch(k_ldl_small<false, true, true>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl);
+        return;
+      }
+      if (xl) launch(k_ldl_small<true, true, false>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl);
+      else launch(k_ldl_small<false, true, false>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl);
       tail();
-      launch(k_ldl_bwd_small, 1, TBS, B.view(), (const int *)Pmap.p, (const double *)D.p, rhs, xw.p, t0, N, ctl);
+      if (xl) launch(k_ldl_small<true, false, true>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl);
+      else launch(k_ldl_small<false, false, true>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl);
       return;
     }
     const int gN = std::max(1, std::min(NB, (N + BS - 1) / BS));
-    launch(k_perm_in, gN, BS, (const int *)Pmap.p, (const double *)rhs, xw.p, N, ctl);
+    launch(k_perm_in, gN, BS, (size_t)0, (const int *)Pmap.p, (const double *)rhs, xw.p, N, ctl);
     auto run = [&](const DevTri &Tr, const std::vector<Segment> &segs) {
       for (const Segment &sg : segs) {
         if (sg.wide) {
           const int rows = Tr.h_lev_ptr[sg.l0 + 1] - Tr.h_lev_ptr[sg.l0];
-          launch(k_tri_wide, std::max(1, std::min(MAXNB, (rows * 8 + BS - 1) / BS)), BS, Tr.view(), xw.p, sg.l0, ctl);
-        } else launch(k_tri_thin, 1, TBS, Tr.view(), xw.p, sg.l0, sg.l1, ctl);
+          launch(k_tri_wide, std::max(1, std::min(MAXNB, (rows * 8 + BS - 1) / BS)), BS, (size_t)0, Tr.view(), xw.p, sg.l0, ctl);
+        } else launch(k_tri_thin, 1, TBS, (size_t)0, Tr.view(), xw.p, sg.l0, sg.l1, ctl);
       }
     };
     run(F, segF);
     tail();
-    launch(k_dscale, gN, BS, xw.p, (const double *)D.p, t0, ctl);
+    launch(k_dscale, gN, BS, (size_t)0, xw.p, (const double *)D.p, t0, ctl);
     run(B, segB);
-    launch(k_perm_out, gN, BS, (const int *)Pmap.p, rhs, (const double *)xw.p, N, ctl);
+    launch(k_perm_out, gN, BS, (size_t)0, (const int *)Pmap.p, rhs, (const double *)xw.p, N, ctl);
   }
 
   void release() { F.release(); B.release(); Pmap.release(); flag.release(); D.release(); xw.release(); W.release(); Wt.release(); tmp.release(); }

@@ -4,8 +4,8 @@
 // triangular solves run in GATHER form over level sets:
 //   forward  (L z = b):  z_i = b_i - sum_{j<i} L_ij z_j      rows of L   (CSR)
 //   backward (L' x = z): x_j = z_j - sum_{i>j} L_ij x_i      columns of L (CSC)
-// A level is a set of rows whose dependencies are all in earlier levels.  Small systems run the whole
-// solve in ONE 1024-thread workgroup (levels separated by workgroup barriers, no launches in between);
+// A level is a set of rows whose dependencies are all in earlier levels.  Small systems run the sparse part of the
+// solve in ONE 1024-thread workgroup (dev_ldl.h: levels separated by workgroup barriers, no launches in between);
 // large systems launch wide levels as grids and runs of thin levels as single-workgroup segments.
 #pragma once
 #include "dev_common.h"
@@ -14,7 +14,7 @@ namespace abip {
 
 constexpr int TBS = 1024; // threads of the single-workgroup triangular kernels
 
-struct Tri {
+struct Tri { // entries in level order: position r of lev_rows owns [ptr[r], ptr[r+1])
   const int *ptr, *idx;
   const double *val;
   const int *lev_ptr, *lev_rows, *lev_g;
@@ -30,32 +30,12 @@ __device__ __forceinline__ void tri_level(const Tri &T, double *x, int a, int b,
     int row = -1;
     if (r < b) {
       row = T.lev_rows[r];
-      const int e = T.ptr[row + 1];
-      for (int k = T.ptr[row] + q; k < e; k += g) acc += T.val[k] * x[T.idx[k]];
+      const int e = T.ptr[r + 1];
+      for (int k = T.ptr[r] + q; k < e; k += g) acc += T.val[k] * x[T.idx[k]];
     }
     for (int off = g >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if (row >= 0 && q == 0) x[row] -= acc;
   }
-}
-
-// whole solve in one workgroup
-static __global__ __launch_bounds__(TBS) void k_ldl_solve_small(Tri F, Tri B, const int *__restrict__ Pmap, const double *__restrict__ D,
-                                                         double *b /* l-vector */, double *x /* work, N */, int N, const Ctl *ctl) {
-  if (ctl->halt) return;
-  const int tid = threadIdx.x;
-  for (int j = tid; j < N; j += TBS) x[j] = b[Pmap[j]]; // LDL_perm
-  __syncthreads();
-  for (int l = 0; l < F.nlev; ++l) {                    // LDL_lsolve
-    tri_level(F, x, F.lev_ptr[l], F.lev_ptr[l + 1], F.lev_g[l], tid, TBS);
-    __syncthreads();
-  }
-  for (int j = tid; j < N; j += TBS) x[j] /= D[j];      // LDL_dsolve
-  __syncthreads();
-  for (int l = 0; l < B.nlev; ++l) {                    // LDL_ltsolve
-    tri_level(B, x, B.lev_ptr[l], B.lev_ptr[l + 1], B.lev_g[l], tid, TBS);
-    __syncthreads();
-  }
-  for (int j = tid; j < N; j += TBS) b[Pmap[j]] = x[j]; // LDL_permt
 }
 
 // segmented variant for systems too large for one workgroup

@@ -282,6 +282,19 @@ void level_sets(int N, TriHost &T, bool backward) {
     while (g > 1 && (long)rows * g > 4096) g >>= 1;
     T.lev_g[l] = std::max(g, 1);
   }
+  // store the entries in level order: position r of lev_rows owns [ptr[r], ptr[r+1]), so that the device reads a row's extent
+  // without first looking its index up
+  const int npos = (int)T.lev_rows.size();
+  std::vector<int> p2(npos + 1, 0), i2;
+  std::vector<double> v2;
+  for (int r = 0; r < npos; ++r) p2[r + 1] = p2[r] + (T.ptr[T.lev_rows[r] + 1] - T.ptr[T.lev_rows[r]]);
+  i2.resize(p2[npos]); v2.resize(p2[npos]);
+  for (int r = 0; r < npos; ++r) {
+    const int row = T.lev_rows[r];
+    std::copy(T.idx.begin() + T.ptr[row], T.idx.begin() + T.ptr[row + 1], i2.begin() + p2[r]);
+    std::copy(T.val.begin() + T.ptr[row], T.val.begin() + T.ptr[row + 1], v2.begin() + p2[r]);
+  }
+  T.ptr.swap(p2); T.idx.swap(i2); T.val.swap(v2);
 }
 
 } // namespace

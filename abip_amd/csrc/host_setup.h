@@ -34,9 +34,10 @@ void jacobi_preconditioner(const ABIPMatrix *A, std::vector<double> &Minv);
 // LDL' = P K P' of K = [[rho_y I, A],[A', -I]] (reference: form_kkt / factorize, linsys/direct.c:49-104,218-270),
 // delivered in the two gather forms the device triangular solves use, with their level sets.
 struct TriHost {
-  std::vector<int> ptr, idx;      // CSR of strictly-lower L (forward) or CSC of L (backward)
-  std::vector<double> val;
   std::vector<int> lev_ptr, lev_rows, lev_g; // level sets (only rows with at least one entry), lanes per row
+  // entries of the rows of L (forward) / columns of L (backward) in level order: position r of lev_rows owns [ptr[r], ptr[r+1])
+  std::vector<int> ptr, idx;
+  std::vector<double> val;
 };
 struct LdlHost {
   int N = 0;

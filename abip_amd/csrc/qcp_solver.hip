@@ -164,7 +164,7 @@ void hcsr_from(const HMat &M, host::HostCsr &out, bool transpose_to_rows) {
 }
 
 void enqueue_solve(QWk *w, double *rhs) { // _ldl_solve, linsys.c:309-316
-  w->ldl.enqueue([&](auto kern, int grid, int block, auto... a) { QLAUNCH(w, kern, grid, block, a...); }, rhs, w->lp_ctl, w->NB);
+  w->ldl.enqueue([&](auto kern, int grid, int block, size_t lds, auto... a) { hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, w->stream, a...); }, rhs, w->lp_ctl, w->NB);
 }
 
 int read_ctl(QWk *w) {

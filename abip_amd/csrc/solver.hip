@@ -123,6 +123,9 @@ struct ABIP_WORK {
   Phase phase = PH_IDLE;
   abip_int i = 0, j = 0, k = 0, inner_stopper = 0;
   bool wg_valid = false;
+  int it_seen = 0;    // ctl.it_count at the last control read
+  int batch = 4;      // iterations enqueued per control read (direct back-end)
+  bool batch_ok = true; // ABIP_HIP_BATCH=0 forces one control read per iteration
   Resid r;
   abip_int status = 0;
   double t_solve0 = 0, cpu0 = 0;
@@ -163,7 +166,7 @@ typedef ABIP_WORK W;
 // launch helper: optional hipEvent bracket per kernel class
 // ------------------------------------------------------------------------------------------------
 template <class K, class... Args>
-inline void launch(W *w, int cls, K kern, int grid, int block, Args... args) {
+inline void launch_lds(W *w, int cls, K kern, int grid, int block, size_t lds_bytes, Args... args) {
   const bool timed = (w->prof_mask >> cls) & 1u;
   W::Ev *ev = nullptr;
   if (timed) {
@@ -176,9 +179,11 @@ inline void launch(W *w, int cls, K kern, int grid, int block, Args... args) {
     ev->cls = cls; ev->tag = w->ev_tag;
     (void)hipEventRecord(ev->a, w->stream);
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, w->stream, args...);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds_bytes, w->stream, args...);
   if (timed) (void)hipEventRecord(ev->b, w->stream);
 }
+template <class K, class... Args>
+inline void launch(W *w, int cls, K kern, int grid, int block, Args... args) { launch_lds(w, cls, kern, grid, block, (size_t)0, args...); }
 
 void harvest_events(W *w) { // call only after the stream has been synchronised
   for (size_t q = 0; q < w->ev_used; ++q) {
@@ -299,7 +304,7 @@ int enqueue_cg_post(W *w, double *rhs) {
 }
 void enqueue_direct(W *w, double *rhs) {
   const Ctl *ctl = w->ctl.p;
-  w->ldl.enqueue([&](auto kern, int grid, int block, auto... a) { launch(w, ABIP_HIP_K_SPTRSV, kern, grid, block, a...); }, rhs, ctl, w->NB);
+  w->ldl.enqueue([&](auto kern, int grid, int block, size_t lds, auto... a) { launch_lds(w, ABIP_HIP_K_SPTRSV, kern, grid, block, lds, a...); }, rhs, ctl, w->NB);
   launch(w, ABIP_HIP_K_VEC, k_post_dot, w->NB, BS, (const double *)rhs, (const double *)w->h.p, dims(w), w->part.p, ctl);
 }
 
@@ -406,6 +411,7 @@ int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty) {
   }
   f.nslots = ns;
   f.u = w->u.p; f.v = w->v.p; f.ua = w->u_avgc.p; f.va = w->v_avgc.p; f.gs = w->gs;
+  f.decide = 1; f.avg_stats = avg_stats ? 1 : 0; f.thr = w->gamma * w->mu; f.sentinel = (double)w->stgs->max_admm_iters;
   if (w->dist) {
     FoldArgs fo; fo.nslots = ns;
     for (int q = 0; q < ns; ++q) fo.slots[q] = f.slots[q];
@@ -417,12 +423,12 @@ int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty) {
   return 0;
 }
 
-UpdArgs upd_args(W *w, bool fuse_avg, bool avg_stats) {
+UpdArgs upd_args(W *w, bool fuse_avg, bool avg_stats, abip_int j) {
   UpdArgs a;
   a.u = w->u.p; a.v = w->v.p; a.ut = w->ut.p;
   a.u_avg = w->u_avg.p; a.v_avg = w->v_avg.p; a.u_sum = w->u_sum.p; a.v_sum = w->v_sum.p; a.u_avgc = w->u_avgc.p; a.v_avgc = w->v_avgc.p;
   a.g = w->g.p; a.b = w->b.p; a.c = w->c.p;
-  a.alpha = w->stgs->alpha; a.mu_over_beta = w->mu / w->beta; a.rho = w->stgs->rho_y; a.dom = (double)(w->j + 1);
+  a.alpha = w->stgs->alpha; a.mu_over_beta = w->mu / w->beta; a.rho = w->stgs->rho_y; a.dom = (double)(j + 1);
   a.xw = w->xwt; a.gs = w->gs;
   a.half_update = (int)w->stgs->half_update; a.fuse_avg = fuse_avg ? 1 : 0; a.avg_stats = avg_stats ? 1 : 0;
   return a;
@@ -431,6 +437,54 @@ UpdArgs upd_args(W *w, bool fuse_avg, bool avg_stats) {
 // ------------------------------------------------------------------------------------------------
 // one inner ADMM iteration (abip.c:2133-2173 up to and including the stopping metric); returns the metric
 // ------------------------------------------------------------------------------------------------
+// everything of ADMM iteration (k, j) up to and including the finalize that evaluates the exit test (direct back-end)
+int enqueue_iteration_direct(W *w, abip_int j, bool restart) {
+  const Dims d = dims(w);
+  const Ctl *ctl = w->ctl.p;
+  ABIPSettings *st = w->stgs;
+  launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, w->ut.p, (const double *)w->h.p, st->rho_y, w->g_th, d,
+         w->part.p, w->NB, ctl, (const double *)w->gs);
+  const bool avg_stats = ((j + 1) % 10 == 0); // abip.c:2000
+  enqueue_direct(w, w->ut.p);
+  launch(w, ABIP_HIP_K_VEC, k_admm_update, w->NB, BS, upd_args(w, !restart, avg_stats, j), d, w->part.p, w->NB, ctl);
+  if (restart) {
+    launch(w, ABIP_HIP_K_VEC, k_restart_apply, w->NB, BS, w->u.p, w->v.p, w->u_avg.p, w->v_avg.p, (double)st->restart_fre, w->LV);
+    launch(w, ABIP_HIP_K_VEC, k_avg_stats, w->NB, BS, upd_args(w, true, avg_stats, j), d, w->part.p, ctl);
+  }
+  return enqueue_q_and_finalize(w, avg_stats, false);
+}
+inline bool restart_due(const W *w, abip_int k, abip_int j) { // abip.c:608-609
+  return !(k < w->stgs->restart_thresh || (j + 1 - w->fre_old) % w->stgs->restart_fre != 0);
+}
+// The exit test has been evaluated on the device; take its verdict (one source for the batched and the stepwise path).
+inline void take_verdict(W *w, double *metric_out) {
+  w->stgs->avg_criterion = w->hctl->avg_crit; // abip.c:2042,2048
+  *metric_out = w->hctl->metric;
+  w->it_seen = w->hctl->it_count;
+}
+int clear_halt(W *w) {
+  if (!w->hctl->halt) return 0;
+  HIP_OK(hipMemsetAsync(&w->ctl.p->halt, 0, sizeof(int), w->stream));
+  w->hctl->halt = 0;
+  return 0;
+}
+
+// Direct back-end on one GPU: enqueue up to nb iterations back to back with no host round trip in between.  k_finalize raises
+// ctl->halt at the iteration whose exit test holds and everything enqueued behind it falls through, so the trajectory is the
+// one the stepwise loop produces.  *done = iterations that ran.
+int admm_batch_direct(W *w, int nb, int *done, double *metric_out) {
+  if (!w->wg_valid) launch(w, ABIP_HIP_K_VEC, k_dot_wg, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->g.p, w->stgs->rho_y, dims(w), w->part.p, w->xwt);
+  for (int q = 0; q < nb; ++q) if (enqueue_iteration_direct(w, w->j + q, false)) return -1;
+  if (sync_ctl(w)) return -1;
+  *done = w->hctl->it_count - w->it_seen;
+  if (*done < 1 || *done > nb) return -1;
+  take_verdict(w, metric_out);
+  w->tot_solves += *done; w->prof.kkt_solves += *done; w->prof.admm_iters += *done;
+  w->wg_valid = true;
+  w->stats_valid = true; w->avg_stats_valid = ((w->j + *done) % 10 == 0);
+  return 0;
+}
+
 int admm_iteration(W *w, double *metric_out) {
   const Dims d = dims(w);
   const Ctl *ctl = w->ctl.p;
@@ -439,27 +493,25 @@ int admm_iteration(W *w, double *metric_out) {
     launch(w, ABIP_HIP_K_VEC, k_dot_wg, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->g.p, st->rho_y, d, w->part.p, w->xwt);
     if (w->dist) { enqueue_fold(w, {S_WG}); if (allreduce_scalars(w)) return -1; }
   }
-  launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, w->ut.p, (const double *)w->h.p, st->rho_y, w->g_th, d,
-         w->part.p, w->NB, ctl, (const double *)w->gs);
-  const bool avg_stats = ((w->j + 1) % 10 == 0);                                                   // abip.c:2000
-  const bool restart = !(w->k < st->restart_thresh || (w->j + 1 - w->fre_old) % st->restart_fre != 0); // abip.c:608-609
-  int err = 0;
-  auto tail = [&]() {
-    launch(w, ABIP_HIP_K_VEC, k_admm_update, w->NB, BS, upd_args(w, !restart, avg_stats), d, w->part.p, w->NB, ctl);
-    if (restart) {
-      launch(w, ABIP_HIP_K_VEC, k_restart_apply, w->NB, BS, w->u.p, w->v.p, w->u_avg.p, w->v_avg.p, (double)st->restart_fre, w->LV);
-      launch(w, ABIP_HIP_K_VEC, k_avg_stats, w->NB, BS, upd_args(w, true, avg_stats), d, w->part.p, ctl);
-    }
-    // T still holds A'u_t,y from the back-substitution; it equals A'u_y iff v_y == 0 and (u, v) were not replaced by the restart mean
-    if (enqueue_q_and_finalize(w, avg_stats, w->vy_zero && !restart)) err = -1;
-  };
+  const bool avg_stats = ((w->j + 1) % 10 == 0);  // abip.c:2000
+  const bool restart = restart_due(w, w->k, w->j);
   w->tot_solves++;
   w->prof.kkt_solves++;
   if (w->linsys == ABIP_HIP_LINSYS_DIRECT) {
-    enqueue_direct(w, w->ut.p);
-    tail();
-    if (err || sync_ctl(w)) return -1;
+    if (enqueue_iteration_direct(w, w->j, restart) || sync_ctl(w)) return -1;
   } else {
+    launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, w->ut.p, (const double *)w->h.p, st->rho_y, w->g_th, d,
+           w->part.p, w->NB, ctl, (const double *)w->gs);
+    int err = 0;
+    auto tail = [&]() {
+      launch(w, ABIP_HIP_K_VEC, k_admm_update, w->NB, BS, upd_args(w, !restart, avg_stats, w->j), d, w->part.p, w->NB, ctl);
+      if (restart) {
+        launch(w, ABIP_HIP_K_VEC, k_restart_apply, w->NB, BS, w->u.p, w->v.p, w->u_avg.p, w->v_avg.p, (double)st->restart_fre, w->LV);
+        launch(w, ABIP_HIP_K_VEC, k_avg_stats, w->NB, BS, upd_args(w, true, avg_stats, w->j), d, w->part.p, ctl);
+      }
+      // T still holds A'u_t,y from the back-substitution; it equals A'u_y iff v_y == 0 and (u, v) were not replaced by the restart mean
+      if (enqueue_q_and_finalize(w, avg_stats, w->vy_zero && !restart)) err = -1;
+    };
     if (enqueue_cg_begin(w, w->ut.p, w->u.p, w->k)) return -1; // warm start = current u[0:m), abip.c:559
     int chunk = next_chunk(w);
     for (;;) {
@@ -478,25 +530,8 @@ int admm_iteration(W *w, double *metric_out) {
   w->wg_valid = true;
   w->stats_valid = true; w->avg_stats_valid = avg_stats;
   w->prof.admm_iters++;
-  // iterate_Q_norm_resd, abip.c:1951-2051 (scalar part)
-  const double *o = w->hctl->out;
-  const double tau = o[80], kap = o[81];
-  (void)tau;
-  double Qres = o[S_QP] + o[S_QD];
-  const double gap = o[S_BY] - o[S_CX] - kap;
-  Qres += gap * gap;
-  const double norm = 1 + std::sqrt(o[S_NU] + o[S_NV]);
-  double Qres_avg = (double)st->max_admm_iters, norm_avg = 1;
-  if (avg_stats) {
-    const double kap_a = o[83];
-    Qres_avg = o[S_QPA] + o[S_QDA];
-    const double gap_a = o[S_BYA] - o[S_CXA] - kap_a;
-    Qres_avg += gap_a * gap_a;
-    norm_avg = 1 + std::sqrt(o[S_NUA] + o[S_NVA]);
-  }
-  if (std::sqrt(Qres_avg) / norm_avg < std::sqrt(Qres) / norm) { st->avg_criterion = 1; *metric_out = std::sqrt(Qres_avg) / norm_avg; }
-  else { st->avg_criterion = 0; *metric_out = std::sqrt(Qres) / norm; }
-  return 0;
+  take_verdict(w, metric_out); // iterate_Q_norm_resd, abip.c:1951-2051 (scalar part, evaluated by k_finalize)
+  return clear_halt(w);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -915,6 +950,7 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
   const double t0 = now_ms();
   W *w = new W();
   w->linsys = chosen_linsys();
+  { const char *e = getenv("ABIP_HIP_BATCH"); w->batch_ok = !(e && atoi(e) == 0); }
   if (d->stgs->verbose) print_init_header(d, w->linsys);
   w->stgs = d->stgs; w->n = d->n; w->A = d->A; w->sp = d->sp;
   w->m_glob = d->m; w->m = d->m; w->row0 = 0;
@@ -1109,6 +1145,7 @@ abip_int abip_hip_step(ABIPWork *w, abip_int max_admm_steps, abip_int *steps_don
           w->wg_valid = false;
         }
         w->j = 0;
+        w->batch = 4;
         w->phase = PH_INNER;
         break;
       }
@@ -1116,6 +1153,25 @@ abip_int abip_hip_step(ABIPWork *w, abip_int max_admm_steps, abip_int *steps_don
         if (w->j >= w->inner_stopper) { w->phase = PH_OUTER_END; break; }
         if (steps >= max_admm_steps) return done(0);
         double metric = 0;
+        if (w->linsys == ABIP_HIP_LINSYS_DIRECT && !w->dist && !w->final_check && !st->half_update && w->batch_ok) {
+          // no host decision is needed between these iterations: run them as one batch (the device finds the exit, see admm_batch_direct)
+          long nb = std::min<long>({(long)w->batch, (long)(max_admm_steps - steps), (long)(w->inner_stopper - w->j)});
+          for (long q = 0; q < nb; ++q) if (restart_due(w, w->k + q, w->j + q)) { nb = q; break; }
+          if (nb >= 2) {
+            int ran = 0;
+            if (admm_batch_direct(w, (int)nb, &ran, &metric)) return hard_fail("error in project_lin_sys");
+            steps += ran; w->k += ran;
+            if (w->hctl->halt) { // the exit test held at the last iteration that ran
+              if (clear_halt(w)) return hard_fail("device memset");
+              w->j += ran - 1;
+              w->phase = PH_OUTER_END;
+            } else {
+              w->j += ran;
+              w->batch = std::min(32, w->batch * 2);
+            }
+            break;
+          }
+        }
         if (admm_iteration(w, &metric)) return hard_fail("error in project_lin_sys");
         ++steps;
         w->k += 1;

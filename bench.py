@@ -176,12 +176,16 @@ def main():
     else:
         lnnz = int(S.scalar("lnnz")); N = m + n
         bytes_solve = 2 * (12 * lnnz + 4 * (N + 1) + 16 * N) + 24 * N + 2 * 20 * N   # SURVEY.md 8(d) B_solve_direct
+        # one solve = the launches of class "sptrsv" between two k_rhs: head levels, the two dense tail mat-vecs, head levels
         nl = max(prof["launches"]["sptrsv"], 1)
-        avg_ms = prof["ms"]["sptrsv"] / nl
+        nsolve = max(prof["kkt_solves"], 1)
+        avg_ms = prof["ms"]["sptrsv"] / nsolve
         ach = bytes_solve / (avg_ms * 1e-3) / 1e9
+        T = int(S.scalar("tail"))
         roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
-                    kernel="k_ldl_solve_small (perm, L, D, L', perm' in one workgroup)", avg_launch_us=avg_ms * 1e3, launches=nl,
-                    algorithmic_bytes_per_launch=bytes_solve, lnnz=lnnz)
+                    kernel="direct solve P' L^-T D^-1 L^-1 P (k_ldl_fwd_small / k_tail_mv x2 / k_ldl_bwd_small, or the segmented level kernels)",
+                    avg_launch_us=avg_ms * 1e3, launches=nsolve, kernel_launches=nl, algorithmic_bytes_per_launch=bytes_solve, lnnz=lnnz,
+                    dense_tail=T, dense_tail_bytes_per_solve=8 * T * (T + 1), levels=[int(S.scalar("levels_fwd")), int(S.scalar("levels_bwd"))])
 
     extra = dict(cg_iters_per_step=prof["cg_iters"] / max(prof["admm_iters"], 1), noop_launches=prof["noop_launches"], events_pass=events_pass,
                  m=m, n=n, nnz=int(nnz))

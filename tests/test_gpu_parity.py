@@ -79,6 +79,36 @@ def test_direct_solve_dense_tail(gpu, oracle_built, tail, monkeypatch):
     assert abs(info["pobj"] - ref.info["pobj"]) <= 1e-8 * (1 + abs(ref.info["pobj"]))
 
 
+@pytest.mark.parametrize("name", ["lp_afiro_like", "lp_staircase"])
+def test_batched_iterations_equal_stepwise(gpu, name, monkeypatch):
+    """Direct back-end: iterations are enqueued in batches and the device finds the inner-loop exit (k_finalize raises halt).
+    That must be bit-identical to one control read per iteration, and to stepping through the public ABI in odd strides."""
+    z, A, b, c = load(name)
+    runs = []
+    for mode in ("batched", "stepwise", "strided"):
+        if mode == "stepwise":
+            monkeypatch.setenv("ABIP_HIP_BATCH", "0")
+        else:
+            monkeypatch.delenv("ABIP_HIP_BATCH", raising=False)
+        with gpu.Solver(A, b, c, linsys="direct", verbose=0, eps=1e-5) as S:
+            if mode == "strided":
+                S.begin()
+                fin, total = False, 0
+                while not fin:
+                    fin, done = S.step(7)
+                    total += done
+                    assert done <= 7
+                info = S.end()
+                assert total == info["admm_iter"] - 1          # get_info reports k + 1 (abip.c:1296-1340)
+            else:
+                info = S.solve()
+            runs.append((info["admm_iter"], info["ipm_iter"], info["pobj"], S.x.copy(), S.y.copy(), S.s.copy()))
+    for r in runs[1:]:
+        assert r[0] == runs[0][0] and r[1] == runs[0][1] and r[2] == runs[0][2]
+        for a2, b2 in zip(r[3:], runs[0][3:]):
+            assert np.array_equal(a2, b2)
+
+
 def test_direct_solve_wide_head_with_tail(gpu):
     """A factor whose head levels are wider than one workgroup (segmented path) and whose tail is several thousand pivots."""
     from abip_amd import problems

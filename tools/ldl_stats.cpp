@@ -18,7 +18,7 @@ int main(int argc, char **argv) {
   const double rho = argc > 2 ? atof(argv[2]) : 1e-3;
   if (host::factor_kkt(&A, rho, F) < 0) { printf("factor failed\n"); return 1; }
   const int N = F.N;
-  printf("t0 %d T %d head nnz %d\n", F.t0, F.T, F.bwd.ptr[N]);
+  printf("t0 %d T %d head nnz %d\n", F.t0, F.T, (int)F.bwd.idx.size());
   printf("N %d Lnnz %ld levF %zu levB %zu\n", N, F.lnnz, F.fwd.lev_ptr.size() - 1, F.bwd.lev_ptr.size() - 1);
   // tail density: nnz of L[t:, t:] / (T(T-1)/2)
   std::vector<long> tailnnz(N + 1, 0); // entries with col >= t (rows > col anyway)
