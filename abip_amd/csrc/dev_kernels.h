@@ -492,13 +492,13 @@ __global__ __launch_bounds__(BS) void k_finalize(FinArgs f, Dims d, const double
     const double *o = ctl->out;
     double Qres = o[S_QP] + o[S_QD];
     const double gap = o[S_BY] - o[S_CX] - o[81];
-    Qres += gap * gap;
+    Qres = __dadd_rn(Qres, __dmul_rn(gap, gap)); // un-fused, like the host code this mirrors: ties between the two candidates must stay ties
     const double norm = 1 + sqrt(o[S_NU] + o[S_NV]);
     double Qres_avg = f.sentinel, norm_avg = 1;
     if (f.avg_stats) {
       Qres_avg = o[S_QPA] + o[S_QDA];
       const double gap_a = o[S_BYA] - o[S_CXA] - o[83];
-      Qres_avg += gap_a * gap_a;
+      Qres_avg = __dadd_rn(Qres_avg, __dmul_rn(gap_a, gap_a));
       norm_avg = 1 + sqrt(o[S_NUA] + o[S_NVA]);
     }
     const double ma = sqrt(Qres_avg) / norm_avg, mc = sqrt(Qres) / norm;

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <numeric>
 
 namespace abip {
@@ -197,11 +198,14 @@ void jacobi_preconditioner(const ABIPMatrix *A, std::vector<double> &Minv) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-// Minimum external degree on the quotient graph (element absorption, exact degrees).  The reference calls
-// SuiteSparse AMD here (direct.c:106-119); any symmetric permutation is admissible because K is quasi-definite.
+// Approximate-minimum-degree ordering on the quotient graph (the bound of Amestoy, Davis & Duff: external degree of i <=
+// |A_i \ Lp| + |Lp \ i| + sum over the other elements e of i of |L_e \ Lp|, the last terms obtained for all i in Lp at once with one
+// pass over their element lists), with element absorption; no supervariables.  The reference calls SuiteSparse AMD here
+// (direct.c:106-119); any symmetric permutation is admissible because K is quasi-definite.
 void min_degree(int N, const std::vector<int> &Gp, const std::vector<int> &Gi, std::vector<int> &perm) {
   std::vector<std::vector<int>> adjv(N), adje(N), elem(N);
   std::vector<int> deg(N), mark(N, -1), head(N + 1, -1), nxt(N, -1), prv(N, -1);
+  std::vector<long> w(N, 0);
   std::vector<char> elim(N, 0), dead(N, 0);
   for (int i = 0; i < N; ++i) { adjv[i].assign(Gi.begin() + Gp[i], Gi.begin() + Gp[i + 1]); deg[i] = (int)adjv[i].size(); }
   auto ins = [&](int x) { const int d = deg[x]; nxt[x] = head[d]; prv[x] = -1; if (head[d] >= 0) prv[head[d]] = x; head[d] = x; };
@@ -209,9 +213,17 @@ void min_degree(int N, const std::vector<int> &Gp, const std::vector<int> &Gi, s
   for (int i = N - 1; i >= 0; --i) ins(i);
   perm.resize(N);
   int stamp = 0, mindeg = 0;
+  long wflg = 1;
   std::vector<int> Lp;
   for (int k = 0; k < N; ++k) {
     while (mindeg <= N && head[mindeg] < 0) ++mindeg;
+    if (N - k > 64 && (double)mindeg >= 0.7 * (double)(N - k - 1)) {
+      // what is left is (close to) a clique: any order fills it in completely.  Finish in degree order; this block becomes
+      // the dense tail of the factor.
+      for (int dgr = mindeg; dgr <= N && k < N; ++dgr)
+        for (int x = head[dgr]; x >= 0; x = nxt[x]) perm[k++] = x;
+      break;
+    }
     const int p = head[mindeg];
     del(p);
     elim[p] = 1; perm[k] = p;
@@ -224,24 +236,43 @@ void min_degree(int N, const std::vector<int> &Gp, const std::vector<int> &Gi, s
       dead[e] = 1; std::vector<int>().swap(elem[e]);
     }
     std::vector<int>().swap(adjv[p]); std::vector<int>().swap(adje[p]);
-    elem[p] = Lp;
-    for (int x : Lp) {
-      auto &av = adjv[x];
-      av.erase(std::remove_if(av.begin(), av.end(), [&](int y) { return elim[y] || mark[y] == stamp; }), av.end());
-      auto &ae = adje[x];
-      ae.erase(std::remove_if(ae.begin(), ae.end(), [&](int e) { return dead[e] != 0; }), ae.end());
-      ae.push_back(p);
-    }
+    const int lp = (int)Lp.size();
+    // |L_e \ Lp| for every element e that touches Lp:  w[e] - wflg
+    long maxlen = lp;
     for (int x : Lp) {
       del(x);
-      const int st2 = ++stamp; mark[x] = st2;
-      int d = 0;
-      for (int y : adjv[x]) if (mark[y] != st2) { mark[y] = st2; ++d; }
-      for (int e : adje[x]) for (int y : elem[e]) if (!elim[y] && mark[y] != st2) { mark[y] = st2; ++d; }
-      deg[x] = d;
-      ins(x);
-      if (d < mindeg) mindeg = d;
+      auto &ae = adje[x];
+      size_t keep = 0;
+      for (int e : ae) {
+        if (dead[e]) continue;
+        ae[keep++] = e;
+        if (w[e] < wflg) { w[e] = (long)elem[e].size() + wflg; maxlen = std::max<long>(maxlen, (long)elem[e].size()); }
+        --w[e];
+      }
+      ae.resize(keep);
     }
+    for (int x : Lp) {
+      long d = 0;
+      auto &ae = adje[x];
+      size_t keep = 0;
+      for (int e : ae) {
+        if (dead[e]) continue;
+        const long ext = w[e] - wflg;
+        if (ext > 0) { d += ext; ae[keep++] = e; }
+        else { dead[e] = 1; std::vector<int>().swap(elem[e]); } // L_e is inside Lp: absorbed
+      }
+      ae.resize(keep);
+      ae.push_back(p);
+      auto &av = adjv[x];
+      av.erase(std::remove_if(av.begin(), av.end(), [&](int y) { return elim[y] || mark[y] == stamp; }), av.end());
+      d += (long)av.size();
+      const long bound = std::min<long>({(long)(N - k - 2), (long)deg[x] + lp - 1, d + lp - 1});
+      deg[x] = (int)std::max<long>(bound, 0);
+      ins(x);
+      if (deg[x] < mindeg) mindeg = deg[x];
+    }
+    wflg += maxlen + 1;
+    elem[p] = Lp;
   }
 }
 
@@ -327,7 +358,11 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
   for (int i = 0; i < N; ++i) Gp[i + 1] += Gp[i];
   std::vector<int> Gi(Gp[N]), pos(Gp.begin(), Gp.end() - 1);
   for (int j = 0; j < N; ++j) for (int q = Kp[j]; q < Kp[j + 1]; ++q) if (Ki[q] != j) { Gi[pos[Ki[q]]++] = j; Gi[pos[j]++] = Ki[q]; }
+  const bool tm = getenv("ABIP_HIP_SETUP_TIMES") != nullptr;
+  auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tq = clk();
   min_degree(N, Gp, Gi, out.P);
+  if (tm) { printf("[setup] ordering %.3f s\n", clk() - tq); tq = clk(); }
   std::vector<int> Pinv(N);
   for (int i = 0; i < N; ++i) Pinv[out.P[i]] = i;
   // C = upper triangle of P K P' by columns (cs_symperm, direct.c:259-260)
@@ -353,27 +388,31 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
   }
   std::vector<long> Lp(N + 1, 0);
   for (int j = 0; j < N; ++j) Lp[j + 1] = Lp[j] + lnz[j];
+  if (tm) { printf("[setup] symbolic %.3f s (nnz(L) = %ld)\n", clk() - tq, Lp[N]); tq = clk(); }
   out.lnnz = Lp[N];
 
   // ---- head / dense-tail split -----------------------------------------------------------------------------------
   // With a fill-reducing ordering the last pivots form a (nearly) dense trailing block whose rows are one level each:
   // the sequential part of a level-scheduled solve.  Columns >= t0 are therefore not kept as a sparse factor: the host
   // computes only the Schur complement S onto them (sparse arithmetic), the device factors S densely and applies
-  // inv(L22) as two dense triangular mat-vecs (dev_ldl.h).  Candidate sizes come from the column counts alone
-  // (column j >= N-T has all its lnz[j] entries inside the trailing block).
+  // inv(L22) as two dense triangular mat-vecs (dev_ldl.h).
   int T = 0;
   {
     const int Tmax = std::min(N - 1, tail_cap());
     const int req = tail_request();
     if (req > 0) T = std::min(req, Tmax) / 64 * 64;
     else if (req < 0 && N >= 256) {
-      long tn = 0;
-      int best = 0;
-      for (int t = 1; t <= Tmax; ++t) {
-        tn += lnz[N - t];
-        if (t % 64 == 0 && (double)tn >= 0.25 * 0.5 * (double)t * (t - 1)) best = t;
+      // The levels of the forward (and backward) solve over the head [0, t0) are the heights of the elimination forest
+      // restricted to it.  Pick T to minimise  levels * (cost of a level) + bytes of the two dense triangles / bandwidth.
+      std::vector<int> hgt(N, 0), pm(N + 1, 0);
+      for (int i = 0; i < N; ++i) if (parent[i] >= 0) hgt[parent[i]] = std::max(hgt[parent[i]], hgt[i] + 1);
+      for (int i = 0; i < N; ++i) pm[i + 1] = std::max(pm[i], hgt[i] + 1);
+      const double c_lev = 1.5, c_mv = 3.0, bw = 3.0e6; // us per level, us per mat-vec launch, bytes per us
+      double best = 2.0 * c_lev * pm[N];
+      for (int t = 64; t <= Tmax; t += 64) {
+        const double cost = 2.0 * c_lev * pm[N - t] + 2.0 * (c_mv + 4.0 * (double)t * t / bw);
+        if (cost < best) { best = cost; T = t; }
       }
-      T = best;
     }
   }
   const int t0 = N - T;
@@ -420,6 +459,7 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
     out.D[k] = dk;
     if (dk == 0.0) return -1;
   }
+  if (tm) { printf("[setup] numeric (head + Schur complement, T = %d) %.3f s\n", T, clk() - tq); tq = clk(); }
   // backward form = CSC of the head columns of L (all rows); forward form = CSR of [L11; L21]
   out.bwd.ptr.assign(N + 1, 0);
   for (int j = 0; j <= N; ++j) out.bwd.ptr[j] = (int)Lp[std::min(j, t0)];

@@ -377,7 +377,7 @@ abip_int has_converged(const W *w, abip_int ipm_iter, abip_int admm_iter) { // a
 // ------------------------------------------------------------------------------------------------
 // statistics pass on the current iterate(s): the two residual SpMVs + finalise + control read
 // ------------------------------------------------------------------------------------------------
-int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty) {
+int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty, bool decide = true) {
   const Dims d = dims(w);
   const Ctl *ctl = w->ctl.p;
   const double *wD = w->stgs->normalize ? w->wD.p : nullptr, *wE = w->stgs->normalize ? w->wE.p : nullptr;
@@ -411,7 +411,7 @@ int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty) {
   }
   f.nslots = ns;
   f.u = w->u.p; f.v = w->v.p; f.ua = w->u_avgc.p; f.va = w->v_avgc.p; f.gs = w->gs;
-  f.decide = 1; f.avg_stats = avg_stats ? 1 : 0; f.thr = w->gamma * w->mu; f.sentinel = (double)w->stgs->max_admm_iters;
+  f.decide = decide ? 1 : 0; f.avg_stats = avg_stats ? 1 : 0; f.thr = w->gamma * w->mu; f.sentinel = (double)w->stgs->max_admm_iters;
   if (w->dist) {
     FoldArgs fo; fo.nslots = ns;
     for (int q = 0; q < ns; ++q) fo.slots[q] = f.slots[q];
@@ -709,7 +709,7 @@ int ensure_stats(W *w) { // make ctl.out describe the CURRENT iterate and the av
   const int zero = 0, one = 1;
   HIP_OK(hipMemcpyAsync(&w->ctl.p->halt, &zero, sizeof(int), hipMemcpyHostToDevice, w->stream));
   HIP_OK(hipMemcpyAsync(&w->ctl.p->cg_done, &one, sizeof(int), hipMemcpyHostToDevice, w->stream));
-  if (enqueue_q_and_finalize(w, true, false)) return -1;
+  if (enqueue_q_and_finalize(w, true, false, /*decide=*/false)) return -1; // statistics only: not an ADMM iteration
   if (sync_ctl(w)) return -1;
   double *o = w->hctl->out;
   double by = 0, cx = 0, bya = 0, cxa = 0;

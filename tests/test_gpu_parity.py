@@ -65,8 +65,9 @@ def test_direct_solve_dense_tail(gpu, oracle_built, tail, monkeypatch):
     rng = np.random.default_rng(7)
     with gpu.Solver(A, b, c, linsys="direct", verbose=0, max_admm_iters=400) as S:
         T = int(S.scalar("tail"))
-        assert T == (768 if tail == "auto" else int(tail)), T
-        assert S.scalar("levels_fwd") <= {0: 464, 64: 401, 128: 400, 512: 109, 768: 8}[T]   # the one-row levels of the tail are gone
+        assert (T >= 256 and S.scalar("levels_fwd") <= 16) if tail == "auto" else T == int(tail), T
+        if T == 0:
+            assert S.scalar("levels_fwd") > 100             # what the tail is there to remove
         Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
         K = kkt_matrix(Asc, 1e-3)
         for _ in range(3):
