@@ -54,35 +54,59 @@ struct DevCsr {
   void release() { ptr.release(); idx.release(); rbd.release(); val.release(); }
 };
 
+struct Segment { bool wide; int l0, l1; int rb0 = 0, nrb = 0; }; // wide: one level streamed over the grid, row blocks [rb0, rb0+nrb)
+
 struct DevTri {
-  DBuf<int> ptr, idx, lev_ptr, lev_rows, lev_g;
+  DBuf<int> ptr, idx, lev_ptr, lev_rows, lev_g, rbd;
   DBuf<double> val;
   int nlev = 0;
-  std::vector<int> h_lev_ptr; // host copy for launch planning
+  std::vector<Segment> segs; // launch plan: runs of thin levels in one workgroup, wide levels as CSR-stream grids
   int upload(const host::TriHost &h, hipStream_t s) {
-    nlev = (int)h.lev_ptr.size() - 1; h_lev_ptr = h.lev_ptr;
+    nlev = (int)h.lev_ptr.size() - 1;
+    // a level is "wide" when it has enough rows or non-zeros to fill the chip; its positions are cut into row blocks
+    // of <= CHUNK non-zeros / rows for the CSR-stream kernel (same greedy rule as host::build_row_blocks)
+    segs.clear();
+    std::vector<int> d4;
+    int l = 0;
+    auto is_wide = [&](int lv) {
+      const int a = h.lev_ptr[lv], b = h.lev_ptr[lv + 1];
+      return (b - a) >= 2048 || (h.ptr[b] - h.ptr[a]) >= 65536;
+    };
+    while (l < nlev) {
+      if (is_wide(l)) {
+        Segment sg{true, l, l + 1, (int)d4.size() / 4, 0};
+        const int a = h.lev_ptr[l], b = h.lev_ptr[l + 1];
+        int r = a;
+        while (r < b) {
+          int nn = 0, rows = 0, e = r;
+          while (e < b) {
+            const int len = h.ptr[e + 1] - h.ptr[e];
+            if (rows > 0 && (nn + len > CHUNK || rows >= CHUNK)) break;
+            nn += len; ++rows; ++e;
+            if (nn > CHUNK) break;
+          }
+          d4.push_back(r); d4.push_back(e); d4.push_back(h.ptr[r]); d4.push_back(h.ptr[e]);
+          r = e;
+        }
+        sg.nrb = (int)d4.size() / 4 - sg.rb0;
+        segs.push_back(sg);
+        ++l;
+      } else {
+        int e = l;
+        while (e < nlev && !is_wide(e)) ++e;
+        segs.push_back(Segment{false, l, e, 0, 0});
+        l = e;
+      }
+    }
+    if (d4.empty()) d4.assign(4, 0);
     if (ptr.upload(h.ptr, s) || idx.upload(h.idx, s) || val.upload(h.val, s) || lev_ptr.upload(h.lev_ptr, s) ||
-        lev_rows.upload(h.lev_rows, s) || lev_g.upload(h.lev_g, s)) return -1;
+        lev_rows.upload(h.lev_rows, s) || lev_g.upload(h.lev_g, s) || rbd.upload(d4, s)) return -1;
     return 0;
   }
+  bool single_workgroup() const { return segs.empty() || (segs.size() == 1 && !segs[0].wide); }
   Tri view() const { return Tri{ptr.p, idx.p, val.p, lev_ptr.p, lev_rows.p, lev_g.p, nlev}; }
-  void release() { ptr.release(); idx.release(); val.release(); lev_ptr.release(); lev_rows.release(); lev_g.release(); }
+  void release() { ptr.release(); idx.release(); val.release(); lev_ptr.release(); lev_rows.release(); lev_g.release(); rbd.release(); }
 };
-
-struct Segment { bool wide; int l0, l1; };
-
-inline std::vector<Segment> plan_segments(const std::vector<int> &lev_ptr) {
-  std::vector<Segment> segs;
-  const int nlev = (int)lev_ptr.size() - 1;
-  int l = 0;
-  while (l < nlev) {
-    const int rows = lev_ptr[l + 1] - lev_ptr[l];
-    if (rows >= 2048) { segs.push_back(Segment{true, l, l + 1}); ++l; }
-    else { int e = l; while (e < nlev && lev_ptr[e + 1] - lev_ptr[e] < 2048) ++e; segs.push_back(Segment{false, l, e}); l = e; }
-  }
-  return segs;
-}
-
 
 } // namespace hostutil
 } // namespace abip

@@ -276,7 +276,6 @@ struct DevLdl {
   DevTri F, B;
   DBuf<int> Pmap, flag;
   DBuf<double> D, xw, W, Wt, tmp;
-  std::vector<Segment> segF, segB;
   bool small = false, xl = false; // one-workgroup sparse part; x in LDS
   int N = 0, t0 = 0, T = 0;
   long lnnz = 0;
@@ -285,8 +284,7 @@ struct DevLdl {
   int setup(const host::LdlHost &H, const std::vector<int> &pmap, hipStream_t s) {
     N = H.N; t0 = H.t0; T = H.T; lnnz = H.lnnz;
     if (Pmap.upload(pmap, s) || D.upload(H.D, s) || xw.alloc(N) || F.upload(H.fwd, s) || B.upload(H.bwd, s)) return -1;
-    segF = plan_segments(H.fwd.lev_ptr); segB = plan_segments(H.bwd.lev_ptr);
-    small = (segF.size() <= 1 && segB.size() <= 1 && (segF.empty() || !segF[0].wide) && (segB.empty() || !segB[0].wide) && N <= 65536);
+    small = F.single_workgroup() && B.single_workgroup() && N <= 65536;
     xl = small && N <= XL_MAX;
     if (xl) { // more than 64 KB of dynamic LDS has to be asked for
       const int bytes = (int)(sizeof(double) * (size_t)N);
@@ -344,18 +342,16 @@ struct DevLdl {
     }
     const int gN = std::max(1, std::min(NB, (N + BS - 1) / BS));
     launch(k_perm_in, gN, BS, (size_t)0, (const int *)Pmap.p, (const double *)rhs, xw.p, N, ctl);
-    auto run = [&](const DevTri &Tr, const std::vector<Segment> &segs) {
-      for (const Segment &sg : segs) {
-        if (sg.wide) {
-          const int rows = Tr.h_lev_ptr[sg.l0 + 1] - Tr.h_lev_ptr[sg.l0];
-          launch(k_tri_wide, std::max(1, std::min(MAXNB, (rows * 8 + BS - 1) / BS)), BS, (size_t)0, Tr.view(), xw.p, sg.l0, ctl);
-        } else launch(k_tri_thin, 1, TBS, (size_t)0, Tr.view(), xw.p, sg.l0, sg.l1, ctl);
+    auto run = [&](const DevTri &Tr) {
+      for (const Segment &sg : Tr.segs) {
+        if (sg.wide) launch(k_tri_wide, std::max(1, std::min(NB, sg.nrb)), BS, (size_t)0, Tr.view(), (const int4 *)Tr.rbd.p + sg.rb0, sg.nrb, xw.p, ctl);
+        else launch(k_tri_thin, 1, TBS, (size_t)0, Tr.view(), xw.p, sg.l0, sg.l1, ctl);
       }
     };
-    run(F, segF);
+    run(F);
     tail();
     launch(k_dscale, gN, BS, (size_t)0, xw.p, (const double *)D.p, t0, ctl);
-    run(B, segB);
+    run(B);
     launch(k_perm_out, gN, BS, (size_t)0, (const int *)Pmap.p, rhs, (const double *)xw.p, N, ctl);
   }
 

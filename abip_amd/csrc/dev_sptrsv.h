@@ -51,10 +51,17 @@ static __global__ __launch_bounds__(BS) void k_dscale(double *__restrict__ x, co
   if (ctl->halt) return;
   for (int j = blockIdx.x * BS + threadIdx.x; j < N; j += gridDim.x * BS) x[j] /= D[j];
 }
-// one wide level over a grid
-static __global__ __launch_bounds__(BS) void k_tri_wide(Tri T, double *x, int lev, const Ctl *ctl) {
+// one wide level over the grid: the level's rows are contiguous positions of the level-ordered storage, i.e. a CSR matrix of
+// its own, and x[row] -= (that matrix) * x is the CSR-stream SpMV of the PCG path (dev_common.h: coalesced value/index stream,
+// products staged in LDS, rows reduced from LDS).  Gathers touch earlier levels only, every row is written by one lane.
+static __global__ __launch_bounds__(BS) void k_tri_wide(Tri T, const int4 *__restrict__ rbd, int nrb, double *x, const Ctl *ctl) {
   if (ctl->halt) return;
-  tri_level(T, x, T.lev_ptr[lev], T.lev_ptr[lev + 1], T.lev_g[lev], blockIdx.x * BS + threadIdx.x, gridDim.x * BS);
+  __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
+  __shared__ double sm[WAVES];
+  const Csr M{T.ptr, T.idx, T.val, rbd, nrb, 0};
+  spmv_stream<1>(M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
+                 [&](int pos, double(&acc)[1]) { const int row = T.lev_rows[pos]; x[row] -= acc[0]; });
 }
 // a run of thin levels [l0, l1) in one workgroup
 static __global__ __launch_bounds__(TBS) void k_tri_thin(Tri T, double *x, int l0, int l1, const Ctl *ctl) {

@@ -5,7 +5,7 @@
 //   kq_dots, kq_Qp   partial r'(rho o p), p_x'Q p_x                                       abip.c:226-239
 //   kq_ut_prox       tau~ from the scalar quadratic; u_t = p - tau~ r; over-relaxed point; y, tau, orthant/free/zero
 //                    blocks of the barrier sub-problem                                    abip.c:241-248, 336-353, 390-409 ; cones.c:255-288
-//   kq_cones         SOC / rotated-SOC barrier prox, one wavefront per cone               cones.c:130-248
+//   kq_cones         SOC / rotated-SOC barrier prox, one wavefront (workgroup if large) per cone  cones.c:130-248
 //   kq_dual          v = u - rel_ut ; v_origin = rho o v                                  abip.c:314-324, 1143-1144
 //   kq_inner_*       Mu = (A x ; -A'y + Q x) and the sums of the inner stopping test      qcp_config.c:518-557
 //   kq_resid         inf-norm residuals, objectives, certificates from the stored A x, A'y, Q x   qcp_config.c:562-691
@@ -139,19 +139,17 @@ __global__ __launch_bounds__(BS) void kq_ut_prox(QProxArgs a, QDims d, const dou
   }
 }
 
-// one wavefront per SOC / RSOC cone: ||tail||^2 by a wave reduction, closed form on lane 0, scaled copy by all lanes
+// SOC / RSOC barrier prox: ||tail||^2 by a reduction, closed form for the head entries and one scale factor for the tail.
+// Small cones: one wavefront per cone.  Large cones (> QC_BIG entries): one 1024-thread workgroup per cone.
 struct QCones { const int *off, *len, *kind; int n; }; // kind 0 SOC, 1 RSOC
-__global__ __launch_bounds__(BS) void kq_cones(QCones C, double *__restrict__ u, const double *__restrict__ rel, double lambda, int MP) {
-  const int wave = (blockIdx.x * BS + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if (wave >= C.n) return;
-  const int off = MP + C.off[wave], len = C.len[wave], kind = C.kind[wave];
-  const int h = (kind == 0) ? 1 : 2; // head entries
-  double sq = 0.0;
-  for (int k = h + lane; k < len; k += 64) { const double t = rel[off + k]; sq += t * t; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-  double x0 = 0, x1 = 0, sc = 0;
-  if (kind == 0) { // cones.c:130-161
+constexpr int QC_BIG = 2048;
+constexpr int QC_TB = 1024;
+
+// closed forms of cones.c:130-161 (SOC) and cones.c:169-248 (RSOC) given sq = ||tail||^2
+__device__ __forceinline__ void cone_closed_form(int kind, const double *__restrict__ rel, const double *u, int off, double sq, double lambda,
+                                                 double &x0, double &x1, double &sc) {
+  x0 = 0; x1 = 0; sc = 0;
+  if (kind == 0) {
     const double a = rel[off];
     if (fabs(a) <= 1e-9) { x0 = sqrt(2 * lambda + sq / 4); sc = 0.5; }
     else {
@@ -161,8 +159,7 @@ __global__ __launch_bounds__(BS) void kq_cones(QCones C, double *__restrict__ u,
       const double s = a > 0 ? s2 : s1;
       x0 = (s + 2) * a / s; sc = (s + 2) / (s + 4);
     }
-    if (lane == 0) u[off] = x0;
-  } else { // cones.c:169-248
+  } else {
     const double ze = rel[off], zn = rel[off + 1];
     if (ze + zn == 0) {
       x1 = (-ze + sqrt(ze * ze + 4 * lambda + sq)) / 2;
@@ -184,9 +181,41 @@ __global__ __launch_bounds__(BS) void kq_cones(QCones C, double *__restrict__ u,
         x0 = (ze * (s + 1) * (s + 1) + zn * (s + 1)) / (s * (s + 2)); x1 = (zn * (s + 1) * (s + 1) + ze * (s + 1)) / (s * (s + 2)); sc = (s + 1) / (s + 2);
       }
     }
-    if (lane == 0) { u[off] = x0; u[off + 1] = x1; }
   }
-  for (int k = h + lane; k < len; k += 64) u[off + k] = rel[off + k] * sc;
+}
+
+// cones [first, C.n) of the (small-first) cone table
+template <bool BIG>
+__global__ __launch_bounds__(BIG ? QC_TB : BS) void kq_cones(QCones C, int first, double *__restrict__ u, const double *__restrict__ rel, double lambda, int MP) {
+  constexpr int NT = BIG ? QC_TB : 64;
+  const int cone = first + (BIG ? (int)blockIdx.x : (int)((blockIdx.x * BS + threadIdx.x) >> 6));
+  const int t = BIG ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+  if (cone >= C.n) return;
+  const int off = MP + C.off[cone], len = C.len[cone], kind = C.kind[cone];
+  const int h = (kind == 0) ? 1 : 2; // head entries
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int k = h + t;
+  for (; k + 3 * NT < len; k += 4 * NT) {
+    const double a = rel[off + k], b = rel[off + k + NT], c = rel[off + k + 2 * NT], d = rel[off + k + 3 * NT];
+    s0 += a * a; s1 += b * b; s2 += c * c; s3 += d * d;
+  }
+  for (; k < len; k += NT) { const double a = rel[off + k]; s0 += a * a; }
+  double sq = (s0 + s1) + (s2 + s3);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  if (BIG) {
+    __shared__ double sm[QC_TB / 64];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    sq = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < QC_TB / 64; ++wv) sq += sm[wv];
+  }
+  double x0, x1, sc;
+  cone_closed_form(kind, rel, u, off, sq, lambda, x0, x1, sc);
+  if (BIG) __syncthreads(); // every thread has read u[off] before it is overwritten
+  if (t == 0) { u[off] = x0; if (kind != 0) u[off + 1] = x1; }
+  for (int q = h + t; q < len; q += NT) u[off + q] = rel[off + q] * sc;
 }
 
 __global__ __launch_bounds__(BS) void kq_dual(const double *__restrict__ u, const double *__restrict__ rel, double *__restrict__ v, double *__restrict__ vo,

@@ -54,7 +54,7 @@ struct QWk {
   DBuf<QCtl> ctl;
   QCtl *hctl = nullptr;
   DevLdl ldl;
-  int ncones = 0;
+  int ncones = 0, nsmall = 0; // cone table: the nsmall cones of <= QC_BIG entries first
   Ctl *lp_ctl = nullptr; // dev_sptrsv kernels are gated on an LP-style control block (halt flag): a zeroed one
 };
 
@@ -377,6 +377,15 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     hu[w->MP + n] = 1.0;
   }
   w->ncones = (int)c_off.size();
+  { // small cones first (one wavefront each), then the large ones (one workgroup each)
+    std::vector<int> ord(w->ncones);
+    for (int q = 0; q < w->ncones; ++q) ord[q] = q;
+    std::stable_partition(ord.begin(), ord.end(), [&](int q) { return c_len[q] <= QC_BIG; });
+    std::vector<int> o2(w->ncones), l2(w->ncones), k2(w->ncones);
+    w->nsmall = 0;
+    for (int q = 0; q < w->ncones; ++q) { o2[q] = c_off[ord[q]]; l2[q] = c_len[ord[q]]; k2[q] = c_kind[ord[q]]; if (l2[q] <= QC_BIG) w->nsmall++; }
+    c_off.swap(o2); c_len.swap(l2); c_kind.swap(k2);
+  }
   if (w->xkind.upload(xkind, w->stream) || w->c_off.upload(c_off, w->stream) || w->c_len.upload(c_len, w->stream) || w->c_kind.upload(c_kind, w->stream))
     return bail("work memory allocation failure");
   if (hipMemcpyAsync(w->u.p, hu.data(), sizeof(double) * w->LV, hipMemcpyHostToDevice, w->stream) != hipSuccess ||
@@ -460,8 +469,9 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       pa.alpha = st->alpha; pa.lambda = w->mu / w->beta; pa.rho_x = st->rho_x; pa.rho_tau = st->rho_tau; pa.a_quad = w->a_quad; pa.iter_pos = k > 0; pa.hasQ = w->hasQ;
       QLAUNCH(w, kq_ut_prox, w->NB, BS, pa, dm, (const double *)w->part.p, w->NB, w->ctl.p);
       if (w->ncones) {
-        QCones C{w->c_off.p, w->c_len.p, w->c_kind.p, w->ncones};
-        QLAUNCH(w, kq_cones, (w->ncones + WAVES - 1) / WAVES, BS, C, w->u.p, (const double *)w->rel.p, (w->mu / w->beta) / st->rho_x, w->MP);
+        const double lam = (w->mu / w->beta) / st->rho_x;
+        if (w->nsmall) { QCones C{w->c_off.p, w->c_len.p, w->c_kind.p, w->nsmall}; QLAUNCH(w, kq_cones<false>, (w->nsmall + WAVES - 1) / WAVES, BS, C, 0, w->u.p, (const double *)w->rel.p, lam, w->MP); }
+        if (w->ncones > w->nsmall) { QCones C{w->c_off.p, w->c_len.p, w->c_kind.p, w->ncones}; QLAUNCH(w, kq_cones<true>, w->ncones - w->nsmall, QC_TB, C, w->nsmall, w->u.p, (const double *)w->rel.p, lam, w->MP); }
       }
       QLAUNCH(w, kq_dual, w->NB, BS, (const double *)w->u.p, (const double *)w->rel.p, w->v.p, w->vo.p, st->rho_y, st->rho_x, st->rho_tau, dm);
       k += 1;

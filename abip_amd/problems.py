@@ -169,3 +169,22 @@ def lp_random_sparse(m: int = 200_000, n: int = 500_000, per_col: int = 16, seed
     b = A @ x0
     c = rng.uniform(0.1, 1.1, size=n)
     return A, np.ascontiguousarray(b), np.ascontiguousarray(c)
+
+
+def qcp_lasso_socp(p: int = 10_000, d: int = 45_000, density: float = 0.005, seed: int = 5):
+    """Config C5: LASSO  min 1/2 ||X beta - y||^2 + lam ||beta||_1  as an SOCP for the conic path.
+    Data as scripts/bench-qcp/get_lasso_simu_data.m:3-14 (sparse Gaussian X, v_i ~ N(0, 1/d) w.p. 1/2, y = X v + noise,
+    lam = ||X'y||_inf / 5).  Variables (q0, q1, z) in SOC(p+2) then (beta+, beta-) >= 0:
+        q0 - q1 = 1,   z - X beta+ + X beta- = -y,   minimise 1/2 (q0 + q1) + lam 1'(beta+ + beta-)
+    (q0^2 - q1^2 = q0 + q1 >= ||z||^2).  Returns (data dict, cone dict): n = p + 2 + 2d, m = p + 1."""
+    rng = np.random.default_rng(seed)
+    X = sp.random(p, d, density=density, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+    v = rng.standard_normal(d) / np.sqrt(d) * (rng.random(d) < 0.5)
+    y = X @ v + 0.01 * rng.standard_normal(p)
+    lam = float(np.abs(X.T @ y).max() / 5)
+    r1 = sp.hstack([sp.csc_matrix(np.array([[1.0, -1.0]])), sp.csc_matrix((1, p + 2 * d))])
+    r2 = sp.hstack([sp.csc_matrix((p, 2)), sp.identity(p), -X, X])
+    A = canonical_csc(sp.vstack([r1, r2]))
+    b = np.concatenate([[1.0], -y])
+    c = np.concatenate([[0.5, 0.5], np.zeros(p), lam * np.ones(2 * d)])
+    return dict(A=A, b=b, c=c), dict(q=[p + 2], l=2 * d)

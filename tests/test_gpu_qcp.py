@@ -57,7 +57,7 @@ def test_toy_qcp_matches_recorded_reference_output(gpu):
     assert np.max(np.abs(sol["x"] - want)) < 6e-7
 
 
-@pytest.mark.parametrize("case", ["toy", "lasso_small", "lasso_mid", "lp_afiro", "lp_rand", "qp", "rsoc_mix"])
+@pytest.mark.parametrize("case", ["toy", "lasso_small", "lasso_mid", "lp_afiro", "lp_rand", "qp", "rsoc_mix", "lasso_bigcone"])
 def test_conic_path_follows_the_oracle(gpu, pq, case):
     rng = np.random.default_rng(11)
     Q = None
@@ -67,6 +67,8 @@ def test_conic_path_follows_the_oracle(gpu, pq, case):
         data, K = lasso_socp(30, 60, 2)
     elif case == "lasso_mid":
         data, K = lasso_socp(400, 1500, 3, density=0.02)
+    elif case == "lasso_bigcone":   # a cone above QC_BIG = 2048 entries takes the one-workgroup-per-cone kernel
+        data, K = lasso_socp(2200, 2600, 4, density=0.004)
     elif case in ("lp_afiro", "lp_rand"):
         z, A, b, c = load("lp_afiro_like" if case == "lp_afiro" else "lp_random_sparse_small")
         data, K = dict(A=A, b=b, c=c), dict(l=A.shape[1])
@@ -76,9 +78,9 @@ def test_conic_path_follows_the_oracle(gpu, pq, case):
         G = rng.standard_normal((n2, n2)); Q = sp.csc_matrix(G @ G.T / n2 + 0.1 * np.eye(n2))
         data, K = dict(A=sp.csc_matrix(A2), b=A2 @ rng.random(n2), c=rng.standard_normal(n2), Q=Q), dict(l=n2)
     else:  # several SOC and rotated cones of different sizes + free + zero + orthant
-        sizes_q, sizes_rq, f, zc, l = [3, 5, 1, 8], [3, 4, 6], 4, 2, 12
-        n2 = sum(sizes_q) + sum(sizes_rq) + f + zc + l; m2 = 9
-        A2 = sp.random(m2, n2, density=0.35, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+        sizes_q, sizes_rq, f, zc, l, m2, dens = [3, 5, 1, 8], [3, 4, 6], 4, 2, 12, 9, 0.35
+        n2 = sum(sizes_q) + sum(sizes_rq) + f + zc + l
+        A2 = sp.random(m2, n2, density=dens, random_state=rng, data_rvs=rng.standard_normal, format="csc")
         x0 = np.zeros(n2); pos = 0
         for sz in sizes_q:
             v = rng.standard_normal(sz); v[0] = np.linalg.norm(v[1:]) + 1.0; x0[pos:pos + sz] = v; pos += sz
@@ -88,7 +90,7 @@ def test_conic_path_follows_the_oracle(gpu, pq, case):
         x0[pos:] = rng.random(l) + 0.1
         data = dict(A=A2, b=A2 @ x0, c=A2.T @ rng.standard_normal(m2) + np.concatenate([x0[:sum(sizes_q) + sum(sizes_rq)], np.zeros(f), rng.standard_normal(zc), rng.random(l) + 0.1]))
         K = dict(q=sizes_q, rq=sizes_rq, f=f, z=zc, l=l)
-    eps = 1e-4 if case == "lp_rand" else 1e-6      # (the LP through the conic path needs ~1e5 iterations at 1e-6)
+    eps = {"lp_rand": 1e-4, "lasso_bigcone": 1e-3}.get(case, 1e-6)      # (the LP through the conic path needs ~1e5 iterations at 1e-6)
     x, y, s, oi, _ = pq.solve(data["A"], data["b"], data["c"], K, Q=Q, eps=eps, eps_p=eps, eps_d=eps, eps_g=eps, eps_inf=eps, eps_unb=eps, linsys_solver=1)
     sol, gi = gpu.abip_qcp(data, K, eps_all(eps))
     assert gi["status"] == oi["status"], (gi["status"], oi["status"])
@@ -114,3 +116,30 @@ def test_unsupported_back_ends_are_rejected(gpu):
     data, K = toy()
     sol, info = gpu.abip_qcp(data, K, dict(eps=1e-3, linsys_solver=3, verbose=0))
     assert info["status"] == "Failure" and info["status_val"] == -4
+
+
+def test_lasso_at_config5_scale_properties(gpu):
+    """BASELINE configs[4] (LASSO-as-SOCP, ~1e5 variables; here p = 4000, d = 18000 to keep the GPU suite short -- scripts/gpu_c5.py
+    runs p = 10000, d = 45000).  Too large for the CPU oracle in test time, so: size-independent properties.  The solution must
+    satisfy the cone constraints and the reference's own residual criteria, and its LASSO objective must agree with the conic
+    objective and beat the two trivial points beta = 0 and a proximal-gradient iterate."""
+    from abip_amd import problems
+    p, d = 4000, 18000
+    data, K = problems.qcp_lasso_socp(p, d)
+    eps = 1e-4
+    sol, info = gpu.abip_qcp(data, K, eps_all(eps))
+    assert info["status"] == "Solved" and info["res_pri"] < eps and info["res_dual"] < eps and info["gap"] < eps
+    x = sol["x"]
+    q0, q1, z = x[0], x[1], x[2:p + 2]
+    bp, bm = x[p + 2:p + 2 + d], x[p + 2 + d:]
+    assert q0 >= np.sqrt(q1 * q1 + z @ z) * (1 - 1e-6) and bp.min() > -1e-9 and bm.min() > -1e-9      # x in K
+    A, b, c = data["A"], data["b"], data["c"]
+    assert np.linalg.norm(A @ x - b) <= 1e-3 * (1 + np.linalg.norm(b))
+    X = -A[1:, p + 2:p + 2 + d]; yv = -b[1:]; lam = c[-1]
+    beta = bp - bm
+    lasso = lambda bb: 0.5 * np.sum((X @ bb - yv) ** 2) + lam * np.abs(bb).sum()
+    assert abs(lasso(beta) - info["pobj"]) <= 5e-3 * (1 + abs(info["pobj"]))
+    assert lasso(beta) < lasso(np.zeros(d))
+    # KKT of the LASSO itself: |X'(X beta - y)|_inf <= lam (1 + small)
+    g = X.T @ (X @ beta - yv)
+    assert np.abs(g).max() <= lam * (1 + 5e-2)
