@@ -54,13 +54,20 @@ struct QWk {
   DBuf<QCtl> ctl;
   QCtl *hctl = nullptr;
   DevLdl ldl;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr; // bracket of the KKT solve of the current iteration (avg_linsys_time)
+  double lin_ms = 0; long lin_n = 0;
   int ncones = 0, nsmall = 0; // cone table: the nsmall cones of <= QC_BIG entries first
   Ctl *lp_ctl = nullptr; // dev_sptrsv kernels are gated on an LP-style control block (halt flag): a zeroed one
 };
 
 #define QLAUNCH(w, kern, grid, block, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (w)->stream, __VA_ARGS__)
 
+double g_stats[8] = {0};
+
 void release(QWk *w) {
+  if (w->ev_a) (void)hipEventDestroy(w->ev_a);
+  if (w->ev_b) (void)hipEventDestroy(w->ev_b);
+  w->ev_a = w->ev_b = nullptr;
   w->dA.release(); w->dAt.release(); w->dQ.release();
   DBuf<double> *bufs[] = {&w->u, &w->v, &w->vo, &w->ut, &w->rel, &w->r, &w->p, &w->bd, &w->cd, &w->Dd, &w->Ed, &w->Ax, &w->ATy, &w->Qx, &w->part};
   for (auto *b : bufs) b->release();
@@ -260,6 +267,8 @@ qcp_int fail(QCPInfo *info, const char *msg) {
 
 extern "C" {
 
+void abip_hip_qcp_last_stats(double *out8) { for (int q = 0; q < 8; ++q) out8[q] = g_stats[q]; }
+
 void abip_qcp_set_default_settings(QCPData *d) { // util.c:203-255
   QCPSettings *s = d->stgs;
   const double nz = d->A ? d->A->p[d->n] : 0, sparsity = nz / ((double)d->m * d->n);
@@ -304,6 +313,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   w->LV = ((w->MP + n + 1 + 31) / 32) * 32;
   auto bail = [&](const char *msg) { release(w); return fail(info, msg); };
   if (hipStreamCreate(&w->stream) != hipSuccess) return bail("hipStreamCreate failed");
+  if (hipEventCreate(&w->ev_a) != hipSuccess || hipEventCreate(&w->ev_b) != hipSuccess) return bail("hipEventCreate failed");
   { // matrices
     host::HostCsr hAt, hA, hQ;
     hcsr_from(w->A, hAt, false); hcsr_from(w->A, hA, true);
@@ -461,7 +471,9 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     for (j = 0; j < st->max_admm_iters; ++j) {
       // projection, abip.c:186-255
       QLAUNCH(w, kq_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->r.p, w->p.p, st->rho_y, st->rho_x, dm, w->part.p);
+      (void)hipEventRecord(w->ev_a, w->stream);
       enqueue_solve(w, w->p.p);
+      (void)hipEventRecord(w->ev_b, w->stream);
       QLAUNCH(w, kq_dots, w->NB, BS, (const double *)w->r.p, (const double *)w->p.p, st->rho_y, st->rho_x, dm, w->part.p);
       if (w->hasQ) QLAUNCH(w, kq_Qp, w->NB, BS, w->dQ.view(), (const double *)w->p.p, dm, w->part.p);
       QProxArgs pa;
@@ -484,6 +496,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       if (hipMemcpyAsync(&tails[0], w->u.p + w->MP + n, sizeof(double), hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
           hipMemcpyAsync(&tails[1], w->vo.p + w->MP + n, sizeof(double), hipMemcpyDeviceToHost, w->stream) != hipSuccess || read_ctl(w))
         return bail("device error in the inner iteration");
+      { float ms = 0.f; if (hipEventElapsedTime(&ms, w->ev_a, w->ev_b) == hipSuccess) { w->lin_ms += ms; w->lin_n++; } }
       const double *o = w->hctl->out;
       const double tau = tails[0], vot = tails[1];
       const double qut = -o[Q_D1] / tau + o[Q_D2] - o[Q_D3];
@@ -510,7 +523,9 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     }
     tol_inner = adjust_barrier(w, r);
   }
-  info->avg_linsys_time = 0; info->avg_cg_iters = 0;
+  info->avg_linsys_time = w->lin_n ? w->lin_ms / (double)w->lin_n : 0; info->avg_cg_iters = 0; // ms per solve, as lin_sys_time_per_iter (abip.c:1228)
+  g_stats[0] = w->ldl.N; g_stats[1] = w->ldl.T; g_stats[2] = (double)w->ldl.lnnz; g_stats[3] = w->ldl.F.nlev; g_stats[4] = w->ldl.B.nlev;
+  g_stats[5] = (double)w->lin_n; g_stats[6] = w->lin_ms; g_stats[7] = (double)(w->ldl.F.idx.n + w->ldl.B.idx.n);
   release(w);
   return info->status_val;
 }

@@ -14,6 +14,9 @@ structure-matched surrogates, labelled as such):
         and the only LP config that partitions over GPUs)
     c2  25fv47-class block-staircase LP (816 x 1879, nnz~1e4), direct LDL' back-end
     c3  pds-class multi-commodity network LP, PCG back-end
+    c5  LASSO-as-SOCP through the conic path (abip_qcp, p=10000 samples, d=45000 features, n=100002), direct LDL' with a dense tail;
+        abip_qcp() is one call (the reference's conic entry point has no stepping form), so a step count cannot be imposed:
+        one untimed full solve warms up, a second one is timed and `steps` is the number of ADMM iterations it took
 
 Prints ONE JSON line (rank 0).
 """
@@ -71,12 +74,67 @@ def cpu_baseline(A, b, c, linsys, budget_s=20.0):
                 sample=f"first {its} ADMM iterations of the same LP and settings (max_admm_iters={max(T, T2)}), {secs:.2f} s, single thread, gcc -O2")
 
 
+def bench_c5(args, rank, world, dist, torch):
+    """BASELINE configs[4]: the conic path on LASSO-as-SOCP.  The direct back-end does not shard: N > 1 = N replicas."""
+    import numpy as np
+    from abip_amd import problems, qcp
+    p, d = 10_000, 45_000
+    data, K = problems.qcp_lasso_socp(p, d)
+    stg = dict(eps=1e-3, linsys_solver=1, verbose=0)     # eps 1e-3: the reference's LASSO protocol (scripts/bench-qcp/test_lasso.m:11)
+    sol, info0 = qcp.abip_qcp(data, K, stg)               # warm-up: pages the library in, JIT-free but first-touch allocations
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    sol, info = qcp.abip_qcp(data, K, stg)
+    torch.cuda.synchronize()
+    elapsed = info["solve_time"]                          # seconds inside abip_qcp between set-up (data resident) and get_solution
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    steps = int(info["admm_iter"])
+    f = info["factor"]
+    N, lnnz, T = f["N"], f["lnnz"], f["dense_tail"]
+    bytes_solve = 2 * (12 * lnnz + 4 * (N + 1) + 16 * N) + 24 * N + 2 * 20 * N      # SURVEY.md 8(d) B_solve_direct
+    avg_ms = f["solve_ms_total"] / max(f["solves_timed"], 1)
+    ach = bytes_solve / (avg_ms * 1e-3) / 1e9
+    roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+                kernel="KKT solve of the conic projection: k_perm_in, k_tri_wide (L21 stream), k_tail_mv x2 (dense inv(L22), inv(L22)'), k_dscale, k_tri_wide, k_perm_out",
+                avg_launch_us=avg_ms * 1e3, launches=f["solves_timed"], algorithmic_bytes_per_launch=bytes_solve, lnnz=lnnz, dense_tail=T,
+                streamed_bytes_per_solve=8 * T * (T + 1) + 12 * f["head_nnz"], levels=f["levels"])
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        # the conic reference needs MKL headers (unbuildable here) and the scalar oracle's LDL' of the full-size KKT matrix takes
+        # hours, so the CPU leg runs the oracle on the same generator at p=1000, d=4500 and says so
+        from oracle import pyoracle_qcp as pq
+        ds, Ks = problems.qcp_lasso_socp(1000, 4500)
+        x, y, s_, oi, _ = pq.solve(ds["A"], ds["b"], ds["c"], Ks, eps=1e-3, eps_p=1e-3, eps_d=1e-3, eps_g=1e-3, eps_inf=1e-3, eps_unb=1e-3, linsys_solver=1)
+        cpu = dict(value=oi["admm_iter"] / (oi["solve_time"] / 1e3), unit="ADMM iterations/s", cores=1, kind="port",
+                   sample=f"REDUCED instance p=1000, d=4500 (n=10002) of the same generator: {oi['admm_iter']} iterations in {oi['solve_time'] / 1e3:.2f} s "
+                          f"(+ {oi['setup_time'] / 1e3:.1f} s set-up), oracle/abip_qcp_oracle.c, single thread, gcc -O2")
+    if rank == 0:
+        beta = sol["x"][p + 2:p + 2 + d] - sol["x"][p + 2 + d:]
+        print(json.dumps({
+            "metric": "ADMM iterations/s", "value": world * steps / elapsed, "unit": "ADMM iterations/s", "n_gpus": world, "steps": steps, "warmup": int(info0["admm_iter"]),
+            "ms_per_step": 1e3 * elapsed / max(steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"LASSO-as-SOCP p={p} d={d} density 0.005 (BASELINE configs[4]): n={p + 2 + 2 * d}, m={p + 1}, K.q=[{p + 2}], K.l={2 * d}; conic path, direct LDL'",
+                       "linsys": "direct", "eps": 1e-3,
+                       "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (the direct back-end does not shard)"},
+            "roofline": roof, "cpu_baseline": cpu,
+            "time_to_tol": dict(seconds=info["runtime"], setup_s=info["setup_time"], solve_s=info["solve_time"], status=info["status"], admm_iter=steps,
+                                ipm_iter=info["ipm_iter"], res_pri=info["res_pri"], res_dual=info["res_dual"], rel_gap=info["gap"]),
+            "extra": {"nnz": int(data["A"].nnz), "nonzero_coefficients": int(np.sum(np.abs(beta) > 1e-6)), "pobj": info["pobj"]},
+        }))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3"])
+    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5"])
     ap.add_argument("--to-tol", action="store_true", help="also run a full solve to eps=1e-6 and report wall-clock")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--events-in-timed-region", action="store_true",
@@ -96,6 +154,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if args.workload == "c5":
+        return bench_c5(args, rank, world, dist, torch)
     steps = args.steps if args.steps is not None else {"c4": 200, "c2": 2000, "c3": 500}[args.workload]
     warmup = args.warmup if args.warmup is not None else {"c4": 20, "c2": 200, "c3": 50}[args.workload]
 
@@ -105,8 +165,21 @@ def main():
     m, n = A.shape
     nnz = A.nnz
     sharded = world > 1 and linsys == "indirect"
+    shard_note = None
     if sharded:
-        adist.init_torch()      # RCCL communicator for the solver; rows of A are split over the ranks inside abip_init
+        # RCCL communicator for the solver; rows of A are split over the ranks inside abip_init.  If the communicator cannot
+        # be built on some rank, every rank falls back to an independent replica of the full problem (and the line says so).
+        ok = 1
+        try:
+            adist.init_torch()
+        except Exception as e:  # noqa: BLE001
+            ok, shard_note = 0, f"sharding unavailable ({e}); ran {world} replicas"
+        t = torch.tensor([ok], device="cuda", dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 0:
+            if ok:
+                adist.finalize()
+            sharded, shard_note = False, shard_note or f"sharding unavailable on another rank; ran {world} replicas"
 
     S = Solver(A, b, c, linsys=linsys, eps=1e-6, verbose=0)
     S.begin()
@@ -224,6 +297,8 @@ def main():
                         else f"{world} independent replicas (the direct back-end does not shard)")},
             "roofline": roof, "cpu_baseline": cpu, "time_to_tol": tt, "extra": extra,
         }
+        if shard_note:
+            out["config"]["note"] = shard_note
         print(json.dumps(out))
     if sharded:
         adist.finalize()

@@ -113,6 +113,10 @@ typedef struct { /* struct ABIP_INFO, abip.h:140-158 */
 qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K);
 /* ABIP(set_default_settings), source/util.c:203-255 (prob_type is left at the mex's value 2 = QCP). */
 void abip_qcp_set_default_settings(QCPData *d);
+/* Shape of the factor and KKT-solve time of the last abip_qcp() call (bench, profiling; no reference counterpart):
+ * out8 = { N, dense-tail size T, nnz(L), forward levels, backward levels, solves timed, total ms of those solves (hipEvents
+ * on the solver's stream), nnz of the sparse head (forward + backward copies) }. */
+void abip_hip_qcp_last_stats(double *out8);
 
 #ifdef __cplusplus
 }
