@@ -67,7 +67,7 @@ EXPORTS = (
     "abip_hip_get_scalar", "abip_hip_profile_enable", "abip_hip_profile_read", "abip_hip_sync",
     "abip_hip_dist_get_unique_id", "abip_hip_dist_init_rccl", "abip_hip_dist_init_callback", "abip_hip_dist_finalize",
     "abip_hip_dist_partition", "abip_hip_dist_rows",
-    "abip_qcp", "abip_qcp_set_default_settings", "abip_hip_qcp_last_stats",
+    "abip_qcp", "abip_qcp_set_default_settings", "abip_hip_qcp_last_stats", "abip_hip_qcp_cone_prox",
 )
 
 ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_long)

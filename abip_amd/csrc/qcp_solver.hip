@@ -267,6 +267,23 @@ qcp_int fail(QCPInfo *info, const char *msg) {
 
 extern "C" {
 
+// unit-level access to the cone kernel (parity tests at the branch boundaries of cones.c:130-248)
+int abip_hip_qcp_cone_prox(int kind, double *x, const double *tmp, double lambda, int len) {
+  if (!x || !tmp || len < (kind == 0 ? 1 : 2) || (kind != 0 && kind != 1)) return -1;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { printf("ERROR: no usable HIP device: libabip_hip has no CPU fallback\n"); return -2; }
+  DBuf<double> u, rel; DBuf<int> meta;
+  std::vector<double> hu(x, x + len), hr(tmp, tmp + len);
+  std::vector<int> hm = {0, len, kind};
+  if (u.upload(hu, nullptr) || rel.upload(hr, nullptr) || meta.upload(hm, nullptr)) return -3;
+  QCones C{meta.p, meta.p + 1, meta.p + 2, 1};
+  if (len > QC_BIG) hipLaunchKernelGGL(kq_cones<true>, dim3(1), dim3(QC_TB), 0, nullptr, C, 0, u.p, (const double *)rel.p, lambda, 0);
+  else hipLaunchKernelGGL(kq_cones<false>, dim3(1), dim3(BS), 0, nullptr, C, 0, u.p, (const double *)rel.p, lambda, 0);
+  const int rc = (hipMemcpy(x, u.p, sizeof(double) * len, hipMemcpyDeviceToHost) == hipSuccess && hipGetLastError() == hipSuccess) ? 0 : -4;
+  u.release(); rel.release(); meta.release();
+  return rc;
+}
+
 void abip_hip_qcp_last_stats(double *out8) { for (int q = 0; q < 8; ++q) out8[q] = g_stats[q]; }
 
 void abip_qcp_set_default_settings(QCPData *d) { // util.c:203-255

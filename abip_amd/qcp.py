@@ -116,6 +116,19 @@ def abip_qcp(data, cones, settings: dict):
     return dict(x=x, y=y, s=s), out
 
 
+def cone_prox(kind: int, tmp, lam: float, x_prev=None):
+    """One SOC (kind 0) / rotated-SOC (kind 1) barrier prox on the device (kq_cones); unit-level mirror of cones.c:130-248."""
+    L = _bind()
+    t = np.ascontiguousarray(tmp, dtype=np.float64)
+    x = np.zeros_like(t) if x_prev is None else np.array(x_prev, dtype=np.float64, copy=True)
+    L.abip_hip_qcp_cone_prox.restype = ci
+    L.abip_hip_qcp_cone_prox.argtypes = [ci, PF, PF, C.c_double, ci]
+    rc = L.abip_hip_qcp_cone_prox(int(kind), x.ctypes.data_as(PF), t.ctypes.data_as(PF), float(lam), int(t.size))
+    if rc != 0:
+        raise RuntimeError(f"abip_hip_qcp_cone_prox failed ({rc})")
+    return x
+
+
 def abip_qcpsolve(data, K, params):
     """scripts/matlab/abip_qcpsolve.m:1-24 (+ abipi_qcpparam_convert :26-52, abipi_qcpinfo_convert :54-66)."""
     q = dict(verbose=params["verbose"], normalize=params["normalize"], max_admm_iter=params["max_admm_iter"],

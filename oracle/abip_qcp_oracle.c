@@ -14,7 +14,10 @@
  *       dobj -0.984063938, x to 6 digits);
  *   (2) the cross-solver check the reference's test performs (test_abip_install.m:24-27): an LP solved through
  *       this conic path must reach the optimum the pinned LP oracle / the LP reference fixtures reach;
- *   (3) KKT conditions of the returned (x, y, s) on seeded SOCP / QP instances (a property, not a pin).
+ *   (3) KKT conditions of the returned (x, y, s) on seeded SOCP / QP instances (a property, not a pin);
+ *   (4) the cone sub-problems on their own (orc_qcp_cone_prox): on every generic branch the closed forms of cones.c:130-288
+ *       satisfy x - t = lambda grad log det(x) to 1e-9, i.e. they are the exact minimisers of the barrier sub-problem the
+ *       reference documents -- a check that does not go through any ABIP code.
  * The ordering of the KKT factorisation is our own minimum-degree code instead of AMD (orc_ldl.h).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's shared object.
@@ -246,6 +249,11 @@ static void rsoc_prox(F *x, const F *tmp, F lambda, I n) { /* :169-248 */
       for (I i = 0; i < nx; ++i) x[2 + i] = zx[i] * ((s + 1) / (s + 2));
     }
   }
+}
+
+/* unit-level access for the parity tests: kind 0 SOC, 1 rotated SOC (reads the previous x[0], cones.c:183), 2 orthant */
+void orc_qcp_cone_prox(I kind, F *x, const F *tmp, F lambda, I n) {
+  if (kind == 0) soc_prox(x, tmp, lambda, n); else if (kind == 1) rsoc_prox(x, tmp, lambda, n); else orthant_prox(x, tmp, lambda, n);
 }
 
 /* ---- abip.c ------------------------------------------------------------------------------------------------ */

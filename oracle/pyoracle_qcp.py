@@ -101,6 +101,8 @@ def lib():
         L.orc_qcp_set_default_settings.argtypes = [C.POINTER(QCPData)]
         L.orc_qcp_set_trace.argtypes = [ci, PF]
         L.orc_qcp_trace_count.restype = ci
+        L.orc_qcp_cone_prox.restype = None
+        L.orc_qcp_cone_prox.argtypes = [ci, PF, PF, cf, ci]
         _lib = L
     return _lib
 
@@ -117,3 +119,12 @@ def solve(A, b, c, K, Q=None, trace: int = 0, **settings):
         tr = tr[: L.orc_qcp_trace_count()]
         L.orc_qcp_set_trace(0, None)
     return P.x.copy(), P.y.copy(), P.s.copy(), P.info_dict(), tr
+
+
+def cone_prox(kind: int, tmp, lam: float, x_prev=None):
+    """Barrier prox of one cone (cones.c:130-288): kind 0 SOC, 1 rotated SOC, 2 orthant."""
+    L = lib()
+    t = np.ascontiguousarray(tmp, dtype=np.float64)
+    x = np.zeros_like(t) if x_prev is None else np.array(x_prev, dtype=np.float64, copy=True)
+    L.orc_qcp_cone_prox(int(kind), x.ctypes.data_as(PF), t.ctypes.data_as(PF), float(lam), int(t.size))
+    return x

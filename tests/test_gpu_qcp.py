@@ -143,3 +143,21 @@ def test_lasso_at_config5_scale_properties(gpu):
     # KKT of the LASSO itself: |X'(X beta - y)|_inf <= lam (1 + small)
     g = X.T @ (X @ beta - yv)
     assert np.abs(g).max() <= lam * (1 + 5e-2)
+
+
+def test_cone_kernel_matches_the_oracle_on_every_branch(gpu, pq):
+    """kq_cones against the oracle's restatement of cones.c:130-248, cone by cone: |a| <= 1e-9, a > 0, a < 0 for the SOC; ze + zn
+    == 0 (reads the incoming x[0]), > 0, < 0 with w <= 10 and w > 10 for the rotated cone; lengths 1..2500 so that the
+    one-wavefront and the one-workgroup (> 2048 entries) kernels both run.  The device reduces |tail|^2 in a different order."""
+    import importlib
+    tq = importlib.import_module("test_qcp_oracle")
+    from abip_amd import qcp
+    rng = np.random.default_rng(0)
+    n_big = 0
+    for kind, t, xp, lam in tq._soc_cases(rng):
+        want = pq.cone_prox(kind, t, lam, xp)
+        got = qcp.cone_prox(kind, t, lam, xp)
+        assert np.all(np.isfinite(got))
+        assert np.max(np.abs(got - want)) <= 1e-13 * (1 + np.max(np.abs(want))), (kind, t.size, t[:2], lam)
+        n_big += t.size > 2048
+    assert n_big >= 8

@@ -82,3 +82,47 @@ def test_socp_and_qp_optimality_conditions(pq):
     assert np.linalg.norm(A2 @ x2 - b2) < 1e-5 * (1 + np.linalg.norm(b2))
     assert np.linalg.norm(Q2 @ x2 + c2 - A2.T @ y2 - s2) < 1e-4 * (1 + np.linalg.norm(c2))
     assert x2.min() > -1e-6 and s2.min() > -1e-6 and abs(x2 @ s2) < 1e-4
+
+
+def _soc_cases(rng):
+    """(kind, tmp, x_prev, lambda) covering every branch of cones.c:130-248."""
+    out = []
+    for n in (1, 2, 3, 70, 2500):
+        for a in (1.5, -0.7, 1e-10, 0.0):                                   # a > 0, a < 0, |a| <= 1e-9 (cones.c:137)
+            out.append((0, np.concatenate([[a], rng.standard_normal(n - 1)]), None, 0.3))
+    for n in (2, 3, 70, 2500):
+        zx = rng.standard_normal(n - 2)
+        out.append((1, np.concatenate([[0.8, 0.5], zx]), None, 0.3))        # ze + zn > 0
+        out.append((1, np.concatenate([[-0.8, -0.5], 0.1 * zx]), None, 2.0))  # ze + zn < 0, w <= 10
+        out.append((1, np.concatenate([[-30.0, -20.0], 0.01 * zx]), None, 1e-3))  # ze + zn < 0, w > 10 (cones.c:228)
+        out.append((1, np.concatenate([[0.6, -0.6], zx]), rng.standard_normal(n), 0.3))  # ze + zn == 0 (cones.c:177-186)
+        out.append((1, np.concatenate([[2.0, 1.0], 0.1 * zx]), None, 0.5))  # 2 ze zn - |zx|^2 >= 0 when n small
+    return out
+
+
+def test_cone_prox_is_the_minimiser_of_the_barrier_subproblem(pq):
+    """Independent of the reference's code: x = prox must be interior and satisfy x - t = lambda * grad log det(x), the
+    stationarity condition of  min -lambda log(det x) + 1/2 |x - t|^2  with det = x0^2 - |x1|^2 (SOC) or 2 x0 x1 - |x2|^2
+    (rotated).  The `ze + zn == 0` shortcut of the reference is not a minimiser (it reuses the previous x[0], cones.c:183) and the
+    |a| <= 1e-9 branch is the a -> 0 limit; both are excluded here and pinned through full solves instead."""
+    rng = np.random.default_rng(0)
+    seen = set()
+    for kind, t, xp, lam in _soc_cases(rng):
+        if (kind == 0 and abs(t[0]) <= 1e-9) or (kind == 1 and t[0] + t[1] == 0):
+            continue
+        x = pq.cone_prox(kind, t, lam, xp)
+        if kind == 0:
+            det = x[0] ** 2 - x[1:] @ x[1:]
+            g = np.concatenate([[2 * x[0]], -2 * x[1:]]) / det
+            assert x[0] > 0
+        else:
+            det = 2 * x[0] * x[1] - x[2:] @ x[2:]
+            g = np.concatenate([[2 * x[1], 2 * x[0]], -2 * x[2:]]) / det
+            assert x[0] > 0 and x[1] > 0
+        assert det > 0
+        assert np.linalg.norm(x - t - lam * g) <= 1e-9 * (1 + np.linalg.norm(t)), (kind, t[:2], lam)
+        seen.add((kind, t.size))
+    assert len(seen) >= 8
+    t = np.array([3.0, -2.0, 1e-3, -50.0])                                   # orthant: x - t = lambda / x
+    x = pq.cone_prox(2, t, 0.25)
+    assert np.all(x > 0) and np.allclose(x - t, 0.25 / x, rtol=1e-12)
