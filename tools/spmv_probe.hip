@@ -52,6 +52,29 @@ __global__ __launch_bounds__(256) void probe_u(const double* __restrict__ val, c
   if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = acc;
 }
 
+// V5: a real SpMV y = At z + beta y on the same matrix, CSR-vector form: VW lanes per row, U rows in flight per lane group,
+// no LDS, no workgroup barrier
+template <int VW, int U>
+__global__ __launch_bounds__(256) void spmv_vec(const int* __restrict__ ptr, const int* __restrict__ idx, const double* __restrict__ val,
+                                                const double* __restrict__ x, double* __restrict__ y, int nrows, double beta) {
+  const int lane = threadIdx.x % VW;
+  const long ngrp = (long)gridDim.x * 256 / VW;
+  for (long r0 = ((long)blockIdx.x * 256 + threadIdx.x) / VW; r0 < nrows; r0 += ngrp * U) {
+    int s[U], e[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const long r = r0 + u * ngrp; s[u] = r < nrows ? ptr[r] : 0; e[u] = r < nrows ? ptr[r + 1] : 0; }
+    double acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { acc[u] = 0.0; for (int k = s[u] + lane; k < e[u]; k += VW) acc[u] += val[k] * x[idx[k]]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      for (int off = VW >> 1; off > 0; off >>= 1) acc[u] += __shfl_xor(acc[u], off, 64);
+      const long r = r0 + u * ngrp;
+      if (lane == 0 && r < nrows) y[r] = acc[u] + beta * y[r];
+    }
+  }
+}
+
 template <class K>
 float time_kernel(K launch, int reps = 20) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -78,8 +101,13 @@ int main() {
   CK(hipMemcpy(dv, val.data(), nnz * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(di, idx.data(), nnz * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dis, idx_sorted.data(), nnz * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(diq, idx_seq.data(), nnz * 4, hipMemcpyHostToDevice));
   std::vector<double> hx(m, 1.0); CK(hipMemcpy(dx, hx.data(), (size_t)m * 8, hipMemcpyHostToDevice));
+  std::vector<int> ptr(n + 1, 0);
+  for (int j = 0; j < n; ++j) ptr[j + 1] = ptr[j] + (j < m ? 1 : per);
+  int *dp; double *dy;
+  CK(hipMalloc(&dp, (size_t)(n + 1) * 4)); CK(hipMalloc(&dy, (size_t)n * 8)); CK(hipMemset(dy, 0, (size_t)n * 8));
+  CK(hipMemcpy(dp, ptr.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
   printf("nnz %ld  stream bytes %.1f MB\n", nnz, nnz * 12 / 1e6);
-  for (int grid : {1024, 2048, 4096, 8192}) {
+  for (int grid : {2048, 8192, 32768}) {
     printf("grid %d\n", grid);
 #define RUN(label, kern, ip) printf("  %-34s %8.2f us\n", label, time_kernel([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, dv, ip, dx, nnz, dout); }));
     RUN("V0 stream only, 8B loads", (probe<0, 1>), di)
@@ -93,6 +121,12 @@ int main() {
     RUN("V2 gather wave-sorted idx, 8B x4", (probe_u<1, 1, 4>), dis)
     RUN("V2' gather sequential idx, 8B x4", (probe_u<1, 1, 4>), diq)
     RUN("V3 idx+gather only, 8B x4", (probe_u<3, 1, 4>), di)
+#define RUNV(label, kern) printf("  %-34s %8.2f us\n", label, time_kernel([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, dp, di, dv, dx, dy, n, 0.5); }));
+    RUNV("V5 CSR-vector 16 lanes/row, U=1", (spmv_vec<16, 1>))
+    RUNV("V5 CSR-vector 16 lanes/row, U=2", (spmv_vec<16, 2>))
+    RUNV("V5 CSR-vector 16 lanes/row, U=4", (spmv_vec<16, 4>))
+    RUNV("V5 CSR-vector 8 lanes/row, U=4", (spmv_vec<8, 4>))
+    RUNV("V5 CSR-vector 4 lanes/row, U=4", (spmv_vec<4, 4>))
   }
   return 0;
 }
