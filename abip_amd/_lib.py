@@ -75,6 +75,29 @@ ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_long)
 _lib = None
 
 
+def _preload_hip_runtime() -> None:
+    """A process can drive the GPU through ONE HIP runtime only.  PyTorch wheels bundle their own libamdhip64.so and load it by
+    path, so if this library were loaded first (binding /opt/rocm's copy) and torch afterwards, the process would hold two
+    runtimes and the second one to touch the device fails ("no usable HIP device").  When torch is installed but not yet
+    imported, load its copy first: libabip_hip.so then binds to it by SONAME and a later `import torch` reuses it."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("ABIP_HIP_SYSTEM_RUNTIME"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> C.CDLL:
     global _lib
     if _lib is not None:
@@ -83,6 +106,7 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  abip_amd has no CPU fallback.")
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     W = C.c_void_p
     L.abip_init.restype = W
