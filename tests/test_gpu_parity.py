@@ -110,6 +110,25 @@ def test_batched_iterations_equal_stepwise(gpu, name, monkeypatch):
             assert np.array_equal(a2, b2)
 
 
+@pytest.mark.parametrize("linsys", ["indirect", "direct"])
+def test_restart_path_follows_the_oracle(gpu, oracle_built, linsys):
+    """restart_vars (abip.c:587-630) with the threshold lowered so that the periodic restart from the running mean fires many
+    times; on the direct back-end a batch of iterations must stop short of an iteration that restarts."""
+    from abip_amd import problems
+    A, b, c = problems.lp_random_sparse(m=120, n=400, per_col=5, seed=13)
+    A = sp.csc_matrix(A); A.sort_indices()
+    kw = dict(eps=1e-5, restart_thresh=40, restart_fre=25)
+    o = oracle_built.solve("oracle", A, b, c, linsys=linsys, **kw)
+    plain = oracle_built.solve("oracle", A, b, c, linsys=linsys, eps=1e-5)
+    assert o.info["admm_iter"] > 100 and o.info["admm_iter"] != plain.info["admm_iter"]
+    with gpu.Solver(A, b, c, linsys=linsys, verbose=0, **kw) as S:
+        info = S.solve()
+        assert info["status_val"] == o.info["status_val"] and info["ipm_iter"] == o.info["ipm_iter"]
+        assert abs(info["admm_iter"] - o.info["admm_iter"]) <= 0.03 * o.info["admm_iter"] + 2
+        for k in "xys":
+            assert rel(getattr(S, k), getattr(o, k)) < (1e-6 if info["admm_iter"] == o.info["admm_iter"] else 1e-4), (linsys, k)
+
+
 def test_direct_solve_wide_head_with_tail(gpu):
     """A factor whose head levels are wider than one workgroup (segmented path) and whose tail is several thousand pivots."""
     from abip_amd import problems

@@ -22,3 +22,23 @@ def test_random_lp_against_live_reference(oracle_built, seed, linsys):
     for k in "xys":
         assert rel(getattr(o, k), getattr(r, k)) < tol
     assert r.settings_after == o.settings_after   # the solver mutates caller-owned settings identically
+
+
+@pytest.mark.parametrize("linsys", ["indirect", "direct"])
+def test_restart_path_against_live_reference(oracle_built, linsys):
+    """restart_vars (abip.c:587-630): with the threshold lowered from 1e5 to 40 iterations and a period of 25 the periodic
+    restart from the running mean fires many times inside one solve."""
+    po = oracle_built
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    A, b, c = problems.lp_random_sparse(m=120, n=400, per_col=5, seed=13)
+    kw = dict(linsys=linsys, eps=1e-5, restart_thresh=40, restart_fre=25)
+    r = po.solve("ref", A, b, c, **kw)
+    o = po.solve("oracle", A, b, c, **kw)
+    plain = po.solve("oracle", A, b, c, linsys=linsys, eps=1e-5)
+    assert r.info["admm_iter"] > 100 and r.info["admm_iter"] != plain.info["admm_iter"]      # the restarts did change the run
+    assert r.info["status_val"] == o.info["status_val"]
+    assert r.info["admm_iter"] == o.info["admm_iter"] and r.info["ipm_iter"] == o.info["ipm_iter"]
+    tol = 1e-12 if linsys == "indirect" else 1e-7
+    for k in "xys":
+        assert rel(getattr(o, k), getattr(r, k)) < tol
