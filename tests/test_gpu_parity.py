@@ -110,6 +110,26 @@ def test_batched_iterations_equal_stepwise(gpu, name, monkeypatch):
             assert np.array_equal(a2, b2)
 
 
+@pytest.mark.parametrize("variant", ["default", "origin", "qp", "scale5", "nonorm"])
+def test_host_scaling_matches_the_oracle(gpu, oracle_built, variant):
+    """a12: ABIP(_normalize_A) (linsys/common.c:150-565: pc / origin / Ruiz x10 / qp rescaling with their clamps),
+    normalize_b_c, sc_b, sc_c and the scaled h = (-b, c): the device's copies against the oracle's after the same set-up."""
+    z, A, b, c = load("lp_staircase")
+    kw = dict(TINY_VARIANTS.get(variant, {}))
+    o = oracle_built.solve("oracle", A, b, c, linsys="indirect", max_admm_iters=3, **kw)
+    with gpu.Solver(A, b, c, linsys="indirect", verbose=0, max_admm_iters=3, **kw) as S:
+        S.begin()
+        for nm in ("b", "c", "h") if variant == "nonorm" else ("D", "E", "b", "c", "h"):   # no D, E without normalisation
+            assert rel(S.vector(nm), o.work[nm]) < 1e-14, (variant, nm)
+        for nm in () if variant == "nonorm" else ("sc_b", "sc_c"):
+            assert abs(S.scalar(nm) - o.work[nm]) <= 1e-14 * abs(o.work[nm]), (variant, nm)
+        Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
+        if variant != "nonorm":     # A_scaled = scale * D^-1 A E^-1
+            want = sp.diags(1.0 / o.work["D"]) @ A @ sp.diags(1.0 / o.work["E"]) * float(kw.get("scale", 1.0))
+            assert abs(Asc - want).max() <= 1e-13 * abs(want).max()
+        S.end()
+
+
 @pytest.mark.parametrize("linsys", ["indirect", "direct"])
 def test_restart_path_follows_the_oracle(gpu, oracle_built, linsys):
     """restart_vars (abip.c:587-630) with the threshold lowered so that the periodic restart from the running mean fires many
