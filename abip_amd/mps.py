@@ -163,3 +163,52 @@ def load_standard_form(path: str):
     """(A_csc, b, c, data) ready for ``abip(data, {'l': n}, params)``; the original variables are ``x[:n_orig] + lb_shift``."""
     data = preprocess(mpsread(path))
     return data["A"], data["b"], data["c"], data
+
+
+def mpswrite(path: str, prob: dict, name: str = "ABIPLP") -> None:
+    """Write ``prob`` (the fields ``mpsread`` returns) as a fixed-name free-format MPS file: equality rows E, inequality rows L,
+    bounds LO/UP/FX/FR/MI, objective constant as the negated RHS of the objective row.  Inverse of ``mpsread`` up to row order."""
+    f = np.asarray(prob["f"], float)
+    Aeq, Ain = sp.csc_matrix(prob["Aeq"]), sp.csc_matrix(prob["Aineq"])
+    beq, bin_ = np.asarray(prob["beq"], float), np.asarray(prob["bineq"], float)
+    lb, ub = np.asarray(prob["lb"], float), np.asarray(prob["ub"], float)
+    n = f.size
+    with open(path, "w") as fh:
+        fh.write(f"NAME {name}\nROWS\n N COST\n")
+        for i in range(Aeq.shape[0]):
+            fh.write(f" E E{i}\n")
+        for i in range(Ain.shape[0]):
+            fh.write(f" L L{i}\n")
+        fh.write("COLUMNS\n")
+        for j in range(n):
+            if f[j] != 0.0:
+                fh.write(f" X{j} COST {float(f[j])!r}\n")
+            for M, tag in ((Aeq, "E"), (Ain, "L")):
+                for q in range(M.indptr[j], M.indptr[j + 1]):
+                    fh.write(f" X{j} {tag}{M.indices[q]} {float(M.data[q])!r}\n")
+            if f[j] == 0.0 and Aeq.indptr[j] == Aeq.indptr[j + 1] and Ain.indptr[j] == Ain.indptr[j + 1]:
+                fh.write(f" X{j} COST 0.0\n")
+        fh.write("RHS\n")
+        if float(prob.get("objcon", 0.0)) != 0.0:
+            fh.write(f" RHS COST {-float(prob['objcon'])!r}\n")
+        for i, v in enumerate(beq):
+            if v != 0.0:
+                fh.write(f" RHS E{i} {float(v)!r}\n")
+        for i, v in enumerate(bin_):
+            if v != 0.0:
+                fh.write(f" RHS L{i} {float(v)!r}\n")
+        fh.write("BOUNDS\n")
+        for j in range(n):
+            lo, hi = lb[j], ub[j]
+            if lo == hi:
+                fh.write(f" FX BND X{j} {float(lo)!r}\n")
+            elif lo == -np.inf and hi == np.inf:
+                fh.write(f" FR BND X{j}\n")
+            else:
+                if lo == -np.inf:
+                    fh.write(f" MI BND X{j}\n")
+                elif lo != 0.0:
+                    fh.write(f" LO BND X{j} {float(lo)!r}\n")
+                if hi != np.inf:
+                    fh.write(f" UP BND X{j} {float(hi)!r}\n")
+        fh.write("ENDATA\n")

@@ -53,3 +53,32 @@ def test_ranges_free_fixed_and_objective_constant():
     xs[data["n_orig"] + m2:] = prob["ub"][ubmask] - r.x[ubmask]
     assert np.linalg.norm(data["A"] @ xs - data["b"]) <= 1e-6 * (1 + np.linalg.norm(data["b"])) and xs.min() >= -1e-9
     assert abs(data["c"] @ xs + data["objcon"] - (r.fun + prob["objcon"])) <= 1e-6 * (1 + abs(r.fun))
+
+
+def bounded_lp(seed=3, n=40, me=6, mi=9):
+    """A feasible bounded LP with equality and inequality rows, shifted lower bounds, finite upper bounds and a fixed variable."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    x0 = rng.random(n) * 2 + 0.5
+    lb = np.where(rng.random(n) < 0.3, 0.5, 0.0); ub = np.where(rng.random(n) < 0.4, 4.0, np.inf)
+    lb[3] = ub[3] = x0[3] = 1.25
+    Aeq = sp.random(me, n, density=0.3, random_state=rng, data_rvs=rng.standard_normal, format="csr")
+    Ain = sp.random(mi, n, density=0.3, random_state=rng, data_rvs=rng.standard_normal, format="csr")
+    return dict(f=rng.random(n) + 0.1, Aeq=Aeq, beq=Aeq @ x0, Aineq=Ain, bineq=Ain @ x0 + rng.random(mi), lb=lb, ub=ub, objcon=2.5)
+
+
+def test_write_read_round_trip(tmp_path):
+    prob = bounded_lp()
+    path = str(tmp_path / "rt.mps")
+    mps.mpswrite(path, prob)
+    back = mps.mpsread(path)
+    for k in ("f", "beq", "bineq", "lb", "ub"):
+        assert np.array_equal(np.asarray(back[k]), np.asarray(prob[k])), k
+    assert abs(back["Aeq"] - prob["Aeq"]).max() == 0 and abs(back["Aineq"] - prob["Aineq"]).max() == 0 and back["objcon"] == 2.5
+    r = highs(prob)
+    data = mps.preprocess(back)
+    from oracle import pyoracle as po
+    po.build(ref=False)
+    o = po.solve("oracle", data["A"], data["b"], data["c"], linsys="direct", eps=1e-7)
+    assert o.info["status"] == "Solved"
+    assert abs(o.info["pobj"] + data["objcon"] - (r.fun + 2.5)) <= 1e-5 * (1 + abs(r.fun))
