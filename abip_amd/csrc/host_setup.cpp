@@ -198,33 +198,63 @@ void jacobi_preconditioner(const ABIPMatrix *A, std::vector<double> &Minv) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-// Approximate-minimum-degree ordering on the quotient graph (the bound of Amestoy, Davis & Duff: external degree of i <=
-// |A_i \ Lp| + |Lp \ i| + sum over the other elements e of i of |L_e \ Lp|, the last terms obtained for all i in Lp at once with one
-// pass over their element lists), with element absorption; no supervariables.  The reference calls SuiteSparse AMD here
-// (direct.c:106-119); any symmetric permutation is admissible because K is quasi-definite.
+// Minimum-degree ordering on the quotient graph with LAZY degree updates.  Eliminating p changes the external degree of its
+// neighbours i by at least -1 and to at least |Lp| - 1, so instead of recomputing every neighbour after every pivot (the cost of a
+// classical minimum-degree code, and still the cost of AMD's approximate update when rows sit in hundreds of elements, as the rows of
+// a LASSO / least-squares KKT matrix do) a neighbour only gets that LOWER BOUND and a "stale" mark.  A stale node is recomputed --
+// exactly, by marking the members of its elements, or by the sum-of-elements bound when that would be too long -- only when it
+// reaches the front of the degree lists; a node that is fresh there is a true minimum.  Element absorption as usual; no
+// supervariables.  The reference calls SuiteSparse AMD here (direct.c:106-119); any symmetric permutation is admissible because K
+// is quasi-definite.
 void min_degree(int N, const std::vector<int> &Gp, const std::vector<int> &Gi, std::vector<int> &perm) {
   std::vector<std::vector<int>> adjv(N), adje(N), elem(N);
   std::vector<int> deg(N), mark(N, -1), head(N + 1, -1), nxt(N, -1), prv(N, -1);
-  std::vector<long> w(N, 0);
-  std::vector<char> elim(N, 0), dead(N, 0);
+  std::vector<char> elim(N, 0), dead(N, 0), stale(N, 0);
   for (int i = 0; i < N; ++i) { adjv[i].assign(Gi.begin() + Gp[i], Gi.begin() + Gp[i + 1]); deg[i] = (int)adjv[i].size(); }
   auto ins = [&](int x) { const int d = deg[x]; nxt[x] = head[d]; prv[x] = -1; if (head[d] >= 0) prv[head[d]] = x; head[d] = x; };
   auto del = [&](int x) { const int d = deg[x]; if (prv[x] >= 0) nxt[prv[x]] = nxt[x]; else head[d] = nxt[x]; if (nxt[x] >= 0) prv[nxt[x]] = prv[x]; };
   for (int i = N - 1; i >= 0; --i) ins(i);
   perm.resize(N);
   int stamp = 0, mindeg = 0;
-  long wflg = 1;
   std::vector<int> Lp;
+  // external degree of x among the nodes not yet eliminated (k of them gone); prunes x's lists on the way
+  auto refresh = [&](int x, int k) {
+    auto &ae = adje[x];
+    size_t keep = 0;
+    long bound = 0;
+    for (int e : ae) if (!dead[e]) { ae[keep++] = e; bound += (long)elem[e].size() - 1; }
+    ae.resize(keep);
+    auto &av = adjv[x];
+    av.erase(std::remove_if(av.begin(), av.end(), [&](int y) { return elim[y] != 0; }), av.end());
+    const long cap = N - k - 1;
+    long d;
+    if (bound > 4L * cap + 64) d = std::min<long>(cap, bound + (long)av.size()); // long element lists: the sum bound (it saturates)
+    else {
+      const int st = ++stamp; mark[x] = st;
+      d = 0;
+      for (int y : av) if (mark[y] != st) { mark[y] = st; ++d; }
+      for (int e : ae) for (int y : elem[e]) if (mark[y] != st) { mark[y] = st; ++d; }
+    }
+    return (int)std::min<long>(d, cap);
+  };
   for (int k = 0; k < N; ++k) {
-    while (mindeg <= N && head[mindeg] < 0) ++mindeg;
+    int p = -1;
+    for (;;) {
+      while (mindeg <= N && head[mindeg] < 0) ++mindeg;
+      p = head[mindeg];
+      if (!stale[p]) break;
+      del(p);
+      deg[p] = refresh(p, k);
+      stale[p] = 0;
+      ins(p); // at or above mindeg: the stored value was a lower bound
+    }
     if (N - k > 64 && (double)mindeg >= 0.7 * (double)(N - k - 1)) {
-      // what is left is (close to) a clique: any order fills it in completely.  Finish in degree order; this block becomes
+      // what is left is (close to) a clique: any order fills it in completely.  Finish in (bound) order; this block becomes
       // the dense tail of the factor.
       for (int dgr = mindeg; dgr <= N && k < N; ++dgr)
         for (int x = head[dgr]; x >= 0; x = nxt[x]) perm[k++] = x;
       break;
     }
-    const int p = head[mindeg];
     del(p);
     elim[p] = 1; perm[k] = p;
     ++stamp; mark[p] = stamp;
@@ -237,41 +267,14 @@ void min_degree(int N, const std::vector<int> &Gp, const std::vector<int> &Gi, s
     }
     std::vector<int>().swap(adjv[p]); std::vector<int>().swap(adje[p]);
     const int lp = (int)Lp.size();
-    // |L_e \ Lp| for every element e that touches Lp:  w[e] - wflg
-    long maxlen = lp;
     for (int x : Lp) {
       del(x);
-      auto &ae = adje[x];
-      size_t keep = 0;
-      for (int e : ae) {
-        if (dead[e]) continue;
-        ae[keep++] = e;
-        if (w[e] < wflg) { w[e] = (long)elem[e].size() + wflg; maxlen = std::max<long>(maxlen, (long)elem[e].size()); }
-        --w[e];
-      }
-      ae.resize(keep);
-    }
-    for (int x : Lp) {
-      long d = 0;
-      auto &ae = adje[x];
-      size_t keep = 0;
-      for (int e : ae) {
-        if (dead[e]) continue;
-        const long ext = w[e] - wflg;
-        if (ext > 0) { d += ext; ae[keep++] = e; }
-        else { dead[e] = 1; std::vector<int>().swap(elem[e]); } // L_e is inside Lp: absorbed
-      }
-      ae.resize(keep);
-      ae.push_back(p);
-      auto &av = adjv[x];
-      av.erase(std::remove_if(av.begin(), av.end(), [&](int y) { return elim[y] || mark[y] == stamp; }), av.end());
-      d += (long)av.size();
-      const long bound = std::min<long>({(long)(N - k - 2), (long)deg[x] + lp - 1, d + lp - 1});
-      deg[x] = (int)std::max<long>(bound, 0);
+      adje[x].push_back(p);
+      deg[x] = std::max(std::max(deg[x] - 1, lp - 1), 0);
+      stale[x] = 1;
       ins(x);
       if (deg[x] < mindeg) mindeg = deg[x];
     }
-    wflg += maxlen + 1;
     elem[p] = Lp;
   }
 }
