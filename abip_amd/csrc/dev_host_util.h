@@ -70,7 +70,7 @@ struct DevTri {
     int l = 0;
     auto is_wide = [&](int lv) {
       const int a = h.lev_ptr[lv], b = h.lev_ptr[lv + 1];
-      return (b - a) >= 2048 || (h.ptr[b] - h.ptr[a]) >= 65536;
+      return (b - a) >= 2048 || (h.ptr[b] - h.ptr[a]) >= 4096; // one workgroup chews ~1k non-zeros per microsecond at best
     };
     while (l < nlev) {
       if (is_wide(l)) {

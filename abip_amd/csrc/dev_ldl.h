@@ -215,22 +215,24 @@ __device__ __forceinline__ RowPre row_pre(const Tri &T, int a, int b, int g, int
   return p;
 }
 
-__device__ __forceinline__ void run_levels(const Tri &T, double *x, int *s_lp, int *s_lg, int tid) {
-  if (T.nlev == 0) return;
-  const bool meta = T.nlev <= MAXLEV_LDS;
+// levels [l0, l1) of T
+__device__ __forceinline__ void run_levels(const Tri &T, double *x, int *s_lp, int *s_lg, int tid, int l0, int l1) {
+  if (l1 <= l0) return;
+  const int nl = l1 - l0;
+  const bool meta = nl <= MAXLEV_LDS;
   if (meta) {
-    for (int l = tid; l <= T.nlev; l += TBS) s_lp[l] = T.lev_ptr[l];
-    for (int l = tid; l < T.nlev; l += TBS) s_lg[l] = T.lev_g[l];
+    for (int l = tid; l <= nl; l += TBS) s_lp[l] = T.lev_ptr[l0 + l];
+    for (int l = tid; l < nl; l += TBS) s_lg[l] = T.lev_g[l0 + l];
     __syncthreads();
   }
-  auto lp = [&](int l) { return meta ? s_lp[l] : T.lev_ptr[l]; };
-  auto lg = [&](int l) { return meta ? s_lg[l] : T.lev_g[l]; };
+  auto lp = [&](int l) { return meta ? s_lp[l] : T.lev_ptr[l0 + l]; };
+  auto lg = [&](int l) { return meta ? s_lg[l] : T.lev_g[l0 + l]; };
   int a = lp(0), b = lp(1), g = lg(0);
   RowPre cur = row_pre(T, a, b, g, tid);
-  for (int l = 0; l < T.nlev; ++l) {
+  for (int l = 0; l < nl; ++l) {
     int nb = b, ng = 1;
     RowPre nxt = cur;
-    if (l + 1 < T.nlev) { nb = lp(l + 2); ng = lg(l + 1); nxt = row_pre(T, b, nb, ng, tid); }
+    if (l + 1 < nl) { nb = lp(l + 2); ng = lg(l + 1); nxt = row_pre(T, b, nb, ng, tid); }
     {
       double acc = 0.0;
       if (cur.s < cur.e) {
@@ -247,6 +249,13 @@ __device__ __forceinline__ void run_levels(const Tri &T, double *x, int *s_lp, i
   }
 }
 
+// a run of thin levels [l0, l1) of a larger system in one workgroup (x in global memory)
+static __global__ __launch_bounds__(TBS) void k_tri_thin(Tri T, double *x, int l0, int l1, const Ctl *ctl) {
+  if (ctl->halt) return;
+  __shared__ int s_lp[MAXLEV_LDS + 1], s_lg[MAXLEV_LDS];
+  run_levels(T, x, s_lp, s_lg, threadIdx.x, l0, l1);
+}
+
 // FWD: x = P b, L-solve over the sparse rows.  BWD: head D^-1, L'-solve over the head columns, b = P' x.  Both when there is no tail.
 template <bool XL, bool FWD, bool BWD>
 static __global__ __launch_bounds__(TBS) void k_ldl_small(Tri F, Tri B, const int *__restrict__ Pmap, const double *__restrict__ D, double *b, double *xg,
@@ -259,14 +268,14 @@ static __global__ __launch_bounds__(TBS) void k_ldl_small(Tri F, Tri B, const in
   if (FWD) {
     for (int j = tid; j < N; j += TBS) x[j] = b[Pmap[j]];
     __syncthreads();
-    run_levels(F, x, s_lp, s_lg, tid);
+    run_levels(F, x, s_lp, s_lg, tid, 0, F.nlev);
     if (!BWD) { if (XL) for (int j = tid; j < N; j += TBS) xg[j] = x[j]; return; }
     for (int j = tid; j < t0; j += TBS) x[j] /= D[j];
   } else {
     for (int j = tid; j < N; j += TBS) { const double v = xg[j]; x[j] = j < t0 ? v / D[j] : v; }
   }
   __syncthreads();
-  run_levels(B, x, s_lp, s_lg, tid);
+  run_levels(B, x, s_lp, s_lg, tid, 0, B.nlev);
   for (int j = tid; j < N; j += TBS) b[Pmap[j]] = x[j];
 }
 

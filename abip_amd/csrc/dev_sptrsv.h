@@ -63,13 +63,4 @@ static __global__ __launch_bounds__(BS) void k_tri_wide(Tri T, const int4 *__res
   spmv_stream<1>(M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
                  [&](int pos, double(&acc)[1]) { const int row = T.lev_rows[pos]; x[row] -= acc[0]; });
 }
-// a run of thin levels [l0, l1) in one workgroup
-static __global__ __launch_bounds__(TBS) void k_tri_thin(Tri T, double *x, int l0, int l1, const Ctl *ctl) {
-  if (ctl->halt) return;
-  for (int l = l0; l < l1; ++l) {
-    tri_level(T, x, T.lev_ptr[l], T.lev_ptr[l + 1], T.lev_g[l], threadIdx.x, TBS);
-    __syncthreads();
-  }
-}
-
 } // namespace abip

@@ -410,7 +410,9 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
       std::vector<int> hgt(N, 0), pm(N + 1, 0);
       for (int i = 0; i < N; ++i) if (parent[i] >= 0) hgt[parent[i]] = std::max(hgt[parent[i]], hgt[i] + 1);
       for (int i = 0; i < N; ++i) pm[i + 1] = std::max(pm[i], hgt[i] + 1);
-      const double c_lev = 1.5, c_mv = 3.0, bw = 3.0e6; // us per level, us per mat-vec launch, bytes per us
+      // us per level (one-workgroup path with x in LDS, or a launch per level on larger systems), us per mat-vec launch, bytes per us
+      const char *ce = getenv("ABIP_HIP_CLEV");
+      const double c_lev = ce ? atof(ce) : (N <= 16384 ? 1.5 : 6.0), c_mv = 3.0, bw = 3.0e6;
       double best = 2.0 * c_lev * pm[N];
       for (int t = 64; t <= Tmax; t += 64) {
         const double cost = 2.0 * c_lev * pm[N - t] + 2.0 * (c_mv + 4.0 * (double)t * t / bw);

@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5"])
+    ap.add_argument("--linsys", default=None, choices=["direct", "indirect"], help="override the workload's KKT back-end (c2/c3/c4)")
     ap.add_argument("--to-tol", action="store_true", help="also run a full solve to eps=1e-6 and report wall-clock")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--events-in-timed-region", action="store_true",
@@ -162,6 +163,9 @@ def main():
     from abip_amd import Solver
     from abip_amd import dist as adist
     A, b, c, linsys, desc = make_workload(args.workload)
+    if args.linsys and args.linsys != linsys:
+        linsys = args.linsys
+        desc += f" [back-end overridden: {linsys}]"
     m, n = A.shape
     nnz = A.nnz
     sharded = world > 1 and linsys == "indirect"

@@ -33,7 +33,7 @@ int main(int argc, char **argv) {
     int thin = 0; long thinrows = 0;
     for (int l = 0; l < nl; ++l) { const int r = T.lev_ptr[l + 1] - T.lev_ptr[l]; if (r < 8) { ++thin; thinrows += r; } }
     printf("  %s: %d levels, %d with <8 rows (%ld rows); first levels:", nm, nl, thin, thinrows);
-    for (int l = 0; l < nl && l < 12; ++l) printf(" %d", T.lev_ptr[l + 1] - T.lev_ptr[l]);
+    for (int l = 0; l < nl && l < 40; ++l) printf(" %d:%d", T.lev_ptr[l + 1] - T.lev_ptr[l], T.ptr[T.lev_ptr[l + 1]] - T.ptr[T.lev_ptr[l]]);
     printf("\n");
   };
   hist(F.fwd, "fwd"); hist(F.bwd, "bwd");
