@@ -150,7 +150,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (libabip_hip has no CPU path)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ABIP_BENCH_FORCE_SHARD") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -168,7 +168,8 @@ def main():
         desc += f" [back-end overridden: {linsys}]"
     m, n = A.shape
     nnz = A.nnz
-    sharded = world > 1 and linsys == "indirect"
+    # (ABIP_BENCH_FORCE_SHARD=1 runs the sharded code path with a single rank: a self-test of the N > 1 plumbing on one GPU)
+    sharded = (world > 1 or os.environ.get("ABIP_BENCH_FORCE_SHARD") == "1") and linsys == "indirect" and dist is not None
     shard_note = None
     if sharded:
         # RCCL communicator for the solver; rows of A are split over the ranks inside abip_init.  If the communicator cannot
