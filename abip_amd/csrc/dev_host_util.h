@@ -61,7 +61,8 @@ struct DevTri {
   DBuf<double> val;
   int nlev = 0;
   std::vector<Segment> segs; // launch plan: runs of thin levels in one workgroup, wide levels as CSR-stream grids
-  int upload(const host::TriHost &h, hipStream_t s) {
+  // all_thin: run every level inside one workgroup (small systems: the launch of a streamed level costs more than it saves)
+  int upload(const host::TriHost &h, hipStream_t s, bool all_thin = false) {
     nlev = (int)h.lev_ptr.size() - 1;
     // a level is "wide" when it has enough rows or non-zeros to fill the chip; its positions are cut into row blocks
     // of <= CHUNK non-zeros / rows for the CSR-stream kernel (same greedy rule as host::build_row_blocks)
@@ -69,6 +70,7 @@ struct DevTri {
     std::vector<int> d4;
     int l = 0;
     auto is_wide = [&](int lv) {
+      if (all_thin) return false;
       const int a = h.lev_ptr[lv], b = h.lev_ptr[lv + 1];
       return (b - a) >= 2048 || (h.ptr[b] - h.ptr[a]) >= 4096; // one workgroup chews ~1k non-zeros per microsecond at best
     };

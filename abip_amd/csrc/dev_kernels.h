@@ -461,12 +461,13 @@ struct FinArgs {
   int decide = 0, avg_stats = 0;
   double thr = 0.0, sentinel = 0.0; // gamma * mu; Qres_avg when no averaged statistics were taken (= max_admm_iters, abip.c:1957)
 };
-__global__ __launch_bounds__(BS) void k_finalize(FinArgs f, Dims d, const double *part, int nb, Ctl *ctl) {
+__global__ __launch_bounds__(1024) void k_finalize(FinArgs f, Dims d, const double *part, int nb, Ctl *ctl) {
   // one wavefront per slot, all loads of a lane in flight at once
   if (f.decide && (ctl->halt || !ctl->cg_done)) return; // cg_done: permanently set for the direct back-end
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int PER = MAXNB / 64;
-  for (int s = wave; s < f.nslots; s += WAVES) {
+  const int nwaves = blockDim.x >> 6; // launched with 1024 threads: one round of loads covers 16 slots
+  for (int s = wave; s < f.nslots; s += nwaves) {
     const int slot = f.slots[s];
     if (f.gs) { if (lane == 0) ctl->out[slot] = f.gs[slot]; continue; }
     double t[PER];

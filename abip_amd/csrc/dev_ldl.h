@@ -256,16 +256,39 @@ static __global__ __launch_bounds__(TBS) void k_tri_thin(Tri T, double *x, int l
   run_levels(T, x, s_lp, s_lg, threadIdx.x, l0, l1);
 }
 
+// Optional neighbours of the solve folded into the one-workgroup kernels (saves two launches per ADMM iteration on small LPs):
+// pre(b, tid) builds the right-hand side in b before the permutation gathers it, post(b, tid) consumes the solution after the
+// inverse permutation has scattered it.  Both run on all TBS threads of the single workgroup.
+struct NoFuse {
+  static constexpr bool active = false;
+  __device__ void pre(double *, int) const {}
+  __device__ void post(const double *, int) const {}
+};
+
+// sum over the 1024-thread workgroup, result to every thread
+__device__ __forceinline__ double tbs_sum(double v, double *red /* TBS/64 */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int wv = 0; wv < TBS / 64; ++wv) t += red[wv];
+  return t;
+}
+
 // FWD: x = P b, L-solve over the sparse rows.  BWD: head D^-1, L'-solve over the head columns, b = P' x.  Both when there is no tail.
-template <bool XL, bool FWD, bool BWD>
+template <bool XL, bool FWD, bool BWD, class Fuse>
 static __global__ __launch_bounds__(TBS) void k_ldl_small(Tri F, Tri B, const int *__restrict__ Pmap, const double *__restrict__ D, double *b, double *xg,
-                                                          int t0, int N, const Ctl *ctl) {
+                                                          int t0, int N, const Ctl *ctl, Fuse fz) {
   if (ctl->halt) return;
   extern __shared__ double x_lds[];
   __shared__ int s_lp[MAXLEV_LDS + 1], s_lg[MAXLEV_LDS];
   double *x = XL ? x_lds : xg;
   const int tid = threadIdx.x;
   if (FWD) {
+    if (Fuse::active) { fz.pre(b, tid); __syncthreads(); }
     for (int j = tid; j < N; j += TBS) x[j] = b[Pmap[j]];
     __syncthreads();
     run_levels(F, x, s_lp, s_lg, tid, 0, F.nlev);
@@ -277,6 +300,7 @@ static __global__ __launch_bounds__(TBS) void k_ldl_small(Tri F, Tri B, const in
   __syncthreads();
   run_levels(B, x, s_lp, s_lg, tid, 0, B.nlev);
   for (int j = tid; j < N; j += TBS) b[Pmap[j]] = x[j];
+  if (Fuse::active) { __syncthreads(); fz.post(b, tid); }
 }
 
 namespace hostutil {
@@ -289,18 +313,24 @@ struct DevLdl {
   int N = 0, t0 = 0, T = 0;
   long lnnz = 0;
 
+  // more than 64 KB of dynamic LDS has to be asked for, per kernel instantiation
+  template <class Fuse>
+  bool allow_lds() const {
+    const int bytes = (int)(sizeof(double) * (size_t)N);
+    return hipFuncSetAttribute((const void *)k_ldl_small<true, true, true, Fuse>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+           hipFuncSetAttribute((const void *)k_ldl_small<true, true, false, Fuse>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+           hipFuncSetAttribute((const void *)k_ldl_small<true, false, true, Fuse>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  }
+
   // pmap[k] = position in the caller's rhs vector of pivot k.  Returns 0, or -1 (allocation / zero pivot).
   int setup(const host::LdlHost &H, const std::vector<int> &pmap, hipStream_t s) {
     N = H.N; t0 = H.t0; T = H.T; lnnz = H.lnnz;
-    if (Pmap.upload(pmap, s) || D.upload(H.D, s) || xw.alloc(N) || F.upload(H.fwd, s) || B.upload(H.bwd, s)) return -1;
+    // small systems: the whole sparse part in one workgroup (x in LDS), whatever the shape of the levels
+    const bool one_wg = N <= XL_MAX && H.fwd.idx.size() <= 32768 && H.bwd.idx.size() <= 32768;
+    if (Pmap.upload(pmap, s) || D.upload(H.D, s) || xw.alloc(N) || F.upload(H.fwd, s, one_wg) || B.upload(H.bwd, s, one_wg)) return -1;
     small = F.single_workgroup() && B.single_workgroup() && N <= 65536;
     xl = small && N <= XL_MAX;
-    if (xl) { // more than 64 KB of dynamic LDS has to be asked for
-      const int bytes = (int)(sizeof(double) * (size_t)N);
-      if (hipFuncSetAttribute((const void *)k_ldl_small<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
-          hipFuncSetAttribute((const void *)k_ldl_small<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
-          hipFuncSetAttribute((const void *)k_ldl_small<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) xl = false;
-    }
+    if (xl && !allow_lds<NoFuse>()) xl = false;
     if (T == 0) return 0;
     const int nt = T / DB;
     DBuf<double> Linv, LD;
@@ -326,8 +356,8 @@ struct DevLdl {
   }
 
   // enqueue rhs <- K^-1 rhs; `launch(kernel, grid, block, lds_bytes, args...)` is the caller's launcher (profiling classes differ)
-  template <class LaunchFn>
-  void enqueue(LaunchFn &&launch, double *rhs, const Ctl *ctl, int NB) const {
+  template <class LaunchFn, class Fuse = NoFuse>
+  void enqueue(LaunchFn &&launch, double *rhs, const Ctl *ctl, int NB, Fuse fz = Fuse{}) const {
     auto tail = [&]() {
       if (T == 0) return;
       const int grid = std::max(1, std::min(MAXNB, (T + BS / 64 - 1) / (BS / 64)));
@@ -338,15 +368,15 @@ struct DevLdl {
       const size_t sh = xl ? sizeof(double) * (size_t)N : 0;
       const int *pm = Pmap.p; const double *dd = D.p;
       if (T == 0) {
-        if (xl) launch(k_ldl_small<true, true, true>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl);
-        else launch(k_ldl_small<false, true, true>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl);
+        if (xl) launch(k_ldl_small<true, true, true, Fuse>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl, fz);
+        else launch(k_ldl_small<false, true, true, Fuse>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl, fz);
         return;
       }
-      if (xl) launch(k_ldl_small<true, true, false>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl);
-      else launch(k_ldl_small<false, true, false>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl);
+      if (xl) launch(k_ldl_small<true, true, false, Fuse>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl, fz);
+      else launch(k_ldl_small<false, true, false, Fuse>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl, fz);
       tail();
-      if (xl) launch(k_ldl_small<true, false, true>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl);
-      else launch(k_ldl_small<false, false, true>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl);
+      if (xl) launch(k_ldl_small<true, false, true, Fuse>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl, fz);
+      else launch(k_ldl_small<false, false, true, Fuse>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl, fz);
       return;
     }
     const int gN = std::max(1, std::min(NB, (N + BS - 1) / BS));

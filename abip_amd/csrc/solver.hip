@@ -125,6 +125,7 @@ struct ABIP_WORK {
   bool wg_valid = false;
   int it_seen = 0;    // ctl.it_count at the last control read
   int batch = 4;      // iterations enqueued per control read (direct back-end)
+  bool fuse_small = false; // small direct systems on one GPU: rhs build and u_t'h inside the solve kernels
   bool batch_ok = true; // ABIP_HIP_BATCH=0 forces one control read per iteration
   Resid r;
   abip_int status = 0;
@@ -302,6 +303,47 @@ int enqueue_cg_post(W *w, double *rhs) {
   if (allreduce_scalars(w)) return -1;
   return 0;
 }
+// project_lin_sys around a small direct solve (abip.c:552-560), folded into the one-workgroup solve kernels: pre = k_rhs,
+// post = k_post_dot.  Same arithmetic per element; the two reductions run over one 1024-thread workgroup.
+struct LpSolveFuse {
+  static constexpr bool active = true;
+  const double *u, *v, *h;
+  double rho, g_th;
+  Dims d;
+  double *part;
+  int nb;
+  __device__ void pre(double *ut, int tid) const {
+    __shared__ double red[TBS / 64];
+    double s = 0.0;
+    for (int i = tid; i < nb; i += TBS) s += part[S_WG * MAXNB + i];
+    const double wg = tbs_sum(s, red);
+    const int tail = d.MP + d.n;
+    const double tsum = u[tail] + v[tail];
+    const double coef = (wg - tsum * g_th) / (g_th + 1.0);
+    for (int i = tid; i < d.m; i += TBS) {
+      double t = (u[i] + v[i]) * rho;
+      t += -tsum * h[i];
+      t += -coef * h[i];
+      ut[i] = t;
+    }
+    for (int j = tid; j < d.n; j += TBS) {
+      double t = u[d.MP + j] + v[d.MP + j];
+      t += -tsum * h[d.MP + j];
+      t += -coef * h[d.MP + j];
+      ut[d.MP + j] = -t;
+    }
+    if (tid == 0) ut[tail] = tsum;
+  }
+  __device__ void post(const double *rhs, int tid) const {
+    __shared__ double red[TBS / 64];
+    double s = 0.0;
+    for (int i = tid; i < d.m; i += TBS) s += rhs[i] * h[i];
+    for (int j = tid; j < d.n; j += TBS) s += rhs[d.MP + j] * h[d.MP + j];
+    const double dh = tbs_sum(s, red);
+    for (int e = tid; e < nb; e += TBS) part[S_DH * MAXNB + e] = (e == 0) ? dh : 0.0;
+  }
+};
+
 void enqueue_direct(W *w, double *rhs) {
   const Ctl *ctl = w->ctl.p;
   w->ldl.enqueue([&](auto kern, int grid, int block, size_t lds, auto... a) { launch_lds(w, ABIP_HIP_K_SPTRSV, kern, grid, block, lds, a...); }, rhs, ctl, w->NB);
@@ -419,7 +461,7 @@ int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty, bool decide =
     launch(w, ABIP_HIP_K_VEC, k_fold, 1, BS, fo, (const double *)w->part.p, w->NB, w->gs);
     if (allreduce_scalars(w)) return -1;
   }
-  launch(w, ABIP_HIP_K_VEC, k_finalize, 1, BS, f, d, (const double *)w->part.p, w->NB, w->ctl.p);
+  launch(w, ABIP_HIP_K_VEC, k_finalize, 1, 1024, f, d, (const double *)w->part.p, w->NB, w->ctl.p);
   return 0;
 }
 
@@ -442,10 +484,15 @@ int enqueue_iteration_direct(W *w, abip_int j, bool restart) {
   const Dims d = dims(w);
   const Ctl *ctl = w->ctl.p;
   ABIPSettings *st = w->stgs;
-  launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, w->ut.p, (const double *)w->h.p, st->rho_y, w->g_th, d,
-         w->part.p, w->NB, ctl, (const double *)w->gs);
   const bool avg_stats = ((j + 1) % 10 == 0); // abip.c:2000
-  enqueue_direct(w, w->ut.p);
+  if (w->fuse_small) { // k_rhs and k_post_dot ride inside the one-workgroup solve kernels
+    LpSolveFuse fz{w->u.p, w->v.p, w->h.p, st->rho_y, w->g_th, d, w->part.p, w->NB};
+    w->ldl.enqueue([&](auto kern, int grid, int block, size_t lds, auto... a) { launch_lds(w, ABIP_HIP_K_SPTRSV, kern, grid, block, lds, a...); }, w->ut.p, ctl, w->NB, fz);
+  } else {
+    launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, w->ut.p, (const double *)w->h.p, st->rho_y, w->g_th, d,
+           w->part.p, w->NB, ctl, (const double *)w->gs);
+    enqueue_direct(w, w->ut.p);
+  }
   launch(w, ABIP_HIP_K_VEC, k_admm_update, w->NB, BS, upd_args(w, !restart, avg_stats, j), d, w->part.p, w->NB, ctl);
   if (restart) {
     launch(w, ABIP_HIP_K_VEC, k_restart_apply, w->NB, BS, w->u.p, w->v.p, w->u_avg.p, w->v_avg.p, (double)st->restart_fre, w->LV);
@@ -582,7 +629,7 @@ int update_barrier_dynamic(W *w) { // LOQO, abip.c:930-977
   launch(w, ABIP_HIP_K_VEC, k_min_fold, 1, 1, (const double *)w->part.p, w->NB, w->ctl.p);
   FinArgs f; f.nslots = 1; f.slots[0] = S_XS; f.u = w->u.p; f.v = w->v.p; f.ua = w->u_avgc.p; f.va = w->v_avgc.p;
   f.gs = nullptr; // (x, tau) are replicated: every rank computes the same sum and minimum, nothing to exchange
-  launch(w, ABIP_HIP_K_VEC, k_finalize, 1, BS, f, dims(w), (const double *)w->part.p, w->NB, w->ctl.p);
+  launch(w, ABIP_HIP_K_VEC, k_finalize, 1, 1024, f, dims(w), (const double *)w->part.p, w->NB, w->ctl.p);
   if (sync_ctl(w)) return -2;
   double xs = w->hctl->out[S_XS];
   const double minxs = w->hctl->out[S_XMIN];
@@ -635,7 +682,7 @@ int adaptive_search(W *w, abip_int iter) {
     const int sl[5] = {S_A0, S_A1, S_A2, S_A3, S_A4};
     for (int q = 0; q < 5; ++q) f.slots[q] = sl[q];
     f.u = w->u.p; f.v = w->v.p; f.ua = nullptr; f.va = nullptr; f.gs = w->gs;
-    launch(w, ABIP_HIP_K_VEC, k_finalize, 1, BS, f, d, (const double *)w->part.p, w->NB, w->ctl.p);
+    launch(w, ABIP_HIP_K_VEC, k_finalize, 1, 1024, f, d, (const double *)w->part.p, w->NB, w->ctl.p);
     if (sync_ctl(w)) return -1;
     const double utut = w->hctl->out[S_A0], utv = w->hctl->out[S_A1], uu = w->hctl->out[S_A2], vv = w->hctl->out[S_A3], uv = w->hctl->out[S_A4];
     const double norm_ut = std::sqrt(utut), norm_u = std::sqrt(uu), norm_v = std::sqrt(vv);
@@ -1027,6 +1074,7 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
     std::vector<int> pmap(F.N);
     for (int q = 0; q < F.N; ++q) pmap[q] = F.P[q] < (int)m ? F.P[q] : w->MP + (F.P[q] - (int)m);
     if (w->ldl.setup(F, pmap, w->stream)) return fail("init_lin_sys_work failure");
+    { const char *e = getenv("ABIP_HIP_FUSE"); w->fuse_small = w->ldl.small && !w->dist && !(e && atoi(e) == 0) && (!w->ldl.xl || w->ldl.allow_lds<LpSolveFuse>()); }
     const int one = 1; // the post-solve kernels are gated on cg_done: permanently set for the direct back-end
     if (hipMemcpyAsync(&w->ctl.p->cg_done, &one, sizeof(int), hipMemcpyHostToDevice, w->stream) != hipSuccess) return fail("memcpy failure");
   }
@@ -1101,7 +1149,7 @@ abip_int abip_hip_solve_begin(ABIPWork *w, const ABIPData *d, const ABIPSolution
     launch(w, ABIP_HIP_K_VEC, k_dot_full, w->NB, BS, (const double *)w->h.p, (const double *)w->g.p, dims(w), (int)S_T0, w->part.p, w->xwt);
     if (w->dist) { enqueue_fold(w, {S_T0}); if (allreduce_scalars(w)) return ABIP_FAILED; }
     FinArgs f; f.nslots = 1; f.slots[0] = S_T0; f.u = w->u.p; f.v = w->v.p; f.ua = nullptr; f.va = nullptr; f.gs = w->gs;
-    launch(w, ABIP_HIP_K_VEC, k_finalize, 1, BS, f, dims(w), (const double *)w->part.p, w->NB, w->ctl.p);
+    launch(w, ABIP_HIP_K_VEC, k_finalize, 1, 1024, f, dims(w), (const double *)w->part.p, w->NB, w->ctl.p);
     if (sync_ctl(w)) return ABIP_FAILED;
     w->g_th = w->hctl->out[S_T0];
   }
