@@ -182,15 +182,20 @@ static __global__ __launch_bounds__(BS) void k_tail_mv(const double *__restrict_
   const int lane = threadIdx.x & 63, wave = blockIdx.x * (BS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (BS / 64);
   for (int r = wave; r < T; r += nw) {
     const int lo = upper ? r : 0, hi = upper ? T : r + 1;
-    const double *row = M + (long)r * ld;
+    const double2 *row2 = reinterpret_cast<const double2 *>(M + (long)r * ld); // rows start 512-byte aligned (ld % 64 == 0)
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int c = (lo & ~63) + lane;
-    if (c >= lo && c < hi) a0 = row[c] * v[c];
-    c += 64;
-    for (; c + 192 < hi; c += 256) {
-      a0 += row[c] * v[c]; a1 += row[c + 64] * v[c + 64]; a2 += row[c + 128] * v[c + 128]; a3 += row[c + 192] * v[c + 192];
-    }
-    for (; c < hi; c += 64) a0 += row[c] * v[c];
+    // 16-byte loads: lane q of an iteration owns entries 2q, 2q+1 of a 128-entry slice; four slices in flight
+    int c = (lo & ~127) + 2 * lane;
+    auto mac = [&](int cc, double &acc) {
+      const double2 m = row2[cc >> 1];
+      if (cc >= lo && cc < hi) acc += m.x * v[cc];
+      if (cc + 1 >= lo && cc + 1 < hi) acc += m.y * v[cc + 1];
+    };
+    auto mac_in = [&](int cc, double &acc) { const double2 m = row2[cc >> 1]; acc += m.x * v[cc]; acc += m.y * v[cc + 1]; }; // fully inside [lo, hi)
+    if (c < hi) mac(c, a0);
+    c += 128;
+    for (; c + 3 * 128 + 1 < hi; c += 512) { mac_in(c, a0); mac_in(c + 128, a1); mac_in(c + 256, a2); mac_in(c + 384, a3); }
+    for (; c < hi; c += 128) mac(c, a0);
     double s = (a0 + a1) + (a2 + a3);
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) out[r] = dsc ? s / dsc[r] : s;

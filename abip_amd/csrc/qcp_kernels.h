@@ -325,10 +325,10 @@ __global__ __launch_bounds__(BS) void kq_resid(const double *__restrict__ u, con
 
 // one block: partials (both halves of the table) -> ctl->out
 struct QFin { int nslots; int slots[24]; int second_half[24]; };
-__global__ __launch_bounds__(BS) void kq_finalize(QFin f, const double *part, int nb, QCtl *ctl) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+__global__ __launch_bounds__(1024) void kq_finalize(QFin f, const double *part, int nb, QCtl *ctl) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
   constexpr int PER = MAXNB / 64;
-  for (int s = wave; s < f.nslots; s += WAVES) {
+  for (int s = wave; s < f.nslots; s += nwaves) {
     const int slot = f.slots[s];
     const bool mx = qslot_is_max(slot);
     double acc = 0.0;

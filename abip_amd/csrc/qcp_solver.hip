@@ -182,7 +182,7 @@ int read_ctl(QWk *w) {
 void finalize(QWk *w, std::initializer_list<int> slots, std::initializer_list<int> both_halves) {
   QFin f; f.nslots = 0;
   for (int s : slots) { f.slots[f.nslots] = s; f.second_half[f.nslots] = 0; for (int bsl : both_halves) if (bsl == s) f.second_half[f.nslots] = 1; ++f.nslots; }
-  QLAUNCH(w, kq_finalize, 1, BS, f, (const double *)w->part.p, w->NB, w->ctl.p);
+  QLAUNCH(w, kq_finalize, 1, 1024, f, (const double *)w->part.p, w->NB, w->ctl.p);
 }
 
 double adjust_barrier(QWk *w, const QResid &r) { // abip.c:994-1071
