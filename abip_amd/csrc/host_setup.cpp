@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <new>
 #include <numeric>
 
 namespace abip {
@@ -288,7 +289,7 @@ int tail_request() {
   const char *e = getenv("ABIP_HIP_TAIL");
   return e ? atoi(e) : -1;
 }
-int tail_cap() { const char *e = getenv("ABIP_HIP_TAIL_MAX"); return e ? atoi(e) : 12288; }
+int tail_cap() { const char *e = getenv("ABIP_HIP_TAIL_MAX"); return e ? atoi(e) : 24576; } // W and W' take 16 T^2 bytes of HBM (9.7 GB at the cap)
 
 void level_sets(int N, TriHost &T, bool backward) {
   std::vector<int> lev(N, 0);
@@ -420,9 +421,12 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
       }
     }
   }
+  if (T > 0) {
+    try { out.S.assign((size_t)T * T, 0.0); }
+    catch (const std::bad_alloc &) { out.S.clear(); T = 0; } // no room for the dense block on the host: plain level-scheduled factor
+  }
   const int t0 = N - T;
   out.t0 = t0; out.T = T;
-  if (T > 0) out.S.assign((size_t)T * T, 0.0);
 
   // numeric, up-looking: row k of L by a sparse triangular solve against the leading block.  For a tail row only the head
   // columns take part; what is left in Y on the tail positions is row k of S.
