@@ -26,7 +26,12 @@ enum QSlot : int { // reuse of the partials table; *_MAX slots are reduced with 
 };
 __host__ __device__ inline bool qslot_is_max(int s) { return s >= Q_M0 && s <= Q_M5; }
 
-struct QCtl { double out[32]; double tau_t; int pad[2]; };
+struct QCtl {
+  double out[32]; double tau_t;
+  double err_inner; // inner stopping metric of the last completed iteration (qcp_config.c:518-557), evaluated by kq_finalize
+  int it_count;     // inner iterations completed since the start of the solve
+  int halted;       // mirror of the halt flag the gated kernels test (the host reads this block once per batch)
+};
 
 __device__ __forceinline__ double wave_max(double x) {
 #pragma unroll
@@ -57,7 +62,8 @@ __device__ __forceinline__ void write_partials_max(double *part, const int (&slo
 
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BS) void kq_rhs(const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ r,
-                                             double *__restrict__ p, double rho_y, double rho_x, QDims d, double *part) {
+                                             double *__restrict__ p, double rho_y, double rho_x, QDims d, double *part, const Ctl *hc) {
+  if (hc->halt) return;
   __shared__ double sm[WAVES];
   double acc[1] = {0.0};
   const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
@@ -66,7 +72,8 @@ __global__ __launch_bounds__(BS) void kq_rhs(const double *__restrict__ u, const
   const int ws[1] = {Q_T0};
   write_partials<1>(part, ws, acc, sm);
 }
-__global__ __launch_bounds__(BS) void kq_dots(const double *__restrict__ r, const double *__restrict__ p, double rho_y, double rho_x, QDims d, double *part) {
+__global__ __launch_bounds__(BS) void kq_dots(const double *__restrict__ r, const double *__restrict__ p, double rho_y, double rho_x, QDims d, double *part, const Ctl *hc) {
+  if (hc->halt) return;
   __shared__ double sm[WAVES];
   double acc[1] = {0.0};
   const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
@@ -75,7 +82,8 @@ __global__ __launch_bounds__(BS) void kq_dots(const double *__restrict__ r, cons
   const int ws[1] = {Q_T1};
   write_partials<1>(part, ws, acc, sm);
 }
-__global__ __launch_bounds__(BS) void kq_Qp(Csr Q, const double *__restrict__ p, QDims d, double *part) {
+__global__ __launch_bounds__(BS) void kq_Qp(Csr Q, const double *__restrict__ p, QDims d, double *part, const Ctl *hc) {
+  if (hc->halt) return;
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
@@ -104,7 +112,8 @@ struct QProxArgs {
   int iter_pos; // iter > 0
   int hasQ;
 };
-__global__ __launch_bounds__(BS) void kq_ut_prox(QProxArgs a, QDims d, const double *part, int nb, QCtl *ctl) {
+__global__ __launch_bounds__(BS) void kq_ut_prox(QProxArgs a, QDims d, const double *part, int nb, QCtl *ctl, const Ctl *hc) {
+  if (hc->halt) return;
   __shared__ double sm[3 * WAVES];
   double s3[3];
   const int rs[3] = {Q_T0, Q_T1, Q_PG};
@@ -186,7 +195,8 @@ __device__ __forceinline__ void cone_closed_form(int kind, const double *__restr
 
 // cones [first, C.n) of the (small-first) cone table
 template <bool BIG>
-__global__ __launch_bounds__(BIG ? QC_TB : BS) void kq_cones(QCones C, int first, double *__restrict__ u, const double *__restrict__ rel, double lambda, int MP) {
+__global__ __launch_bounds__(BIG ? QC_TB : BS) void kq_cones(QCones C, int first, double *__restrict__ u, const double *__restrict__ rel, double lambda, int MP, const Ctl *hc) {
+  if (hc && hc->halt) return;
   constexpr int NT = BIG ? QC_TB : 64;
   const int cone = first + (BIG ? (int)blockIdx.x : (int)((blockIdx.x * BS + threadIdx.x) >> 6));
   const int t = BIG ? (int)threadIdx.x : (int)(threadIdx.x & 63);
@@ -219,7 +229,8 @@ __global__ __launch_bounds__(BIG ? QC_TB : BS) void kq_cones(QCones C, int first
 }
 
 __global__ __launch_bounds__(BS) void kq_dual(const double *__restrict__ u, const double *__restrict__ rel, double *__restrict__ v, double *__restrict__ vo,
-                                              double rho_y, double rho_x, double rho_tau, QDims d) {
+                                              double rho_y, double rho_x, double rho_tau, QDims d, const Ctl *hc) {
+  if (hc->halt) return;
   const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
   for (int i = t0; i < d.m; i += stride) { const double t = u[i] - rel[i]; v[i] = t; vo[i] = t * rho_y; }
   for (int j = t0; j <= d.n; j += stride) { const int q = d.MP + j; const double t = u[q] - rel[q]; v[q] = t; vo[q] = t * (j == d.n ? rho_tau : rho_x); }
@@ -227,7 +238,8 @@ __global__ __launch_bounds__(BS) void kq_dual(const double *__restrict__ u, cons
 
 // ---- inner stopping test (qcp_config.c:518-557); the tau entry of Qu is completed by the host from the sums ----
 __global__ __launch_bounds__(BS) void kq_inner_A(Csr A, const double *__restrict__ u, const double *__restrict__ vo, const double *__restrict__ b,
-                                                 double *__restrict__ Ax, QDims d, double *part) {
+                                                 double *__restrict__ Ax, QDims d, double *part, const Ctl *hc) {
+  if (hc->halt) return;
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[5 * WAVES];
@@ -246,7 +258,8 @@ __global__ __launch_bounds__(BS) void kq_inner_A(Csr A, const double *__restrict
 }
 // rows of A' (and of Q): with Q the A'y product is only stored and kq_inner_Q finishes the row
 __global__ __launch_bounds__(BS) void kq_inner_At(Csr At, const double *__restrict__ u, const double *__restrict__ vo, const double *__restrict__ c,
-                                                  double *__restrict__ ATy, double *__restrict__ Qx, int finish, QDims d, double *part) {
+                                                  double *__restrict__ ATy, double *__restrict__ Qx, int finish, QDims d, double *part, const Ctl *hc) {
+  if (hc->halt) return;
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[5 * WAVES];
@@ -272,7 +285,8 @@ __global__ __launch_bounds__(BS) void kq_inner_At(Csr At, const double *__restri
   }
 }
 __global__ __launch_bounds__(BS) void kq_inner_Q(Csr Q, const double *__restrict__ u, const double *__restrict__ vo, const double *__restrict__ c,
-                                                 const double *__restrict__ ATy, double *__restrict__ Qx, QDims d, double *part) {
+                                                 const double *__restrict__ ATy, double *__restrict__ Qx, QDims d, double *part, const Ctl *hc) {
+  if (hc->halt) return;
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[5 * WAVES];
@@ -324,8 +338,16 @@ __global__ __launch_bounds__(BS) void kq_resid(const double *__restrict__ u, con
 }
 
 // one block: partials (both halves of the table) -> ctl->out
-struct QFin { int nslots; int slots[24]; int second_half[24]; };
-__global__ __launch_bounds__(1024) void kq_finalize(QFin f, const double *part, int nb, QCtl *ctl) {
+struct QFin {
+  int nslots; int slots[24]; int second_half[24];
+  // decide = 1 (the finalize that closes an inner iteration): complete the inner stopping metric with the tau entries, count the
+  // iteration and raise the halt flag when the metric is below tol_inner, so that iterations enqueued behind it fall through
+  int decide = 0;
+  double tol_inner = 0.0;
+  const double *u_tau = nullptr, *vo_tau = nullptr;
+};
+__global__ __launch_bounds__(1024) void kq_finalize(QFin f, const double *part, int nb, QCtl *ctl, Ctl *hc) {
+  if (f.decide && hc->halt) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
   constexpr int PER = MAXNB / 64;
   for (int s = wave; s < f.nslots; s += nwaves) {
@@ -344,6 +366,18 @@ __global__ __launch_bounds__(1024) void kq_finalize(QFin f, const double *part, 
       acc = mx ? fmax(acc, a2) : acc + a2;
     }
     if (lane == 0) ctl->out[slot] = acc;
+  }
+  if (!f.decide) return;
+  __syncthreads();
+  if (threadIdx.x == 0) { // un-fused arithmetic: the host code this replaces was compiled without FMA contraction
+    const double *o = ctl->out;
+    const double tau = *f.u_tau, vot = *f.vo_tau;
+    const double qut = -o[Q_D1] / tau + o[Q_D2] - o[Q_D3];
+    const double dq = qut - vot;
+    const double e1 = __dadd_rn(o[Q_E1], __dmul_rn(dq, dq)), e2 = __dadd_rn(o[Q_E2], __dmul_rn(qut, qut)), e3 = o[Q_E3];
+    const double err = sqrt(e1) / (1 + sqrt(e2) + sqrt(e3));
+    ctl->err_inner = err; ctl->it_count = ctl->it_count + 1;
+    if (err < f.tol_inner) { hc->halt = 1; ctl->halted = 1; }
   }
 }
 

@@ -174,15 +174,23 @@ void enqueue_solve(QWk *w, double *rhs) { // _ldl_solve, linsys.c:309-316
   w->ldl.enqueue([&](auto kern, int grid, int block, size_t lds, auto... a) { hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, w->stream, a...); }, rhs, w->lp_ctl, w->NB);
 }
 
+// the device raised the halt flag at the inner exit: lower it (and its mirror) for the next inner loop
+int clear_halt(QWk *w) {
+  HIP_OK(hipMemsetAsync(&w->lp_ctl->halt, 0, sizeof(int), w->stream));
+  HIP_OK(hipMemsetAsync(&w->ctl.p->halted, 0, sizeof(int), w->stream));
+  w->hctl->halted = 0;
+  return 0;
+}
 int read_ctl(QWk *w) {
   HIP_OK(hipMemcpyAsync(w->hctl, w->ctl.p, sizeof(QCtl), hipMemcpyDeviceToHost, w->stream));
   HIP_OK(hipStreamSynchronize(w->stream));
   return 0;
 }
-void finalize(QWk *w, std::initializer_list<int> slots, std::initializer_list<int> both_halves) {
+void finalize(QWk *w, std::initializer_list<int> slots, std::initializer_list<int> both_halves, double tol_inner = -1.0) {
   QFin f; f.nslots = 0;
   for (int s : slots) { f.slots[f.nslots] = s; f.second_half[f.nslots] = 0; for (int bsl : both_halves) if (bsl == s) f.second_half[f.nslots] = 1; ++f.nslots; }
-  QLAUNCH(w, kq_finalize, 1, 1024, f, (const double *)w->part.p, w->NB, w->ctl.p);
+  if (tol_inner >= 0) { f.decide = 1; f.tol_inner = tol_inner; f.u_tau = w->u.p + w->MP + w->n; f.vo_tau = w->vo.p + w->MP + w->n; }
+  QLAUNCH(w, kq_finalize, 1, 1024, f, (const double *)w->part.p, w->NB, w->ctl.p, w->lp_ctl);
 }
 
 double adjust_barrier(QWk *w, const QResid &r) { // abip.c:994-1071
@@ -277,8 +285,8 @@ int abip_hip_qcp_cone_prox(int kind, double *x, const double *tmp, double lambda
   std::vector<int> hm = {0, len, kind};
   if (u.upload(hu, nullptr) || rel.upload(hr, nullptr) || meta.upload(hm, nullptr)) return -3;
   QCones C{meta.p, meta.p + 1, meta.p + 2, 1};
-  if (len > QC_BIG) hipLaunchKernelGGL(kq_cones<true>, dim3(1), dim3(QC_TB), 0, nullptr, C, 0, u.p, (const double *)rel.p, lambda, 0);
-  else hipLaunchKernelGGL(kq_cones<false>, dim3(1), dim3(BS), 0, nullptr, C, 0, u.p, (const double *)rel.p, lambda, 0);
+  if (len > QC_BIG) hipLaunchKernelGGL(kq_cones<true>, dim3(1), dim3(QC_TB), 0, nullptr, C, 0, u.p, (const double *)rel.p, lambda, 0, (const Ctl *)nullptr);
+  else hipLaunchKernelGGL(kq_cones<false>, dim3(1), dim3(BS), 0, nullptr, C, 0, u.p, (const double *)rel.p, lambda, 0, (const Ctl *)nullptr);
   const int rc = (hipMemcpy(x, u.p, sizeof(double) * len, hipMemcpyDeviceToHost) == hipSuccess && hipGetLastError() == hipSuccess) ? 0 : -4;
   u.release(); rel.release(); meta.release();
   return rc;
@@ -484,50 +492,67 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   };
   auto stop_now = [&](int ii) { return (double)k + 1 >= (double)st->max_admm_iters * st->max_ipm_iters || ii + 1 >= st->max_ipm_iters || (now_ms() - t0) > time_limit_left; };
 
+  const Ctl *hc = w->lp_ctl;
+  const bool batch_ok = !(getenv("ABIP_HIP_BATCH") && atoi(getenv("ABIP_HIP_BATCH")) == 0);
+  int seen = 0; // QCtl.it_count at the last control read
+  // one inner iteration (abip.c:1120-1160), everything on the stream; `timed` brackets the KKT solve with events
+  auto enqueue_iteration = [&](int kk, bool timed) {
+    // projection, abip.c:186-255
+    QLAUNCH(w, kq_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->r.p, w->p.p, st->rho_y, st->rho_x, dm, w->part.p, hc);
+    if (timed) (void)hipEventRecord(w->ev_a, w->stream);
+    enqueue_solve(w, w->p.p);
+    if (timed) (void)hipEventRecord(w->ev_b, w->stream);
+    QLAUNCH(w, kq_dots, w->NB, BS, (const double *)w->r.p, (const double *)w->p.p, st->rho_y, st->rho_x, dm, w->part.p, hc);
+    if (w->hasQ) QLAUNCH(w, kq_Qp, w->NB, BS, w->dQ.view(), (const double *)w->p.p, dm, w->part.p, hc);
+    QProxArgs pa;
+    pa.u = w->u.p; pa.v = w->v.p; pa.ut = w->ut.p; pa.rel = w->rel.p; pa.p = w->p.p; pa.r = w->r.p; pa.xkind = w->xkind.p;
+    pa.alpha = st->alpha; pa.lambda = w->mu / w->beta; pa.rho_x = st->rho_x; pa.rho_tau = st->rho_tau; pa.a_quad = w->a_quad; pa.iter_pos = kk > 0; pa.hasQ = w->hasQ;
+    QLAUNCH(w, kq_ut_prox, w->NB, BS, pa, dm, (const double *)w->part.p, w->NB, w->ctl.p, hc);
+    if (w->ncones) {
+      const double lam = (w->mu / w->beta) / st->rho_x;
+      if (w->nsmall) { QCones C{w->c_off.p, w->c_len.p, w->c_kind.p, w->nsmall}; QLAUNCH(w, kq_cones<false>, (w->nsmall + WAVES - 1) / WAVES, BS, C, 0, w->u.p, (const double *)w->rel.p, lam, w->MP, hc); }
+      if (w->ncones > w->nsmall) { QCones C{w->c_off.p, w->c_len.p, w->c_kind.p, w->ncones}; QLAUNCH(w, kq_cones<true>, w->ncones - w->nsmall, QC_TB, C, w->nsmall, w->u.p, (const double *)w->rel.p, lam, w->MP, hc); }
+    }
+    QLAUNCH(w, kq_dual, w->NB, BS, (const double *)w->u.p, (const double *)w->rel.p, w->v.p, w->vo.p, st->rho_y, st->rho_x, st->rho_tau, dm, hc);
+    // inner stopping test, qcp_config.c:518-557 (the tau entries and the comparison with tol_inner happen in kq_finalize)
+    QLAUNCH(w, kq_inner_A, w->NB, BS, w->dA.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->bd.p, w->Ax.p, dm, w->part.p, hc);
+    QLAUNCH(w, kq_inner_At, w->NB, BS, w->dAt.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->cd.p, w->ATy.p, w->Qx.p, w->hasQ ? 0 : 1, dm, w->part.p, hc);
+    if (w->hasQ) QLAUNCH(w, kq_inner_Q, w->NB, BS, w->dQ.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->cd.p, (const double *)w->ATy.p, w->Qx.p, dm, w->part.p, hc);
+    finalize(w, {Q_D1, Q_D2, Q_D3, Q_E1, Q_E2, Q_E3}, {Q_D1, Q_D3, Q_E1, Q_E2, Q_E3}, tol_inner);
+  };
+
   for (i = 0; i < st->max_ipm_iters && !finished; ++i) {
-    for (j = 0; j < st->max_admm_iters; ++j) {
-      // projection, abip.c:186-255
-      QLAUNCH(w, kq_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->r.p, w->p.p, st->rho_y, st->rho_x, dm, w->part.p);
-      (void)hipEventRecord(w->ev_a, w->stream);
-      enqueue_solve(w, w->p.p);
-      (void)hipEventRecord(w->ev_b, w->stream);
-      QLAUNCH(w, kq_dots, w->NB, BS, (const double *)w->r.p, (const double *)w->p.p, st->rho_y, st->rho_x, dm, w->part.p);
-      if (w->hasQ) QLAUNCH(w, kq_Qp, w->NB, BS, w->dQ.view(), (const double *)w->p.p, dm, w->part.p);
-      QProxArgs pa;
-      pa.u = w->u.p; pa.v = w->v.p; pa.ut = w->ut.p; pa.rel = w->rel.p; pa.p = w->p.p; pa.r = w->r.p; pa.xkind = w->xkind.p;
-      pa.alpha = st->alpha; pa.lambda = w->mu / w->beta; pa.rho_x = st->rho_x; pa.rho_tau = st->rho_tau; pa.a_quad = w->a_quad; pa.iter_pos = k > 0; pa.hasQ = w->hasQ;
-      QLAUNCH(w, kq_ut_prox, w->NB, BS, pa, dm, (const double *)w->part.p, w->NB, w->ctl.p);
-      if (w->ncones) {
-        const double lam = (w->mu / w->beta) / st->rho_x;
-        if (w->nsmall) { QCones C{w->c_off.p, w->c_len.p, w->c_kind.p, w->nsmall}; QLAUNCH(w, kq_cones<false>, (w->nsmall + WAVES - 1) / WAVES, BS, C, 0, w->u.p, (const double *)w->rel.p, lam, w->MP); }
-        if (w->ncones > w->nsmall) { QCones C{w->c_off.p, w->c_len.p, w->c_kind.p, w->ncones}; QLAUNCH(w, kq_cones<true>, w->ncones - w->nsmall, QC_TB, C, w->nsmall, w->u.p, (const double *)w->rel.p, lam, w->MP); }
+    int batch = 2;
+    for (j = 0; j < st->max_admm_iters;) {
+      // Between residual checks the host has nothing to decide but the inner exit, and that is found on the device: enqueue a
+      // batch of iterations and read the control block once (the iterations behind the exit fall through on the halt flag).
+      int nb = 1;
+      if (batch_ok && r.error_ratio > 8) {
+        const int to_check = st->inner_check_period - (j % st->inner_check_period); // the iteration with (j+1) % period == 0 closes a batch
+        nb = std::max(1, std::min(std::min(batch, to_check), (int)st->max_admm_iters - j));
       }
-      QLAUNCH(w, kq_dual, w->NB, BS, (const double *)w->u.p, (const double *)w->rel.p, w->v.p, w->vo.p, st->rho_y, st->rho_x, st->rho_tau, dm);
-      k += 1;
-      // inner stopping test, qcp_config.c:518-557
-      QLAUNCH(w, kq_inner_A, w->NB, BS, w->dA.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->bd.p, w->Ax.p, dm, w->part.p);
-      QLAUNCH(w, kq_inner_At, w->NB, BS, w->dAt.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->cd.p, w->ATy.p, w->Qx.p, w->hasQ ? 0 : 1, dm, w->part.p);
-      if (w->hasQ) QLAUNCH(w, kq_inner_Q, w->NB, BS, w->dQ.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->cd.p, (const double *)w->ATy.p, w->Qx.p, dm, w->part.p);
-      finalize(w, {Q_D1, Q_D2, Q_D3, Q_E1, Q_E2, Q_E3}, {Q_D1, Q_D3, Q_E1, Q_E2, Q_E3});
-      double tails[2];
-      if (hipMemcpyAsync(&tails[0], w->u.p + w->MP + n, sizeof(double), hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
-          hipMemcpyAsync(&tails[1], w->vo.p + w->MP + n, sizeof(double), hipMemcpyDeviceToHost, w->stream) != hipSuccess || read_ctl(w))
-        return bail("device error in the inner iteration");
+      for (int q = 0; q < nb; ++q) enqueue_iteration(k + q, q == 0);
+      if (read_ctl(w)) return bail("device error in the inner iteration");
       { float ms = 0.f; if (hipEventElapsedTime(&ms, w->ev_a, w->ev_b) == hipSuccess) { w->lin_ms += ms; w->lin_n++; } }
-      const double *o = w->hctl->out;
-      const double tau = tails[0], vot = tails[1];
-      const double qut = -o[Q_D1] / tau + o[Q_D2] - o[Q_D3];
-      const double e1 = o[Q_E1] + (qut - vot) * (qut - vot), e2 = o[Q_E2] + qut * qut, e3 = o[Q_E3];
-      const double err_inner = std::sqrt(e1) / (1 + std::sqrt(e2) + std::sqrt(e3));
-      if (err_inner < tol_inner || (now_ms() - t0) > time_limit_left) break;
-      if ((j + 1) % st->inner_check_period == 0 || r.error_ratio <= 8) {
+      const int ran = w->hctl->it_count - seen;
+      seen = w->hctl->it_count;
+      if (ran < 1 || ran > nb) return bail("device error in the inner iteration");
+      k += ran;
+      const int j_last = j + ran - 1;
+      const bool halted = w->hctl->halted != 0;
+      if (halted && clear_halt(w)) return bail("device error in the inner iteration");
+      if (halted || (now_ms() - t0) > time_limit_left) { j = j_last; break; } // err_inner < tol_inner, abip.c:1147
+      if ((j_last + 1) % st->inner_check_period == 0 || r.error_ratio <= 8) {
         if (calc_residuals(w, r, i, k)) return bail("device error in calc_residuals");
         if ((info->status_val = has_converged(w, r, i, k)) != 0 || stop_now(i)) {
           if (get_solution(i, k)) return bail("device error in get_solution");
           finished = true;
+          j = j_last;
           break;
         }
       }
+      j = j_last + 1;
+      batch = std::min(32, batch * 2);
     }
     if (finished) break;
     if (w->sparsity || (i + 1) % st->outer_check_period == 0) {

@@ -161,3 +161,21 @@ def test_cone_kernel_matches_the_oracle_on_every_branch(gpu, pq):
         assert np.max(np.abs(got - want)) <= 1e-13 * (1 + np.max(np.abs(want))), (kind, t.size, t[:2], lam)
         n_big += t.size > 2048
     assert n_big >= 8
+
+
+@pytest.mark.parametrize("case", ["toy", "lasso_mid"])
+def test_conic_batched_iterations_equal_stepwise(gpu, case, monkeypatch):
+    """The inner exit test is evaluated by kq_finalize and iterations are enqueued in batches between residual checks; one control
+    read per iteration (ABIP_HIP_BATCH=0) must give the same run bit for bit."""
+    data, K = toy() if case == "toy" else lasso_socp(400, 1500, 3, density=0.02)
+    runs = []
+    for mode in ("batched", "stepwise"):
+        if mode == "stepwise":
+            monkeypatch.setenv("ABIP_HIP_BATCH", "0")
+        else:
+            monkeypatch.delenv("ABIP_HIP_BATCH", raising=False)
+        sol, info = gpu.abip_qcp(data, K, eps_all(1e-6))
+        runs.append((info["admm_iter"], info["ipm_iter"], info["pobj"], sol["x"].copy(), sol["y"].copy(), sol["s"].copy()))
+    assert runs[0][:3] == runs[1][:3]
+    for a2, b2 in zip(runs[0][3:], runs[1][3:]):
+        assert np.array_equal(a2, b2)
