@@ -48,6 +48,7 @@ enum Slot : int {
   S_XS, S_XMIN,                   // sum u_i v_i, min u_i v_i       (abip.c:962-965)
   S_A0, S_A1, S_A2, S_A3, S_A4,   // BB search: utut, utv, uu, vv, uv (adaptive.c:170-174)
   S_T0, S_T1,                     // scratch dots
+  S_ZZ, S_ZP, S_TT,               // sharded PCG: z'z, z'p_old (summed over ranks), ||A'p||^2 (replicated) -> p'Gp without a second collective
   S_COUNT
 };
 
@@ -66,6 +67,7 @@ struct Ctl {
   double metric;   // min(sqrt(Qres)/norm, sqrt(Qres_avg)/norm_avg)
   int avg_crit;    // 1: the averaged iterate gave the smaller value
   int it_count;    // ADMM iterations completed since abip_init (never reset)
+  double pp_cur;   // sharded PCG: ||p||^2 of the current direction, by the recurrence ||z + beta p||^2 = z'z + 2 beta z'p + beta^2 ||p||^2
 };
 
 __device__ __forceinline__ double wave_sum(double x) {

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(BS) void k_cg_init_At(Csr At /* rows = columns of A
       [&](int row, double(&acc)[1]) { tmp[row] = acc[0]; });
 }
 
+template <bool DIST> // DIST: also the partial of z'z (= ||p||^2 of the first direction) for the sharded path
 __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rhs /* l-vector: y in/out (x0), x read */,
                                                   const double *__restrict__ tmp, const double *__restrict__ s,
                                                   const double *__restrict__ Minv, double *__restrict__ r, double *__restrict__ z,
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rh
   ABIP_GATE_HALT(ctl);
   __shared__ double lds[2 * CHUNK];
   __shared__ int lptr[CHUNK + 1];
-  __shared__ double sm[2 * WAVES];
+  __shared__ double sm[3 * WAVES];
   double bn[1];
   const int rs[1] = {S_BN};
   get_scalars<1>(part, rs, nb, bn, sm, gs);
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rh
     ctl->cg_done = 0;
   }
   const double *bx = rhs + d.MP;
-  double acc2[2] = {0.0, 0.0};
+  double acc2[3] = {0.0, 0.0, 0.0};
   if (s) {
     spmv_stream<2>(
         A, lds, lptr, sm, [&](int c, double a, double(&pr)[2]) { pr[0] = a * bx[c]; pr[1] = a * tmp[c]; },
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rh
           const double zi = ri * Minv[i];
           rhs[i] = si; r[i] = ri; z[i] = zi; p[i] = zi;
           acc2[0] += ri * ri; acc2[1] += zi * ri;
+          if (DIST) acc2[2] += zi * zi;
         });
   } else {
     spmv_stream<1>(
@@ -139,10 +141,17 @@ __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rh
           const double zi = ri * Minv[i];
           rhs[i] = 0.0; r[i] = ri; z[i] = zi; p[i] = zi;
           acc2[0] += ri * ri; acc2[1] += zi * ri;
+          if (DIST) acc2[2] += zi * zi;
         });
   }
-  const int ws[2] = {S_RR0, S_ZR0};
-  write_partials<2>(part, ws, acc2, sm);
+  if (DIST) {
+    const int ws[3] = {S_RR0, S_ZR0, S_ZZ};
+    write_partials<3>(part, ws, acc2, sm);
+  } else {
+    const int ws[2] = {S_RR0, S_ZR0};
+    double a2[2] = {acc2[0], acc2[1]};
+    write_partials<2>(part, ws, a2, sm);
+  }
 }
 
 // Convergence test shared by the first SpMV of an iteration and by the post-solve kernel.
@@ -213,32 +222,50 @@ __global__ __launch_bounds__(BS) void k_cg_spmv_A(Csr A, const double *__restric
 }
 
 // x += alpha p ; r -= alpha Gp ; z = M r ; S_RR, S_ZR (next parity)          (indirect.c:371-385)
+template <bool DIST> // DIST (sharded): p'Gp = rho ||p||^2 + ||A'p||^2 from replicated data, plus the partials of z'z and z'p
 __global__ __launch_bounds__(BS) void k_cg_update(double *__restrict__ x, double *__restrict__ r, double *__restrict__ z,
                                                   const double *__restrict__ p, const double *__restrict__ Gp,
-                                                  const double *__restrict__ Minv, int m, double *part, int nb, Ctl *ctl, const double *gs) {
+                                                  const double *__restrict__ Minv, int m, double rho, double *part, int nb, Ctl *ctl, const double *gs) {
   ABIP_GATE_HALT(ctl);
   if (ctl->cg_done) return;
-  __shared__ double sm[2 * WAVES];
+  __shared__ double sm[4 * WAVES];
   double pg[1];
-  const int rs[1] = {S_PG};
-  get_scalars<1>(part, rs, nb, pg, sm, gs);
+  if (DIST) {
+    const int rs[1] = {S_TT};
+    read_partials<1>(part, rs, nb, pg, sm); // ||A'p||^2: every rank holds the same A'p and reduces it on the same grid
+    pg[0] += rho * ctl->pp_cur;
+  } else {
+    const int rs[1] = {S_PG};
+    get_scalars<1>(part, rs, nb, pg, sm, gs);
+  }
   const int it = ctl->it_cur;
   const double alpha = ctl->zr_cur / pg[0];
-  double acc[2] = {0.0, 0.0};
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
   for (int i = blockIdx.x * BS + threadIdx.x; i < m; i += gridDim.x * BS) {
-    x[i] += alpha * p[i];
+    const double pi = p[i];
+    x[i] += alpha * pi;
     const double ri = r[i] - alpha * Gp[i];
     const double zi = ri * Minv[i];
     r[i] = ri; z[i] = zi;
     acc[0] += ri * ri; acc[1] += zi * ri;
+    if (DIST) { acc[2] += zi * zi; acc[3] += zi * pi; }
   }
   const int par = (it + 1) & 1;
-  const int ws[2] = {S_RR0 + par, S_ZR0 + par};
-  write_partials<2>(part, ws, acc, sm);
   // this kernel runs on a smaller grid than the SpMVs (dispatching NB workgroups costs more than its work): the
   // partial entries of the workgroups that do not exist are zeroed so that consumers can keep summing nb entries
-  if (threadIdx.x == 0)
-    for (int e = blockIdx.x + gridDim.x; e < nb; e += gridDim.x) { part[ws[0] * MAXNB + e] = 0.0; part[ws[1] * MAXNB + e] = 0.0; }
+  if (DIST) {
+    const int ws[4] = {S_RR0 + par, S_ZR0 + par, S_ZZ, S_ZP};
+    write_partials<4>(part, ws, acc, sm);
+    if (threadIdx.x == 0)
+      for (int e = blockIdx.x + gridDim.x; e < nb; e += gridDim.x)
+        for (int q = 0; q < 4; ++q) part[ws[q] * MAXNB + e] = 0.0;
+  } else {
+    const int ws[2] = {S_RR0 + par, S_ZR0 + par};
+    double a2[2] = {acc[0], acc[1]};
+    write_partials<2>(part, ws, a2, sm);
+    if (threadIdx.x == 0)
+      for (int e = blockIdx.x + gridDim.x; e < nb; e += gridDim.x) { part[ws[0] * MAXNB + e] = 0.0; part[ws[1] * MAXNB + e] = 0.0; }
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) ctl->cg_it = it + 1;
 }
 
@@ -625,8 +652,10 @@ __global__ __launch_bounds__(BS) void k_adapt_vprev(double *vp, const double *up
 // A_g' y_g is a PARTIAL n-vector that the host all-reduces (RCCL) together with the packed scalars in `gs`.
 // ---------------------------------------------------------------------------------------------
 // partials -> local scalars gs[slot] (one wavefront per slot); the all-reduce then sums gs over the ranks
+// out = M x (overwrites), gated: mode 0 always, 1 while the PCG runs, 2 once it has converged
 struct FoldArgs { int nslots; int slots[40]; };
-__global__ __launch_bounds__(BS) void k_fold(FoldArgs f, const double *part, int nb, double *gs) {
+// partials -> one number per slot in gs (the packed scalars that ride along with an all-reduce); one wavefront per slot
+__device__ __forceinline__ void fold_slots(const FoldArgs &f, const double *part, int nb, double *gs) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int PER = MAXNB / 64;
   for (int s = wave; s < f.nslots; s += WAVES) {
@@ -644,7 +673,22 @@ __global__ __launch_bounds__(BS) void k_fold(FoldArgs f, const double *part, int
     if (lane == 0) gs[slot] = acc;
   }
 }
-// out = M x (overwrites), gated: mode 0 always, 1 while the PCG runs, 2 once it has converged
+__global__ __launch_bounds__(BS) void k_fold(FoldArgs f, const double *part, int nb, double *gs) { fold_slots(f, part, nb, gs); }
+// out = M x on the rows of this rank; FOLD: the last workgroup also folds the partials of the previous kernel into gs
+template <bool FOLD>
+__global__ __launch_bounds__(BS) void k_spmv_set_t(Csr M, const double *__restrict__ x, double *__restrict__ out, int mode, const Ctl *ctl,
+                                                   FoldArgs f, const double *part, int nb, double *gs) {
+  ABIP_GATE_HALT(ctl);
+  if (FOLD && blockIdx.x == gridDim.x - 1) fold_slots(f, part, nb, gs); // (before the gates: the convergence test needs the sums)
+  if (mode == 1 && ctl->cg_done) return;
+  if (mode == 2 && !ctl->cg_done) return;
+  __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
+  __shared__ double sm[WAVES];
+  spmv_stream<1>(
+      M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
+      [&](int row, double(&acc)[1]) { out[row] = acc[0]; });
+}
 __global__ __launch_bounds__(BS) void k_spmv_set(Csr M, const double *__restrict__ x, double *__restrict__ out, int mode, const Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
   if (mode == 1 && ctl->cg_done) return;
@@ -659,7 +703,7 @@ __global__ __launch_bounds__(BS) void k_spmv_set(Csr M, const double *__restrict
 // After the all-reduce of [A_g'z_g | rr | zr]: the convergence decision and beta (identical on every rank) and, when
 // `vec`, tmp = T + beta*tmp  (k_cg_spmv_At's second half).  vec == 0: decision only (end of a chunk).
 __global__ __launch_bounds__(BS) void k_dist_cg_step(const double *__restrict__ T, double *__restrict__ tmp, int n, int max_its, int vec,
-                                                     const double *gs, Ctl *ctl) {
+                                                     const double *gs, double *part, Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
   if (ctl->cg_done) return;
   int it; double zr;
@@ -668,10 +712,22 @@ __global__ __launch_bounds__(BS) void k_dist_cg_step(const double *__restrict__ 
     return;
   }
   if (!vec) return;
+  __shared__ double sm[WAVES];
   const int par = it & 1;
   const double beta = (it == 0) ? 0.0 : zr / ctl->zr_hist[par ^ 1];
-  if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->it_cur = it; ctl->beta_cur = beta; ctl->zr_cur = zr; ctl->zr_hist[par] = zr; }
-  for (int j = blockIdx.x * BS + threadIdx.x; j < n; j += gridDim.x * BS) tmp[j] = (it == 0) ? T[j] : T[j] + beta * tmp[j];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ctl->it_cur = it; ctl->beta_cur = beta; ctl->zr_cur = zr; ctl->zr_hist[par] = zr;
+    // ||p||^2 of the direction p = z + beta p_old about to be formed (z'z and z'p_old arrived summed with this all-reduce)
+    ctl->pp_cur = (it == 0) ? gs[S_ZZ] : gs[S_ZZ] + 2.0 * beta * gs[S_ZP] + beta * beta * ctl->pp_cur;
+  }
+  double acc[1] = {0.0};
+  for (int j = blockIdx.x * BS + threadIdx.x; j < n; j += gridDim.x * BS) {
+    const double t = (it == 0) ? T[j] : T[j] + beta * tmp[j];
+    tmp[j] = t;
+    acc[0] += t * t; // ||A'p||^2, replicated
+  }
+  const int ws[1] = {S_TT};
+  write_partials<1>(part, ws, acc, sm);
 }
 // rhs_x <- T - rhs_x with T = A'rhs_y all-reduced; S_DH partial (x part weighted: replicated)      (indirect.c:419-420, abip.c:560)
 __global__ __launch_bounds__(BS) void k_dist_post(const double *__restrict__ T, double *__restrict__ rhs, const double *__restrict__ h, Dims d,

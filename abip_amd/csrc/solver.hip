@@ -244,14 +244,15 @@ double cg_tol_factor(const W *w, abip_int iter) { // indirect.c:406-407
 
 // PCG pieces.  Single GPU: everything stays on the device (dev_kernels.h).  Multi-GPU (w->dist): the rank's A_g' x_g is
 // a partial n-vector in T[0:n); it is all-reduced together with the packed scalars in T[n:] (one collective), and the
-// second half of each step runs on the summed data.  Per CG iteration: 1 vector+scalar all-reduce, 1 scalar all-reduce.
+// second half of each step runs on the summed data.  Per CG iteration: ONE collective (vector + packed scalars): p'Gp is
+// rebuilt from rho ||p||^2 (recurrence on the summed z'z, z'p) + ||A'p||^2 (replicated), not reduced on its own.
 int enqueue_cg_begin(W *w, double *rhs, const double *warm, abip_int iter) {
   const Dims d = dims(w);
   w->cg_enq = 0;
   const Ctl *ctl = w->ctl.p;
   if (!w->dist) {
     if (warm) launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_At, w->NB, BS, w->dAt.view(), warm, w->cg_tmp.p, ctl);
-    launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_A, w->NB, BS, w->dA.view(), rhs, (const double *)w->cg_tmp.p, warm, (const double *)w->cg_M.p,
+    launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_A<false>, w->NB, BS, w->dA.view(), rhs, (const double *)w->cg_tmp.p, warm, (const double *)w->cg_M.p,
            w->cg_r.p, w->cg_z.p, w->cg_p.p, w->stgs->rho_y, cg_tol_factor(w, iter), d, w->part.p, w->NB, w->ctl.p, (const double *)nullptr);
     return 0;
   }
@@ -260,7 +261,7 @@ int enqueue_cg_begin(W *w, double *rhs, const double *warm, abip_int iter) {
     launch(w, ABIP_HIP_K_CG_EDGE, k_spmv_set, w->NB, BS, w->dAt.view(), warm, w->T.p, 0, ctl);
     if (allreduce_vec_and_scalars(w)) return -1;
   } else if (allreduce_scalars(w)) return -1;
-  launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_A, w->NB, BS, w->dA.view(), rhs, (const double *)w->T.p, warm, (const double *)w->cg_M.p,
+  launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_A<true>, w->NB, BS, w->dA.view(), rhs, (const double *)w->T.p, warm, (const double *)w->cg_M.p,
          w->cg_r.p, w->cg_z.p, w->cg_p.p, w->stgs->rho_y, cg_tol_factor(w, iter), d, w->part.p, w->NB, w->ctl.p, (const double *)w->gs);
   return 0;
 }
@@ -273,16 +274,22 @@ int enqueue_cg_chunk(W *w, double *rhs, int its) {
       launch(w, ABIP_HIP_K_SPMV_AT, k_cg_spmv_At, w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, w->cg_tmp.p,
              max_its, w->part.p, w->NB, w->ctl.p);
     } else {
-      enqueue_fold(w, {S_RR0, S_RR1, S_ZR0, S_ZR1});
-      launch(w, ABIP_HIP_K_SPMV_AT, k_spmv_set, w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, w->T.p, 1, (const Ctl *)w->ctl.p);
+      FoldArgs fo; fo.nslots = 0;
+      for (int sl : {S_RR0, S_RR1, S_ZR0, S_ZR1, S_ZZ, S_ZP}) fo.slots[fo.nslots++] = sl;
+      launch(w, ABIP_HIP_K_SPMV_AT, k_spmv_set_t<true>, w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, w->T.p, 1, (const Ctl *)w->ctl.p,
+             fo, (const double *)w->part.p, w->NB, w->gs);
       if (allreduce_vec_and_scalars(w)) return -1;
-      launch(w, ABIP_HIP_K_CG_VEC, k_dist_cg_step, w->NB, BS, (const double *)w->T.p, w->cg_tmp.p, (int)w->n, max_its, 1, (const double *)w->gs, w->ctl.p);
+      launch(w, ABIP_HIP_K_CG_VEC, k_dist_cg_step, w->NB, BS, (const double *)w->T.p, w->cg_tmp.p, (int)w->n, max_its, 1, (const double *)w->gs, w->part.p, w->ctl.p);
     }
     launch(w, ABIP_HIP_K_SPMV_A, k_cg_spmv_A, w->NB, BS, w->dA.view(), (const double *)w->cg_tmp.p, (const double *)w->cg_z.p, w->cg_p.p,
            w->cg_Gp.p, w->stgs->rho_y, w->part.p, (const Ctl *)w->ctl.p);
-    if (w->dist) { enqueue_fold(w, {S_PG}); if (allreduce_scalars(w)) return -1; }
-    launch(w, ABIP_HIP_K_CG_VEC, k_cg_update, gvec, BS, rhs, w->cg_r.p, w->cg_z.p, (const double *)w->cg_p.p, (const double *)w->cg_Gp.p,
-           (const double *)w->cg_M.p, (int)w->m, w->part.p, w->NB, w->ctl.p, (const double *)w->gs);
+    // sharded: p'Gp = rho ||p||^2 + ||A'p||^2 needs no collective of its own (k_dist_cg_step left both pieces behind)
+    if (w->dist)
+      launch(w, ABIP_HIP_K_CG_VEC, k_cg_update<true>, gvec, BS, rhs, w->cg_r.p, w->cg_z.p, (const double *)w->cg_p.p, (const double *)w->cg_Gp.p,
+             (const double *)w->cg_M.p, (int)w->m, w->stgs->rho_y, w->part.p, w->NB, w->ctl.p, (const double *)w->gs);
+    else
+      launch(w, ABIP_HIP_K_CG_VEC, k_cg_update<false>, gvec, BS, rhs, w->cg_r.p, w->cg_z.p, (const double *)w->cg_p.p, (const double *)w->cg_Gp.p,
+             (const double *)w->cg_M.p, (int)w->m, w->stgs->rho_y, w->part.p, w->NB, w->ctl.p, (const double *)w->gs);
   }
   w->ev_tag = -1;
   return 0;
@@ -295,7 +302,7 @@ int enqueue_cg_post(W *w, double *rhs) {
   // late convergence decision on the summed ||r||^2, then (only if converged) the back-substitution A'y
   enqueue_fold(w, {S_RR0, S_RR1, S_ZR0, S_ZR1});
   if (allreduce_scalars(w)) return -1;
-  launch(w, ABIP_HIP_K_CG_VEC, k_dist_cg_step, 1, BS, (const double *)w->T.p, w->cg_tmp.p, (int)w->n, (int)w->m_glob, 0, (const double *)w->gs, w->ctl.p);
+  launch(w, ABIP_HIP_K_CG_VEC, k_dist_cg_step, 1, BS, (const double *)w->T.p, w->cg_tmp.p, (int)w->n, (int)w->m_glob, 0, (const double *)w->gs, w->part.p, w->ctl.p);
   launch(w, ABIP_HIP_K_CG_EDGE, k_spmv_set, w->NB, BS, w->dAt.view(), (const double *)rhs, w->T.p, 2, (const Ctl *)w->ctl.p);
   if (allreduce_vec_and_scalars(w)) return -1;
   launch(w, ABIP_HIP_K_CG_EDGE, k_dist_post, w->NB, BS, (const double *)w->T.p, rhs, (const double *)w->h.p, dims(w), w->xwt, w->part.p, (const Ctl *)w->ctl.p);
