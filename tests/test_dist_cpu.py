@@ -13,33 +13,36 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def pcg_kkt(A_rows, rhs_y, rhs_x, rho, tol, allreduce, m_glob):
-    """indirect.c:393-434 / 321-391 on a row block: returns (y_block, x, iterations)."""
+    """indirect.c:393-434 / 321-391 on a row block, with the communication pattern of the device path (solver.hip:
+    enqueue_cg_chunk): ONE collective per CG iteration carrying [A_g'z_g | r'r, z'r, z'z, z'p]; p'Gp is rebuilt as
+    rho ||p||^2 + ||A'p||^2 from the replicated A'p and the recurrence ||z + beta p||^2 = z'z + 2 beta z'p + beta^2 ||p||^2.
+    Returns (y_block, x, iterations, collectives)."""
+    n = A_rows.shape[1]
+    ncoll = 0
     M = 1.0 / np.asarray(A_rows.multiply(A_rows).sum(axis=1)).ravel()
     b = rhs_y + A_rows @ rhs_x
-
-    def G(p):
-        t = A_rows.T @ p
-        allreduce(t)                       # A'p = sum_g A_g' p_g
-        return A_rows @ t + rho * p
-
-    x = np.zeros_like(b); r = b.copy(); z = M * r; p = z.copy()
-    s = np.array([z @ r]); allreduce(s); ipzr = s[0]
+    x = np.zeros_like(b); r = b.copy(); z = M * r; p = np.zeros_like(b)
+    tmp = np.zeros(n); pp = 0.0; zr_old = 1.0
     its = 0
     for its in range(1, m_glob + 1):
-        Gp = G(p)
-        s = np.array([p @ Gp]); allreduce(s)
-        alpha = ipzr / s[0]
-        x += alpha * p; r -= alpha * Gp
-        s = np.array([r @ r]); allreduce(s)
-        if np.sqrt(s[0]) < tol:
+        pack = np.concatenate([A_rows.T @ z, [r @ r, z @ r, z @ z, z @ p]])
+        allreduce(pack); ncoll += 1
+        rr, zr, zz, zp = pack[n:]
+        if its > 1 and np.sqrt(rr) < tol:   # the stopping test of the previous update, seen one collective later
+            its -= 1
             break
+        beta = 0.0 if its == 1 else zr / zr_old
+        tmp = pack[:n] + beta * tmp          # A'(z + beta p), replicated
+        pp = zz + 2.0 * beta * zp + beta * beta * pp
+        p = z + beta * p
+        Gp = A_rows @ tmp + rho * p
+        alpha = zr / (rho * pp + tmp @ tmp)
+        x += alpha * p; r -= alpha * Gp
         z = M * r
-        s = np.array([z @ r]); allreduce(s)
-        p = z + (s[0] / ipzr) * p
-        ipzr = s[0]
+        zr_old = zr
     t = A_rows.T @ x
-    allreduce(t)
-    return x, t - rhs_x, its
+    allreduce(t); ncoll += 1
+    return x, t - rhs_x, its, ncoll
 
 
 def _worker(rank, world, port, q):
@@ -56,10 +59,10 @@ def _worker(rank, world, port, q):
     rng = np.random.default_rng(5)
     rhs = rng.standard_normal(A.shape[0] + A.shape[1])
     ar = lambda arr: dist.all_reduce(torch.from_numpy(arr))
-    y_blk, x, its = pcg_kkt(A[r0:r1], rhs[r0:r1], rhs[A.shape[0]:], 1e-3, 1e-10, ar, A.shape[0])
+    y_blk, x, its, ncoll = pcg_kkt(A[r0:r1], rhs[r0:r1], rhs[A.shape[0]:], 1e-3, 1e-10, ar, A.shape[0])
     y_full = np.zeros(A.shape[0]); y_full[r0:r1] = y_blk; ar(y_full)
     if rank == 0:
-        q.put((bounds.tolist(), y_full, x, its))
+        q.put((bounds.tolist(), y_full, x, its, ncoll))
     dist.destroy_process_group()
 
 
@@ -74,7 +77,7 @@ def test_sharded_pcg_equals_unsharded(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    bounds, y, x, its = q.get(timeout=120)
+    bounds, y, x, its, ncoll = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -89,8 +92,8 @@ def test_sharded_pcg_equals_unsharded(world):
     K = sp.bmat([[1e-3 * sp.identity(m), A], [A.T, -sp.identity(n)]], format="csc")
     ref = spla.spsolve(K, rhs)
     assert np.linalg.norm(np.concatenate([y, x]) - ref) / np.linalg.norm(ref) < 1e-7
-    y1, x1, its1 = pcg_kkt(A, rhs[:m], rhs[m:], 1e-3, 1e-10, lambda arr: None, m)     # one "rank", no communication
-    assert its == its1
+    y1, x1, its1, _ = pcg_kkt(A, rhs[:m], rhs[m:], 1e-3, 1e-10, lambda arr: None, m)     # one "rank", no communication
+    assert its == its1 and ncoll == its + 2          # one collective per CG iteration (+ the late stopping test, + the back-substitution)
     assert np.linalg.norm(y - y1) / np.linalg.norm(y1) < 1e-10 and np.linalg.norm(x - x1) / np.linalg.norm(x1) < 1e-10
 
 
