@@ -158,11 +158,14 @@ __device__ __forceinline__ int pow2_floor(int x) { return x <= 1 ? 1 : 1 << (31 
 // only the gather itself sits on the critical path of an iteration.
 // (Double-buffering the LDS stage to drop the second barrier was measured: 24 KB of LDS per workgroup costs more
 // occupancy than the barrier costs time -- 36 -> 44 us per SpMV on C4 -- so the stage is single-buffered.)
-template <int NV, class ProdF, class RowF>
+// `pre` (optional) runs once per workgroup AFTER the first block's descriptor, values and indices have been requested and before
+// anything is consumed: a kernel's own entry test (reduce the previous kernel's partials, decide "converged?") then overlaps with
+// those loads instead of preceding them.  It returns false to abandon the kernel; it may use sm and workgroup barriers.
+template <int NV, class ProdF, class RowF, class PreF>
 __device__ __forceinline__ void spmv_stream(const Csr M, double *lds /* NV*CHUNK */, int *lptr /* CHUNK+1 */, double *sm /* NV*WAVES */,
-                                            ProdF prod, RowF rowf) {
+                                            ProdF prod, RowF rowf, PreF pre) {
   int b = blockIdx.x;
-  if (b >= M.nrb) return;
+  if (b >= M.nrb) { (void)pre(); return; }
   int4 d = M.rbd[b];
   double a[4];
   int c[4];
@@ -178,6 +181,7 @@ __device__ __forceinline__ void spmv_stream(const Csr M, double *lds /* NV*CHUNK
     }
   };
   fetch(d, a, c);
+  if (!pre()) return;
   for (;;) {
     const int bn = b + gridDim.x;
     const bool has_next = bn < M.nrb;
@@ -243,6 +247,11 @@ __device__ __forceinline__ void spmv_stream(const Csr M, double *lds /* NV*CHUNK
 #pragma unroll
     for (int u = 0; u < 4; ++u) { a[u] = an[u]; c[u] = cn[u]; }
   }
+}
+
+template <int NV, class ProdF, class RowF>
+__device__ __forceinline__ void spmv_stream(const Csr M, double *lds, int *lptr, double *sm, ProdF prod, RowF rowf) {
+  spmv_stream<NV>(M, lds, lptr, sm, prod, rowf, [] { return true; });
 }
 
 } // namespace abip

@@ -180,23 +180,24 @@ __global__ __launch_bounds__(BS) void k_cg_spmv_At(Csr At, const double *__restr
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[2 * WAVES];
-  int it; double zr;
-  if (cg_converged(ctl, part, nb, max_its, sm, it, zr)) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->cg_done = 1;
-    return;
-  }
-  const int par = it & 1;
-  const double beta = (it == 0) ? 0.0 : zr / ctl->zr_hist[par ^ 1];
-  if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->it_cur = it; ctl->beta_cur = beta; ctl->zr_cur = zr; ctl->zr_hist[par] = zr; }
-  if (it == 0) {
-    spmv_stream<1>(
-        At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * z[c]; },
-        [&](int row, double(&acc)[1]) { tmp[row] = acc[0]; });
-  } else {
-    spmv_stream<1>(
-        At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * z[c]; },
-        [&](int row, double(&acc)[1]) { tmp[row] = acc[0] + beta * tmp[row]; });
-  }
+  double beta = 0.0;
+  bool first = true;
+  // the convergence test on the previous update's partials runs while the first row block's stream is in flight
+  auto pre = [&]() -> bool {
+    int it; double zr;
+    if (cg_converged(ctl, part, nb, max_its, sm, it, zr)) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) ctl->cg_done = 1;
+      return false;
+    }
+    const int par = it & 1;
+    first = (it == 0);
+    beta = first ? 0.0 : zr / ctl->zr_hist[par ^ 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->it_cur = it; ctl->beta_cur = beta; ctl->zr_cur = zr; ctl->zr_hist[par] = zr; }
+    return true;
+  };
+  spmv_stream<1>(
+      At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * z[c]; },
+      [&](int row, double(&acc)[1]) { tmp[row] = first ? acc[0] : acc[0] + beta * tmp[row]; }, pre);
 }
 
 // p <- z + beta p ; Gp = A tmp + rho p ; S_PG <- p'Gp            (indirect.c:214-219, 371)
