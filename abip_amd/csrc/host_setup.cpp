@@ -336,6 +336,42 @@ void level_sets(int N, TriHost &T, bool backward) {
 
 void set_tail_request(int t) { g_tail_request = t; }
 
+int host_solve(const LdlHost &F, std::vector<double> &b) {
+  const int N = F.N, t0 = F.t0, T = F.T;
+  if ((int)b.size() != N) return -1;
+  std::vector<double> x(N);
+  for (int k = 0; k < N; ++k) x[k] = b[F.P[k]];
+  auto sweep = [&](const TriHost &Tr) { // levels in order; position r of lev_rows owns [ptr[r], ptr[r+1])
+    for (size_t r = 0; r < Tr.lev_rows.size(); ++r) {
+      double acc = 0.0;
+      for (int q = Tr.ptr[r]; q < Tr.ptr[r + 1]; ++q) acc += Tr.val[q] * x[Tr.idx[q]];
+      x[Tr.lev_rows[r]] -= acc;
+    }
+  };
+  sweep(F.fwd);
+  std::vector<double> D(F.D);
+  if (T > 0) { // dense LDL' of the Schur complement, then the two triangular solves of the tail (the device applies inv(L22) instead)
+    std::vector<double> S(F.S);
+    for (int c = 0; c < T; ++c) {
+      const double d = S[(size_t)c * T + c];
+      if (d == 0.0) return -2;
+      D[t0 + c] = d;
+      for (int r = c + 1; r < T; ++r) S[(size_t)r * T + c] /= d;
+      for (int r = c + 1; r < T; ++r) {
+        const double lr = S[(size_t)r * T + c] * d;
+        for (int cc = c + 1; cc <= r; ++cc) S[(size_t)r * T + cc] -= lr * S[(size_t)cc * T + c];
+      }
+    }
+    for (int r = 0; r < T; ++r) { double acc = 0.0; for (int c = 0; c < r; ++c) acc += S[(size_t)r * T + c] * x[t0 + c]; x[t0 + r] -= acc; }
+    for (int r = 0; r < T; ++r) x[t0 + r] /= D[t0 + r];
+    for (int r = T - 1; r >= 0; --r) { double acc = 0.0; for (int c = r + 1; c < T; ++c) acc += S[(size_t)c * T + r] * x[t0 + c]; x[t0 + r] -= acc; }
+  }
+  for (int k = 0; k < t0; ++k) x[k] /= D[k];
+  sweep(F.bwd);
+  for (int k = 0; k < N; ++k) b[F.P[k]] = x[k];
+  return 0;
+}
+
 int factor_kkt(const ABIPMatrix *A, double rho_y, LdlHost &out) {
   const int m = (int)A->m, n = (int)A->n, N = m + n;
   const long nnzA = (long)A->p[n];

@@ -50,6 +50,9 @@ struct LdlHost {
 };
 // override the tail choice (tests): -2 = environment / automatic, -1 automatic, 0 none, T > 0 forced
 void set_tail_request(int t);
+// Host-only reference solve with a factor as the device would use it (level-ordered head, Schur complement factored densely on
+// the host instead of the device): b <- K^-1 b in pivot order.  For the CPU tests of the ordering / numeric / tail-split code.
+int host_solve(const LdlHost &F, std::vector<double> &b);
 int factor_kkt(const ABIPMatrix *A, double rho_y, LdlHost &out);
 // the same for any symmetric quasi-definite matrix given by its upper triangle in CSC form (QCP KKT, qcp_config.c:699-748)
 int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, const std::vector<double> &Kx, LdlHost &out);

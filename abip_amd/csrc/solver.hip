@@ -1439,6 +1439,23 @@ abip_float abip_hip_get_scalar(ABIPWork *w, const char *name) {
   return NAN;
 }
 
+// pure host code: order + factor K = [[rho I, A],[A', -I]] the way abip_init does (tail = -1 automatic, 0 none, T forced), solve
+// K z = rhs with it on the host and return the factor's shape; rhs (m+n) is overwritten with z
+int abip_hip_host_factor_solve(const ABIPMatrix *A, double rho_y, int tail, double *rhs, double *stats8) {
+  if (!A || !rhs || !stats8) return -1;
+  host::LdlHost F;
+  host::set_tail_request(tail);
+  const int rc = host::factor_kkt(A, rho_y, F);
+  host::set_tail_request(-2);
+  if (rc < 0) return -2;
+  std::vector<double> b(rhs, rhs + F.N);
+  if (host::host_solve(F, b)) return -3;
+  std::copy(b.begin(), b.end(), rhs);
+  stats8[0] = F.N; stats8[1] = (double)F.lnnz; stats8[2] = F.T; stats8[3] = (double)F.fwd.lev_ptr.size() - 1; stats8[4] = (double)F.bwd.lev_ptr.size() - 1;
+  stats8[5] = (double)F.fwd.idx.size(); stats8[6] = 0; stats8[7] = 0;
+  return 0;
+}
+
 int abip_hip_dist_partition(const ABIPMatrix *A, int world, abip_int *bounds) { // pure host code
   if (!A || !bounds || world < 1 || A->m < world) return -1;
   const abip_int mg = A->m, nnz = A->p[A->n];

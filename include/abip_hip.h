@@ -68,6 +68,12 @@ int abip_hip_dist_init_callback(int rank, int world, abip_hip_allreduce_fn fn, v
 void abip_hip_dist_finalize(void);
 /* Row ranges the sharded path uses: bounds[g] .. bounds[g+1] are rank g's rows (world+1 entries out).  Pure host code. */
 int abip_hip_dist_partition(const ABIPMatrix *A, int world, abip_int *bounds);
+
+/* Pure host code (no device needed; CPU tests of the set-up path): order and factor K = [[rho_y I, A],[A', -I]] as abip_init does
+ * for the direct back-end (reference: factorize, linsys/direct.c:218-270) with the dense tail chosen automatically (tail = -1),
+ * disabled (0) or forced (T), complete the factorisation on the host and overwrite rhs (m+n) with K^-1 rhs.
+ * stats8 = { N, nnz(L), T, forward levels, backward levels, nnz of the sparse head, 0, 0 }.  0 on success. */
+int abip_hip_host_factor_solve(const ABIPMatrix *A, double rho_y, int tail, double *rhs, double *stats8);
 /* this rank's row range [row0, row1) of the last abip_init (0, m on a single GPU) */
 void abip_hip_dist_rows(ABIPWork *w, abip_int *row0, abip_int *row1);
 
