@@ -66,7 +66,7 @@ EXPORTS = (
     "abip_hip_accum_by_A", "abip_hip_accum_by_Atrans", "abip_hip_kkt_solve", "abip_hip_get_vector",
     "abip_hip_get_scalar", "abip_hip_profile_enable", "abip_hip_profile_read", "abip_hip_sync",
     "abip_hip_dist_get_unique_id", "abip_hip_dist_init_rccl", "abip_hip_dist_init_callback", "abip_hip_dist_finalize",
-    "abip_hip_dist_partition", "abip_hip_dist_rows", "abip_hip_host_factor_solve",
+    "abip_hip_dist_partition", "abip_hip_dist_rows", "abip_hip_host_factor_solve", "abip_hip_host_normalize_A",
     "abip_qcp", "abip_qcp_set_default_settings", "abip_hip_qcp_last_stats", "abip_hip_qcp_cone_prox",
 )
 

@@ -1456,6 +1456,15 @@ int abip_hip_host_factor_solve(const ABIPMatrix *A, double rho_y, int tail, doub
   return 0;
 }
 
+// pure host code: ABIP(_normalize_A) as abip_init applies it (A scaled in place; D has m entries, E has n, means = {row, col})
+int abip_hip_host_normalize_A(ABIPMatrix *A, const ABIPSettings *stgs, double *D, double *E, double *means2) {
+  if (!A || !stgs || !D || !E || !means2) return -1;
+  std::vector<double> d, e;
+  host::normalize_A(A, stgs, d, e, &means2[0], &means2[1]);
+  std::copy(d.begin(), d.end(), D); std::copy(e.begin(), e.end(), E);
+  return 0;
+}
+
 int abip_hip_dist_partition(const ABIPMatrix *A, int world, abip_int *bounds) { // pure host code
   if (!A || !bounds || world < 1 || A->m < world) return -1;
   const abip_int mg = A->m, nnz = A->p[A->n];

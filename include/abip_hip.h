@@ -74,6 +74,9 @@ int abip_hip_dist_partition(const ABIPMatrix *A, int world, abip_int *bounds);
  * disabled (0) or forced (T), complete the factorisation on the host and overwrite rhs (m+n) with K^-1 rhs.
  * stats8 = { N, nnz(L), T, forward levels, backward levels, nnz of the sparse head, 0, 0 }.  0 on success. */
 int abip_hip_host_factor_solve(const ABIPMatrix *A, double rho_y, int tail, double *rhs, double *stats8);
+/* Pure host code: ABIP(_normalize_A) (linsys/common.c:150-565) exactly as abip_init applies it -- A is scaled in place, D (m) and E (n)
+ * receive the scaling vectors, means2 the mean row / column norms of the scaled matrix.  0 on success. */
+int abip_hip_host_normalize_A(ABIPMatrix *A, const ABIPSettings *stgs, double *D, double *E, double *means2);
 /* this rank's row range [row0, row1) of the last abip_init (0, m on a single GPU) */
 void abip_hip_dist_rows(ABIPWork *w, abip_int *row0, abip_int *row1);
 

@@ -68,3 +68,32 @@ def test_tail_removes_the_sequential_levels_and_fill_is_sane():
     import scipy.sparse.linalg as spla
     lu = spla.splu(kkt(A, 1e-3).tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0)
     assert plain["lnnz"] <= 1.5 * lu.L.nnz                                                    # fill comparable to SuperLU's minimum-degree ordering
+
+
+@pytest.mark.parametrize("variant", ["default", "origin", "qp", "scale5", "ruiz3"])
+def test_host_scaling_is_bit_identical_to_the_oracle(oracle_built, variant):
+    """ABIP(_normalize_A) (linsys/common.c:150-565): the product's host code against the oracle's restatement (itself bit-exact
+    against the live reference, test_oracle_vs_ref.py) -- same D, E, scaled values and mean norms to the last bit."""
+    po = oracle_built
+    L = _lib.load()
+    A0 = sp.csc_matrix(problems.lp_staircase()[0]); A0.sort_indices()
+    m, n = A0.shape
+    kw = dict(default={}, origin=dict(origin_rescale=1, pc_ruiz_rescale=0), qp=dict(qp_rescale=1, pc_ruiz_rescale=0), scale5=dict(scale=5.0), ruiz3=dict(ruiz_iter=3))[variant]
+    # product
+    Ax = np.array(A0.data, dtype=np.float64, copy=True); Ai = A0.indices.astype(np.int64); Ap = A0.indptr.astype(np.int64)
+    D, E, means = np.zeros(m), np.zeros(n), np.zeros(2)
+    mat = _lib.ABIPMatrix(Ax.ctypes.data_as(_lib.PF), Ai.ctypes.data_as(_lib.PI), Ap.ctypes.data_as(_lib.PI), m, n)
+    st = _lib.ABIPSettings()
+    dd = _lib.ABIPData(m, n, C.pointer(mat), None, None, 0.0, C.pointer(st))
+    L.abip_set_default_settings(C.byref(dd))
+    for k, v in kw.items():
+        setattr(st, k, v)
+    L.abip_hip_host_normalize_A.restype = C.c_int
+    L.abip_hip_host_normalize_A.argtypes = [C.POINTER(_lib.ABIPMatrix), C.POINTER(_lib.ABIPSettings), _lib.PF, _lib.PF, _lib.PF]
+    assert L.abip_hip_host_normalize_A(C.byref(mat), C.byref(st), D.ctypes.data_as(_lib.PF), E.ctypes.data_as(_lib.PF), means.ctypes.data_as(_lib.PF)) == 0
+    # oracle
+    P = po.Problem(A0, np.zeros(m), np.zeros(n), **kw)
+    Do, Eo, mr, mc = np.zeros(m), np.zeros(n), np.zeros(1), np.zeros(1)
+    po.lib("oracle").orc_normalize_A(C.byref(P.mat), C.byref(P.stgs), po._f(Do), po._f(Eo), po._f(mr), po._f(mc))
+    assert np.array_equal(Ax, P.Ax) and np.array_equal(D, Do) and np.array_equal(E, Eo)
+    assert means[0] == mr[0] and means[1] == mc[0]
