@@ -98,12 +98,16 @@ __device__ __forceinline__ void block_sum(double (&v)[NS], double *sm /* NS*WAVE
 }
 
 template <int NS>
-__device__ __forceinline__ void write_partials(double *part, const int (&slots)[NS], double (&v)[NS], double *sm) {
+__device__ __forceinline__ void write_partials(double *part, const int (&slots)[NS], double (&v)[NS], double *sm, int vb) {
   block_sum<NS>(v, sm);
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) part[slots[s] * MAXNB + blockIdx.x] = v[s];
+    for (int s = 0; s < NS; ++s) part[slots[s] * MAXNB + vb] = v[s];
   }
+}
+template <int NS>
+__device__ __forceinline__ void write_partials(double *part, const int (&slots)[NS], double (&v)[NS], double *sm) {
+  write_partials<NS>(part, slots, v, sm, (int)blockIdx.x);
 }
 
 // Re-reduce the nb per-block partials of NS slots; all threads of all blocks get identical totals.
@@ -161,10 +165,12 @@ __device__ __forceinline__ int pow2_floor(int x) { return x <= 1 ? 1 : 1 << (31 
 // `pre` (optional) runs once per workgroup AFTER the first block's descriptor, values and indices have been requested and before
 // anything is consumed: a kernel's own entry test (reduce the previous kernel's partials, decide "converged?") then overlaps with
 // those loads instead of preceding them.  It returns false to abandon the kernel; it may use sm and workgroup barriers.
+// (vb, vgrid): the workgroup's index and count among the workgroups working on M -- blockIdx.x / gridDim.x unless one launch
+// carries two products side by side (k_q_both).
 template <int NV, class ProdF, class RowF, class PreF>
 __device__ __forceinline__ void spmv_stream(const Csr M, double *lds /* NV*CHUNK */, int *lptr /* CHUNK+1 */, double *sm /* NV*WAVES */,
-                                            ProdF prod, RowF rowf, PreF pre) {
-  int b = blockIdx.x;
+                                            ProdF prod, RowF rowf, PreF pre, int vb, int vgrid) {
+  int b = vb;
   if (b >= M.nrb) { (void)pre(); return; }
   int4 d = M.rbd[b];
   double a[4];
@@ -183,7 +189,7 @@ __device__ __forceinline__ void spmv_stream(const Csr M, double *lds /* NV*CHUNK
   fetch(d, a, c);
   if (!pre()) return;
   for (;;) {
-    const int bn = b + gridDim.x;
+    const int bn = b + vgrid;
     const bool has_next = bn < M.nrb;
     int4 dn = d;
     if (has_next) dn = M.rbd[bn];
@@ -249,9 +255,13 @@ __device__ __forceinline__ void spmv_stream(const Csr M, double *lds /* NV*CHUNK
   }
 }
 
+template <int NV, class ProdF, class RowF, class PreF>
+__device__ __forceinline__ void spmv_stream(const Csr M, double *lds, int *lptr, double *sm, ProdF prod, RowF rowf, PreF pre) {
+  spmv_stream<NV>(M, lds, lptr, sm, prod, rowf, pre, (int)blockIdx.x, (int)gridDim.x);
+}
 template <int NV, class ProdF, class RowF>
 __device__ __forceinline__ void spmv_stream(const Csr M, double *lds, int *lptr, double *sm, ProdF prod, RowF rowf) {
-  spmv_stream<NV>(M, lds, lptr, sm, prod, rowf, [] { return true; });
+  spmv_stream<NV>(M, lds, lptr, sm, prod, rowf, [] { return true; }, (int)blockIdx.x, (int)gridDim.x);
 }
 
 } // namespace abip

@@ -436,14 +436,10 @@ __global__ __launch_bounds__(BS) void k_avg_stats(UpdArgs a, Dims d, double *par
 // Residual SpMV pair: the inner stopping metric (abip.c:1976-1992) and the D/E-weighted outer
 // residuals (abip.c:407-413, 443-449) from ONE pass over each matrix; pr/dr are never stored.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BS) void k_q_A(Csr A, const double *__restrict__ uu /* l-vector */, const double *__restrict__ b,
-                                            const double *__restrict__ wD /* D_i/(sc_b*scale) or null */, Dims d, int slot0,
-                                            double *part, const Ctl *ctl) {
-  ABIP_GATE_HALT(ctl);
-  if (!ctl->cg_done) return;
-  __shared__ double lds[CHUNK];
-  __shared__ int lptr[CHUNK + 1];
-  __shared__ double sm[3 * WAVES];
+// bodies: (vb, vgrid) = this workgroup's index / count among those working on the product
+__device__ __forceinline__ void d_q_A(const Csr &A, const double *__restrict__ uu /* l-vector */, const double *__restrict__ b,
+                                      const double *__restrict__ wD /* D_i/(sc_b*scale) or null */, const Dims &d, int slot0, double *part,
+                                      double *lds, int *lptr, double *sm, int vb, int vgrid) {
   const double *x = uu + d.MP;
   const double tau = uu[d.MP + d.n];
   double acc3[3] = {0.0, 0.0, 0.0};
@@ -454,18 +450,14 @@ __global__ __launch_bounds__(BS) void k_q_A(Csr A, const double *__restrict__ uu
         double sc = wD ? wD[i] : 1.0;
         sc = sc * sc;
         acc3[0] += e * e; acc3[1] += (e * e) * sc; acc3[2] += (pri * pri) * sc;
-      });
+      },
+      [] { return true; }, vb, vgrid);
   const int ws[3] = {slot0, slot0 + 1, slot0 + 2};
-  write_partials<3>(part, ws, acc3, sm);
+  write_partials<3>(part, ws, acc3, sm, vb);
 }
-__global__ __launch_bounds__(BS) void k_q_At(Csr At, const double *__restrict__ uu, const double *__restrict__ vv, const double *__restrict__ c,
-                                             const double *__restrict__ wE /* E_j/(sc_c*scale) or null */, Dims d, int slot0,
-                                             double *part, const Ctl *ctl) {
-  ABIP_GATE_HALT(ctl);
-  if (!ctl->cg_done) return;
-  __shared__ double lds[CHUNK];
-  __shared__ int lptr[CHUNK + 1];
-  __shared__ double sm[3 * WAVES];
+__device__ __forceinline__ void d_q_At(const Csr &At, const double *__restrict__ uu, const double *__restrict__ vv, const double *__restrict__ c,
+                                       const double *__restrict__ wE /* E_j/(sc_c*scale) or null */, const Dims &d, int slot0, double *part,
+                                       double *lds, int *lptr, double *sm, int vb, int vgrid) {
   const double *s = vv + d.MP;
   const double tau = uu[d.MP + d.n];
   double acc3[3] = {0.0, 0.0, 0.0};
@@ -476,9 +468,41 @@ __global__ __launch_bounds__(BS) void k_q_At(Csr At, const double *__restrict__ 
         double sc = wE ? wE[j] : 1.0;
         sc = sc * sc;
         acc3[0] += e * e; acc3[1] += (e * e) * sc; acc3[2] += (drj * drj) * sc;
-      });
+      },
+      [] { return true; }, vb, vgrid);
   const int ws[3] = {slot0, slot0 + 1, slot0 + 2};
-  write_partials<3>(part, ws, acc3, sm);
+  write_partials<3>(part, ws, acc3, sm, vb);
+}
+__global__ __launch_bounds__(BS) void k_q_A(Csr A, const double *__restrict__ uu, const double *__restrict__ b, const double *__restrict__ wD, Dims d, int slot0,
+                                            double *part, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (!ctl->cg_done) return;
+  __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
+  __shared__ double sm[3 * WAVES];
+  d_q_A(A, uu, b, wD, d, slot0, part, lds, lptr, sm, (int)blockIdx.x, (int)gridDim.x);
+}
+__global__ __launch_bounds__(BS) void k_q_At(Csr At, const double *__restrict__ uu, const double *__restrict__ vv, const double *__restrict__ c,
+                                             const double *__restrict__ wE, Dims d, int slot0, double *part, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (!ctl->cg_done) return;
+  __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
+  __shared__ double sm[3 * WAVES];
+  d_q_At(At, uu, vv, c, wE, d, slot0, part, lds, lptr, sm, (int)blockIdx.x, (int)gridDim.x);
+}
+// both residual products of the stopping test in one launch: workgroups [0, nbA) take A u_x, the rest A'u_y (independent products,
+// each with its own nbA partial entries per slot)
+__global__ __launch_bounds__(BS) void k_q_both(Csr A, Csr At, const double *__restrict__ uu, const double *__restrict__ vv, const double *__restrict__ b,
+                                               const double *__restrict__ c, const double *__restrict__ wD, const double *__restrict__ wE, Dims d,
+                                               int slotA, int slotAt, int nbA, double *part, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (!ctl->cg_done) return;
+  __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
+  __shared__ double sm[3 * WAVES];
+  if ((int)blockIdx.x < nbA) d_q_A(A, uu, b, wD, d, slotA, part, lds, lptr, sm, (int)blockIdx.x, nbA);
+  else d_q_At(At, uu, vv, c, wE, d, slotAt, part, lds, lptr, sm, (int)blockIdx.x - nbA, (int)gridDim.x - nbA);
 }
 
 // One block: fold the listed slots into ctl->out[slot] and append the tau/kappa entries the host needs.

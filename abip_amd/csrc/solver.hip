@@ -435,10 +435,11 @@ int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty, bool decide =
   const int base[] = {S_NU, S_NV, S_CX, S_BY, S_QP, S_RP, S_NAX, S_QD, S_RD, S_NATY};
   const int extra[] = {S_NUA, S_NVA, S_CXA, S_BYA, S_QPA, S_RPA, S_NAXA, S_QDA, S_RDA, S_NATYA};
   for (int s : base) f.slots[ns++] = s;
-  launch(w, ABIP_HIP_K_QNORM, k_q_A, w->NB, BS, w->dA.view(), (const double *)w->u.p, (const double *)w->b.p, wD, d, (int)S_QP, w->part.p, ctl);
   if (!w->dist) {
-    launch(w, ABIP_HIP_K_QNORM, k_q_At, w->NB, BS, w->dAt.view(), (const double *)w->u.p, (const double *)w->v.p, (const double *)w->c.p, wE, d, (int)S_QD, w->part.p, ctl);
+    launch(w, ABIP_HIP_K_QNORM, k_q_both, 2 * w->NB, BS, w->dA.view(), w->dAt.view(), (const double *)w->u.p, (const double *)w->v.p, (const double *)w->b.p,
+           (const double *)w->c.p, wD, wE, d, (int)S_QP, (int)S_QD, w->NB, w->part.p, ctl);
   } else {
+    launch(w, ABIP_HIP_K_QNORM, k_q_A, w->NB, BS, w->dA.view(), (const double *)w->u.p, (const double *)w->b.p, wD, d, (int)S_QP, w->part.p, ctl);
     if (!T_holds_Aty) { // A'u_y differs from the A'u_t,y the back-substitution left in T (v_y != 0): one more partial + all-reduce
       launch(w, ABIP_HIP_K_QNORM, k_spmv_set, w->NB, BS, w->dAt.view(), (const double *)w->u.p, w->T.p, 2, ctl);
       if (allreduce_vec_and_scalars(w)) return -1;
@@ -447,10 +448,11 @@ int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty, bool decide =
            (int)S_QD, w->xwt, w->part.p, ctl);
   }
   if (avg_stats) {
-    launch(w, ABIP_HIP_K_QNORM, k_q_A, w->NB, BS, w->dA.view(), (const double *)w->u_avgc.p, (const double *)w->b.p, wD, d, (int)S_QPA, w->part.p, ctl);
     if (!w->dist) {
-      launch(w, ABIP_HIP_K_QNORM, k_q_At, w->NB, BS, w->dAt.view(), (const double *)w->u_avgc.p, (const double *)w->v_avgc.p, (const double *)w->c.p, wE, d, (int)S_QDA, w->part.p, ctl);
+      launch(w, ABIP_HIP_K_QNORM, k_q_both, 2 * w->NB, BS, w->dA.view(), w->dAt.view(), (const double *)w->u_avgc.p, (const double *)w->v_avgc.p, (const double *)w->b.p,
+             (const double *)w->c.p, wD, wE, d, (int)S_QPA, (int)S_QDA, w->NB, w->part.p, ctl);
     } else {
+      launch(w, ABIP_HIP_K_QNORM, k_q_A, w->NB, BS, w->dA.view(), (const double *)w->u_avgc.p, (const double *)w->b.p, wD, d, (int)S_QPA, w->part.p, ctl);
       launch(w, ABIP_HIP_K_QNORM, k_spmv_set, w->NB, BS, w->dAt.view(), (const double *)w->u_avgc.p, w->T.p, 2, ctl);
       if (allreduce_vec_and_scalars(w)) return -1;
       launch(w, ABIP_HIP_K_QNORM, k_dist_q, w->NB, BS, (const double *)w->T.p, (const double *)w->u_avgc.p, (const double *)w->v_avgc.p, (const double *)w->c.p, wE, d,
