@@ -513,7 +513,8 @@ struct FinArgs {
   int decide = 0, avg_stats = 0;
   double thr = 0.0, sentinel = 0.0; // gamma * mu; Qres_avg when no averaged statistics were taken (= max_admm_iters, abip.c:1957)
 };
-__global__ __launch_bounds__(1024) void k_finalize(FinArgs f, Dims d, const double *part, int nb, Ctl *ctl) {
+// (a device function so that the one-workgroup solve kernel of the NEXT iteration can run it as its prologue, dev_ldl.h / LpSolveFuse)
+__device__ __forceinline__ void d_finalize(const FinArgs &f, const Dims &d, const double *part, int nb, Ctl *ctl) {
   // one wavefront per slot, all loads of a lane in flight at once
   if (f.decide && (ctl->halt || !ctl->cg_done)) return; // cg_done: permanently set for the direct back-end
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -561,6 +562,7 @@ __global__ __launch_bounds__(1024) void k_finalize(FinArgs f, Dims d, const doub
     if (metric < f.thr) ctl->halt = 1;
   }
 }
+__global__ __launch_bounds__(1024) void k_finalize(FinArgs f, Dims d, const double *part, int nb, Ctl *ctl) { d_finalize(f, d, part, nb, ctl); }
 
 // ---------------------------------------------------------------------------------------------
 // outer-iteration element-wise kernels

@@ -266,7 +266,7 @@ static __global__ __launch_bounds__(TBS) void k_tri_thin(Tri T, double *x, int l
 // inverse permutation has scattered it.  Both run on all TBS threads of the single workgroup.
 struct NoFuse {
   static constexpr bool active = false;
-  __device__ void pre(double *, int) const {}
+  __device__ bool pre(double *, int) const { return true; } // false: leave the kernel
   __device__ void post(const double *, int) const {}
 };
 
@@ -293,7 +293,7 @@ static __global__ __launch_bounds__(TBS) void k_ldl_small(Tri F, Tri B, const in
   double *x = XL ? x_lds : xg;
   const int tid = threadIdx.x;
   if (FWD) {
-    if (Fuse::active) { fz.pre(b, tid); __syncthreads(); }
+    if (Fuse::active) { if (!fz.pre(b, tid)) return; __syncthreads(); }
     for (int j = tid; j < N; j += TBS) x[j] = b[Pmap[j]];
     __syncthreads();
     run_levels(F, x, s_lp, s_lg, tid, 0, F.nlev);

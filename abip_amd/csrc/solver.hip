@@ -319,7 +319,15 @@ struct LpSolveFuse {
   Dims d;
   double *part;
   int nb;
-  __device__ void pre(double *ut, int tid) const {
+  Ctl *ctl;
+  int has_fin;   // 1: first close the PREVIOUS iteration (its k_finalize, exit test included) -- one launch less per iteration
+  FinArgs fin;
+  __device__ bool pre(double *ut, int tid) const {
+    if (has_fin) {
+      d_finalize(fin, d, part, nb, ctl);
+      __syncthreads();
+      if (__hip_atomic_load(&ctl->halt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false; // the exit test held: this iteration does not run
+    }
     __shared__ double red[TBS / 64];
     double s = 0.0;
     for (int i = tid; i < nb; i += TBS) s += part[S_WG * MAXNB + i];
@@ -340,6 +348,7 @@ struct LpSolveFuse {
       ut[d.MP + j] = -t;
     }
     if (tid == 0) ut[tail] = tsum;
+    return true;
   }
   __device__ void post(const double *rhs, int tid) const {
     __shared__ double red[TBS / 64];
@@ -426,7 +435,7 @@ abip_int has_converged(const W *w, abip_int ipm_iter, abip_int admm_iter) { // a
 // ------------------------------------------------------------------------------------------------
 // statistics pass on the current iterate(s): the two residual SpMVs + finalise + control read
 // ------------------------------------------------------------------------------------------------
-int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty, bool decide = true) {
+int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty, bool decide = true, FinArgs *defer = nullptr) {
   const Dims d = dims(w);
   const Ctl *ctl = w->ctl.p;
   const double *wD = w->stgs->normalize ? w->wD.p : nullptr, *wE = w->stgs->normalize ? w->wE.p : nullptr;
@@ -470,6 +479,7 @@ int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty, bool decide =
     launch(w, ABIP_HIP_K_VEC, k_fold, 1, BS, fo, (const double *)w->part.p, w->NB, w->gs);
     if (allreduce_scalars(w)) return -1;
   }
+  if (defer) { *defer = f; return 0; } // the next iteration's solve kernel runs it as its prologue
   launch(w, ABIP_HIP_K_VEC, k_finalize, 1, 1024, f, d, (const double *)w->part.p, w->NB, w->ctl.p);
   return 0;
 }
@@ -489,13 +499,14 @@ UpdArgs upd_args(W *w, bool fuse_avg, bool avg_stats, abip_int j) {
 // one inner ADMM iteration (abip.c:2133-2173 up to and including the stopping metric); returns the metric
 // ------------------------------------------------------------------------------------------------
 // everything of ADMM iteration (k, j) up to and including the finalize that evaluates the exit test (direct back-end)
-int enqueue_iteration_direct(W *w, abip_int j, bool restart) {
+// prev_fin: the finalize of the previous iteration, still pending (fused path); defer: hand this iteration's finalize to the next one
+int enqueue_iteration_direct(W *w, abip_int j, bool restart, const FinArgs *prev_fin = nullptr, FinArgs *defer = nullptr) {
   const Dims d = dims(w);
   const Ctl *ctl = w->ctl.p;
   ABIPSettings *st = w->stgs;
   const bool avg_stats = ((j + 1) % 10 == 0); // abip.c:2000
   if (w->fuse_small) { // k_rhs and k_post_dot ride inside the one-workgroup solve kernels
-    LpSolveFuse fz{w->u.p, w->v.p, w->h.p, st->rho_y, w->g_th, d, w->part.p, w->NB};
+    LpSolveFuse fz{w->u.p, w->v.p, w->h.p, st->rho_y, w->g_th, d, w->part.p, w->NB, w->ctl.p, prev_fin ? 1 : 0, prev_fin ? *prev_fin : FinArgs{}};
     w->ldl.enqueue([&](auto kern, int grid, int block, size_t lds, auto... a) { launch_lds(w, ABIP_HIP_K_SPTRSV, kern, grid, block, lds, a...); }, w->ut.p, ctl, w->NB, fz);
   } else {
     launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, w->ut.p, (const double *)w->h.p, st->rho_y, w->g_th, d,
@@ -507,7 +518,7 @@ int enqueue_iteration_direct(W *w, abip_int j, bool restart) {
     launch(w, ABIP_HIP_K_VEC, k_restart_apply, w->NB, BS, w->u.p, w->v.p, w->u_avg.p, w->v_avg.p, (double)st->restart_fre, w->LV);
     launch(w, ABIP_HIP_K_VEC, k_avg_stats, w->NB, BS, upd_args(w, true, avg_stats, j), d, w->part.p, ctl);
   }
-  return enqueue_q_and_finalize(w, avg_stats, false);
+  return enqueue_q_and_finalize(w, avg_stats, false, true, defer);
 }
 inline bool restart_due(const W *w, abip_int k, abip_int j) { // abip.c:608-609
   return !(k < w->stgs->restart_thresh || (j + 1 - w->fre_old) % w->stgs->restart_fre != 0);
@@ -530,7 +541,13 @@ int clear_halt(W *w) {
 // one the stepwise loop produces.  *done = iterations that ran.
 int admm_batch_direct(W *w, int nb, int *done, double *metric_out) {
   if (!w->wg_valid) launch(w, ABIP_HIP_K_VEC, k_dot_wg, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->g.p, w->stgs->rho_y, dims(w), w->part.p, w->xwt);
-  for (int q = 0; q < nb; ++q) if (enqueue_iteration_direct(w, w->j + q, false)) return -1;
+  FinArgs pend, cur;
+  bool have = false;
+  for (int q = 0; q < nb; ++q) {
+    const bool defer = w->fuse_small && q + 1 < nb; // the last iteration of the batch closes itself
+    if (enqueue_iteration_direct(w, w->j + q, false, have ? &pend : nullptr, defer ? &cur : nullptr)) return -1;
+    have = defer; pend = cur;
+  }
   if (sync_ctl(w)) return -1;
   *done = w->hctl->it_count - w->it_seen;
   if (*done < 1 || *done > nb) return -1;
