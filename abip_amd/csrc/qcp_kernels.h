@@ -28,6 +28,7 @@ __host__ __device__ inline bool qslot_is_max(int s) { return s >= Q_M0 && s <= Q
 
 struct QCtl {
   double out[32]; double tau_t;
+  double u_tail;    // new tau entry of u from kq_ut_prox; committed by kq_dual (every workgroup of kq_ut_prox still reads the old one)
   double err_inner; // inner stopping metric of the last completed iteration (qcp_config.c:518-557), evaluated by kq_finalize
   int it_count;     // inner iterations completed since the start of the solve
   int halted;       // mirror of the halt flag the gated kernels test (the host reads this block once per batch)
@@ -143,7 +144,9 @@ __global__ __launch_bounds__(BS) void kq_ut_prox(QProxArgs a, QDims d, const dou
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     const double rl = tt * a.alpha + (1 - a.alpha) * a.u[tail] - a.v[tail];
     a.ut[tail] = tt; a.rel[tail] = rl;
-    a.u[tail] = (rl + sqrt(rl * rl + 4 * a.lambda / a.rho_tau)) / 2; // abip.c:348-350
+    // abip.c:348-350.  NOT stored into u[tail] here: the other workgroups of this launch read u[tail] for eta above, and nothing
+    // orders their reads before this write; kq_dual, the next kernel to touch the tau entry, commits it.
+    ctl->u_tail = (rl + sqrt(rl * rl + 4 * a.lambda / a.rho_tau)) / 2;
     ctl->tau_t = tt;
   }
 }
@@ -228,21 +231,24 @@ __global__ __launch_bounds__(BIG ? QC_TB : BS) void kq_cones(QCones C, int first
   for (int q = h + t; q < len; q += NT) u[off + q] = rel[off + q] * sc;
 }
 
-__global__ __launch_bounds__(BS) void kq_dual(const double *__restrict__ u, const double *__restrict__ rel, double *__restrict__ v, double *__restrict__ vo,
-                                              double rho_y, double rho_x, double rho_tau, QDims d, const Ctl *hc) {
+__global__ __launch_bounds__(BS) void kq_dual(double *__restrict__ u, const double *__restrict__ rel, double *__restrict__ v, double *__restrict__ vo,
+                                              double rho_y, double rho_x, double rho_tau, QDims d, const QCtl *qc, const Ctl *hc) {
   if (hc->halt) return;
   const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
   for (int i = t0; i < d.m; i += stride) { const double t = u[i] - rel[i]; v[i] = t; vo[i] = t * rho_y; }
-  for (int j = t0; j <= d.n; j += stride) { const int q = d.MP + j; const double t = u[q] - rel[q]; v[q] = t; vo[q] = t * (j == d.n ? rho_tau : rho_x); }
+  for (int j = t0; j <= d.n; j += stride) {
+    const int q = d.MP + j;
+    double uq = u[q];
+    if (j == d.n) { uq = qc->u_tail; u[q] = uq; } // the tau entry kq_ut_prox computed
+    const double t = uq - rel[q];
+    v[q] = t; vo[q] = t * (j == d.n ? rho_tau : rho_x);
+  }
 }
 
 // ---- inner stopping test (qcp_config.c:518-557); the tau entry of Qu is completed by the host from the sums ----
-__global__ __launch_bounds__(BS) void kq_inner_A(Csr A, const double *__restrict__ u, const double *__restrict__ vo, const double *__restrict__ b,
-                                                 double *__restrict__ Ax, QDims d, double *part, const Ctl *hc) {
-  if (hc->halt) return;
-  __shared__ double lds[CHUNK];
-  __shared__ int lptr[CHUNK + 1];
-  __shared__ double sm[5 * WAVES];
+// bodies; (vb, vgrid) = this workgroup's index / count among those working on the product
+__device__ __forceinline__ void dq_inner_A(const Csr &A, const double *__restrict__ u, const double *__restrict__ vo, const double *__restrict__ b,
+                                           double *__restrict__ Ax, const QDims &d, double *part, double *lds, int *lptr, double *sm, int vb, int vgrid) {
   const double *x = u + d.MP;
   const double tau = u[d.MP + d.n];
   double a5[5] = {0, 0, 0, 0, 0};
@@ -252,17 +258,14 @@ __global__ __launch_bounds__(BS) void kq_inner_A(Csr A, const double *__restrict
         const double mu = acc[0], qu = mu + (-tau) * b[i], dv = qu - vo[i];
         Ax[i] = mu;
         a5[0] += u[i] * mu; a5[1] += u[i] * b[i]; a5[2] += dv * dv; a5[3] += qu * qu; a5[4] += vo[i] * vo[i];
-      });
+      },
+      [] { return true; }, vb, vgrid);
   const int ws[5] = {Q_D1, Q_D2, Q_E1, Q_E2, Q_E3};
-  write_partials<5>(part, ws, a5, sm);
+  write_partials<5>(part, ws, a5, sm, vb);
 }
-// rows of A' (and of Q): with Q the A'y product is only stored and kq_inner_Q finishes the row
-__global__ __launch_bounds__(BS) void kq_inner_At(Csr At, const double *__restrict__ u, const double *__restrict__ vo, const double *__restrict__ c,
-                                                  double *__restrict__ ATy, double *__restrict__ Qx, int finish, QDims d, double *part, const Ctl *hc) {
-  if (hc->halt) return;
-  __shared__ double lds[CHUNK];
-  __shared__ int lptr[CHUNK + 1];
-  __shared__ double sm[5 * WAVES];
+__device__ __forceinline__ void dq_inner_At(const Csr &At, const double *__restrict__ u, const double *__restrict__ vo, const double *__restrict__ c,
+                                            double *__restrict__ ATy, double *__restrict__ Qx, int finish, const QDims &d, double *part,
+                                            double *lds, int *lptr, double *sm, int vb, int vgrid) {
   const double tau = u[d.MP + d.n];
   double a5[5] = {0, 0, 0, 0, 0};
   spmv_stream<1>(
@@ -275,14 +278,42 @@ __global__ __launch_bounds__(BS) void kq_inner_At(Csr At, const double *__restri
           Qx[j] = 0.0;
           a5[0] += u[q] * mu; a5[1] += u[q] * c[j]; a5[2] += dv * dv; a5[3] += qu * qu; a5[4] += vo[q] * vo[q];
         }
-      });
+      },
+      [] { return true; }, vb, vgrid);
   if (finish) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { const double t = vo[d.MP + d.n]; a5[4] += t * t; }
+    if (vb == 0 && threadIdx.x == 0) { const double t = vo[d.MP + d.n]; a5[4] += t * t; }
     const int ws[5] = {Q_D1 + 0, Q_D3, Q_E1, Q_E2, Q_E3};
     // the y rows already own slots D1, E1..E3: use the second half of the table (offset Q_COUNT) for the x rows
     double *part2 = part + (size_t)Q_COUNT * MAXNB;
-    write_partials<5>(part2, ws, a5, sm);
+    write_partials<5>(part2, ws, a5, sm, vb);
   }
+}
+__global__ __launch_bounds__(BS) void kq_inner_A(Csr A, const double *__restrict__ u, const double *__restrict__ vo, const double *__restrict__ b,
+                                                 double *__restrict__ Ax, QDims d, double *part, const Ctl *hc) {
+  if (hc->halt) return;
+  __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
+  __shared__ double sm[5 * WAVES];
+  dq_inner_A(A, u, vo, b, Ax, d, part, lds, lptr, sm, (int)blockIdx.x, (int)gridDim.x);
+}
+__global__ __launch_bounds__(BS) void kq_inner_At(Csr At, const double *__restrict__ u, const double *__restrict__ vo, const double *__restrict__ c,
+                                                  double *__restrict__ ATy, double *__restrict__ Qx, int finish, QDims d, double *part, const Ctl *hc) {
+  if (hc->halt) return;
+  __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
+  __shared__ double sm[5 * WAVES];
+  dq_inner_At(At, u, vo, c, ATy, Qx, finish, d, part, lds, lptr, sm, (int)blockIdx.x, (int)gridDim.x);
+}
+// the two products of the inner stopping test in one launch: workgroups [0, nbA) take A u_x, the rest A'u_y
+__global__ __launch_bounds__(BS) void kq_inner_both(Csr A, Csr At, const double *__restrict__ u, const double *__restrict__ vo, const double *__restrict__ b,
+                                                    const double *__restrict__ c, double *__restrict__ Ax, double *__restrict__ ATy, double *__restrict__ Qx,
+                                                    int finish, QDims d, int nbA, double *part, const Ctl *hc) {
+  if (hc->halt) return;
+  __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
+  __shared__ double sm[5 * WAVES];
+  if ((int)blockIdx.x < nbA) dq_inner_A(A, u, vo, b, Ax, d, part, lds, lptr, sm, (int)blockIdx.x, nbA);
+  else dq_inner_At(At, u, vo, c, ATy, Qx, finish, d, part, lds, lptr, sm, (int)blockIdx.x - nbA, (int)gridDim.x - nbA);
 }
 __global__ __launch_bounds__(BS) void kq_inner_Q(Csr Q, const double *__restrict__ u, const double *__restrict__ vo, const double *__restrict__ c,
                                                  const double *__restrict__ ATy, double *__restrict__ Qx, QDims d, double *part, const Ctl *hc) {

@@ -494,6 +494,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
 
   const Ctl *hc = w->lp_ctl;
   const bool batch_ok = !(getenv("ABIP_HIP_BATCH") && atoi(getenv("ABIP_HIP_BATCH")) == 0);
+  const bool qmerge = !(getenv("ABIP_HIP_QMERGE") && atoi(getenv("ABIP_HIP_QMERGE")) == 0);
   int seen = 0; // QCtl.it_count at the last control read
   // one inner iteration (abip.c:1120-1160), everything on the stream; `timed` brackets the KKT solve with events
   auto enqueue_iteration = [&](int kk, bool timed) {
@@ -513,10 +514,15 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       if (w->nsmall) { QCones C{w->c_off.p, w->c_len.p, w->c_kind.p, w->nsmall}; QLAUNCH(w, kq_cones<false>, (w->nsmall + WAVES - 1) / WAVES, BS, C, 0, w->u.p, (const double *)w->rel.p, lam, w->MP, hc); }
       if (w->ncones > w->nsmall) { QCones C{w->c_off.p, w->c_len.p, w->c_kind.p, w->ncones}; QLAUNCH(w, kq_cones<true>, w->ncones - w->nsmall, QC_TB, C, w->nsmall, w->u.p, (const double *)w->rel.p, lam, w->MP, hc); }
     }
-    QLAUNCH(w, kq_dual, w->NB, BS, (const double *)w->u.p, (const double *)w->rel.p, w->v.p, w->vo.p, st->rho_y, st->rho_x, st->rho_tau, dm, hc);
+    QLAUNCH(w, kq_dual, w->NB, BS, w->u.p, (const double *)w->rel.p, w->v.p, w->vo.p, st->rho_y, st->rho_x, st->rho_tau, dm, (const QCtl *)w->ctl.p, hc);
     // inner stopping test, qcp_config.c:518-557 (the tau entries and the comparison with tol_inner happen in kq_finalize)
-    QLAUNCH(w, kq_inner_A, w->NB, BS, w->dA.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->bd.p, w->Ax.p, dm, w->part.p, hc);
-    QLAUNCH(w, kq_inner_At, w->NB, BS, w->dAt.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->cd.p, w->ATy.p, w->Qx.p, w->hasQ ? 0 : 1, dm, w->part.p, hc);
+    if (qmerge) {
+      QLAUNCH(w, kq_inner_both, 2 * w->NB, BS, w->dA.view(), w->dAt.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->bd.p,
+              (const double *)w->cd.p, w->Ax.p, w->ATy.p, w->Qx.p, w->hasQ ? 0 : 1, dm, w->NB, w->part.p, hc);
+    } else {
+      QLAUNCH(w, kq_inner_A, w->NB, BS, w->dA.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->bd.p, w->Ax.p, dm, w->part.p, hc);
+      QLAUNCH(w, kq_inner_At, w->NB, BS, w->dAt.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->cd.p, w->ATy.p, w->Qx.p, w->hasQ ? 0 : 1, dm, w->part.p, hc);
+    }
     if (w->hasQ) QLAUNCH(w, kq_inner_Q, w->NB, BS, w->dQ.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->cd.p, (const double *)w->ATy.p, w->Qx.p, dm, w->part.p, hc);
     finalize(w, {Q_D1, Q_D2, Q_D3, Q_E1, Q_E2, Q_E3}, {Q_D1, Q_D3, Q_E1, Q_E2, Q_E3}, tol_inner);
   };

@@ -169,13 +169,14 @@ def test_conic_batched_iterations_equal_stepwise(gpu, case, monkeypatch):
     read per iteration (ABIP_HIP_BATCH=0) must give the same run bit for bit."""
     data, K = toy() if case == "toy" else lasso_socp(400, 1500, 3, density=0.02)
     runs = []
-    for mode in ("batched", "stepwise"):
+    for mode in ("batched", "stepwise", "stepwise", "batched", "stepwise"):     # (repeats: the runs must also be reproducible)
         if mode == "stepwise":
             monkeypatch.setenv("ABIP_HIP_BATCH", "0")
         else:
             monkeypatch.delenv("ABIP_HIP_BATCH", raising=False)
         sol, info = gpu.abip_qcp(data, K, eps_all(1e-6))
         runs.append((info["admm_iter"], info["ipm_iter"], info["pobj"], sol["x"].copy(), sol["y"].copy(), sol["s"].copy()))
-    assert runs[0][:3] == runs[1][:3]
-    for a2, b2 in zip(runs[0][3:], runs[1][3:]):
-        assert np.array_equal(a2, b2)
+    for other in runs[1:]:
+        assert runs[0][:3] == other[:3]
+        for a2, b2 in zip(runs[0][3:], other[3:]):
+            assert np.array_equal(a2, b2)
