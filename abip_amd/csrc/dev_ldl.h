@@ -176,9 +176,12 @@ static __global__ __launch_bounds__(256) void k_dtranspose_lower(const double *W
 // ---- solve time ---------------------------------------------------------------------------------------------------------
 // out[r] = (sum_c M[r, c] v[c]) / (dsc ? dsc[r] : 1),  c in [0, r] (lower) or [r, T) (upper); one wavefront per row,
 // rows dealt round-robin so that the triangle's long and short rows mix in every workgroup
+// (xh, Dh, nh): optionally also xh[j] /= Dh[j] for j < nh -- the head's D^-1 of the segmented path rides on the second mat-vec
 static __global__ __launch_bounds__(BS) void k_tail_mv(const double *__restrict__ M, int ld, int T, int upper, const double *__restrict__ v,
-                                                       double *__restrict__ out, const double *__restrict__ dsc, const Ctl *ctl) {
+                                                       double *__restrict__ out, const double *__restrict__ dsc, const Ctl *ctl,
+                                                       double *__restrict__ xh, const double *__restrict__ Dh, int nh) {
   if (ctl->halt) return;
+  for (int j = blockIdx.x * BS + threadIdx.x; j < nh; j += gridDim.x * BS) xh[j] /= Dh[j];
   const int lane = threadIdx.x & 63, wave = blockIdx.x * (BS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (BS / 64);
   for (int r = wave; r < T; r += nw) {
     const int lo = upper ? r : 0, hi = upper ? T : r + 1;
@@ -363,11 +366,13 @@ struct DevLdl {
   // enqueue rhs <- K^-1 rhs; `launch(kernel, grid, block, lds_bytes, args...)` is the caller's launcher (profiling classes differ)
   template <class LaunchFn, class Fuse = NoFuse>
   void enqueue(LaunchFn &&launch, double *rhs, const Ctl *ctl, int NB, Fuse fz = Fuse{}) const {
-    auto tail = [&]() {
+    auto tail = [&](bool scale_head) {
       if (T == 0) return;
       const int grid = std::max(1, std::min(MAXNB, (T + BS / 64 - 1) / (BS / 64)));
-      launch(k_tail_mv, grid, BS, (size_t)0, (const double *)W.p, T, T, 0, (const double *)(xw.p + t0), tmp.p, (const double *)(D.p + t0), ctl);
-      launch(k_tail_mv, grid, BS, (size_t)0, (const double *)Wt.p, T, T, 1, (const double *)tmp.p, xw.p + t0, (const double *)nullptr, ctl);
+      launch(k_tail_mv, grid, BS, (size_t)0, (const double *)W.p, T, T, 0, (const double *)(xw.p + t0), tmp.p, (const double *)(D.p + t0), ctl,
+             (double *)nullptr, (const double *)nullptr, 0);
+      launch(k_tail_mv, grid, BS, (size_t)0, (const double *)Wt.p, T, T, 1, (const double *)tmp.p, xw.p + t0, (const double *)nullptr, ctl,
+             xw.p, (const double *)D.p, scale_head ? t0 : 0);
     };
     if (small) {
       const size_t sh = xl ? sizeof(double) * (size_t)N : 0;
@@ -379,7 +384,7 @@ struct DevLdl {
       }
       if (xl) launch(k_ldl_small<true, true, false, Fuse>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl, fz);
       else launch(k_ldl_small<false, true, false, Fuse>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl, fz);
-      tail();
+      tail(false);
       if (xl) launch(k_ldl_small<true, false, true, Fuse>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl, fz);
       else launch(k_ldl_small<false, false, true, Fuse>, 1, TBS, sh, F.view(), B.view(), pm, dd, rhs, xw.p, t0, N, ctl, fz);
       return;
@@ -393,8 +398,8 @@ struct DevLdl {
       }
     };
     run(F);
-    tail();
-    launch(k_dscale, gN, BS, (size_t)0, xw.p, (const double *)D.p, t0, ctl);
+    tail(true);
+    if (T == 0) launch(k_dscale, gN, BS, (size_t)0, xw.p, (const double *)D.p, t0, ctl);
     run(B);
     launch(k_perm_out, gN, BS, (size_t)0, (const int *)Pmap.p, rhs, (const double *)xw.p, N, ctl);
   }
