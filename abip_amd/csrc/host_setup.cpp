@@ -242,12 +242,16 @@ void min_degree(int N, const std::vector<int> &Gp, const std::vector<int> &Gi, s
     int p = -1;
     for (;;) {
       while (mindeg <= N && head[mindeg] < 0) ++mindeg;
+      if (mindeg > N) { mindeg = 0; continue; } // (cannot happen while nodes remain; never index past the lists)
       p = head[mindeg];
       if (!stale[p]) break;
       del(p);
       deg[p] = refresh(p, k);
       stale[p] = 0;
-      ins(p); // at or above mindeg: the stored value was a lower bound
+      ins(p);
+      // normally at or above mindeg (the stored value was a lower bound) -- but a value that came from the saturating sum bound,
+      // or from a cap that has shrunk since, can be above the true degree: follow it down
+      if (deg[p] < mindeg) mindeg = deg[p];
     }
     if (N - k > 64 && (double)mindeg >= 0.7 * (double)(N - k - 1)) {
       // what is left is (close to) a clique: any order fills it in completely.  Finish in (bound) order; this block becomes

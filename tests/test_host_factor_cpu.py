@@ -24,6 +24,14 @@ def host_solve(A, rho, tail, rhs):
     return z, dict(N=int(st[0]), lnnz=int(st[1]), T=int(st[2]), levels=(int(st[3]), int(st[4])), head_nnz=int(st[5]))
 
 
+def _wide_lasso(p, d):
+    rng = np.random.default_rng(7)
+    X = sp.random(p, d, density=min(1.0, 8.0 / p + 0.01), random_state=rng, data_rvs=rng.standard_normal, format="csc")
+    r1 = sp.hstack([sp.csc_matrix(np.array([[1.0, -1.0]])), sp.csc_matrix((1, p + 2 * d))])
+    r2 = sp.hstack([sp.csc_matrix((p, 2)), sp.identity(p), -X, X])
+    return sp.vstack([r1, r2]).tocsc()
+
+
 def kkt(A, rho):
     m, n = A.shape
     return sp.bmat([[rho * sp.identity(m), A], [A.T, -sp.identity(n)]], format="csc")
@@ -34,6 +42,10 @@ CASES = {
     "staircase": lambda: problems.lp_staircase()[0],
     "network": lambda: problems.lp_multicommodity()[0],
     "random": lambda: problems.lp_random_sparse(m=300, n=800, per_col=6, seed=5)[0],
+    # few rows, many columns (a LASSO KKT with p << d): every row node ends up in hundreds of elements, the refreshed degrees use
+    # the saturating sum bound -- the shape on which the lazy-update ordering once ran off the end of its degree lists
+    "wide_lasso": lambda: _wide_lasso(20, 575),
+    "wide_lasso2": lambda: _wide_lasso(69, 810),
     "dense_column": lambda: sp.hstack([problems.lp_random_sparse(m=200, n=500, per_col=3, seed=9)[0], sp.csc_matrix(np.ones((200, 1)))]).tocsc(),
 }
 

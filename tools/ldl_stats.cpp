@@ -20,13 +20,6 @@ int main(int argc, char **argv) {
   const int N = F.N;
   printf("t0 %d T %d head nnz %d\n", F.t0, F.T, (int)F.bwd.idx.size());
   printf("N %d Lnnz %ld levF %zu levB %zu\n", N, F.lnnz, F.fwd.lev_ptr.size() - 1, F.bwd.lev_ptr.size() - 1);
-  // tail density: nnz of L[t:, t:] / (T(T-1)/2)
-  std::vector<long> tailnnz(N + 1, 0); // entries with col >= t (rows > col anyway)
-  if (F.T == 0) for (int j = N - 1; j >= 0; --j) tailnnz[j] = tailnnz[j + 1] + (F.bwd.ptr[j + 1] - F.bwd.ptr[j]);
-  if (F.T == 0) for (int T : {32, 64, 128, 256, 384, 512, 768, 1024, 1536, 2048, 4096}) {
-    if (T >= N) break;
-    printf("  tail T=%5d density %.3f  (nnz %ld = %.1f%% of L)\n", T, tailnnz[N - T] / (0.5 * T * (T - 1)), tailnnz[N - T], 100.0 * tailnnz[N - T] / F.lnnz);
-  }
   // level histogram forward
   auto hist = [&](const host::TriHost &T, const char *nm) {
     const int nl = (int)T.lev_ptr.size() - 1;
