@@ -130,6 +130,46 @@ def test_host_scaling_matches_the_oracle(gpu, oracle_built, variant):
         S.end()
 
 
+def _dense_lp(m, n, density, seed):
+    rng = np.random.default_rng(seed)
+    A = sp.random(m, n, density=density, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+    A = sp.csc_matrix(A + sp.hstack([sp.identity(m), sp.csc_matrix((m, n - m))]))
+    x0 = rng.random(n) + 0.1
+    return A, A @ x0, rng.random(n) + 0.1
+
+
+@pytest.mark.parametrize("linsys", ["indirect", "direct"])
+@pytest.mark.parametrize("shape", ["1x2", "2x3", "dense_mid", "dense_full", "tall_warned"])
+def test_edge_shapes_and_sparsity_branches(gpu, oracle_built, shape, linsys):
+    """Tiny systems, and the two inner-loop caps that depend on the sparsity of A (abip.c:2104-2115: sp > 0.5 -> mu^-0.35 iterations,
+    0.2 < sp <= 0.5 -> 1/mu iterations), which no other fixture reaches; `tall_warned` has m close to n (validation warns, solves)."""
+    if shape == "1x2":
+        A, b, c = sp.csc_matrix(np.array([[1.0, 2.0]])), np.array([2.0]), np.array([1.0, 1.0])
+    elif shape == "2x3":
+        A, b, c = sp.csc_matrix(np.array([[1.0, 1.0, 0.0], [0.0, 1.0, 1.0]])), np.array([1.0, 1.5]), np.array([1.0, 0.5, 2.0])
+    elif shape == "dense_mid":
+        A, b, c = _dense_lp(12, 40, 0.3, 1)        # 0.2 < sp <= 0.5
+    elif shape == "dense_full":
+        A, b, c = _dense_lp(10, 30, 0.9, 2)        # sp > 0.5
+    else:
+        A, b, c = _dense_lp(30, 34, 0.2, 3)
+    sp_ratio = A.nnz / (A.shape[0] * A.shape[1])
+    if shape == "dense_mid":
+        assert 0.2 < sp_ratio <= 0.5
+    if shape == "dense_full":
+        assert sp_ratio > 0.5
+    o = oracle_built.solve("oracle", A, b, c, linsys=linsys, eps=1e-6, max_admm_iters=100000)
+    with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-6, max_admm_iters=100000) as S:
+        info = S.solve()
+        assert info["status_val"] == o.info["status_val"], (shape, info["status"], o.info["status"])
+        if o.info["status_val"] == 1:       # (the PCG back-end stalls on `tall_warned` at its 1e-7 CG floor -- reference, oracle and device
+            assert info["ipm_iter"] == o.info["ipm_iter"]   # all end "Solved/Inaccurate" at the iteration cap; nothing finer to compare there)
+            assert abs(info["admm_iter"] - o.info["admm_iter"]) <= 0.03 * o.info["admm_iter"] + 2
+            assert abs(info["pobj"] - o.info["pobj"]) <= 1e-5 * (1 + abs(o.info["pobj"]))
+            for k in "xys":
+                assert rel(getattr(S, k), getattr(o, k)) < 1e-4, (shape, linsys, k)
+
+
 @pytest.mark.parametrize("linsys", ["indirect", "direct"])
 def test_restart_path_follows_the_oracle(gpu, oracle_built, linsys):
     """restart_vars (abip.c:587-630) with the threshold lowered so that the periodic restart from the running mean fires many
