@@ -24,7 +24,19 @@ def main():
     from _golden import load
     from abip_amd import Solver
     from abip_amd import dist as adist
-    z, A, b, c = load(fixture)
+    if fixture.startswith("gen:"):     # gen:<kind>:<seed>  -- seeded generator instead of a golden fixture (scripts/gpu_sweep_dist.py)
+        from abip_amd import problems
+        _, kind, seed = fixture.split(":")
+        seed = int(seed)
+        rng = np.random.default_rng(seed)
+        if kind == "rand":
+            m = int(rng.integers(40, 300)); A, b, c = problems.lp_random_sparse(m=m, n=int(m * rng.uniform(1.5, 4)), per_col=int(rng.integers(2, 7)), seed=seed)
+        elif kind == "stair":
+            A, b, c = problems.lp_staircase(seed=seed, stages=int(rng.integers(2, 6)), rows_per=int(rng.integers(8, 30)), cols_per=int(rng.integers(20, 60)))[:3]
+        else:
+            nd = int(rng.integers(8, 30)); A, b, c = problems.lp_multicommodity(seed=seed, nodes=nd, arcs=int(nd * rng.uniform(2, 4)), commodities=int(rng.integers(2, 5)))[:3]
+    else:
+        z, A, b, c = load(fixture)
     if mode == "gloo-callback":
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
