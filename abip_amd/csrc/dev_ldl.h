@@ -16,6 +16,7 @@
 // Set-up kernels are plain LDS-tiled fp64 FMA code (MI355X's fp64 MFMA rate equals its vector rate; set-up is not the hot path).
 #pragma once
 #include <cmath>
+#include <cstdlib>
 
 #include "dev_host_util.h"
 #include "dev_sptrsv.h"
@@ -340,6 +341,7 @@ struct DevLdl {
     xl = small && N <= XL_MAX;
     if (xl && !allow_lds<NoFuse>()) xl = false;
     if (T == 0) return 0;
+    if (getenv("ABIP_HIP_TAIL_FAIL")) return -1; // test hook: pretend the dense set-up failed (the callers fall back to T = 0)
     const int nt = T / DB;
     DBuf<double> Linv, LD;
     const std::vector<int> zero(1, 0);

@@ -370,7 +370,21 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     if (host::factor_upper(N, Kp, Ki, Kx, F) < 0) { printf("\nerror in LDL factorization\n"); return bail("init_lin_sys_work failure"); }
     std::vector<int> pmap(N);
     for (int q = 0; q < N; ++q) pmap[q] = F.P[q] < m ? F.P[q] : w->MP + (F.P[q] - m);
-    if (w->ldl.setup(F, pmap, w->stream)) { printf("\nerror in LDL factorization\n"); return bail("init_lin_sys_work failure"); }
+    if (w->ldl.setup(F, pmap, w->stream)) {
+      bool ok = false;
+      if (F.T > 0) { // no dense tail then (see solver.hip: abip_init)
+        (void)hipGetLastError();
+        w->ldl.release();
+        host::set_tail_request(0);
+        const int rc = host::factor_upper(N, Kp, Ki, Kx, F);
+        host::set_tail_request(-2);
+        if (rc == 0) {
+          for (int q = 0; q < N; ++q) pmap[q] = F.P[q] < m ? F.P[q] : w->MP + (F.P[q] - m);
+          ok = w->ldl.setup(F, pmap, w->stream) == 0;
+        }
+      }
+      if (!ok) { printf("\nerror in LDL factorization\n"); return bail("init_lin_sys_work failure"); }
+    }
     if (hipMalloc((void **)&w->lp_ctl, sizeof(Ctl)) != hipSuccess || hipMemsetAsync(w->lp_ctl, 0, sizeof(Ctl), w->stream) != hipSuccess) return bail("allocation failure");
   }
   DBuf<double> *lv[] = {&w->u, &w->v, &w->vo, &w->ut, &w->rel, &w->r, &w->p};

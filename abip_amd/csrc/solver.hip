@@ -1099,7 +1099,19 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
     if (host::factor_kkt(w->A, w->stgs->rho_y, F) < 0) return fail("init_lin_sys_work failure");
     std::vector<int> pmap(F.N);
     for (int q = 0; q < F.N; ++q) pmap[q] = F.P[q] < (int)m ? F.P[q] : w->MP + (F.P[q] - (int)m);
-    if (w->ldl.setup(F, pmap, w->stream)) return fail("init_lin_sys_work failure");
+    if (w->ldl.setup(F, pmap, w->stream)) {
+      if (F.T == 0) return fail("init_lin_sys_work failure");
+      // the dense tail could not be set up (no room for its two T x T triangles, or a pivot the un-pivoted dense LDL' cannot take):
+      // fall back to the plain level-scheduled factor
+      (void)hipGetLastError();
+      w->ldl.release();
+      host::set_tail_request(0);
+      const int rc = host::factor_kkt(w->A, w->stgs->rho_y, F);
+      host::set_tail_request(-2);
+      if (rc < 0) return fail("init_lin_sys_work failure");
+      for (int q = 0; q < F.N; ++q) pmap[q] = F.P[q] < (int)m ? F.P[q] : w->MP + (F.P[q] - (int)m);
+      if (w->ldl.setup(F, pmap, w->stream)) return fail("init_lin_sys_work failure");
+    }
     { const char *e = getenv("ABIP_HIP_FUSE"); w->fuse_small = w->ldl.small && !w->dist && !(e && atoi(e) == 0) && (!w->ldl.xl || w->ldl.allow_lds<LpSolveFuse>()); }
     const int one = 1; // the post-solve kernels are gated on cg_done: permanently set for the direct back-end
     if (hipMemcpyAsync(&w->ctl.p->cg_done, &one, sizeof(int), hipMemcpyHostToDevice, w->stream) != hipSuccess) return fail("memcpy failure");

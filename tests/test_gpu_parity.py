@@ -189,6 +189,21 @@ def test_restart_path_follows_the_oracle(gpu, oracle_built, linsys):
             assert rel(getattr(S, k), getattr(o, k)) < (1e-6 if info["admm_iter"] == o.info["admm_iter"] else 1e-4), (linsys, k)
 
 
+def test_dense_tail_failure_falls_back_to_the_level_scheduled_factor(gpu, monkeypatch):
+    """If the dense tail cannot be set up (no room for the two T x T triangles, a pivot the dense LDL' cannot take) abip_init
+    re-factors without it instead of failing."""
+    monkeypatch.delenv("ABIP_HIP_TAIL", raising=False)
+    monkeypatch.setenv("ABIP_HIP_TAIL_FAIL", "1")
+    z, A, b, c = load("lp_staircase")
+    rng = np.random.default_rng(2)
+    with gpu.Solver(A, b, c, linsys="direct", verbose=0, max_admm_iters=50) as S:
+        assert S.scalar("tail") == 0 and S.scalar("levels_fwd") > 100
+        Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
+        rhs = rng.standard_normal(S.m + S.n)
+        sol, its = S.kkt_solve(rhs, None, -1)
+        assert rel(kkt_matrix(Asc, 1e-3) @ sol, rhs) < 1e-11
+
+
 def test_direct_solve_wide_head_with_tail(gpu):
     """A factor whose head levels are wider than one workgroup (segmented path) and whose tail is several thousand pivots."""
     from abip_amd import problems
