@@ -51,5 +51,25 @@ int main() {
   CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
   float ms; CK(hipEventElapsedTime(&ms, a, b));
   printf("empty kernel boundary (256 workgroups back to back): %7.2f us per kernel\n", ms * 1000.f / 2000);
+  // the same 2000 kernels as ONE hipGraph launch
+  hipStream_t st; CK(hipStreamCreate(&st));
+  hipGraph_t graph; hipGraphExec_t exec;
+  CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+  for (int r = 0; r < 2000; ++r) hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, sink);
+  CK(hipStreamEndCapture(st, &graph));
+  CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  CK(hipGraphLaunch(exec, st)); CK(hipStreamSynchronize(st));
+  CK(hipEventRecord(a, st));
+  CK(hipGraphLaunch(exec, st));
+  CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+  CK(hipEventElapsedTime(&ms, a, b));
+  printf("the same 2000 kernels captured in one hipGraph:            %7.2f us per kernel\n", ms * 1000.f / 2000);
+  for (int G : {1, 16}) {
+    CK(hipEventRecord(a, st));
+    for (int r = 0; r < 2000; ++r) hipLaunchKernelGGL(k_empty, dim3(G), dim3(256), 0, st, sink);
+    CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+    CK(hipEventElapsedTime(&ms, a, b));
+    printf("empty kernel boundary (%d workgroup(s) back to back): %7.2f us per kernel\n", G, ms * 1000.f / 2000);
+  }
   return 0;
 }
