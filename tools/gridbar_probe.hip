@@ -64,6 +64,20 @@ int main() {
   CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
   CK(hipEventElapsedTime(&ms, a, b));
   printf("the same 2000 kernels captured in one hipGraph:            %7.2f us per kernel\n", ms * 1000.f / 2000);
+  for (int nodes : {3, 12, 48}) { // small graphs launched back to back: the per-launch cost
+    hipGraph_t g2; hipGraphExec_t e2;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int r = 0; r < nodes; ++r) hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, sink);
+    CK(hipStreamEndCapture(st, &g2));
+    CK(hipGraphInstantiate(&e2, g2, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(e2, st)); CK(hipStreamSynchronize(st));
+    const int reps = 1200 / nodes;
+    CK(hipEventRecord(a, st));
+    for (int r = 0; r < reps; ++r) CK(hipGraphLaunch(e2, st));
+    CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+    CK(hipEventElapsedTime(&ms, a, b));
+    printf("%d-kernel hipGraph launched %d times back to back: %7.2f us per kernel (%.2f us per graph)\n", nodes, reps, ms * 1000.f / (reps * nodes), ms * 1000.f / reps);
+  }
   for (int G : {1, 16}) {
     CK(hipEventRecord(a, st));
     for (int r = 0; r < 2000; ++r) hipLaunchKernelGGL(k_empty, dim3(G), dim3(256), 0, st, sink);
