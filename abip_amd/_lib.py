@@ -55,7 +55,8 @@ K_CLASSES = ("spmv_At", "spmv_A", "cg_vec", "sptrsv", "vec", "qnorm", "cg_edge")
 
 class AbipHipProfile(C.Structure):
     _fields_ = [("ms", C.c_double * 7), ("launches", C.c_long * 7), ("noop_ms", C.c_double), ("noop_launches", C.c_long),
-                ("admm_iters", C.c_long), ("cg_iters", C.c_long), ("kkt_solves", C.c_long)]
+                ("admm_iters", C.c_long), ("cg_iters", C.c_long), ("kkt_solves", C.c_long),
+                ("stamp_ms", C.c_double * 7), ("stamp_launches", C.c_long * 7), ("stamp_noop_launches", C.c_long)]
 
 
 # every symbol include/abip.h and include/abip_hip.h declare
@@ -67,6 +68,7 @@ EXPORTS = (
     "abip_hip_get_scalar", "abip_hip_profile_enable", "abip_hip_profile_read", "abip_hip_sync",
     "abip_hip_dist_get_unique_id", "abip_hip_dist_init_rccl", "abip_hip_dist_init_callback", "abip_hip_dist_finalize",
     "abip_hip_dist_partition", "abip_hip_dist_rows", "abip_hip_host_factor_solve", "abip_hip_host_normalize_A",
+    "abip_hip_dist_comm_count", "abip_hip_profile_enable_stamps", "abip_hip_set_copy_a_matrix",
     "abip_qcp", "abip_qcp_set_default_settings", "abip_hip_qcp_last_stats", "abip_hip_qcp_cone_prox",
 )
 
@@ -123,6 +125,8 @@ def load() -> C.CDLL:
     L.abip_hip_set_linsys.restype = None
     L.abip_hip_set_linsys.argtypes = [C.c_int]
     L.abip_hip_get_linsys.restype = C.c_int
+    L.abip_hip_set_copy_a_matrix.restype = None
+    L.abip_hip_set_copy_a_matrix.argtypes = [C.c_int]
     L.abip_hip_device_info.restype = C.c_int
     L.abip_hip_device_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_int)]
     L.abip_hip_solve_begin.restype = c_int
@@ -154,6 +158,9 @@ def load() -> C.CDLL:
     L.abip_hip_dist_init_callback.restype = C.c_int
     L.abip_hip_dist_init_callback.argtypes = [C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
     L.abip_hip_dist_finalize.restype = None
+    L.abip_hip_dist_comm_count.restype = C.c_int
+    L.abip_hip_profile_enable_stamps.restype = C.c_int
+    L.abip_hip_profile_enable_stamps.argtypes = [W, C.c_uint]
     L.abip_hip_dist_partition.restype = C.c_int
     L.abip_hip_dist_partition.argtypes = [C.POINTER(ABIPMatrix), C.c_int, PI]
     L.abip_hip_dist_rows.restype = None

@@ -70,6 +70,18 @@ struct Ctl {
   double pp_cur;   // sharded PCG: ||p||^2 of the current direction, by the recurrence ||z + beta p||^2 = z'z + 2 beta z'p + beta^2 ||p||^2
 };
 
+// Device-side launch timing (bench.py's roofline leg, inside the timed region: no hipEvent records, no second pass).  A kernel handed a
+// Stamp notes when its first sampled workgroup began and when its last sampled one ended, in ticks of the constant-rate wall clock
+// (hipDeviceAttributeWallClockRate).  Every 64th workgroup is sampled (one atomic each: ~32 per launch of the full grid); the begin
+// tick is stored inverted so that a zeroed record serves both atomicMax.  A launch that returns at one of its gates leaves t1 == 0.
+struct Stamp { unsigned long long t0_inv, t1; };
+__device__ __forceinline__ void stamp_begin(Stamp *st) {
+  if (st && threadIdx.x == 0 && (blockIdx.x & 63) == 0) atomicMax(&st->t0_inv, ~(unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void stamp_end(Stamp *st) {
+  if (st && threadIdx.x == 0 && (blockIdx.x & 63) == 0) atomicMax(&st->t1, (unsigned long long)wall_clock64());
+}
+
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);

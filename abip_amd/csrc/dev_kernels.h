@@ -82,31 +82,38 @@ __global__ __launch_bounds__(BS) void k_rhs(const double *__restrict__ u, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// PCG set-up (indirect.c:345-365).  tmp = A' s ; then in ONE pass over the rows of A:
-//   b_i = rhs_y[i] + (A rhs_x)_i      (indirect.c:415)
-//   r_i = b_i - ((A tmp)_i + rho s_i) (indirect.c:352-354)      x0 = s
-//   z_i = M_i r_i ; p = z             (indirect.c:364-365)
-// Without a warm start (s == nullptr): r = b, x0 = 0 (indirect.c:347-348).
+// PCG set-up (indirect.c:345-365).  With a warm start s:  d = rhs_x - A' s  (one pass over A'), then in ONE pass over the rows of A
+// with ONE gather per non-zero
+//   r_i = (rhs_y[i] + (A d)_i) - rho s_i     = b_i - ((A A's)_i + rho s_i),  b = rhs_y + A rhs_x      (indirect.c:415, 352-354)
+//   x0 = s ; z_i = M_i r_i ; p = z                                                                  (indirect.c:364-365)
+// (b and G s are never formed on their own: gathering rhs_x and A's separately costs a second trip through the texture path per
+// non-zero -- measured 82 us and 4.6x the algorithmic traffic on C4, against 35 us for every other product of the same matrix.)
+// Without a warm start (s == nullptr): d = rhs_x, r = b, x0 = 0 (indirect.c:347-348).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BS) void k_cg_init_At(Csr At /* rows = columns of A */, const double *__restrict__ s,
-                                                   double *__restrict__ tmp, const Ctl *ctl) {
+__global__ __launch_bounds__(BS) void k_cg_init_At(Csr At /* rows = columns of A */, const double *__restrict__ s, const double *__restrict__ bx,
+                                                   double *__restrict__ dvec, const Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
   spmv_stream<1>(
       At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * s[c]; },
-      [&](int row, double(&acc)[1]) { tmp[row] = acc[0]; });
+      [&](int row, double(&acc)[1]) { dvec[row] = bx[row] - acc[0]; });
+}
+// sharded: T holds A's summed over the ranks -> d = rhs_x - T in place
+__global__ __launch_bounds__(BS) void k_cg_init_sub(double *__restrict__ T, const double *__restrict__ bx, int n, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  for (int j = blockIdx.x * BS + threadIdx.x; j < n; j += gridDim.x * BS) T[j] = bx[j] - T[j];
 }
 
 template <bool DIST> // DIST: also the partial of z'z (= ||p||^2 of the first direction) for the sharded path
 __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rhs /* l-vector: y in/out (x0), x read */,
-                                                  const double *__restrict__ tmp, const double *__restrict__ s,
-                                                  const double *__restrict__ Minv, double *__restrict__ r, double *__restrict__ z,
-                                                  double *__restrict__ p, double rho, double tol_factor, Dims d,
+                                                  const double *__restrict__ dvec /* rhs_x - A's, or rhs_x itself without a warm start */,
+                                                  const double *__restrict__ s, const double *__restrict__ Minv, double *__restrict__ r,
+                                                  double *__restrict__ z, double *__restrict__ p, double rho, double tol_factor, Dims d,
                                                   double *part, int nb, Ctl *ctl, const double *gs) {
   ABIP_GATE_HALT(ctl);
-  __shared__ double lds[2 * CHUNK];
+  __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[3 * WAVES];
   double bn[1];
@@ -119,31 +126,17 @@ __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rh
     ctl->cg_it = 0;
     ctl->cg_done = 0;
   }
-  const double *bx = rhs + d.MP;
   double acc2[3] = {0.0, 0.0, 0.0};
-  if (s) {
-    spmv_stream<2>(
-        A, lds, lptr, sm, [&](int c, double a, double(&pr)[2]) { pr[0] = a * bx[c]; pr[1] = a * tmp[c]; },
-        [&](int i, double(&acc)[2]) {
-          const double si = s[i];
-          const double b = rhs[i] + acc[0];
-          const double ri = b - (acc[1] + rho * si);
-          const double zi = ri * Minv[i];
-          rhs[i] = si; r[i] = ri; z[i] = zi; p[i] = zi;
-          acc2[0] += ri * ri; acc2[1] += zi * ri;
-          if (DIST) acc2[2] += zi * zi;
-        });
-  } else {
-    spmv_stream<1>(
-        A, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * bx[c]; },
-        [&](int i, double(&acc)[1]) {
-          const double ri = rhs[i] + acc[0];
-          const double zi = ri * Minv[i];
-          rhs[i] = 0.0; r[i] = ri; z[i] = zi; p[i] = zi;
-          acc2[0] += ri * ri; acc2[1] += zi * ri;
-          if (DIST) acc2[2] += zi * zi;
-        });
-  }
+  spmv_stream<1>(
+      A, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * dvec[c]; },
+      [&](int i, double(&acc)[1]) {
+        double ri = rhs[i] + acc[0], x0 = 0.0;
+        if (s) { x0 = s[i]; ri -= rho * x0; }
+        const double zi = ri * Minv[i];
+        rhs[i] = x0; r[i] = ri; z[i] = zi; p[i] = zi;
+        acc2[0] += ri * ri; acc2[1] += zi * ri;
+        if (DIST) acc2[2] += zi * zi;
+      });
   if (DIST) {
     const int ws[3] = {S_RR0, S_ZR0, S_ZZ};
     write_partials<3>(part, ws, acc2, sm);
@@ -174,14 +167,15 @@ __device__ __forceinline__ bool cg_converged(Ctl *ctl, const double *part, int n
 // costs a second pass through the texture path, so the identity A'(z + beta p) = A'z + beta (A'p) is used instead:
 // tmp still holds A'p of the previous iteration (it is rebuilt from scratch, beta = 0, at every solve).
 __global__ __launch_bounds__(BS) void k_cg_spmv_At(Csr At, const double *__restrict__ z,
-                                                   double *__restrict__ tmp, int max_its, double *part, int nb, Ctl *ctl) {
+                                                   double *__restrict__ tmp, int max_its, double *part, int nb, Ctl *ctl, Stamp *st) {
   ABIP_GATE_HALT(ctl);
   if (ctl->cg_done) return;
+  stamp_begin(st);
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[2 * WAVES];
   double beta = 0.0;
-  bool first = true;
+  bool first = true, ran = false;
   // the convergence test on the previous update's partials runs while the first row block's stream is in flight
   auto pre = [&]() -> bool {
     int it; double zr;
@@ -193,18 +187,21 @@ __global__ __launch_bounds__(BS) void k_cg_spmv_At(Csr At, const double *__restr
     first = (it == 0);
     beta = first ? 0.0 : zr / ctl->zr_hist[par ^ 1];
     if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->it_cur = it; ctl->beta_cur = beta; ctl->zr_cur = zr; ctl->zr_hist[par] = zr; }
+    ran = true;
     return true;
   };
   spmv_stream<1>(
       At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * z[c]; },
       [&](int row, double(&acc)[1]) { tmp[row] = first ? acc[0] : acc[0] + beta * tmp[row]; }, pre);
+  if (ran) stamp_end(st); // a launch that found the PCG converged leaves t1 == 0: not counted
 }
 
 // p <- z + beta p ; Gp = A tmp + rho p ; S_PG <- p'Gp            (indirect.c:214-219, 371)
 __global__ __launch_bounds__(BS) void k_cg_spmv_A(Csr A, const double *__restrict__ tmp, const double *__restrict__ z,
-                                                  double *__restrict__ p, double *__restrict__ Gp, double rho, double *part, const Ctl *ctl) {
+                                                  double *__restrict__ p, double *__restrict__ Gp, double rho, double *part, const Ctl *ctl, Stamp *st) {
   ABIP_GATE_HALT(ctl);
   if (ctl->cg_done) return;
+  stamp_begin(st);
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
@@ -220,6 +217,7 @@ __global__ __launch_bounds__(BS) void k_cg_spmv_A(Csr A, const double *__restric
       });
   const int ws[1] = {S_PG};
   write_partials<1>(part, ws, acc1, sm);
+  stamp_end(st);
 }
 
 // x += alpha p ; r -= alpha Gp ; z = M r ; S_RR, S_ZR (next parity)          (indirect.c:371-385)
@@ -704,17 +702,19 @@ __global__ __launch_bounds__(BS) void k_fold(FoldArgs f, const double *part, int
 // out = M x on the rows of this rank; FOLD: the last workgroup also folds the partials of the previous kernel into gs
 template <bool FOLD>
 __global__ __launch_bounds__(BS) void k_spmv_set_t(Csr M, const double *__restrict__ x, double *__restrict__ out, int mode, const Ctl *ctl,
-                                                   FoldArgs f, const double *part, int nb, double *gs) {
+                                                   FoldArgs f, const double *part, int nb, double *gs, Stamp *st) {
   ABIP_GATE_HALT(ctl);
   if (FOLD && blockIdx.x == gridDim.x - 1) fold_slots(f, part, nb, gs); // (before the gates: the convergence test needs the sums)
   if (mode == 1 && ctl->cg_done) return;
   if (mode == 2 && !ctl->cg_done) return;
+  stamp_begin(st);
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
   spmv_stream<1>(
       M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
       [&](int row, double(&acc)[1]) { out[row] = acc[0]; });
+  stamp_end(st);
 }
 __global__ __launch_bounds__(BS) void k_spmv_set(Csr M, const double *__restrict__ x, double *__restrict__ out, int mode, const Ctl *ctl) {
   ABIP_GATE_HALT(ctl);

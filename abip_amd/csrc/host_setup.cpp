@@ -376,12 +376,11 @@ int host_solve(const LdlHost &F, std::vector<double> &b) {
   return 0;
 }
 
-int factor_kkt(const ABIPMatrix *A, double rho_y, LdlHost &out) {
+void kkt_upper(const ABIPMatrix *A, double rho_y, std::vector<int> &Kp, std::vector<int> &Ki, std::vector<double> &Kx) {
   const int m = (int)A->m, n = (int)A->n, N = m + n;
   const long nnzA = (long)A->p[n];
   // upper triangle of K by columns (direct.c:49-104)
-  std::vector<int> Kp(N + 1), Ki(N + nnzA);
-  std::vector<double> Kx(N + nnzA);
+  Kp.assign(N + 1, 0); Ki.assign(N + nnzA, 0); Kx.assign(N + nnzA, 0.0);
   long kk = 0;
   for (int i = 0; i < m; ++i) { Kp[i] = (int)kk; Ki[kk] = i; Kx[kk] = rho_y; ++kk; }
   for (int j = 0; j < n; ++j) {
@@ -390,7 +389,31 @@ int factor_kkt(const ABIPMatrix *A, double rho_y, LdlHost &out) {
     Ki[kk] = m + j; Kx[kk] = -1.0; ++kk;
   }
   Kp[N] = (int)kk;
-  return factor_upper(N, Kp, Ki, Kx, out);
+}
+int factor_kkt(const ABIPMatrix *A, double rho_y, LdlHost &out) {
+  std::vector<int> Kp, Ki;
+  std::vector<double> Kx;
+  kkt_upper(A, rho_y, Kp, Ki, Kx);
+  return factor_upper((int)(A->m + A->n), Kp, Ki, Kx, out);
+}
+double sym_upper_residual(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, const std::vector<double> &Kx,
+                          const std::vector<double> &z, const std::vector<double> &rhs) {
+  std::vector<double> y(N, 0.0);
+  for (int j = 0; j < N; ++j)
+    for (int q = Kp[j]; q < Kp[j + 1]; ++q) {
+      const int i = Ki[q];
+      y[i] += Kx[q] * z[j];
+      if (i != j) y[j] += Kx[q] * z[i];
+    }
+  double num = 0, den = 0;
+  for (int i = 0; i < N; ++i) { const double e = y[i] - rhs[i]; num += e * e; den += rhs[i] * rhs[i]; }
+  const double r = std::sqrt(num) / std::max(std::sqrt(den), 1e-300);
+  return (r == r) ? r : 1e300; // NaN -> fail
+}
+void guard_rhs(int N, std::vector<double> &rhs) {
+  rhs.resize(N);
+  unsigned long long st = 0x9E3779B97F4A7C15ull;
+  for (int i = 0; i < N; ++i) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; rhs[i] = (double)(st >> 11) / 9007199254740992.0 * 2.0 - 1.0; }
 }
 
 int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, const std::vector<double> &Kx, LdlHost &out) {

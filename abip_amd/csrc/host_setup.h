@@ -54,6 +54,15 @@ void set_tail_request(int t);
 // the host instead of the device): b <- K^-1 b in pivot order.  For the CPU tests of the ordering / numeric / tail-split code.
 int host_solve(const LdlHost &F, std::vector<double> &b);
 int factor_kkt(const ABIPMatrix *A, double rho_y, LdlHost &out);
+// upper triangle of K = [[rho_y I, A],[A', -I]] by columns (direct.c:49-104), as factor_kkt builds it
+void kkt_upper(const ABIPMatrix *A, double rho_y, std::vector<int> &Kp, std::vector<int> &Ki, std::vector<double> &Kx);
+// Set-up guard of the direct back-ends: ||K z - rhs|| / ||rhs|| for a symmetric K given by its upper triangle (host arithmetic).
+// The device forms W = inv(L22) explicitly for the dense tail (dev_ldl.h); one solve of a known right-hand side at set-up, checked
+// here, catches a tail whose conditioning that cannot take (the callers then re-factor without a tail).
+double sym_upper_residual(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, const std::vector<double> &Kx,
+                          const std::vector<double> &z, const std::vector<double> &rhs);
+// the deterministic right-hand side of that check
+void guard_rhs(int N, std::vector<double> &rhs);
 // the same for any symmetric quasi-definite matrix given by its upper triangle in CSC form (QCP KKT, qcp_config.c:699-748)
 int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, const std::vector<double> &Kx, LdlHost &out);
 

@@ -367,25 +367,45 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     }
     Kp[N] = (int)Ki.size();
     host::LdlHost F;
-    if (host::factor_upper(N, Kp, Ki, Kx, F) < 0) { printf("\nerror in LDL factorization\n"); return bail("init_lin_sys_work failure"); }
     std::vector<int> pmap(N);
-    for (int q = 0; q < N; ++q) pmap[q] = F.P[q] < m ? F.P[q] : w->MP + (F.P[q] - m);
-    if (w->ldl.setup(F, pmap, w->stream)) {
-      bool ok = false;
-      if (F.T > 0) { // no dense tail then (see solver.hip: abip_init)
-        (void)hipGetLastError();
-        w->ldl.release();
-        host::set_tail_request(0);
-        const int rc = host::factor_upper(N, Kp, Ki, Kx, F);
-        host::set_tail_request(-2);
-        if (rc == 0) {
-          for (int q = 0; q < N; ++q) pmap[q] = F.P[q] < m ? F.P[q] : w->MP + (F.P[q] - m);
-          ok = w->ldl.setup(F, pmap, w->stream) == 0;
+    auto set_up = [&](int tail_request) -> int {
+      if (tail_request != -2) host::set_tail_request(tail_request);
+      const int rc = host::factor_upper(N, Kp, Ki, Kx, F);
+      host::set_tail_request(-2);
+      if (rc < 0) return -2;
+      for (int q = 0; q < N; ++q) pmap[q] = F.P[q] < m ? F.P[q] : w->MP + (F.P[q] - m);
+      return w->ldl.setup(F, pmap, w->stream) ? -1 : 0;
+    };
+    if (hipMalloc((void **)&w->lp_ctl, sizeof(Ctl)) != hipSuccess || hipMemsetAsync(w->lp_ctl, 0, sizeof(Ctl), w->stream) != hipSuccess) return bail("allocation failure");
+    // set-up guard (see solver.hip: abip_init): one known right-hand side through the factor, ||K z - rhs|| checked on the host
+    auto residual = [&]() -> double {
+      std::vector<double> rhs, lv(w->LV, 0.0), z(N);
+      host::guard_rhs(N, rhs);
+      for (int i = 0; i < N; ++i) lv[i < m ? i : w->MP + (i - m)] = rhs[i];
+      DBuf<double> tmp;
+      if (tmp.alloc(w->LV)) return 1e300;
+      double out = 1e300;
+      if (hipMemcpyAsync(tmp.p, lv.data(), sizeof(double) * w->LV, hipMemcpyHostToDevice, w->stream) == hipSuccess) {
+        w->ldl.enqueue([&](auto kern, int grid, int block, size_t lds, auto... a) { hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, w->stream, a...); }, tmp.p, (const Ctl *)w->lp_ctl, w->NB);
+        if (hipMemcpyAsync(lv.data(), tmp.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream) == hipSuccess && hipStreamSynchronize(w->stream) == hipSuccess) {
+          for (int i = 0; i < N; ++i) z[i] = lv[i < m ? i : w->MP + (i - m)];
+          out = (getenv("ABIP_HIP_TAIL_RESID_FAIL") && F.T > 0) ? 1.0 : host::sym_upper_residual(N, Kp, Ki, Kx, z, rhs);
         }
       }
-      if (!ok) { printf("\nerror in LDL factorization\n"); return bail("init_lin_sys_work failure"); }
+      tmp.release();
+      return out;
+    };
+    constexpr double kGuardTol = 1e-8;
+    int rc = set_up(-2);
+    double res = rc == 0 ? residual() : 1e300;
+    bool ok = rc == 0 && res <= kGuardTol;
+    if (!ok && rc != -2 && F.T > 0) { // no dense tail then
+      if (st->verbose) printf("dense tail rejected (T = %d, set-up residual %.2e): using the level-scheduled factor\n", F.T, res);
+      (void)hipGetLastError();
+      w->ldl.release();
+      ok = set_up(0) == 0 && residual() <= kGuardTol;
     }
-    if (hipMalloc((void **)&w->lp_ctl, sizeof(Ctl)) != hipSuccess || hipMemsetAsync(w->lp_ctl, 0, sizeof(Ctl), w->stream) != hipSuccess) return bail("allocation failure");
+    if (!ok) { printf("\nerror in LDL factorization\n"); return bail("init_lin_sys_work failure"); }
   }
   DBuf<double> *lv[] = {&w->u, &w->v, &w->vo, &w->ut, &w->rel, &w->r, &w->p};
   for (auto *b : lv) { if (b->alloc(w->LV)) return bail("work memory allocation failure"); if (hipMemsetAsync(b->p, 0, sizeof(double) * w->LV, w->stream) != hipSuccess) return bail("memset failure"); }

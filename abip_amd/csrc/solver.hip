@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -33,6 +34,16 @@ using namespace abip::hostutil;
 namespace {
 
 int g_linsys = -1; // -1: not chosen yet -> environment / default
+int g_copy_a = -1; // -1: environment / default (copy)
+// The reference scales the caller's A in place unless it is built with COPYAMATRIX (abip.c:1799-1807), which its mex build is
+// (make_abip.m:13): Matlab owns A.  A shared library cannot know which build it replaces, so the safe behaviour is the default:
+// work on a private copy of the values and never touch the caller's matrix; abip_hip_set_copy_a_matrix(0) / ABIP_HIP_COPYAMATRIX=0
+// gives the in-place scaling (and the un-scaling in abip_finish, abip.c:2310-2317) of the plain C build.
+bool copy_a_matrix() {
+  if (g_copy_a >= 0) return g_copy_a != 0;
+  const char *e = getenv("ABIP_HIP_COPYAMATRIX");
+  return !(e && atoi(e) == 0);
+}
 
 // ---- multi-GPU context (one process per GPU; set before abip_init) --------------------------------------
 // RCCL is bound with dlopen so that the library neither needs it for single-GPU use nor clashes with the copy a host
@@ -45,6 +56,8 @@ struct RcclApi {
   int (*CommInitRank)(rcclComm_t *, int, Uid128, int) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
   int (*CommDestroy)(rcclComm_t) = nullptr;
+  int (*CommAbort)(rcclComm_t) = nullptr;       // optional
+  int (*CommCount)(rcclComm_t, int *) = nullptr; // optional
 };
 struct DistCtx {
   int kind = 0; // 0 none, 1 RCCL, 2 host callback (tests)
@@ -55,6 +68,16 @@ struct DistCtx {
   RcclApi api;
 };
 DistCtx g_dist;
+bool g_dist_aborted = false;
+
+// A rank that fails inside a sharded solve stops issuing collectives; its peers would wait in ncclAllReduce for ever.  Abort the
+// communicator so that they fail too, and leave tearing the job down to the launcher: the caller must exit non-zero, not retry.
+void dist_abort(const char *why) {
+  if (g_dist.kind != 1 || !g_dist.comm || g_dist_aborted) return;
+  fprintf(stderr, "abip_hip: rank %d aborts the RCCL communicator (%s); exit non-zero, do not retry in-process\n", g_dist.rank, why);
+  if (g_dist.api.CommAbort) g_dist.api.CommAbort(g_dist.comm);
+  g_dist.comm = nullptr; g_dist_aborted = true;
+}
 
 bool load_rccl(RcclApi &a) {
   if (a.handle) return true;
@@ -65,6 +88,8 @@ bool load_rccl(RcclApi &a) {
   a.CommInitRank = (int (*)(rcclComm_t *, int, Uid128, int))dlsym(a.handle, "ncclCommInitRank");
   a.AllReduce = (int (*)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t))dlsym(a.handle, "ncclAllReduce");
   a.CommDestroy = (int (*)(rcclComm_t))dlsym(a.handle, "ncclCommDestroy");
+  a.CommAbort = (int (*)(rcclComm_t))dlsym(a.handle, "ncclCommAbort");
+  a.CommCount = (int (*)(rcclComm_t, int *))dlsym(a.handle, "ncclCommCount");
   if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy) { fprintf(stderr, "abip_hip: librccl lacks a required symbol\n"); return false; }
   return true;
 }
@@ -99,7 +124,8 @@ struct ABIP_WORK {
   int NB = 1;         // persistent grid size == partials per slot
   int linsys = ABIP_HIP_LINSYS_DIRECT;
   ABIPSettings *stgs = nullptr;
-  ABIPMatrix *A = nullptr; // caller's matrix, scaled in place until abip_finish
+  ABIPMatrix *A = nullptr; // the matrix being scaled: the caller's (in place, until abip_finish) or Aown; null once a private copy is no longer needed
+  ABIPMatrix Aown{}; std::vector<double> Aown_x; // private copy of the values (COPYAMATRIX behaviour, the default)
   double sp = 0;
   std::vector<double> D, E; // host copies of the scalings
   double mean_norm_row_A = 0, mean_norm_col_A = 0;
@@ -132,6 +158,7 @@ struct ABIP_WORK {
   double t_solve0 = 0, cpu0 = 0;
   bool stats_valid = false, avg_stats_valid = false; // ctl.out holds the sums of the current (averaged) iterate
   int last_cg_its = 6;
+  double factor_resid = 0; // set-up guard of the direct back-end: ||K z - rhs|| / ||rhs|| of one known right-hand side
   int cg_enq = 0; // CG iterations enqueued so far for the solve in flight
   long tot_cg_its = 0, tot_solves = 0;
   // solution staged on the host by finish_solution()
@@ -156,6 +183,13 @@ struct ABIP_WORK {
   int ev_tag = -1; // CG iteration index of the launches being enqueued (-1: always effective)
   std::vector<Ev> ev_pool; size_t ev_used = 0;
   AbipHipProfile prof{};
+  // device-side launch stamps (dev_common.h Stamp): a ring of records, harvested with the once-per-iteration control read
+  static constexpr size_t ST_RING = 1u << 15;
+  unsigned stamp_mask = 0;
+  DBuf<Stamp> stamps; Stamp *hstamps = nullptr;
+  std::vector<signed char> st_cls; // class of the launch that owns a slot
+  size_t st_head = 0, st_tail = 0; // next free slot / first slot not yet harvested (monotonic; slot = counter % ST_RING)
+  double tick_ms = 1e-5;           // one wall-clock tick in milliseconds
   std::vector<double> scratch; // host scratch (LV)
 };
 
@@ -198,10 +232,43 @@ void harvest_events(W *w) { // call only after the stream has been synchronised
   w->ev_used = 0;
 }
 
+Stamp *next_stamp(W *w, int cls) { // a fresh record for the launch about to be enqueued, or null when this class is not being stamped
+  if (!((w->stamp_mask >> cls) & 1u) || !w->stamps.p || w->st_head - w->st_tail >= W::ST_RING) return nullptr;
+  const size_t slot = w->st_head++ % W::ST_RING;
+  w->st_cls[slot] = (signed char)cls;
+  return w->stamps.p + slot;
+}
+int enqueue_stamp_readback(W *w, size_t *lo, size_t *hi) { // D2H of the records written since the last harvest (the stream is synchronised by the caller)
+  *lo = w->st_tail; *hi = w->st_head;
+  for (size_t a = *lo; a < *hi;) {
+    const size_t slot = a % W::ST_RING, len = std::min(*hi - a, W::ST_RING - slot);
+    HIP_OK(hipMemcpyAsync(w->hstamps + slot, w->stamps.p + slot, len * sizeof(Stamp), hipMemcpyDeviceToHost, w->stream));
+    HIP_OK(hipMemsetAsync(w->stamps.p + slot, 0, len * sizeof(Stamp), w->stream)); // ready for reuse
+    a += len;
+  }
+  return 0;
+}
+void harvest_stamps(W *w, size_t lo, size_t hi) {
+  for (size_t a = lo; a < hi; ++a) {
+    const size_t slot = a % W::ST_RING;
+    const Stamp &r = w->hstamps[slot];
+    if (r.t1 == 0) { w->prof.stamp_noop_launches++; continue; } // returned at a gate (enqueued past PCG convergence)
+    const unsigned long long t0 = ~r.t0_inv;
+    if (r.t1 <= t0) continue;
+    const int cls = w->st_cls[slot];
+    w->prof.stamp_ms[cls] += (double)(r.t1 - t0) * w->tick_ms;
+    w->prof.stamp_launches[cls]++;
+  }
+  w->st_tail = hi;
+}
+
 int sync_ctl(W *w) { // the once-per-iteration control read
+  size_t lo = 0, hi = 0;
+  if (w->stamp_mask && enqueue_stamp_readback(w, &lo, &hi)) return -1;
   HIP_OK(hipMemcpyAsync(w->hctl, w->ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, w->stream));
   HIP_OK(hipStreamSynchronize(w->stream));
   harvest_events(w);
+  if (hi > lo) harvest_stamps(w, lo, hi);
   return 0;
 }
 
@@ -213,6 +280,7 @@ inline Dims dims(const W *w) { return Dims{(int)w->m, (int)w->n, w->MP}; }
 int allreduce_dev(W *w, double *buf, size_t count) {
   if (!w->dist) return 0;
   if (g_dist.kind == 1) {
+    if (!g_dist.comm) return -1; // aborted
     const int rc = g_dist.api.AllReduce(buf, buf, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, g_dist.comm, w->stream);
     if (rc != 0) { fprintf(stderr, "abip_hip: ncclAllReduce failed (%d)\n", rc); return -1; }
     return 0;
@@ -250,9 +318,10 @@ int enqueue_cg_begin(W *w, double *rhs, const double *warm, abip_int iter) {
   const Dims d = dims(w);
   w->cg_enq = 0;
   const Ctl *ctl = w->ctl.p;
+  const double *bx = rhs + w->MP;
   if (!w->dist) {
-    if (warm) launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_At, w->NB, BS, w->dAt.view(), warm, w->cg_tmp.p, ctl);
-    launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_A<false>, w->NB, BS, w->dA.view(), rhs, (const double *)w->cg_tmp.p, warm, (const double *)w->cg_M.p,
+    if (warm) launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_At, w->NB, BS, w->dAt.view(), warm, bx, w->cg_tmp.p, ctl);
+    launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_A<false>, w->NB, BS, w->dA.view(), rhs, warm ? (const double *)w->cg_tmp.p : bx, warm, (const double *)w->cg_M.p,
            w->cg_r.p, w->cg_z.p, w->cg_p.p, w->stgs->rho_y, cg_tol_factor(w, iter), d, w->part.p, w->NB, w->ctl.p, (const double *)nullptr);
     return 0;
   }
@@ -260,8 +329,9 @@ int enqueue_cg_begin(W *w, double *rhs, const double *warm, abip_int iter) {
   if (warm) {
     launch(w, ABIP_HIP_K_CG_EDGE, k_spmv_set, w->NB, BS, w->dAt.view(), warm, w->T.p, 0, ctl);
     if (allreduce_vec_and_scalars(w)) return -1;
+    launch(w, ABIP_HIP_K_VEC, k_cg_init_sub, w->NB, BS, w->T.p, bx, (int)w->n, ctl);
   } else if (allreduce_scalars(w)) return -1;
-  launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_A<true>, w->NB, BS, w->dA.view(), rhs, (const double *)w->T.p, warm, (const double *)w->cg_M.p,
+  launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_A<true>, w->NB, BS, w->dA.view(), rhs, warm ? (const double *)w->T.p : bx, warm, (const double *)w->cg_M.p,
          w->cg_r.p, w->cg_z.p, w->cg_p.p, w->stgs->rho_y, cg_tol_factor(w, iter), d, w->part.p, w->NB, w->ctl.p, (const double *)w->gs);
   return 0;
 }
@@ -272,17 +342,17 @@ int enqueue_cg_chunk(W *w, double *rhs, int its) {
     w->ev_tag = w->cg_enq++;
     if (!w->dist) {
       launch(w, ABIP_HIP_K_SPMV_AT, k_cg_spmv_At, w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, w->cg_tmp.p,
-             max_its, w->part.p, w->NB, w->ctl.p);
+             max_its, w->part.p, w->NB, w->ctl.p, next_stamp(w, ABIP_HIP_K_SPMV_AT));
     } else {
       FoldArgs fo; fo.nslots = 0;
       for (int sl : {S_RR0, S_RR1, S_ZR0, S_ZR1, S_ZZ, S_ZP}) fo.slots[fo.nslots++] = sl;
       launch(w, ABIP_HIP_K_SPMV_AT, k_spmv_set_t<true>, w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, w->T.p, 1, (const Ctl *)w->ctl.p,
-             fo, (const double *)w->part.p, w->NB, w->gs);
+             fo, (const double *)w->part.p, w->NB, w->gs, next_stamp(w, ABIP_HIP_K_SPMV_AT));
       if (allreduce_vec_and_scalars(w)) return -1;
       launch(w, ABIP_HIP_K_CG_VEC, k_dist_cg_step, w->NB, BS, (const double *)w->T.p, w->cg_tmp.p, (int)w->n, max_its, 1, (const double *)w->gs, w->part.p, w->ctl.p);
     }
     launch(w, ABIP_HIP_K_SPMV_A, k_cg_spmv_A, w->NB, BS, w->dA.view(), (const double *)w->cg_tmp.p, (const double *)w->cg_z.p, w->cg_p.p,
-           w->cg_Gp.p, w->stgs->rho_y, w->part.p, (const Ctl *)w->ctl.p);
+           w->cg_Gp.p, w->stgs->rho_y, w->part.p, (const Ctl *)w->ctl.p, next_stamp(w, ABIP_HIP_K_SPMV_A));
     // sharded: p'Gp = rho ||p||^2 + ||A'p||^2 needs no collective of its own (k_dist_cg_step left both pieces behind)
     if (w->dist)
       launch(w, ABIP_HIP_K_CG_VEC, k_cg_update<true>, gvec, BS, rhs, w->cg_r.p, w->cg_z.p, (const double *)w->cg_p.p, (const double *)w->cg_Gp.p,
@@ -944,6 +1014,8 @@ void free_work(W *w) {
   for (auto *b : bufs) b->release();
   w->ctl.release(); w->ldl.release(); w->T.release();
   if (w->hctl) (void)hipHostFree(w->hctl);
+  w->stamps.release();
+  if (w->hstamps) (void)hipHostFree(w->hstamps);
   for (auto &e : w->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (w->stream) (void)hipStreamDestroy(w->stream);
   delete w;
@@ -970,6 +1042,7 @@ extern "C" {
 const char *abip_version(void) { return ABIP_VERSION; }
 
 void abip_hip_set_linsys(int which) { g_linsys = which ? ABIP_HIP_LINSYS_INDIRECT : ABIP_HIP_LINSYS_DIRECT; }
+void abip_hip_set_copy_a_matrix(int on) { g_copy_a = on ? 1 : 0; }
 int abip_hip_get_linsys(void) { return chosen_linsys(); }
 
 int abip_hip_device_info(char *name, int name_len, long *total_mem_bytes, int *num_cu) {
@@ -1026,6 +1099,13 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
   { const char *e = getenv("ABIP_HIP_BATCH"); w->batch_ok = !(e && atoi(e) == 0); }
   if (d->stgs->verbose) print_init_header(d, w->linsys);
   w->stgs = d->stgs; w->n = d->n; w->A = d->A; w->sp = d->sp;
+  const bool own_copy = copy_a_matrix();
+  if (own_copy) { // scaling changes the values only: the index arrays are shared read-only
+    w->Aown = *d->A;
+    w->Aown_x.assign(d->A->x, d->A->x + d->A->p[d->n]);
+    w->Aown.x = w->Aown_x.data();
+    w->A = &w->Aown;
+  }
   w->m_glob = d->m; w->m = d->m; w->row0 = 0;
   const abip_int n = d->n;
   auto fail = [&](const char *msg) -> ABIPWork * { printf("ERROR: %s\n", msg); free_work(w); return nullptr; };
@@ -1072,7 +1152,11 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
   if (w->dAt.upload(hAt, w->stream) || w->dA.upload(hA, w->stream)) return fail("device allocation failure (matrix)");
   { // persistent grid: every kernel uses the same NB (== partials per slot).  Sized so that the SpMV kernels give each
     // workgroup the same whole number of row blocks (no tail), at most MAXNB (8 workgroups per CU on 256 CUs).
-    const long nrb = std::max<long>(std::max<long>(w->dAt.nrb, w->dA.nrb), (std::max<long>(m, n) + 4 * BS - 1) / (4 * BS));
+    long nrb = std::max<long>(std::max<long>(w->dAt.nrb, w->dA.nrb), (std::max<long>(m, n) + 4 * BS - 1) / (4 * BS));
+    // sharded: NB also fixes the order in which the REPLICATED n-space reductions (||A'p||^2, the LOQO sum and minimum) add up,
+    // and those must come out bit-identical on every rank (they steer alpha, mu and with them the host's control flow): derive
+    // it from global quantities only, never from this rank's row block
+    if (w->dist) nrb = std::max<long>(((long)w->A->p[n] / w->world + CHUNK - 1) / CHUNK + 1, (std::max<long>((long)w->m_glob / w->world + 1, n) + 4 * BS - 1) / (4 * BS));
     const long per = (nrb + MAXNB - 1) / MAXNB;
     w->NB = (int)std::max<long>(1, (nrb + per - 1) / per);
   }
@@ -1096,27 +1180,53 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
     if (hipMemsetAsync(w->cg_tmp.p, 0, sizeof(double) * n, w->stream) != hipSuccess) return fail("memset failure");
   } else { // init_lin_sys_work / factorize, direct.c:218-303
     host::LdlHost F;
-    if (host::factor_kkt(w->A, w->stgs->rho_y, F) < 0) return fail("init_lin_sys_work failure");
-    std::vector<int> pmap(F.N);
-    for (int q = 0; q < F.N; ++q) pmap[q] = F.P[q] < (int)m ? F.P[q] : w->MP + (F.P[q] - (int)m);
-    if (w->ldl.setup(F, pmap, w->stream)) {
-      if (F.T == 0) return fail("init_lin_sys_work failure");
-      // the dense tail could not be set up (no room for its two T x T triangles, or a pivot the un-pivoted dense LDL' cannot take):
-      // fall back to the plain level-scheduled factor
+    std::vector<int> Kp, Ki;
+    std::vector<double> Kx;
+    host::kkt_upper(w->A, w->stgs->rho_y, Kp, Ki, Kx);
+    const int N = (int)(m + n);
+    std::vector<int> pmap(N);
+    auto set_up = [&](int tail_request) -> int { // factor on the host, upload, build the dense tail on the device; < 0: cannot
+      if (tail_request != -2) host::set_tail_request(tail_request);
+      const int rc = host::factor_upper(N, Kp, Ki, Kx, F);
+      host::set_tail_request(-2);
+      if (rc < 0) return -2;
+      for (int q = 0; q < N; ++q) pmap[q] = F.P[q] < (int)m ? F.P[q] : w->MP + (F.P[q] - (int)m);
+      return w->ldl.setup(F, pmap, w->stream) ? -1 : 0;
+    };
+    // set-up guard: solve one known right-hand side with the factor as the hot loop will and check ||K z - rhs|| on the host
+    auto residual = [&]() -> double {
+      std::vector<double> rhs, lv(w->LV, 0.0), z(N);
+      host::guard_rhs(N, rhs);
+      for (int i = 0; i < N; ++i) lv[i < (int)m ? i : w->MP + (i - (int)m)] = rhs[i];
+      if (hipMemcpyAsync(w->a_ut.p, lv.data(), sizeof(double) * w->LV, hipMemcpyHostToDevice, w->stream) != hipSuccess) return 1e300;
+      w->ldl.enqueue([&](auto kern, int grid, int block, size_t lds, auto... a) { launch_lds(w, ABIP_HIP_K_SPTRSV, kern, grid, block, lds, a...); }, w->a_ut.p, (const Ctl *)w->ctl.p, w->NB);
+      if (hipMemcpyAsync(lv.data(), w->a_ut.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess) return 1e300;
+      for (int i = 0; i < N; ++i) z[i] = lv[i < (int)m ? i : w->MP + (i - (int)m)];
+      if (getenv("ABIP_HIP_TAIL_RESID_FAIL") && F.T > 0) return 1.0; // test hook: pretend the tail is too ill-conditioned for inv(L22)
+      return host::sym_upper_residual(N, Kp, Ki, Kx, z, rhs);
+    };
+    constexpr double kGuardTol = 1e-8; // healthy factors sit at 1e-16 ... 1e-11
+    int rc = set_up(-2);
+    double res = rc == 0 ? residual() : 1e300;
+    if (rc == -2 || (rc != 0 && F.T == 0)) return fail("init_lin_sys_work failure");
+    if (rc != 0 || res > kGuardTol) {
+      // the dense tail could not be set up (no room for its two T x T triangles, a pivot the un-pivoted dense LDL' cannot take) or its
+      // explicit inverse lost the solve's accuracy: fall back to the plain level-scheduled factor
+      if (F.T == 0) return fail("init_lin_sys_work failure (KKT solve residual above 1e-8)");
+      if (w->stgs->verbose) printf("dense tail rejected (T = %d, set-up residual %.2e): using the level-scheduled factor\n", F.T, res);
       (void)hipGetLastError();
       w->ldl.release();
-      host::set_tail_request(0);
-      const int rc = host::factor_kkt(w->A, w->stgs->rho_y, F);
-      host::set_tail_request(-2);
-      if (rc < 0) return fail("init_lin_sys_work failure");
-      for (int q = 0; q < F.N; ++q) pmap[q] = F.P[q] < (int)m ? F.P[q] : w->MP + (F.P[q] - (int)m);
-      if (w->ldl.setup(F, pmap, w->stream)) return fail("init_lin_sys_work failure");
+      if (set_up(0) != 0) return fail("init_lin_sys_work failure");
+      res = residual();
+      if (res > kGuardTol) return fail("init_lin_sys_work failure (KKT solve residual above 1e-8)");
     }
+    w->factor_resid = res;
     { const char *e = getenv("ABIP_HIP_FUSE"); w->fuse_small = w->ldl.small && !w->dist && !(e && atoi(e) == 0) && (!w->ldl.xl || w->ldl.allow_lds<LpSolveFuse>()); }
     const int one = 1; // the post-solve kernels are gated on cg_done: permanently set for the direct back-end
     if (hipMemcpyAsync(&w->ctl.p->cg_done, &one, sizeof(int), hipMemcpyHostToDevice, w->stream) != hipSuccess) return fail("memcpy failure");
   }
   if (hipStreamSynchronize(w->stream) != hipSuccess) return fail("device set-up failed");
+  if (own_copy) { w->A = nullptr; std::vector<double>().swap(w->Aown_x); } // everything lives on the device now
   info->setup_time = now_ms() - t0;
   if (d->stgs->verbose) printf("Setup time: %1.2es\n", info->setup_time / 1e3);
   return w;
@@ -1207,6 +1317,7 @@ abip_int abip_hip_step(ABIPWork *w, abip_int max_admm_steps, abip_int *steps_don
   auto hard_fail = [&](const char *msg) { // failure(), abip.c:282-303
     fail_fill(w, info, ABIP_FAILED, "Failure");
     printf("Failure:%s\n", msg);
+    if (w->dist) dist_abort(msg);
     w->phase = PH_DONE;
     return done(1);
   };
@@ -1354,7 +1465,7 @@ abip_int abip_solve(ABIPWork *w, const ABIPData *d, ABIPSolution *sol, ABIPInfo 
     abip_hip_solve_end(w, sol, info);
     return ABIP_FAILED;
   }
-  while (!abip_hip_step(w, 1L << 40, nullptr, info)) {}
+  while (!abip_hip_step(w, std::numeric_limits<abip_int>::max() / 2, nullptr, info)) {}
   if (w->have_solution) abip_hip_solve_end(w, sol, info);
   info->setup_time = setup;
   return info->status_val;
@@ -1455,8 +1566,12 @@ abip_int abip_hip_get_vector(ABIPWork *w, const char *name, abip_float *out, abi
       HIP_OK(hipStreamSynchronize(w->stream));
       return e.len;
     }
-  if (!strcmp(name, "D")) { if (cap < m || w->D.empty()) return -1; std::copy(w->D.begin(), w->D.end(), out); return m; }
-  if (!strcmp(name, "E")) { if (cap < n || w->E.empty()) return -1; std::copy(w->E.begin(), w->E.end(), out); return n; }
+  if (!strcmp(name, "D")) { // all rows of the problem (the scaling is computed from the full matrix on every rank), not only this rank's
+    if (w->D.empty() || cap < (abip_int)w->D.size()) return -1;
+    std::copy(w->D.begin(), w->D.end(), out);
+    return (abip_int)w->D.size();
+  }
+  if (!strcmp(name, "E")) { if (w->E.empty() || cap < (abip_int)w->E.size()) return -1; std::copy(w->E.begin(), w->E.end(), out); return n; }
   return -1;
 }
 abip_float abip_hip_get_scalar(ABIPWork *w, const char *name) {
@@ -1465,7 +1580,7 @@ abip_float abip_hip_get_scalar(ABIPWork *w, const char *name) {
   RET("mu", w->mu) RET("beta", w->beta) RET("sigma", w->sigma) RET("gamma", w->gamma) RET("g_th", w->g_th)
   RET("sc_b", w->sc_b) RET("sc_c", w->sc_c) RET("nm_b", w->nm_b) RET("nm_c", w->nm_c) RET("tot_cg_its", w->tot_cg_its)
   RET("lnnz", w->ldl.lnnz) RET("levels_fwd", w->ldl.F.nlev) RET("levels_bwd", w->ldl.B.nlev) RET("tail", w->ldl.T) RET("admm_iter", w->k) RET("ipm_iter", w->i)
-  RET("nb", w->NB) RET("small_solve", w->ldl.small ? 1 : 0)
+  RET("nb", w->NB) RET("small_solve", w->ldl.small ? 1 : 0) RET("factor_resid", w->factor_resid)
 #undef RET
   return NAN;
 }
@@ -1531,8 +1646,16 @@ int abip_hip_dist_init_callback(int rank, int world, abip_hip_allreduce_fn fn, v
   g_dist.kind = 2; g_dist.rank = rank; g_dist.world = world; g_dist.fn = fn; g_dist.fn_ctx = ctx;
   return 0;
 }
+int abip_hip_dist_comm_count(void) { // ranks of the live communicator as RCCL reports them (callback transport: the world it was given; none: 0)
+  if (g_dist.kind == 2) return g_dist.world;
+  if (g_dist.kind != 1 || !g_dist.comm) return 0;
+  int cnt = g_dist.world;
+  if (g_dist.api.CommCount && g_dist.api.CommCount(g_dist.comm, &cnt) != 0) return -1;
+  return cnt;
+}
 void abip_hip_dist_finalize(void) {
   if (g_dist.kind == 1 && g_dist.comm) g_dist.api.CommDestroy(g_dist.comm);
+  g_dist_aborted = false;
   g_dist.kind = 0; g_dist.rank = 0; g_dist.world = 1; g_dist.comm = nullptr; g_dist.fn = nullptr; g_dist.fn_ctx = nullptr;
 }
 void abip_hip_dist_rows(ABIPWork *w, abip_int *row0, abip_int *row1) {
@@ -1542,6 +1665,22 @@ void abip_hip_dist_rows(ABIPWork *w, abip_int *row0, abip_int *row1) {
 }
 
 void abip_hip_profile_enable(ABIPWork *w, unsigned mask) { if (w) w->prof_mask = mask; }
+int abip_hip_profile_enable_stamps(ABIPWork *w, unsigned mask) { // classes ABIP_HIP_K_SPMV_AT / _A only (the kernels that take a Stamp)
+  if (!w) return -1;
+  mask &= (1u << ABIP_HIP_K_SPMV_AT) | (1u << ABIP_HIP_K_SPMV_A);
+  if (mask && !w->stamps.p) {
+    if (w->stamps.alloc(W::ST_RING)) return -1;
+    if (hipMemsetAsync(w->stamps.p, 0, sizeof(Stamp) * W::ST_RING, w->stream) != hipSuccess) return -1;
+    if (hipHostMalloc((void **)&w->hstamps, sizeof(Stamp) * W::ST_RING, hipHostMallocDefault) != hipSuccess) return -1;
+    w->st_cls.assign(W::ST_RING, 0);
+    int dev = 0, khz = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) w->tick_ms = 1.0 / (double)khz;
+  }
+  if (!mask && w->stamp_mask) { (void)hipStreamSynchronize(w->stream); w->st_tail = w->st_head; if (w->stamps.p) (void)hipMemsetAsync(w->stamps.p, 0, sizeof(Stamp) * W::ST_RING, w->stream); }
+  w->stamp_mask = mask;
+  return 0;
+}
 void abip_hip_profile_read(ABIPWork *w, AbipHipProfile *out, int reset) {
   if (!w || !out) return;
   *out = w->prof;

@@ -71,6 +71,11 @@ def init_callback(rank: int, world: int, allreduce) -> None:
         raise RuntimeError("abip_hip_dist_init_callback failed")
 
 
+def comm_count() -> int:
+    """Ranks of the live communicator as the transport itself reports them (RCCL: ncclCommCount); 0 without one."""
+    return int(_lib.load().abip_hip_dist_comm_count())
+
+
 def finalize() -> None:
     _lib.load().abip_hip_dist_finalize()
     _keepalive.clear()

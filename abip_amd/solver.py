@@ -46,7 +46,7 @@ def info_dict(info: ABIPInfo) -> dict:
 
 
 class Solver:
-    """Owns host copies of (A, b, c) -- abip_init scales A in place, as the reference does -- and the device work."""
+    """Owns host copies of (A, b, c) and the device work (abip_init scales a private copy of A unless abip_hip_set_copy_a_matrix(0))."""
 
     def __init__(self, A, b, c, linsys: int | str = LINSYS_DIRECT, **settings):
         self.w = None
@@ -139,6 +139,12 @@ class Solver:
             raise KeyError(name)
         return out[:ln].copy()
 
+    def rows(self) -> tuple[int, int]:
+        """This rank's row range [row0, row1) of the sharded PCG path ((0, m) on a single GPU)."""
+        r0, r1 = c_int(0), c_int(0)
+        self.L.abip_hip_dist_rows(self.w, C.byref(r0), C.byref(r1))
+        return int(r0.value), int(r1.value)
+
     def scalar(self, name: str) -> float:
         return float(self.L.abip_hip_get_scalar(self.w, name.encode()))
 
@@ -149,13 +155,24 @@ class Solver:
             mask |= 1 << K_CLASSES.index(cname)
         self.L.abip_hip_profile_enable(self.w, mask)
 
+    def profile_enable_stamps(self, classes=("spmv_At", "spmv_A")) -> None:
+        """Device-side begin/end ticks of the PCG SpMV launches (no event records; cheap enough for a timed region)."""
+        mask = 0
+        for cname in classes:
+            mask |= 1 << K_CLASSES.index(cname)
+        if self.L.abip_hip_profile_enable_stamps(self.w, mask) != 0:
+            raise RuntimeError("abip_hip_profile_enable_stamps failed")
+
     def profile_read(self, reset: bool = True) -> dict:
         p = AbipHipProfile()
         self.L.abip_hip_profile_read(self.w, C.byref(p), 1 if reset else 0)
         return dict(ms={k: p.ms[i] for i, k in enumerate(K_CLASSES)},
                     launches={k: p.launches[i] for i, k in enumerate(K_CLASSES)},
                     noop_ms=p.noop_ms, noop_launches=p.noop_launches,
-                    admm_iters=p.admm_iters, cg_iters=p.cg_iters, kkt_solves=p.kkt_solves)
+                    admm_iters=p.admm_iters, cg_iters=p.cg_iters, kkt_solves=p.kkt_solves,
+                    stamp_ms={k: p.stamp_ms[i] for i, k in enumerate(K_CLASSES)},
+                    stamp_launches={k: p.stamp_launches[i] for i, k in enumerate(K_CLASSES)},
+                    stamp_noop_launches=p.stamp_noop_launches)
 
     def close(self) -> None:
         if getattr(self, "w", None):

@@ -1,22 +1,31 @@
 #!/usr/bin/env python
 """bench.py -- ADMM iterations/s of the MI355X-native ABIP-LP hot path (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W [--workload c4|c2|c3|c5] [--no-to-tol] [--no-cpu]
+    python bench.py --gpus N --steps K --warmup W [--workload c4|c2|c3|c5] [--no-to-tol] [--no-cpu] [--no-extra]
 
 One "step" = one inner ADMM iteration of the real solver trajectory (KKT solve incl. all its PCG
 iterations, barrier prox, dual update, averages, stopping test; outer-iteration work -- residuals,
 mu update, Barzilai-Borwein search -- runs when the trajectory reaches it and is inside the timed region).
 The problem is resident in HBM before the timed region starts (abip_init + abip_hip_solve_begin).
 
+Launching.  `--gpus 1` runs in this process.  `--gpus N` (N > 1) under a launcher (torchrun / the driver: RANK, WORLD_SIZE, ... in
+the environment) is one rank of N.  `--gpus N` WITHOUT such an environment starts the N ranks itself -- `python -m
+torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a child process, before this process has touched the
+GPU -- forwards rank 0's JSON line and exits with the child's code.  A node with fewer than N GPUs, a rank that fails or a
+WORLD_SIZE that contradicts --gpus is an error (non-zero exit, no JSON line): there is no silent replica fall-back.
+ABIP_BENCH_TRANSPORT=gloo-callback puts every rank on cuda:0 with the host-staged collective over gloo (a plumbing dry run
+for one-GPU boxes; the line says so and is not a scaling number).
+
 Workloads (BASELINE.json configs; no Netlib/Mittelmann files exist offline, so C2/C3 are seeded
 structure-matched surrogates, labelled as such):
     c4  synthetic random sparse LP m=200k n=500k nnz~5M, PCG back-end        (default: the roofline config
-        and the only LP config that partitions over GPUs)
+        and the only LP config that partitions over GPUs; N > 1 shards its rows: strong scaling)
     c2  25fv47-class block-staircase LP (816 x 1879, nnz~1e4), direct LDL' back-end
     c3  pds-class multi-commodity network LP, PCG back-end
     c5  LASSO-as-SOCP through the conic path (abip_qcp, p=10000 samples, d=45000 features, n=100002), direct LDL' with a dense tail;
         abip_qcp() is one call (the reference's conic entry point has no stepping form), so a step count cannot be imposed:
         one untimed full solve warms up, a second one is timed and `steps` is the number of ADMM iterations it took
+On one GPU the default (c4) line also carries short c2 and c3 records under extra.configs (each with its own roofline and cpu_baseline).
 
 Prints ONE JSON line (rank 0).
 """
@@ -25,8 +34,11 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+import traceback
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -43,9 +55,50 @@ def emit(record: dict) -> None:
     os.write(_REAL_STDOUT, (json.dumps(record) + "\n").encode())
 
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
+def die(msg: str, code: int = 2):
+    sys.stderr.write("bench.py: " + msg + "\n")
+    sys.stderr.flush()
+    os._exit(code)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# launching N ranks
+# ---------------------------------------------------------------------------------------------------------
+def spawn_ranks(args) -> None:
+    """--gpus N > 1 outside a launcher: start the ranks as children of this (GPU-free) process and relay rank 0's line."""
+    import torch  # device_count() does not initialise the GPU on this image
+    transport = os.environ.get("ABIP_BENCH_TRANSPORT", "rccl")
+    if transport not in ("rccl", "gloo-callback"):
+        die(f"unknown ABIP_BENCH_TRANSPORT={transport!r} (rccl | gloo-callback)")
+    ndev = torch.cuda.device_count()
+    if transport == "rccl" and ndev < args.gpus:
+        die(f"--gpus {args.gpus} needs {args.gpus} GPUs on this node, found {ndev}: not launching (one process per GPU over RCCL; "
+            "ABIP_BENCH_TRANSPORT=gloo-callback runs an N-rank plumbing dry run on one GPU)")
+    if ndev < 1:
+        die("no GPU visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, timeout=float(os.environ.get("ABIP_BENCH_TIMEOUT", "3000")))
+    except subprocess.TimeoutExpired:
+        die("the ranks did not finish in time (killed)", 3)
+    lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        die(f"the {args.gpus}-rank launch failed (exit code {p.returncode}, {len(lines)} result line(s)); see the ranks' stderr above", p.returncode or 1)
+    os.write(_REAL_STDOUT, (lines[-1] + "\n").encode())
+    os._exit(0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# workloads, byte counts, CPU leg
+# ---------------------------------------------------------------------------------------------------------
 def make_workload(name: str):
     from abip_amd import problems
     if name == "c4":
@@ -65,27 +118,52 @@ def b_spmv(R, C, nnz):
     return 12 * nnz + 4 * (R + 1) + 8 * C + 16 * R
 
 
-def cpu_baseline(A, b, c, linsys, budget_s=20.0):
-    """The reference itself (oracle/_ref, kind 'reference') or our C restatement (kind 'port'), one host thread,
-    on a bounded prefix of the same trajectory."""
+def host_cores() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(A, b, c, linsys, budget_s=12.0, window=None):
+    """The reference itself (oracle/_ref, kind 'reference') or our C restatement (kind 'port') on ONE host thread, on a bounded prefix
+    of the same trajectory -- and the restatement with the reference's OpenMP loop enabled (common.c:620-622) on several threads."""
     from oracle import pyoracle as po
     kind = "reference" if po.have_ref() else "port"
     which = "ref" if kind == "reference" else "oracle"
-    # probe with a few iterations, then size the sample to the budget
-    T = 4
-    t0 = time.time()
-    r = po.solve(which, A, b, c, linsys=linsys, eps=1e-6, max_admm_iters=T)
-    probe = max(r.info["solve_time"] / 1e3, 1e-6)
-    per_it = probe / max(r.info["admm_iter"], 1)
-    T2 = int(min(max(budget_s / per_it, 8), 20000))
-    if T2 > 2 * T and (time.time() - t0) < budget_s:
-        r = po.solve(which, A, b, c, linsys=linsys, eps=1e-6, max_admm_iters=T2)
-    secs = r.info["solve_time"] / 1e3
-    its = r.info["admm_iter"]
-    return dict(value=its / secs, unit="ADMM iterations/s", cores=1, kind=kind,
-                sample=f"first {its} ADMM iterations of the same LP and settings (max_admm_iters={max(T, T2)}), {secs:.2f} s, single thread, gcc -O2")
+
+    def sample(which_, budget):
+        T = 4
+        t0 = time.time()
+        r = po.solve(which_, A, b, c, linsys=linsys, eps=1e-6, max_admm_iters=T)
+        per_it = max(r.info["solve_time"] / 1e3, 1e-6) / max(r.info["admm_iter"], 1)
+        T2 = int(min(max(budget / per_it, 8), 20000))
+        if window:
+            T2 = max(T2, min(window, int(4 * budget / per_it)))   # cover the GPU leg's window where that stays bounded
+        if T2 > 2 * T and (time.time() - t0) < budget:
+            r = po.solve(which_, A, b, c, linsys=linsys, eps=1e-6, max_admm_iters=T2)
+        return r.info["admm_iter"], r.info["solve_time"] / 1e3, max(T, T2)
+
+    its, secs, cap = sample(which, budget_s)
+    rec = dict(value=its / secs, unit="ADMM iterations/s", cores=1, kind=kind, host_cores=host_cores(),
+               sample=f"first {its} ADMM iterations of the same LP and settings (max_admm_iters={cap}), {secs:.2f} s, single thread, gcc -O2")
+    if linsys == "indirect":   # the reference's OpenMP site is the SpMV of the PCG path
+        try:
+            L = po.lib("oracle_omp")
+            thr = max(1, min(host_cores(), 32))
+            L.orc_set_threads(thr)
+            its2, secs2, cap2 = sample("oracle_omp", budget_s / 2)
+            rec["openmp"] = dict(value=its2 / secs2, unit="ADMM iterations/s", cores=thr, kind="port",
+                                 sample=f"first {its2} ADMM iterations, {secs2:.2f} s, oracle/abip_lp_oracle.c built -fopenmp (the reference's own "
+                                        f"OpenMP loop, linsys/common.c:620-622; its build must not define _OPENMP), {thr} threads of {host_cores()} host cores")
+        except Exception as e:  # noqa: BLE001
+            rec["openmp"] = dict(error=str(e))
+    return rec
 
 
+# ---------------------------------------------------------------------------------------------------------
+# the conic workload
+# ---------------------------------------------------------------------------------------------------------
 def bench_c5(args, rank, world, dist, torch):
     """BASELINE configs[4]: the conic path on LASSO-as-SOCP.  The direct back-end does not shard: N > 1 = N replicas."""
     import numpy as np
@@ -121,7 +199,7 @@ def bench_c5(args, rank, world, dist, torch):
         from oracle import pyoracle_qcp as pq
         ds, Ks = problems.qcp_lasso_socp(1000, 4500)
         x, y, s_, oi, _ = pq.solve(ds["A"], ds["b"], ds["c"], Ks, eps=1e-3, eps_p=1e-3, eps_d=1e-3, eps_g=1e-3, eps_inf=1e-3, eps_unb=1e-3, linsys_solver=1)
-        cpu = dict(value=oi["admm_iter"] / (oi["solve_time"] / 1e3), unit="ADMM iterations/s", cores=1, kind="port",
+        cpu = dict(value=oi["admm_iter"] / (oi["solve_time"] / 1e3), unit="ADMM iterations/s", cores=1, kind="port", host_cores=host_cores(),
                    sample=f"REDUCED instance p=1000, d=4500 (n=10002) of the same generator: {oi['admm_iter']} iterations in {oi['solve_time'] / 1e3:.2f} s "
                           f"(+ {oi['setup_time'] / 1e3:.1f} s set-up), oracle/abip_qcp_oracle.c, single thread, gcc -O2")
     if rank == 0:
@@ -141,71 +219,28 @@ def bench_c5(args, rank, world, dist, torch):
         dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5"])
-    ap.add_argument("--linsys", default=None, choices=["direct", "indirect"], help="override the workload's KKT back-end (c2/c3/c4)")
-    ap.add_argument("--to-tol", action="store_true", help="(default on one GPU) also run a full solve to eps=1e-6 and report wall-clock")
-    ap.add_argument("--no-to-tol", action="store_true", help="skip the full solve to eps=1e-6 (the second half of BASELINE.json's metric)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--events-in-timed-region", action="store_true",
-                    help="bracket the dominant kernels with hipEvents inside the timed K steps (default: in a second pass of K steps right after)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (libabip_hip has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or os.environ.get("ABIP_BENCH_FORCE_SHARD") == "1":
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
-    if args.workload == "c5":
-        return bench_c5(args, rank, world, dist, torch)
-    steps = args.steps if args.steps is not None else {"c4": 200, "c2": 2000, "c3": 500}[args.workload]
-    warmup = args.warmup if args.warmup is not None else {"c4": 20, "c2": 200, "c3": 50}[args.workload]
-
+# ---------------------------------------------------------------------------------------------------------
+# one LP workload: W untimed steps, K timed steps between barriers, roofline of the dominant kernel from device-side stamps
+# taken INSIDE the timed window, optionally the full solve to eps 1e-6 and the CPU leg
+# ---------------------------------------------------------------------------------------------------------
+def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_override=None, to_tol=True, cpu=True, cpu_budget=12.0, pmc=True):
     from abip_amd import Solver
-    from abip_amd import dist as adist
-    A, b, c, linsys, desc = make_workload(args.workload)
-    if args.linsys and args.linsys != linsys:
-        linsys = args.linsys
+    A, b, c, linsys, desc = make_workload(name)
+    if linsys_override and linsys_override != linsys:
+        linsys = linsys_override
         desc += f" [back-end overridden: {linsys}]"
     m, n = A.shape
     nnz = A.nnz
-    # (ABIP_BENCH_FORCE_SHARD=1 runs the sharded code path with a single rank: a self-test of the N > 1 plumbing on one GPU)
-    sharded = (world > 1 or os.environ.get("ABIP_BENCH_FORCE_SHARD") == "1") and linsys == "indirect" and dist is not None
-    shard_note = None
-    if sharded:
-        # RCCL communicator for the solver; rows of A are split over the ranks inside abip_init.  If the communicator cannot
-        # be built on some rank, every rank falls back to an independent replica of the full problem (and the line says so).
-        ok = 1
-        try:
-            adist.init_torch()
-        except Exception as e:  # noqa: BLE001
-            ok, shard_note = 0, f"sharding unavailable ({e}); ran {world} replicas"
-        t = torch.tensor([ok], device="cuda", dtype=torch.int32)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if int(t.item()) == 0:
-            if ok:
-                adist.finalize()
-            sharded, shard_note = False, shard_note or f"sharding unavailable on another rank; ran {world} replicas"
+    sharded = sharded and linsys == "indirect"
 
     S = Solver(A, b, c, linsys=linsys, eps=1e-6, verbose=0)
     S.begin()
     fin, done_w = S.step(warmup)
     S.sync()
-    dom = ("spmv_At", "spmv_A") if linsys == "indirect" else ("sptrsv",)
-    if args.events_in_timed_region:
-        S.profile_enable(dom)
+    if linsys == "indirect":
+        S.profile_enable_stamps(("spmv_At", "spmv_A"))    # device-side begin/end ticks, no event records: stays on in the timed region
+    elif args.events_in_timed_region:
+        S.profile_enable(("sptrsv",))
     S.profile_read(reset=True)
 
     def barrier():
@@ -224,69 +259,64 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = S.profile_read(reset=True)
-    if not args.events_in_timed_region and not fin:
-        # second pass: the same number of steps with hipEvents around every launch of the dominant kernels (two event
-        # records per launch cost ~20 % of wall time on this launch-dense path, so they are kept out of `value`)
-        S.profile_enable(dom)
+    events_pass = None
+    if linsys == "direct" and not args.events_in_timed_region and not fin:
+        # direct back-end: a solve is several launches; bracket them with hipEvents in a second pass of the same length
+        # (two event records per launch cost ~20 % of wall time on this launch-dense path, so they are kept out of `value`)
+        S.profile_enable(("sptrsv",))
         S.step(steps)
         S.sync()
         pe = S.profile_read(reset=True)
         for key in ("ms", "launches"):
             prof[key] = pe[key]
-        prof["noop_launches"] = pe["noop_launches"]
-        prof["noop_ms"] = pe["noop_ms"]
-        events_pass = dict(steps=steps, cg_iters_per_step=pe["cg_iters"] / max(pe["admm_iters"], 1))
-    else:
-        events_pass = None
+        prof["kkt_solves_events"] = pe["kkt_solves"]
+        events_pass = dict(steps=steps)
     S.profile_enable(())
-    if done != steps:
-        # the solve terminated inside the timed window: the number is still exact for `done` steps
-        steps_eff = done
-    else:
-        steps_eff = steps
+    steps_eff = done if done != steps else steps   # the solve may terminate inside the window: the number is exact for `done` steps
     # N > 1, PCG: ONE problem, rows of A sharded over the ranks (strong scaling: total work fixed).
     # N > 1, direct: the LDL' solve does not shard -> N independent replicas (weak scaling).
     value = steps_eff / elapsed if sharded or world == 1 else world * steps_eff / elapsed
+    row0, row1 = S.rows()
 
     roof = None
     if linsys == "indirect":
-        m_loc = m // world if sharded else m          # this rank's share (rows balanced by non-zeros)
+        m_loc = row1 - row0
         nnz_loc = nnz // world if sharded else nnz
-        cand = {"spmv_At": (b_spmv(n, m_loc, nnz_loc), "k_cg_spmv_At / k_spmv_set (tmp = A'(z + beta p), CSC gather over n rows)"),
+        cand = {"spmv_At": (b_spmv(n, m_loc, nnz_loc), "k_cg_spmv_At / k_spmv_set_t (tmp = A'(z + beta p), CSC gather over n rows)"),
                 "spmv_A": (b_spmv(m_loc, n, nnz_loc), "k_cg_spmv_A (Gp = A tmp + rho p, CSR gather over m rows)")}
-        name = max(cand, key=lambda k: prof["ms"][k])
-        nl = max(prof["launches"][name], 1)
-        avg_ms = prof["ms"][name] / nl
-        ach = cand[name][0] / (avg_ms * 1e-3) / 1e9
+        kname = max(cand, key=lambda k: prof["stamp_ms"][k])
+        nl = max(prof["stamp_launches"][kname], 1)
+        avg_ms = prof["stamp_ms"][kname] / nl
+        ach = cand[kname][0] / max(avg_ms * 1e-3, 1e-12) / 1e9
         traffic, tsrc = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # PMC counters need rocprofv3: measured in separate passes, committed
-        if args.workload == "c4" and world == 1 and os.path.exists(pmc):
-            rec = json.load(open(pmc)).get("k_cg_" + name, {})
-            traffic, tsrc = rec.get("traffic_bytes"), "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        pmcf = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # PMC counters need rocprofv3: measured in separate passes, committed
+        if pmc and name == "c4" and world == 1 and os.path.exists(pmcf):
+            rec = json.load(open(pmcf)).get("k_cg_" + kname, {})
+            traffic, tsrc = rec.get("traffic_bytes"), "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=tsrc,
-                    kernel=cand[name][1], avg_launch_us=avg_ms * 1e3, launches=nl, algorithmic_bytes_per_launch=cand[name][0])
-        # for comparison with a rocprofv3 --stats CSV, whose per-kernel average also counts the launches enqueued past PCG
-        # convergence (~3.6 us no-ops): both PCG SpMV kernels, all launches
-        n_all = prof["launches"]["spmv_At"] + prof["launches"]["spmv_A"] + prof["noop_launches"]
-        if n_all:
-            roof["avg_us_both_spmv_incl_noop_launches"] = 1e3 * (prof["ms"]["spmv_At"] + prof["ms"]["spmv_A"] + prof["noop_ms"]) / n_all
-            roof["noop_launches"] = prof["noop_launches"]
+                    kernel=cand[kname][1], avg_launch_us=avg_ms * 1e3, launches=nl, algorithmic_bytes_per_launch=cand[kname][0],
+                    timing="device wall-clock ticks (first sampled workgroup begin .. last sampled workgroup end) of every launch that did work, "
+                           "inside the timed region",
+                    other_spmv={k: dict(avg_launch_us=1e3 * prof["stamp_ms"][k] / max(prof["stamp_launches"][k], 1), launches=prof["stamp_launches"][k],
+                                        algorithmic_bytes_per_launch=cand[k][0]) for k in cand if k != kname},
+                    noop_launches=prof["stamp_noop_launches"])
     else:
         lnnz = int(S.scalar("lnnz")); N = m + n
         bytes_solve = 2 * (12 * lnnz + 4 * (N + 1) + 16 * N) + 24 * N + 2 * 20 * N   # SURVEY.md 8(d) B_solve_direct
         # one solve = the launches of class "sptrsv" between two k_rhs: head levels, the two dense tail mat-vecs, head levels
         nl = max(prof["launches"]["sptrsv"], 1)
-        nsolve = max(prof["kkt_solves"], 1)
+        nsolve = max(prof.get("kkt_solves_events", prof["kkt_solves"]), 1)
         avg_ms = prof["ms"]["sptrsv"] / nsolve
-        ach = bytes_solve / (avg_ms * 1e-3) / 1e9
+        ach = bytes_solve / max(avg_ms * 1e-3, 1e-12) / 1e9
         T = int(S.scalar("tail"))
         roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
-                    kernel="direct solve P' L^-T D^-1 L^-1 P (k_ldl_fwd_small / k_tail_mv x2 / k_ldl_bwd_small, or the segmented level kernels)",
+                    kernel="direct solve P' L^-T D^-1 L^-1 P (k_ldl_small<fwd> / k_tail_mv x2 / k_ldl_small<bwd>, or the segmented level kernels; "
+                           "k_lp_persist when the whole iteration is one launch)",
                     avg_launch_us=avg_ms * 1e3, launches=nsolve, kernel_launches=nl, algorithmic_bytes_per_launch=bytes_solve, lnnz=lnnz,
-                    dense_tail=T, dense_tail_bytes_per_solve=8 * T * (T + 1), levels=[int(S.scalar("levels_fwd")), int(S.scalar("levels_bwd"))])
+                    dense_tail=T, dense_tail_bytes_per_solve=8 * T * (T + 1), levels=[int(S.scalar("levels_fwd")), int(S.scalar("levels_bwd"))],
+                    timing="hipEvents around the solve's launches in a second pass of the same length" if events_pass else "hipEvents in the timed region")
 
-    extra = dict(cg_iters_per_step=prof["cg_iters"] / max(prof["admm_iters"], 1), noop_launches=prof["noop_launches"], events_pass=events_pass,
-                 m=m, n=n, nnz=int(nnz))
+    extra = dict(cg_iters_per_step=prof["cg_iters"] / max(prof["admm_iters"], 1), events_pass=events_pass, m=m, n=n, nnz=int(nnz), rows=[int(row0), int(row1)])
     if linsys == "indirect":
         cg = extra["cg_iters_per_step"]
         l = m + n + 1
@@ -298,38 +328,117 @@ def main():
 
     tt = None
     # the metric's second half, time to eps = 1e-6 with status Solved: one GPU only (a sharded solve needs every rank in it)
-    if (args.to_tol or world == 1) and not args.no_to_tol and rank == 0 and world == 1:
+    if to_tol and rank == 0 and world == 1:
         S2 = Solver(A, b, c, linsys=linsys, eps=1e-6, verbose=0)
         t1 = time.perf_counter()
         info = S2.solve()
         tt = dict(seconds=time.perf_counter() - t1, setup_s=info["setup_time"] / 1e3, solve_s=info["solve_time"] / 1e3,
                   status=info["status"], admm_iter=info["admm_iter"], ipm_iter=info["ipm_iter"],
-                  res_pri=info["res_pri"], res_dual=info["res_dual"], rel_gap=info["rel_gap"])
+                  res_pri=info["res_pri"], res_dual=info["res_dual"], rel_gap=info["rel_gap"],
+                  cg_iters_per_step=S2.scalar("tot_cg_its") / max(info["admm_iter"], 1) if linsys == "indirect" else None)
         S2.close()
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(A, b, c, linsys)
+    cpu_rec = None
+    if cpu and rank == 0 and world == 1:
+        cpu_rec = cpu_baseline(A, b, c, linsys, budget_s=cpu_budget, window=warmup + steps)
 
-    if rank == 0:
-        out = {
-            "metric": "ADMM iterations/s", "value": value, "unit": "ADMM iterations/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": 1e3 * elapsed / max(steps_eff, 1), "higher_is_better": True,
-            "scaling": "strong" if sharded else "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc, "linsys": linsys, "eps": 1e-6,
-                       "parallelism": "single GPU" if world == 1 else
-                       (f"rows of A sharded over {world} GPUs, RCCL all-reduce of A'-partials and packed scalars" if sharded
-                        else f"{world} independent replicas (the direct back-end does not shard)")},
-            "roofline": roof, "cpu_baseline": cpu, "time_to_tol": tt, "extra": extra,
-        }
-        if shard_note:
-            out["config"]["note"] = shard_note
-        emit(out)
-    if sharded:
-        adist.finalize()
-    if dist is not None:
-        dist.destroy_process_group()
+    rec = {
+        "metric": "ADMM iterations/s", "value": value, "unit": "ADMM iterations/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / max(steps_eff, 1), "higher_is_better": True,
+        "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": desc, "linsys": linsys, "eps": 1e-6,
+                   "parallelism": "single GPU" if world == 1 else
+                   (f"rows of A sharded over {world} ranks, one all-reduce of A'-partials + packed scalars per PCG iteration" if sharded
+                    else f"{world} independent replicas (the direct back-end does not shard)")},
+        "roofline": roof, "cpu_baseline": cpu_rec, "time_to_tol": tt, "extra": extra,
+    }
+    if tt and tt["status"] == "Solved":
+        # the whole solve from the start point to eps 1e-6 (every outer iteration, BB search and residual check included): the window-free rate
+        rec["value_whole_solve"] = tt["admm_iter"] / tt["solve_s"]
+    return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5"])
+    ap.add_argument("--linsys", default=None, choices=["direct", "indirect"], help="override the workload's KKT back-end (c2/c3/c4)")
+    ap.add_argument("--to-tol", action="store_true", help="(default on one GPU) also run a full solve to eps=1e-6 and report wall-clock")
+    ap.add_argument("--no-to-tol", action="store_true", help="skip the full solve to eps=1e-6 (the second half of BASELINE.json's metric)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short c2 / c3 records the default one-GPU line carries under extra.configs")
+    ap.add_argument("--events-in-timed-region", action="store_true",
+                    help="direct back-end: bracket the solve's launches with hipEvents inside the timed K steps (default: in a second pass of K steps)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        die("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)          # does not return
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        die(f"--gpus {args.gpus} contradicts WORLD_SIZE={world} (launch one rank per GPU, or drop the launcher and let bench.py start them)")
+    transport = os.environ.get("ABIP_BENCH_TRANSPORT", "rccl")
+    force_shard = os.environ.get("ABIP_BENCH_FORCE_SHARD") == "1"   # the sharded code path with a single rank: self-test of the N > 1 plumbing
+    import torch
+    if not torch.cuda.is_available():
+        die("needs a GPU (libabip_hip has no CPU path)")
+    if transport == "rccl" and world > torch.cuda.device_count():
+        die(f"{world} ranks but {torch.cuda.device_count()} GPUs visible")
+    torch.cuda.set_device(local_rank if transport == "rccl" else 0)
+    dist = None
+    if world > 1 or force_shard:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if transport == "rccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    try:
+        if args.workload == "c5":
+            return bench_c5(args, rank, world, dist, torch)
+        steps = args.steps if args.steps is not None else {"c4": 200, "c2": 2000, "c3": 500}[args.workload]
+        warmup = args.warmup if args.warmup is not None else {"c4": 20, "c2": 200, "c3": 50}[args.workload]
+        from abip_amd import dist as adist
+        linsys0 = args.linsys or {"c4": "indirect", "c3": "indirect", "c2": "direct"}[args.workload]
+        sharded = dist is not None and linsys0 == "indirect"
+        if sharded:   # communicator for the solver; rows of A are split over the ranks inside abip_init.  Failure here is fatal (no replica fall-back).
+            if transport == "rccl":
+                adist.init_torch()
+            else:
+                adist.init_callback(rank, world, lambda arr: dist.all_reduce(torch.from_numpy(arr)))
+        rec = run_lp(args.workload, steps, warmup, args, rank, world, dist, torch, sharded, linsys_override=args.linsys,
+                     to_tol=(args.to_tol or world == 1) and not args.no_to_tol, cpu=not args.no_cpu)
+        if dist is not None:
+            rows = [None] * world
+            dist.all_gather_object(rows, rec["extra"]["rows"])
+            rec["rank_rows"] = rows
+            rec["transport"] = ("rccl" if transport == "rccl" else "gloo-callback (host-staged sums, every rank on cuda:0: a plumbing dry run, NOT a scaling number)") if sharded else "none (replicas)"
+            rec["rccl_ranks"] = adist.comm_count() if sharded else 0
+        if rank == 0 and world == 1 and args.workload == "c4" and not args.no_extra and not force_shard:
+            # the Netlib-class and the pds-class configs, short windows, inside the same driver-run line
+            sub = {}
+            for nm, k_, w_ in (("c2", 2000, 200), ("c3", 300, 50)):
+                r = run_lp(nm, k_, w_, args, 0, 1, None, torch, False, to_tol=not args.no_to_tol, cpu=not args.no_cpu, cpu_budget=4.0)
+                sub[nm] = {k: r[k] for k in ("value", "value_whole_solve", "ms_per_step", "steps", "warmup", "config", "roofline", "cpu_baseline", "time_to_tol", "extra") if k in r}
+            rec["extra"]["configs"] = sub
+        if rank == 0:
+            emit(rec)
+        if sharded:
+            adist.finalize()
+        if dist is not None:
+            dist.destroy_process_group()
+    except BaseException:  # noqa: BLE001 -- a failing rank must take the job down: its peers may be waiting in a collective
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)
 
 
 if __name__ == "__main__":

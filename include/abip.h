@@ -35,6 +35,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: these declarations ARE its export list */
+#endif
 
 /* The mex build of the reference defines DLONG (make_abip.m:50-54); so do we
  * unless the integrator asks for 32-bit indices with -DABIP_INT32. */
@@ -180,6 +183,15 @@ void abip_free_sol(ABIPSolution *sol);
 void abip_hip_set_linsys(int which);
 int abip_hip_get_linsys(void);
 
+/* ---- ownership of A (replaces the reference's COPYAMATRIX build switch, abip.c:1799-1807, make_abip.m:13) ----
+ * on = 1 (default, also ABIP_HIP_COPYAMATRIX unset): abip_init scales a private copy of A's values; the caller's matrix is never written
+ *          (what the reference's mex build does -- Matlab owns A).
+ * on = 0 (or ABIP_HIP_COPYAMATRIX=0): A is scaled in place and un-scaled by abip_finish (abip.c:2310-2317), like the plain C build. */
+void abip_hip_set_copy_a_matrix(int on);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

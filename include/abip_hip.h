@@ -24,6 +24,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: these declarations ARE its export list */
+#endif
 
 /* 0 when a usable gfx950 device is present, else a negative code; fills name (<=127 chars). */
 int abip_hip_device_info(char *name, int name_len, long *total_mem_bytes, int *num_cu);
@@ -47,7 +50,8 @@ abip_int abip_hip_accum_by_Atrans(ABIPWork *w, const abip_float *x, abip_float *
  * solve_lin_sys (-1 = setup accuracy).  Returns CG iterations used (0 for the direct back-end), <0 on error. */
 abip_int abip_hip_kkt_solve(ABIPWork *w, abip_float *rhs, const abip_float *warm, abip_int iter);
 /* Copy a device vector to out.  name: "u","v","u_t","h","g","b","c","D","E","Ax" (scaled CSC values),
- * "u_avgcon","v_avgcon".  Layout of the l-vectors is the reference's [y(m) | x(n) | tau].  Returns length or -1. */
+ * "u_avgcon","v_avgcon".  Layout of the l-vectors is the reference's [y(m) | x(n) | tau].  On a sharded solve the y block and "b" are this
+ * rank's rows; "D" always has the m entries of the whole problem (see abip_hip_dist_rows).  Returns length or -1. */
 abip_int abip_hip_get_vector(ABIPWork *w, const char *name, abip_float *out, abip_int cap);
 /* Scalars: "mu","beta","sigma","gamma","g_th","sc_b","sc_c","nm_b","nm_c","tot_cg_its","lnnz","levels_fwd","levels_bwd","admm_iter","ipm_iter". */
 abip_float abip_hip_get_scalar(ABIPWork *w, const char *name);
@@ -66,6 +70,11 @@ int abip_hip_dist_get_unique_id(void *out128);
 int abip_hip_dist_init_rccl(int rank, int world, const void *unique_id128);
 int abip_hip_dist_init_callback(int rank, int world, abip_hip_allreduce_fn fn, void *ctx);
 void abip_hip_dist_finalize(void);
+/* Ranks in the live communicator as the transport reports them (RCCL: ncclCommCount; callback: the world given; none: 0). */
+int abip_hip_dist_comm_count(void);
+/* Failure protocol of a sharded solve: a rank that hits an error (HIP, a failed collective, an invalid LOQO product) aborts the
+ * communicator (ncclCommAbort) before it returns ABIP_FAILED, so that its peers fail instead of waiting in a collective.  The
+ * caller must then exit non-zero and let the launcher tear the job down; the library does not retry in-process. */
 /* Row ranges the sharded path uses: bounds[g] .. bounds[g+1] are rank g's rows (world+1 entries out).  Pure host code. */
 int abip_hip_dist_partition(const ABIPMatrix *A, int world, abip_int *bounds);
 
@@ -98,14 +107,25 @@ typedef struct {
   long admm_iters;                   /* inner iterations covered */
   long cg_iters;                     /* CG iterations covered */
   long kkt_solves;                   /* linear solves covered */
+  /* device-side stamps (abip_hip_profile_enable_stamps): per class, first-workgroup-begin .. last-workgroup-end of the launches that did work */
+  double stamp_ms[ABIP_HIP_K_CLASSES];
+  long stamp_launches[ABIP_HIP_K_CLASSES];
+  long stamp_noop_launches;          /* stamped launches that returned at a gate (enqueued past PCG convergence) */
 } AbipHipProfile;
 /* mask = bitmask of classes to bracket with events (0 disables).  Timing a class adds two event
  * records per launch of that class only. */
 void abip_hip_profile_enable(ABIPWork *w, unsigned mask);
 void abip_hip_profile_read(ABIPWork *w, AbipHipProfile *out, int reset);
+/* The same durations without event records: the kernels of the masked classes (ABIP_HIP_K_SPMV_AT, ABIP_HIP_K_SPMV_A) write wall-clock
+ * ticks from their first and last sampled workgroup into a device ring that rides back with the once-per-iteration control read.
+ * Cheap enough to stay on inside a timed region (bench.py does).  0 on success. */
+int abip_hip_profile_enable_stamps(ABIPWork *w, unsigned mask);
 /* Block until everything queued on the solver's stream has finished. */
 void abip_hip_sync(ABIPWork *w);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

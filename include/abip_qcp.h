@@ -20,6 +20,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: these declarations ARE its export list */
+#endif
 
 typedef int qcp_int;
 typedef double qcp_float;
@@ -121,6 +124,9 @@ void abip_hip_qcp_last_stats(double *out8);
  * rsoc_barrier_subproblem cones.c:169-248 for kind 1; the latter reads the incoming x[0], cones.c:183).  0 on success. */
 int abip_hip_qcp_cone_prox(int kind, double *x, const double *tmp, double lambda, int len);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

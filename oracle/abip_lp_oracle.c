@@ -60,7 +60,21 @@ static F v_minabs_sqrt(const F *a, I len, F ref) { /* linalg.c:126-144 */
 /* ------------------------------------------------------------------------- */
 /* sparse matrix-vector products -- linsys/common.c                           */
 /* ------------------------------------------------------------------------- */
+/* The reference carries one OpenMP pragma on the path, on this loop (common.c:620-622).  Its own build must not define _OPENMP
+ * (the pragma's private list is broken), so the multi-core CPU baseline is this restatement built with
+ * -fopenmp (liboracle_lp_omp.so): every y[j] is still one sequential sum, so the result is bit-identical to the serial build. */
+#ifdef _OPENMP
+#include <omp.h>
+void orc_set_threads(int t) { omp_set_num_threads(t > 0 ? t : 1); }
+int orc_get_threads(void) { return omp_get_max_threads(); }
+#else
+void orc_set_threads(int t) { (void)t; }
+int orc_get_threads(void) { return 1; }
+#endif
 void orc_accum_by_Atrans(I n, const F *Ax, const I *Ai, const I *Ap, const F *x, F *y) { /* common.c:598-639 */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
   for (I j = 0; j < n; ++j) {
     F yj = y[j];
     for (I p = Ap[j]; p < Ap[j + 1]; ++p) yj += Ax[p] * x[Ai[p]];

@@ -103,12 +103,12 @@ _libs: dict = {}
 
 
 def lib(kind: str, linsys: str = "indirect"):
-    """kind in {'oracle','ref'}; linsys in {'direct','indirect'} (only meaningful for 'ref')."""
+    """kind in {'oracle','oracle_omp','ref'}; linsys in {'direct','indirect'} (only meaningful for 'ref')."""
     key = (kind, linsys if kind == "ref" else "")
     if key in _libs:
         return _libs[key]
-    if kind == "oracle":
-        path = os.path.join(HERE, "liboracle_lp.so")
+    if kind in ("oracle", "oracle_omp"):
+        path = os.path.join(HERE, "liboracle_lp.so" if kind == "oracle" else "liboracle_lp_omp.so")
         if not os.path.exists(path):
             build(ref=False)
     else:
@@ -116,7 +116,9 @@ def lib(kind: str, linsys: str = "indirect"):
     if not os.path.exists(path):
         raise FileNotFoundError(path)
     L = C.CDLL(path, mode=getattr(os, "RTLD_LOCAL", 0))
-    if kind == "oracle":
+    if kind in ("oracle", "oracle_omp"):
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_get_threads.restype = C.c_int
         L.orc_lp_init.restype = C.c_void_p
         L.orc_lp_init.argtypes = [C.POINTER(ABIPData), C.POINTER(ABIPInfo), C.c_int]
         L.orc_lp_solve.restype = c_int
@@ -205,7 +207,7 @@ def solve(kind: str, A, b, c, linsys: str = "indirect", trace: int = 0, warm=Non
     l = m + n + 1
     tr = None
     work = {}
-    if kind == "oracle":
+    if kind in ("oracle", "oracle_omp"):
         w = L.orc_lp_init(C.byref(P.data), C.byref(info), 0 if linsys == "direct" else 1)
         if not w:
             return Result(x, y, s, dict(status="Failure", status_val=-4))

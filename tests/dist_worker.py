@@ -49,13 +49,16 @@ def main():
         info = S.solve()
         out = dict(rank=rank, world=world, status=info["status"], admm_iter=info["admm_iter"], ipm_iter=info["ipm_iter"], pobj=info["pobj"],
                    dobj=info["dobj"], cg=S.scalar("tot_cg_its"), x=S.x.tolist(), y=S.y.tolist(), s=S.s.tolist())
-    # every rank must hold the same full solution
-    t = torch.tensor([out["pobj"], float(out["admm_iter"]), float(np.sum(S.y)), float(np.sum(S.x))], dtype=torch.float64)
+        extra = np.array([S.scalar("mu"), S.scalar("beta"), S.scalar("nb"), S.scalar("tot_cg_its"), float(info["admm_iter"]), info["pobj"]])
+    # every rank must hold the same full solution, BIT for bit (replicated n-space state and every host decision derive from all-reduced
+    # values and from reductions whose grid is the same on every rank), and the same persistent grid NB
+    t = torch.from_numpy(np.concatenate([extra, S.x, S.y, S.s]).astype(np.float64))
     if mode != "gloo-callback":
         t = t.cuda()
     gathered = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(gathered, t)
-    out["consistent"] = bool(all(torch.equal(g, gathered[0]) for g in gathered))
+    out["consistent"] = bool(all(torch.equal(g.view(torch.int64), gathered[0].view(torch.int64)) for g in gathered))
+    out["nb"] = float(extra[2])
     if rank == 0:
         print("RESULT " + json.dumps(out), flush=True)
     adist.finalize()

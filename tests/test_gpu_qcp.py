@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from _golden import load, rel
+from _golden import info_of, load, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -100,6 +100,15 @@ def test_conic_path_follows_the_oracle(gpu, pq, case):
         tol = 1e-6 if gi["admm_iter"] == oi["admm_iter"] else 10 * eps
         assert rel(sol["x"], x) < tol and rel(sol["y"], y) < tol and rel(sol["s"], s) < max(tol, 1e-5)
         assert abs(gi["pobj"] - oi["pobj"]) <= tol * (1 + abs(oi["pobj"])) and abs(gi["dobj"] - oi["dobj"]) <= tol * (1 + abs(oi["dobj"]))
+    if case in ("lp_afiro", "lp_rand"):
+        # a pin that does not pass through the (unpinned) conic oracle: the same LP solved by the REAL LP reference (fixtures from
+        # oracle/_ref at eps 1e-8) -- a different algorithm on the same problem, so agreement is at the conic run's own tolerance
+        # (cf. the cross-solver check of the reference's test/test_abip_install.m:24-27)
+        g = info_of(z, "direct_1e-08")
+        lp_tol = 30 * eps
+        assert abs(gi["pobj"] - g["pobj"]) <= lp_tol * (1 + abs(g["pobj"])) and abs(gi["dobj"] - g["dobj"]) <= lp_tol * (1 + abs(g["pobj"]))
+        assert rel(sol["x"], z["direct_1e-08_x"]) < (1e-3 if case == "lp_afiro" else 5e-2)
+        assert np.linalg.norm(A @ sol["x"] - b) / (1 + np.linalg.norm(b)) < 10 * eps and sol["x"].min() > -10 * eps
 
 
 def test_conic_api_dispatch(gpu):
@@ -112,19 +121,30 @@ def test_conic_api_dispatch(gpu):
     assert info["solver"] == "abip-qcp" and info["status"] == "Solved" and abs(info["pobj"] + 0.9840638) < 1e-5
 
 
+def test_conic_tail_residual_guard(gpu, monkeypatch):
+    """The set-up guard of the conic KKT factor: with the check forced to fail the dense tail is dropped and the solve still follows."""
+    data, K = lasso_socp(400, 1500, 3, density=0.02)
+    sol0, i0 = gpu.abip_qcp(data, K, eps_all(1e-5))
+    assert i0["factor"]["dense_tail"] > 0
+    monkeypatch.setenv("ABIP_HIP_TAIL_RESID_FAIL", "1")
+    sol1, i1 = gpu.abip_qcp(data, K, eps_all(1e-5))
+    assert i1["factor"]["dense_tail"] == 0 and i1["status"] == i0["status"] == "Solved" and i1["ipm_iter"] == i0["ipm_iter"]
+    assert rel(sol1["x"], sol0["x"]) < 1e-4 and abs(i1["pobj"] - i0["pobj"]) < 1e-5 * (1 + abs(i0["pobj"]))
+
+
 def test_unsupported_back_ends_are_rejected(gpu):
     data, K = toy()
     sol, info = gpu.abip_qcp(data, K, dict(eps=1e-3, linsys_solver=3, verbose=0))
     assert info["status"] == "Failure" and info["status_val"] == -4
 
 
-def test_lasso_at_config5_scale_properties(gpu):
-    """BASELINE configs[4] (LASSO-as-SOCP, ~1e5 variables; here p = 4000, d = 18000 to keep the GPU suite short -- scripts/gpu_c5.py
-    runs p = 10000, d = 45000).  Too large for the CPU oracle in test time, so: size-independent properties.  The solution must
+@pytest.mark.parametrize("p,d", [(4000, 18000), (10000, 45000)])
+def test_lasso_at_config5_scale_properties(gpu, p, d):
+    """BASELINE configs[4] (LASSO-as-SOCP, ~1e5 variables) at a reduced size and at the FULL size p = 10000, d = 45000 (n = 100 002).
+    Too large for the CPU oracle in test time, so: size-independent properties.  The solution must
     satisfy the cone constraints and the reference's own residual criteria, and its LASSO objective must agree with the conic
     objective and beat the two trivial points beta = 0 and a proximal-gradient iterate."""
     from abip_amd import problems
-    p, d = 4000, 18000
     data, K = problems.qcp_lasso_socp(p, d)
     eps = 1e-4
     sol, info = gpu.abip_qcp(data, K, eps_all(eps))

@@ -96,8 +96,11 @@ int main() {
   std::vector<int> idx_sorted(idx);
   for (long k = 0; k + 64 <= nnz; k += 64) std::sort(idx_sorted.begin() + k, idx_sorted.begin() + k + 64);
   std::vector<int> idx_seq(nnz); for (long k = 0; k < nnz; ++k) idx_seq[k] = (int)(k % m);
-  double *dv, *dx, *dout; int *di, *dis, *diq;
+  std::vector<int> idx_big(nnz); for (long k = 0; k < nnz; ++k) idx_big[k] = (int)(rng() % n); // gather target of n doubles (4 MB): the A tmp product
+  double *dv, *dx, *dout, *dxb; int *di, *dis, *diq, *dib;
   CK(hipMalloc(&dv, nnz * 8)); CK(hipMalloc(&di, nnz * 4)); CK(hipMalloc(&dis, nnz * 4)); CK(hipMalloc(&diq, nnz * 4)); CK(hipMalloc(&dx, (size_t)m * 8)); CK(hipMalloc(&dout, 1 << 20));
+  CK(hipMalloc(&dib, nnz * 4)); CK(hipMalloc(&dxb, (size_t)n * 8)); CK(hipMemcpy(dib, idx_big.data(), nnz * 4, hipMemcpyHostToDevice));
+  { std::vector<double> hb(n, 1.0); CK(hipMemcpy(dxb, hb.data(), (size_t)n * 8, hipMemcpyHostToDevice)); }
   CK(hipMemcpy(dv, val.data(), nnz * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(di, idx.data(), nnz * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dis, idx_sorted.data(), nnz * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(diq, idx_seq.data(), nnz * 4, hipMemcpyHostToDevice));
   std::vector<double> hx(m, 1.0); CK(hipMemcpy(dx, hx.data(), (size_t)m * 8, hipMemcpyHostToDevice));
@@ -121,6 +124,10 @@ int main() {
     RUN("V2 gather wave-sorted idx, 8B x4", (probe_u<1, 1, 4>), dis)
     RUN("V2' gather sequential idx, 8B x4", (probe_u<1, 1, 4>), diq)
     RUN("V3 idx+gather only, 8B x4", (probe_u<3, 1, 4>), di)
+#define RUNB(label, kern) printf("  %-34s %8.2f us\n", label, time_kernel([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, dv, dib, dxb, nnz, dout); }));
+    RUNB("V1b stream+gather from 4 MB, 8B x4", (probe_u<1, 1, 4>))
+    RUNB("V1b stream+gather from 4 MB, 8B x8", (probe_u<1, 1, 8>))
+    RUNB("V3b idx+gather from 4 MB only, x4", (probe_u<3, 1, 4>))
 #define RUNV(label, kern) printf("  %-34s %8.2f us\n", label, time_kernel([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, dp, di, dv, dx, dy, n, 0.5); }));
     RUNV("V5 CSR-vector 16 lanes/row, U=1", (spmv_vec<16, 1>))
     RUNV("V5 CSR-vector 16 lanes/row, U=2", (spmv_vec<16, 2>))
