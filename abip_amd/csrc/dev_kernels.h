@@ -82,38 +82,39 @@ __global__ __launch_bounds__(BS) void k_rhs(const double *__restrict__ u, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// PCG set-up (indirect.c:345-365).  With a warm start s:  d = rhs_x - A' s  (one pass over A'), then in ONE pass over the rows of A
-// with ONE gather per non-zero
-//   r_i = (rhs_y[i] + (A d)_i) - rho s_i     = b_i - ((A A's)_i + rho s_i),  b = rhs_y + A rhs_x      (indirect.c:415, 352-354)
-//   x0 = s ; z_i = M_i r_i ; p = z                                                                  (indirect.c:364-365)
-// (b and G s are never formed on their own: gathering rhs_x and A's separately costs a second trip through the texture path per
-// non-zero -- measured 82 us and 4.6x the algorithmic traffic on C4, against 35 us for every other product of the same matrix.)
-// Without a warm start (s == nullptr): d = rhs_x, r = b, x0 = 0 (indirect.c:347-348).
+// PCG set-up (indirect.c:345-365).  tmp = A' s ; then in ONE pass over the rows of A:
+//   b_i = rhs_y[i] + (A rhs_x)_i      (indirect.c:415)
+//   r_i = b_i - ((A tmp)_i + rho s_i) (indirect.c:352-354)      x0 = s
+//   z_i = M_i r_i ; p = z             (indirect.c:364-365)
+// Both products gather at the same column, so k_cg_init_At leaves (rhs_x[j], tmp[j]) side by side and k_cg_init_A fetches the pair
+// with ONE 16-byte gather per non-zero: two separate 8-byte gathers cost a second trip through the texture path (measured on C4:
+// 82 us and 4.6x the algorithmic traffic against ~35 us for every other product of the same matrix).  The two sums stay separate,
+// exactly as the reference forms them.  Without a warm start (s == nullptr): r = b, x0 = 0 (indirect.c:347-348), one plain gather.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BS) void k_cg_init_At(Csr At /* rows = columns of A */, const double *__restrict__ s, const double *__restrict__ bx,
-                                                   double *__restrict__ dvec, const Ctl *ctl) {
+                                                   double2 *__restrict__ pair, const Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
   spmv_stream<1>(
       At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * s[c]; },
-      [&](int row, double(&acc)[1]) { dvec[row] = bx[row] - acc[0]; });
+      [&](int row, double(&acc)[1]) { pair[row] = make_double2(bx[row], acc[0]); });
 }
-// sharded: T holds A's summed over the ranks -> d = rhs_x - T in place
-__global__ __launch_bounds__(BS) void k_cg_init_sub(double *__restrict__ T, const double *__restrict__ bx, int n, const Ctl *ctl) {
+// sharded: T holds A's summed over the ranks -> the same pairs
+__global__ __launch_bounds__(BS) void k_cg_init_pair(const double *__restrict__ T, const double *__restrict__ bx, double2 *__restrict__ pair, int n, const Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
-  for (int j = blockIdx.x * BS + threadIdx.x; j < n; j += gridDim.x * BS) T[j] = bx[j] - T[j];
+  for (int j = blockIdx.x * BS + threadIdx.x; j < n; j += gridDim.x * BS) pair[j] = make_double2(bx[j], T[j]);
 }
 
 template <bool DIST> // DIST: also the partial of z'z (= ||p||^2 of the first direction) for the sharded path
 __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rhs /* l-vector: y in/out (x0), x read */,
-                                                  const double *__restrict__ dvec /* rhs_x - A's, or rhs_x itself without a warm start */,
-                                                  const double *__restrict__ s, const double *__restrict__ Minv, double *__restrict__ r,
-                                                  double *__restrict__ z, double *__restrict__ p, double rho, double tol_factor, Dims d,
+                                                  const double2 *__restrict__ pair /* (rhs_x, A's) per column; unused without a warm start */,
+                                                  const double *__restrict__ s, const double *__restrict__ Minv, double *__restrict__ r, double *__restrict__ z,
+                                                  double *__restrict__ p, double rho, double tol_factor, Dims d,
                                                   double *part, int nb, Ctl *ctl, const double *gs) {
   ABIP_GATE_HALT(ctl);
-  __shared__ double lds[CHUNK];
+  __shared__ double lds[2 * CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[3 * WAVES];
   double bn[1];
@@ -126,17 +127,31 @@ __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rh
     ctl->cg_it = 0;
     ctl->cg_done = 0;
   }
+  const double *bx = rhs + d.MP;
   double acc2[3] = {0.0, 0.0, 0.0};
-  spmv_stream<1>(
-      A, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * dvec[c]; },
-      [&](int i, double(&acc)[1]) {
-        double ri = rhs[i] + acc[0], x0 = 0.0;
-        if (s) { x0 = s[i]; ri -= rho * x0; }
-        const double zi = ri * Minv[i];
-        rhs[i] = x0; r[i] = ri; z[i] = zi; p[i] = zi;
-        acc2[0] += ri * ri; acc2[1] += zi * ri;
-        if (DIST) acc2[2] += zi * zi;
-      });
+  if (s) {
+    spmv_stream<2>(
+        A, lds, lptr, sm, [&](int c, double a, double(&pr)[2]) { const double2 t = pair[c]; pr[0] = a * t.x; pr[1] = a * t.y; },
+        [&](int i, double(&acc)[2]) {
+          const double si = s[i];
+          const double b = rhs[i] + acc[0];
+          const double ri = b - (acc[1] + rho * si);
+          const double zi = ri * Minv[i];
+          rhs[i] = si; r[i] = ri; z[i] = zi; p[i] = zi;
+          acc2[0] += ri * ri; acc2[1] += zi * ri;
+          if (DIST) acc2[2] += zi * zi;
+        });
+  } else {
+    spmv_stream<1>(
+        A, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * bx[c]; },
+        [&](int i, double(&acc)[1]) {
+          const double ri = rhs[i] + acc[0];
+          const double zi = ri * Minv[i];
+          rhs[i] = 0.0; r[i] = ri; z[i] = zi; p[i] = zi;
+          acc2[0] += ri * ri; acc2[1] += zi * ri;
+          if (DIST) acc2[2] += zi * zi;
+        });
+  }
   if (DIST) {
     const int ws[3] = {S_RR0, S_ZR0, S_ZZ};
     write_partials<3>(part, ws, acc2, sm);

@@ -329,7 +329,9 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   const double t_init = now_ms();
   QWk W; QWk *w = &W;
   w->m = m; w->n = n; w->st = st; w->hasQ = d->Q != nullptr;
-  w->sparsity = ((d->A->p[n] / (m * n)) < 0.05); // integer division, qcp_config.c:22
+  // integer division, qcp_config.c:22 -- taken in 64 bits: the reference's 32-bit m * n overflows from m * n = 2^31 on (and divides by
+  // zero at m = 32768, n = 131072); for every size the reference can run, the quotient below is the same number
+  w->sparsity = (((long long)d->A->p[n] / std::max(1LL, (long long)m * (long long)n)) < 0.05);
   copy_in(w->A, d->A);
   if (w->hasQ) copy_in(w->Q, d->Q);
   w->nm_inf_b = vnrminf(d->b, m); w->nm_inf_c = vnrminf(d->c, n);

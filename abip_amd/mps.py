@@ -3,12 +3,15 @@
 ``mpsread`` returns what Matlab's ``mpsread`` returns to the reference's ``scripts/bench-lp/preprocess.m:16``
 (``f, Aineq, bineq, Aeq, beq, lb, ub`` and, when present, ``objcon``); ``preprocess`` is that script's conversion
 (:22-82) to ``min c'x  s.t.  Ax = b, x >= 0``: inequality rows get slacks, finite upper bounds become rows
-``x_j + w_j = ub_j - lb_j``, variables are shifted by their lower bound (``-inf`` is replaced by ``-1e8`` exactly as upstream,
-:34-36) and ``data.objcon = f'lb (+ objcon)``.
+``x_j + w_j = ub_j - lb_j``, variables are shifted by their lower bound (``-inf`` becomes ``-1e6 - 1e8`` exactly as upstream:
+:33 forms ``0 * -inf = NaN``, :34 sets the NaN to ``-1e6``, :35 adds ``-1e8``) and ``data.objcon = f'lb (+ objcon)``.  One documented
+deviation: upstream multiplies ``f`` with the ORIGINAL ``prob.lb`` (:76), which is ``-inf``/NaN as soon as one variable is free; here the
+shifted finite bound is used for those entries so that ``objcon`` stays a number.
 
 Fixed and free MPS are both accepted (fields are split on white space; names must not contain blanks).  Sections: NAME,
 ROWS (N/E/L/G), COLUMNS (MARKER lines ignored), RHS (a value on the objective row is minus the objective constant), RANGES,
-BOUNDS (UP, LO, FX, FR, MI, PL, BV, LI, UI), ENDATA.
+BOUNDS (UP, LO, FX, FR, MI, PL, BV, LI, UI), ENDATA.  An ``OBJSENSE`` / ``OBJSENSE MAX`` section asking for maximisation is refused
+(the reference pipeline minimises ``f'x`` whatever the file says; silently minimising a MAX model would return the wrong answer).
 """
 from __future__ import annotations
 
@@ -28,11 +31,18 @@ def mpsread(path: str) -> dict:
             if not raw.strip() or raw.lstrip().startswith("*"):
                 continue
             if not raw[0].isspace():
-                section = raw.split()[0].upper()
+                head = raw.split()
+                section = head[0].upper()
                 if section == "ENDATA":
                     break
+                if section in ("OBJSENSE", "OBJSENSEMAX") and (section == "OBJSENSEMAX" or (len(head) > 1 and head[1].upper().startswith("MAX"))):
+                    raise ValueError(f"{path}: OBJSENSE MAX is not supported (negate the objective and minimise)")
                 continue
             t = raw.split()
+            if section == "OBJSENSE":
+                if t[0].upper().startswith("MAX"):
+                    raise ValueError(f"{path}: OBJSENSE MAX is not supported (negate the objective and minimise)")
+                continue
             if section == "ROWS":
                 kind, name = t[0].upper(), t[1]
                 if kind == "N":
@@ -58,7 +68,9 @@ def mpsread(path: str) -> dict:
             elif section == "BOUNDS":
                 kind = t[0].upper()
                 if kind in ("FR", "MI", "PL", "BV"):
-                    bounds.append((kind, t[-1], 0.0))
+                    # "FR BND X" / "FR X" / "FR BND X 0": the column is the last field that names a column, not blindly the last field
+                    cn = t[2] if len(t) >= 3 and t[2] in cols else (t[1] if t[1] in cols else t[-1])
+                    bounds.append((kind, cn, 0.0))
                 else:
                     bounds.append((kind, t[-2], float(t[-1])))
     n, mrows = len(cols), len(sense)
@@ -140,9 +152,8 @@ def preprocess(prob: dict) -> dict:
     beq, bineq = np.asarray(prob["beq"], float), np.asarray(prob["bineq"], float)
     m2, m1, n = Aineq.shape[0], Aeq.shape[0], Aeq.shape[1]
     plb, pub = np.asarray(prob["lb"], float), np.asarray(prob["ub"], float)
-    lb = np.where(plb > -np.inf, plb, 0.0)                     # :33  (prob.lb > -inf) .* prob.lb  (NaN from -inf*0 -> -1e6, :34)
-    lb = np.where(np.isnan(lb), -1e6, lb)
-    lb = lb + (plb == -np.inf) * (-1e8)                        # :35
+    # :33 (prob.lb > -inf) .* prob.lb is NaN (0 * -inf) where the bound is -inf; :34 turns the NaN into -1e6; :35 adds -1e8 there
+    lb = np.where(plb == -np.inf, -1e6 + -1e8, plb)
     idxub = pub < np.inf
     m3 = int(idxub.sum())
     Dm = sp.identity(n, format="csr")[np.flatnonzero(idxub)]

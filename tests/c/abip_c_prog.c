@@ -48,6 +48,11 @@ int main(int argc, char **argv) {
     abip_solve(w, &d, &sol, &info);
     dump(o, &info, &sol, m, n);
     d.b = b2; d.c = c2;                    /* new right-hand side and cost, same A, same work */
+    /* the solver WRITES three settings while it runs, here exactly as in the reference (abip.c:2042/2048 avg_criterion, :2254 dynamic_sigma,
+     * :2220 max_admm_iters; w->stgs aliases d->stgs, abip.c:1760).  Left as the first solve leaves them, dynamic_sigma = dynamic_sigma_second
+     * > 0 disables the first-phase mu rule (abip.c:2251-2277) and the second solve never leaves mu = 1 -- upstream too.  A caller that
+     * re-solves puts them back: */
+    stgs.dynamic_sigma = -1.0; stgs.avg_criterion = 0; stgs.max_admm_iters = 1000000;
     abip_solve(w, &d, &sol, &info);
     dump(o, &info, &sol, m, n);
     abip_finish(w);

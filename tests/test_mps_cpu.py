@@ -44,7 +44,7 @@ def test_ranges_free_fixed_and_objective_constant():
     assert prob["Aineq"].shape[0] == 5 and prob["Aeq"].shape[0] == 1      # r1, r2 ranged -> two rows each, r4 one row
     r = highs(prob)
     data = mps.preprocess(prob)
-    assert data["lb_shift"][1] == -1e8                                     # preprocess.m:35
+    assert data["lb_shift"][1] == -1e6 - 1e8                              # preprocess.m:33-35: 0 * -inf = NaN -> -1e6, then + -1e8
     # the -1e8 shift makes the converted instance badly scaled on purpose (upstream behaviour); check it by feasibility of HiGHS' point
     xs = np.concatenate([r.x - data["lb_shift"], np.zeros(data["n"] - data["n_orig"])])
     m1 = prob["Aeq"].shape[0]; m2 = prob["Aineq"].shape[0]
@@ -82,3 +82,15 @@ def test_write_read_round_trip(tmp_path):
     o = po.solve("oracle", data["A"], data["b"], data["c"], linsys="direct", eps=1e-7)
     assert o.info["status"] == "Solved"
     assert abs(o.info["pobj"] + data["objcon"] - (r.fun + 2.5)) <= 1e-5 * (1 + abs(r.fun))
+
+
+def test_objsense_max_is_refused_and_free_bound_with_value(tmp_path):
+    """A MAX model must not be minimised silently; 'FR BND X 0' (a value behind the column) names column X, not '0'."""
+    import pytest
+    p = tmp_path / "m.mps"
+    p.write_text("NAME T\nOBJSENSE\n    MAX\nROWS\n N COST\n E R1\nCOLUMNS\n X COST 1.0 R1 1.0\nRHS\n RHS R1 1.0\nENDATA\n")
+    with pytest.raises(ValueError):
+        mps.mpsread(str(p))
+    p.write_text("NAME T\nROWS\n N COST\n E R1\nCOLUMNS\n X COST 1.0 R1 1.0\n Y COST 2.0 R1 1.0\nRHS\n RHS R1 1.0\nBOUNDS\n FR BND X 0\n MI BND Y\nENDATA\n")
+    prob = mps.mpsread(str(p))
+    assert prob["lb"][0] == -np.inf and prob["ub"][0] == np.inf and prob["lb"][1] == -np.inf
