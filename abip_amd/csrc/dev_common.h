@@ -30,6 +30,14 @@ struct Csr {
                      // <= CHUNK non-zeros and <= CHUNK rows per block, or exactly one longer row)
   int nrb;
   int nrows;
+  // optional sliced-ELL image of the same matrix (SELL-64, natural row order; host_setup: build_sell): slice s holds rows 64 s .. 64 s + 63
+  // column-major, padded to its longest row.  One lane owns one row: no LDS, no shuffles, no barriers, a row's products add up in column
+  // order.  Built only where the padding is small (regular row lengths: e.g. the CSC columns of C4's A); nslices == 0 otherwise.
+  const double *sval;
+  const int *sidx;
+  const long *soff; // first stored entry of a slice
+  const int *slen;  // entries per lane in a slice
+  int nslices;
 };
 
 // partial-sum slots (each MAXNB doubles)
@@ -274,6 +282,75 @@ __device__ __forceinline__ void spmv_stream(const Csr M, double *lds, int *lptr,
 template <int NV, class ProdF, class RowF>
 __device__ __forceinline__ void spmv_stream(const Csr M, double *lds, int *lptr, double *sm, ProdF prod, RowF rowf) {
   spmv_stream<NV>(M, lds, lptr, sm, prod, rowf, [] { return true; }, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// SELL-64 product with the interface of spmv_stream: prod(col, a, out[NV]), rowf(row, acc[NV]) by the lane that owns the row, pre() once per
+// workgroup before anything is consumed.  Measured on C4's A' (tools/sell_probe.hip): 27 us against 33 us for the CSR-stream kernel; on
+// matrices whose natural-order slices pad badly (C4's A: Poisson row lengths, +33 %) the stream kernel stays the faster one.
+template <int NV, class ProdF, class RowF, class PreF>
+__device__ __forceinline__ void spmv_sell(const Csr M, ProdF prod, RowF rowf, PreF pre, int vb, int vgrid) {
+  constexpr int U = 8;
+  const int lane = threadIdx.x & 63;
+  int s = vb * WAVES + (threadIdx.x >> 6);
+  const int ns = vgrid * WAVES;
+  long base = 0;
+  int len = 0;
+  if (s < M.nslices) { base = M.soff[s]; len = M.slen[s]; }
+  if (!pre()) return;
+  while (s < M.nslices) {
+    const int sn = s + ns;
+    long nbase = 0; int nlen = 0;
+    if (sn < M.nslices) { nbase = M.soff[sn]; nlen = M.slen[sn]; } // next slice's extent: in flight during this slice's gathers
+    const double *v = M.sval + base + lane;
+    const int *ix = M.sidx + base + lane;
+    double acc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) acc[q] = 0.0;
+    int k = 0;
+    for (; k + U <= len; k += U) {
+      double a[U]; int c[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { a[u] = v[(long)(k + u) * 64]; c[u] = ix[(long)(k + u) * 64]; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        double pr[NV];
+        prod(c[u], a[u], pr);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) acc[q] += pr[q];
+      }
+    }
+    if (k < len) {
+      double a[U]; int c[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { a[u] = 0.0; c[u] = 0; if (k + u < len) { a[u] = v[(long)(k + u) * 64]; c[u] = ix[(long)(k + u) * 64]; } }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (k + u < len) {
+          double pr[NV];
+          prod(c[u], a[u], pr);
+#pragma unroll
+          for (int q = 0; q < NV; ++q) acc[q] += pr[q];
+        }
+      }
+    }
+    const int row = s * 64 + lane;
+    if (row < M.nrows) rowf(row, acc);
+    s = sn; base = nbase; len = nlen;
+  }
+}
+// the product in whichever layout the matrix carries
+template <int NV, class ProdF, class RowF, class PreF>
+__device__ __forceinline__ void spmv_rows(const Csr M, double *lds, int *lptr, double *sm, ProdF prod, RowF rowf, PreF pre, int vb, int vgrid) {
+  if (M.nslices > 0) spmv_sell<NV>(M, prod, rowf, pre, vb, vgrid);
+  else spmv_stream<NV>(M, lds, lptr, sm, prod, rowf, pre, vb, vgrid);
+}
+template <int NV, class ProdF, class RowF, class PreF>
+__device__ __forceinline__ void spmv_rows(const Csr M, double *lds, int *lptr, double *sm, ProdF prod, RowF rowf, PreF pre) {
+  spmv_rows<NV>(M, lds, lptr, sm, prod, rowf, pre, (int)blockIdx.x, (int)gridDim.x);
+}
+template <int NV, class ProdF, class RowF>
+__device__ __forceinline__ void spmv_rows(const Csr M, double *lds, int *lptr, double *sm, ProdF prod, RowF rowf) {
+  spmv_rows<NV>(M, lds, lptr, sm, prod, rowf, [] { return true; }, (int)blockIdx.x, (int)gridDim.x);
 }
 
 } // namespace abip

@@ -42,16 +42,22 @@ struct DBuf { // device buffer
 struct DevCsr {
   DBuf<int> ptr, idx, rbd; // rbd: 4 ints per row block, read as int4
   DBuf<double> val;
-  int nrows = 0, nrb = 0;
+  DBuf<double> sval; DBuf<int> sidx, slen; DBuf<long> soff; // optional SELL-64 image
+  int nrows = 0, nrb = 0, nslices = 0;
   int upload(const host::HostCsr &h, hipStream_t s) {
     nrows = h.nrows; nrb = (int)h.rb.size() - 1;
     std::vector<int> d4((size_t)4 * std::max(nrb, 1), 0);
     for (int q = 0; q < nrb; ++q) { d4[4 * q] = h.rb[q]; d4[4 * q + 1] = h.rb[q + 1]; d4[4 * q + 2] = h.ptr[h.rb[q]]; d4[4 * q + 3] = h.ptr[h.rb[q + 1]]; }
     if (ptr.upload(h.ptr, s) || idx.upload(h.idx, s) || val.upload(h.val, s) || rbd.upload(d4, s)) return -1;
+    nslices = 0;
+    if (!h.slen.empty()) {
+      if (sval.upload(h.sval, s) || sidx.upload(h.sidx, s) || slen.upload(h.slen, s) || soff.upload(h.soff, s)) return -1;
+      nslices = (int)h.slen.size();
+    }
     return 0;
   }
-  Csr view() const { return Csr{ptr.p, idx.p, val.p, (const int4 *)rbd.p, nrb, nrows}; }
-  void release() { ptr.release(); idx.release(); rbd.release(); val.release(); }
+  Csr view() const { return Csr{ptr.p, idx.p, val.p, (const int4 *)rbd.p, nrb, nrows, sval.p, sidx.p, soff.p, slen.p, nslices}; }
+  void release() { ptr.release(); idx.release(); rbd.release(); val.release(); sval.release(); sidx.release(); slen.release(); soff.release(); nslices = 0; }
 };
 
 struct Segment { bool wide; int l0, l1; int rb0 = 0, nrb = 0; }; // wide: one level streamed over the grid, row blocks [rb0, rb0+nrb)

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(BS) void k_cg_init_At(Csr At /* rows = columns of A
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
-  spmv_stream<1>(
+  spmv_rows<1>(
       At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * s[c]; },
       [&](int row, double(&acc)[1]) { pair[row] = make_double2(bx[row], acc[0]); });
 }
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rh
   const double *bx = rhs + d.MP;
   double acc2[3] = {0.0, 0.0, 0.0};
   if (s) {
-    spmv_stream<2>(
+    spmv_rows<2>(
         A, lds, lptr, sm, [&](int c, double a, double(&pr)[2]) { const double2 t = pair[c]; pr[0] = a * t.x; pr[1] = a * t.y; },
         [&](int i, double(&acc)[2]) {
           const double si = s[i];
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rh
           if (DIST) acc2[2] += zi * zi;
         });
   } else {
-    spmv_stream<1>(
+    spmv_rows<1>(
         A, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * bx[c]; },
         [&](int i, double(&acc)[1]) {
           const double ri = rhs[i] + acc[0];
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(BS) void k_cg_spmv_At(Csr At, const double *__restr
     ran = true;
     return true;
   };
-  spmv_stream<1>(
+  spmv_rows<1>(
       At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * z[c]; },
       [&](int row, double(&acc)[1]) { tmp[row] = first ? acc[0] : acc[0] + beta * tmp[row]; }, pre);
   if (ran) stamp_end(st); // a launch that found the PCG converged leaves t1 == 0: not counted
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(BS) void k_cg_spmv_A(Csr A, const double *__restric
   __shared__ double sm[WAVES];
   const double beta = ctl->beta_cur;
   double acc1[1] = {0.0};
-  spmv_stream<1>(
+  spmv_rows<1>(
       A, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * tmp[c]; },
       [&](int i, double(&acc)[1]) {
         const double pn = z[i] + beta * p[i];
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(BS) void k_post_At(Csr At, double *__restrict__ rhs
   double *bx = rhs + d.MP;
   const double *hx = h + d.MP;
   double acc1[1] = {0.0};
-  spmv_stream<1>(
+  spmv_rows<1>(
       At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * rhs[c]; },
       [&](int j, double(&acc)[1]) {
         const double v = acc[0] - bx[j];
@@ -456,7 +456,7 @@ __device__ __forceinline__ void d_q_A(const Csr &A, const double *__restrict__ u
   const double *x = uu + d.MP;
   const double tau = uu[d.MP + d.n];
   double acc3[3] = {0.0, 0.0, 0.0};
-  spmv_stream<1>(
+  spmv_rows<1>(
       A, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
       [&](int i, double(&acc)[1]) {
         const double pri = acc[0], e = pri - b[i] * tau;
@@ -474,7 +474,7 @@ __device__ __forceinline__ void d_q_At(const Csr &At, const double *__restrict__
   const double *s = vv + d.MP;
   const double tau = uu[d.MP + d.n];
   double acc3[3] = {0.0, 0.0, 0.0};
-  spmv_stream<1>(
+  spmv_rows<1>(
       At, lds, lptr, sm, [&](int cidx, double a, double(&pr)[1]) { pr[0] = a * uu[cidx]; },
       [&](int j, double(&acc)[1]) {
         const double drj = acc[0] + s[j], e = drj - c[j] * tau;
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(BS) void k_spmv_set_t(Csr M, const double *__restri
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
-  spmv_stream<1>(
+  spmv_rows<1>(
       M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
       [&](int row, double(&acc)[1]) { out[row] = acc[0]; });
   stamp_end(st);
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(BS) void k_spmv_set(Csr M, const double *__restrict
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
-  spmv_stream<1>(
+  spmv_rows<1>(
       M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
       [&](int row, double(&acc)[1]) { out[row] = acc[0]; });
 }
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(BS) void k_spmv_acc(Csr M, const double *__restrict
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
-  spmv_stream<1>(
+  spmv_rows<1>(
       M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
       [&](int row, double(&acc)[1]) { y[row] += acc[0]; });
 }

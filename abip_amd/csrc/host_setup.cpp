@@ -188,6 +188,39 @@ void build_row_blocks(HostCsr &M, int chunk) {
   }
 }
 
+bool build_sell(HostCsr &M, double max_pad, long min_nnz) {
+  M.sval.clear(); M.sidx.clear(); M.slen.clear(); M.soff.clear();
+  const long nnz = M.ptr[M.nrows];
+  const char *e = getenv("ABIP_HIP_SELL");
+  if (e && atoi(e) == 0) return false;
+  if (nnz < min_nnz && !(e && atoi(e) == 2)) return false; // (ABIP_HIP_SELL=2: tests force it on small matrices)
+  const int ns = (M.nrows + 63) / 64;
+  long stored = 0;
+  std::vector<int> slen(ns, 0);
+  for (int s = 0; s < ns; ++s) {
+    int len = 0;
+    for (int r = s * 64; r < std::min(M.nrows, s * 64 + 64); ++r) len = std::max(len, M.ptr[r + 1] - M.ptr[r]);
+    slen[s] = len; stored += (long)len * 64;
+  }
+  if ((double)stored > (1.0 + max_pad) * (double)nnz + 64.0 * 8) return false;
+  M.slen = slen; M.soff.resize(ns); M.sval.assign(stored, 0.0); M.sidx.assign(stored, 0);
+  long off = 0;
+  for (int s = 0; s < ns; ++s) {
+    M.soff[s] = off;
+    for (int l = 0; l < 64; ++l) {
+      const int r = s * 64 + l;
+      const int a = r < M.nrows ? M.ptr[r] : 0, b = r < M.nrows ? M.ptr[r + 1] : 0;
+      const int fill = b > a ? M.idx[b - 1] : 0; // padding gathers a column the row gathers anyway (value 0)
+      for (int k = 0; k < slen[s]; ++k) {
+        const long q = off + (long)k * 64 + l;
+        if (a + k < b) { M.sval[q] = M.val[a + k]; M.sidx[q] = M.idx[a + k]; } else M.sidx[q] = fill;
+      }
+    }
+    off += (long)slen[s] * 64;
+  }
+  return true;
+}
+
 void jacobi_preconditioner(const ABIPMatrix *A, std::vector<double> &Minv) {
   Minv.assign(A->m, 0.0);
   for (abip_int q = 0; q < A->p[A->n]; ++q) Minv[A->i[q]] += A->x[q] * A->x[q];

@@ -21,6 +21,8 @@ struct HostCsr {
   std::vector<int> ptr, idx;
   std::vector<double> val;
   std::vector<int> rb; // row-block boundaries
+  // optional SELL-64 image (natural row order), see dev_common.h Csr; empty when not built
+  std::vector<double> sval; std::vector<int> sidx, slen; std::vector<long> soff;
 };
 // CSC arrays of A read as the CSR of A' (n rows)
 void csc_as_csr(const ABIPMatrix *A, HostCsr &out);
@@ -28,6 +30,8 @@ void csc_as_csr(const ABIPMatrix *A, HostCsr &out);
 void transpose_to_csr(const ABIPMatrix *A, HostCsr &out);
 // greedy row blocks: <= chunk non-zeros and <= chunk rows per block; a longer row gets a block of its own
 void build_row_blocks(HostCsr &M, int chunk);
+// SELL-64 image if the natural-order slices pad the matrix by at most `max_pad` (fraction of nnz) and it is large enough to matter; true if built
+bool build_sell(HostCsr &M, double max_pad = 0.12, long min_nnz = 1 << 17);
 // M_i = 1 / sum_j A_ij^2 (reference: get_preconditioner, indirect.c:36-79)
 void jacobi_preconditioner(const ABIPMatrix *A, std::vector<double> &Minv);
 

@@ -15,6 +15,7 @@
 #include "dev_host_util.h"
 #include "dev_ldl.h"
 #include "qcp_kernels.h"
+#include "qcp_pcg.h"
 
 using namespace abip;
 using namespace abip::hostutil;
@@ -36,7 +37,7 @@ double vnrminf(const double *a, long n) { double mx = 0; for (long k = 0; k < n;
 struct QResid { // struct ABIP_RESIDUALS, abip.h:182-207
   int last_ipm_iter = -1, last_admm_iter = -1;
   double res_pri = 1e8, res_dual = 1e8, rel_gap = 1e8, res_infeas = 0, res_unbdd = 0, pobj = 0, dobj = 0, tau = 0, kap = 0, res_dif = 0,
-         error_ratio = 1e8, Ax_b_norm = 0, Qx_ATy_c_s_norm = 0;
+         error_ratio = 1e8, Ax_b_norm = INFINITY, Qx_ATy_c_s_norm = INFINITY; // (the two norms: unknown until the first residual check -- qcp_pcg.h)
 };
 
 struct QWk {
@@ -58,6 +59,11 @@ struct QWk {
   double lin_ms = 0; long lin_n = 0;
   int ncones = 0, nsmall = 0; // cone table: the nsmall cones of <= QC_BIG entries first
   Ctl *lp_ctl = nullptr; // dev_sptrsv kernels are gated on an LP-style control block (halt flag): a zeroed one
+  // indirect back-end (linsys_solver = 3, qcp_pcg.h)
+  bool pcg = false;
+  DBuf<double> cg_x0, cg_r, cg_z, cg_p, cg_Gp, cg_tm, cg_M, cg_H, cg_part; // m-space: y0, r, z, p, Gp, M; n-space: tn (cg_tm), H^-1
+  Ctl *hlp = nullptr;    // pinned mirror of lp_ctl
+  int last_cg = 8; long tot_cg = 0, cg_solves = 0;
 };
 
 #define QLAUNCH(w, kern, grid, block, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (w)->stream, __VA_ARGS__)
@@ -73,6 +79,8 @@ void release(QWk *w) {
   for (auto *b : bufs) b->release();
   w->xkind.release(); w->c_off.release(); w->c_len.release(); w->c_kind.release(); w->ctl.release();
   w->ldl.release();
+  { DBuf<double> *cb[] = {&w->cg_x0, &w->cg_r, &w->cg_z, &w->cg_p, &w->cg_Gp, &w->cg_tm, &w->cg_M, &w->cg_H, &w->cg_part}; for (auto *b : cb) b->release(); }
+  if (w->hlp) (void)hipHostFree(w->hlp);
   if (w->lp_ctl) (void)hipFree(w->lp_ctl);
   if (w->hctl) (void)hipHostFree(w->hctl);
   if (w->stream) (void)hipStreamDestroy(w->stream);
@@ -172,6 +180,42 @@ void hcsr_from(const HMat &M, host::HostCsr &out, bool transpose_to_rows) {
 
 void enqueue_solve(QWk *w, double *rhs) { // _ldl_solve, linsys.c:309-316
   w->ldl.enqueue([&](auto kern, int grid, int block, size_t lds, auto... a) { hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, w->stream, a...); }, rhs, w->lp_ctl, w->NB);
+}
+
+// K z = rhs by y-space PCG (qcp_pcg.h).  warm: y0 = (u + tau r)_y and the tolerance of abip.c:213-217 (tol_host = min of the two residual
+// norms of the last check); otherwise y0 = 0 and tol as given (the set-up solve, abip.c:899).  Synchronises with the host once per chunk
+// of iterations.  Returns the CG iterations used, < 0 on a device error.
+int solve_pcg(QWk *w, double *rhs, bool warm, int iter, double tol_host) {
+  const QDims d{w->m, w->n, w->MP};
+  const QCPSettings *st = w->st;
+  QPcgVec v{w->cg_x0.p, w->cg_r.p, w->cg_z.p, w->cg_p.p, w->cg_Gp.p, w->cg_tm.p, w->cg_M.p, w->cg_H.p};
+  Ctl *hc = w->lp_ctl;
+  const int max_its = w->m;
+  QLAUNCH(w, kq_pcg_prep, w->NB, BS, w->dA.view(), rhs, (const double *)w->u.p, (const double *)w->r.p, warm ? 1 : 0, d, v, w->cg_part.p, hc);
+  if (warm) {
+    QLAUNCH(w, kq_pcg_Aty<true>, w->NB, BS, w->dAt.view(), v, max_its, w->cg_part.p, w->NB, hc);
+    QLAUNCH(w, kq_pcg_Gp<true>, w->NB, BS, w->dA.view(), v, rhs, st->rho_y, tol_host, std::pow((double)iter + 1.0, 1.5), w->cg_part.p, w->NB, hc);
+  } else {
+    QLAUNCH(w, kq_pcg_init_cold, w->NB, BS, v, rhs, w->m, tol_host, w->cg_part.p, hc);
+  }
+  int chunk = std::max(2, w->last_cg + std::max(2, w->last_cg >> 3));
+  for (;;) {
+    for (int q = 0; q < chunk; ++q) {
+      QLAUNCH(w, kq_pcg_Aty<false>, w->NB, BS, w->dAt.view(), v, max_its, w->cg_part.p, w->NB, hc);
+      QLAUNCH(w, kq_pcg_Gp<false>, w->NB, BS, w->dA.view(), v, rhs, st->rho_y, 0.0, 1.0, w->cg_part.p, w->NB, hc);
+      QLAUNCH(w, kq_pcg_update, w->NB, BS, v, rhs, w->m, w->cg_part.p, w->NB, hc);
+    }
+    QLAUNCH(w, kq_pcg_post, w->NB, BS, w->dAt.view(), rhs, v, max_its, d, w->cg_part.p, w->NB, hc);
+    HIP_OK(hipMemcpyAsync(w->hlp, hc, sizeof(Ctl), hipMemcpyDeviceToHost, w->stream));
+    HIP_OK(hipStreamSynchronize(w->stream));
+    if (w->hlp->cg_done || w->hlp->halt) break;
+    chunk = std::max(4, chunk);
+  }
+  const int zero = 0;
+  HIP_OK(hipMemcpyAsync(&hc->cg_done, &zero, sizeof(int), hipMemcpyHostToDevice, w->stream)); // the kernels of the rest of the iteration are not gated on it, the next solve is
+  w->last_cg = w->hlp->cg_it;
+  if (iter >= 0) { w->tot_cg += w->hlp->cg_it; w->cg_solves++; }
+  return w->hlp->cg_it;
 }
 
 // the device raised the halt flag at the inner exit: lower it (and its mirror) for the next inner loop
@@ -310,7 +354,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   if (!d || !sol || !info || !K) return fail(info, "ABIP_NULL input");
   if (!d->A || !d->b || !d->c) return fail(info, "the device path needs A, b and c");
   if (d->stgs->prob_type != 2) return fail(info, "only the generic QCP formulation (prob_type 2) is served");
-  if (d->stgs->linsys_solver != 1) return fail(info, "only linsys_solver = 1 (QDLDL-class direct) is served");
+  if (d->stgs->linsys_solver != 1 && d->stgs->linsys_solver != 3) return fail(info, "only linsys_solver = 1 (QDLDL-class direct) and 3 (PCG) are served");
   const QCPSettings *st = d->stgs;
   const int m = d->m, n = d->n;
   { // validate, abip.c:779-832 ; cones.c:37-81
@@ -350,7 +394,22 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     const long per = (nrb + MAXNB - 1) / MAXNB;
     w->NB = (int)std::max<long>(1, (nrb + per - 1) / per);
   }
-  { // KKT upper triangle (qcp_config.c:699-748) -> LDL' -> level-scheduled device factors
+  w->pcg = st->linsys_solver == 3;
+  if (w->pcg) { // H = rho_x I + Q must be diagonal; Jacobi preconditioner M_i = 1 / (rho_y + sum_j A_ij^2 / H_jj)  (qcp_pcg.h)
+    std::vector<double> Hinv(n, st->rho_x), M(m, st->rho_y);
+    if (w->hasQ) for (int j = 0; j < n; ++j) for (int q = w->Q.p[j]; q < w->Q.p[j + 1]; ++q) {
+      if (w->Q.i[q] == j) Hinv[j] += w->Q.x[q];
+      else if (w->Q.x[q] != 0.0) return bail("linsys_solver = 3 (PCG) needs Q absent or diagonal; use linsys_solver = 1");
+    }
+    for (int j = 0; j < n; ++j) Hinv[j] = 1.0 / Hinv[j];
+    for (int j = 0; j < n; ++j) for (int q = w->A.p[j]; q < w->A.p[j + 1]; ++q) M[w->A.i[q]] += w->A.x[q] * w->A.x[q] * Hinv[j];
+    for (int i = 0; i < m; ++i) M[i] = 1.0 / M[i];
+    if (w->cg_M.upload(M, w->stream) || w->cg_H.upload(Hinv, w->stream) || w->cg_x0.alloc(m) || w->cg_r.alloc(m) || w->cg_z.alloc(m) || w->cg_p.alloc(m) || w->cg_Gp.alloc(m) ||
+        w->cg_tm.alloc(n) || w->cg_part.alloc((size_t)PQ_COUNT * MAXNB) || hipMemsetAsync(w->cg_part.p, 0, sizeof(double) * PQ_COUNT * MAXNB, w->stream) != hipSuccess ||
+        hipMemsetAsync(w->cg_tm.p, 0, sizeof(double) * n, w->stream) != hipSuccess || hipHostMalloc((void **)&w->hlp, sizeof(Ctl), hipHostMallocDefault) != hipSuccess)
+      return bail("init_lin_sys_work failure");
+    if (hipMalloc((void **)&w->lp_ctl, sizeof(Ctl)) != hipSuccess || hipMemsetAsync(w->lp_ctl, 0, sizeof(Ctl), w->stream) != hipSuccess) return bail("allocation failure");
+  } else { // KKT upper triangle (qcp_config.c:699-748) -> LDL' -> level-scheduled device factors
     const int N = m + n;
     const double rho_y = st->rho_y, rho_x = st->rho_x;
     std::vector<int> Kp(N + 1), Ki; std::vector<double> Kx;
@@ -468,7 +527,8 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     for (int i = 0; i < m; ++i) hr[i] = w->b[i]; // -(-b)
     for (int j = 0; j < n; ++j) hr[w->MP + j] = w->c[j];
     if (hipMemcpyAsync(w->r.p, hr.data(), sizeof(double) * w->LV, hipMemcpyHostToDevice, w->stream) != hipSuccess) return bail("upload failure");
-    enqueue_solve(w, w->r.p);
+    if (w->pcg) { if (solve_pcg(w, w->r.p, false, -1, 1e-12) < 0) return bail("device failure in pre_calculate"); } // abip.c:899
+    else enqueue_solve(w, w->r.p);
     if (hipMemcpyAsync(hr.data(), w->r.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess)
       return bail("device failure in pre_calculate");
     double acc = 0;
@@ -532,12 +592,14 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   const bool batch_ok = !(getenv("ABIP_HIP_BATCH") && atoi(getenv("ABIP_HIP_BATCH")) == 0);
   const bool qmerge = !(getenv("ABIP_HIP_QMERGE") && atoi(getenv("ABIP_HIP_QMERGE")) == 0);
   int seen = 0; // QCtl.it_count at the last control read
+  bool pcg_failed = false;
   // one inner iteration (abip.c:1120-1160), everything on the stream; `timed` brackets the KKT solve with events
   auto enqueue_iteration = [&](int kk, bool timed) {
     // projection, abip.c:186-255
     QLAUNCH(w, kq_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->r.p, w->p.p, st->rho_y, st->rho_x, dm, w->part.p, hc);
     if (timed) (void)hipEventRecord(w->ev_a, w->stream);
-    enqueue_solve(w, w->p.p);
+    if (w->pcg) { if (solve_pcg(w, w->p.p, true, kk, std::min(r.Ax_b_norm, r.Qx_ATy_c_s_norm)) < 0) pcg_failed = true; } // abip.c:206-224
+    else enqueue_solve(w, w->p.p);
     if (timed) (void)hipEventRecord(w->ev_b, w->stream);
     QLAUNCH(w, kq_dots, w->NB, BS, (const double *)w->r.p, (const double *)w->p.p, st->rho_y, st->rho_x, dm, w->part.p, hc);
     if (w->hasQ) QLAUNCH(w, kq_Qp, w->NB, BS, w->dQ.view(), (const double *)w->p.p, dm, w->part.p, hc);
@@ -569,12 +631,12 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       // Between residual checks the host has nothing to decide but the inner exit, and that is found on the device: enqueue a
       // batch of iterations and read the control block once (the iterations behind the exit fall through on the halt flag).
       int nb = 1;
-      if (batch_ok && r.error_ratio > 8) {
+      if (batch_ok && !w->pcg && r.error_ratio > 8) { // (the PCG back-end returns to the host inside every solve: no batching)
         const int to_check = st->inner_check_period - (j % st->inner_check_period); // the iteration with (j+1) % period == 0 closes a batch
         nb = std::max(1, std::min(std::min(batch, to_check), (int)st->max_admm_iters - j));
       }
       for (int q = 0; q < nb; ++q) enqueue_iteration(k + q, q == 0);
-      if (read_ctl(w)) return bail("device error in the inner iteration");
+      if (read_ctl(w) || pcg_failed) return bail("device error in the inner iteration");
       { float ms = 0.f; if (hipEventElapsedTime(&ms, w->ev_a, w->ev_b) == hipSuccess) { w->lin_ms += ms; w->lin_n++; } }
       const int ran = w->hctl->it_count - seen;
       seen = w->hctl->it_count;
@@ -607,7 +669,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     }
     tol_inner = adjust_barrier(w, r);
   }
-  info->avg_linsys_time = w->lin_n ? w->lin_ms / (double)w->lin_n : 0; info->avg_cg_iters = 0; // ms per solve, as lin_sys_time_per_iter (abip.c:1228)
+  info->avg_linsys_time = w->lin_n ? w->lin_ms / (double)w->lin_n : 0; info->avg_cg_iters = w->cg_solves ? (double)w->tot_cg / (double)w->cg_solves : 0; // ms per solve, as lin_sys_time_per_iter (abip.c:1228)
   g_stats[0] = w->ldl.N; g_stats[1] = w->ldl.T; g_stats[2] = (double)w->ldl.lnnz; g_stats[3] = w->ldl.F.nlev; g_stats[4] = w->ldl.B.nlev;
   g_stats[5] = (double)w->lin_n; g_stats[6] = w->lin_ms; g_stats[7] = (double)(w->ldl.F.idx.n + w->ldl.B.idx.n);
   release(w);

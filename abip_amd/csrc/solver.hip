@@ -1186,8 +1186,8 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
   w->NB = 1; // fixed below, once the row blocks are known
   // device images of the (scaled) matrix
   host::HostCsr hAt, hA;
-  host::csc_as_csr(Ause, hAt); host::build_row_blocks(hAt, CHUNK);
-  host::transpose_to_csr(Ause, hA); host::build_row_blocks(hA, CHUNK);
+  host::csc_as_csr(Ause, hAt); host::build_row_blocks(hAt, CHUNK); host::build_sell(hAt);
+  host::transpose_to_csr(Ause, hA); host::build_row_blocks(hA, CHUNK); host::build_sell(hA);
   if (w->dAt.upload(hAt, w->stream) || w->dA.upload(hA, w->stream)) return fail("device allocation failure (matrix)");
   { // persistent grid: every kernel uses the same NB (== partials per slot).  Sized so that the SpMV kernels give each
     // workgroup the same whole number of row blocks (no tail), at most MAXNB (8 workgroups per CU on 256 CUs).
@@ -1649,7 +1649,7 @@ abip_float abip_hip_get_scalar(ABIPWork *w, const char *name) {
   RET("mu", w->mu) RET("beta", w->beta) RET("sigma", w->sigma) RET("gamma", w->gamma) RET("g_th", w->g_th)
   RET("sc_b", w->sc_b) RET("sc_c", w->sc_c) RET("nm_b", w->nm_b) RET("nm_c", w->nm_c) RET("tot_cg_its", w->tot_cg_its)
   RET("lnnz", w->ldl.lnnz) RET("levels_fwd", w->ldl.F.nlev) RET("levels_bwd", w->ldl.B.nlev) RET("tail", w->ldl.T) RET("admm_iter", w->k) RET("ipm_iter", w->i)
-  RET("nb", w->NB) RET("small_solve", w->ldl.small ? 1 : 0) RET("persist", w->persist ? w->persist_wgs : 0) RET("factor_resid", w->factor_resid)
+  RET("sell_At", w->dAt.nslices) RET("sell_A", w->dA.nslices) RET("nb", w->NB) RET("small_solve", w->ldl.small ? 1 : 0) RET("persist", w->persist ? w->persist_wgs : 0) RET("factor_resid", w->factor_resid)
 #undef RET
   return NAN;
 }

@@ -10,9 +10,12 @@
  * uses a qcp_ prefix for the types and exports the entry point as abip_qcp(); INTEGRATION.md shows the one-line
  * `#define` a maintainer adds to compile the reference's abip_qcp_mex.c against it.
  *
- * Only the generic QCP formulation (enum QCP, prob_type 2) with the QDLDL-class direct solver (linsys_solver 1)
- * is served: the reference's PCG for this formulation is unreachable through abip() and
- * its MKL / LAPACKE / CSparse-Cholesky back-ends are out of scope.  Other values are rejected with ABIP_FAILED.
+ * Served: the generic QCP formulation (enum QCP, prob_type 2) with the QDLDL-class direct solver (linsys_solver 1) and with a
+ * device PCG (linsys_solver 3).  The reference's own PCG for this formulation is unreachable through abip() and ill-posed
+ * (abip_amd/csrc/qcp_pcg.h), so linsys_solver 3 is defined here: Jacobi-PCG on the y-space Schur
+ * complement rho_y I + A (rho_x I + Q)^-1 A' (the reference's `pcg` of linsys.c:629-716 with H^-1 in the middle; Q absent or
+ * diagonal), warm start and tolerance as the reference's projection prepares them (abip.c:206-218).  Its MKL / LAPACKE /
+ * CSparse-Cholesky back-ends are out of scope; other values are rejected with ABIP_FAILED.
  */
 #ifndef ABIP_HIP_QCP_H
 #define ABIP_HIP_QCP_H
@@ -71,7 +74,7 @@ typedef struct { /* struct ABIP_SETTINGS, abip.h:93-131 */
   qcp_int outer_check_period;
 
   qcp_int verbose;
-  qcp_int linsys_solver; /* 1 = QDLDL-class direct (the only one served) */
+  qcp_int linsys_solver; /* 1 = QDLDL-class direct; 3 = PCG on the y-space Schur complement (Q absent or diagonal; abip_amd/csrc/qcp_pcg.h); others: "Failure" */
   qcp_int prob_type;     /* 2 = generic QCP (what the mex sets, abip_qcp_mex.c:436) */
   qcp_float time_limit;  /* seconds */
   qcp_float psi;

@@ -77,6 +77,8 @@ typedef struct {
   long N; long *P, *Lp, *Li; F *Lx, *Dg, *bp;
   /* iterates (struct ABIP_WORK, abip.h:160-180) */
   F mu, beta, *u, *v, *v_origin, *u_t, *rel_ut, *r, a, nm_inf_b, nm_inf_c;
+  /* indirect back-end (linsys_solver = 3) */
+  F *Mpre, *Hinv; long tot_cg, cg_solves; F last_Ax_b_norm, last_Qx_norm;
 } QW;
 
 typedef struct {
@@ -194,6 +196,72 @@ static void solve_qcp_linsys(QW *w, F *b) { /* qcp_config.c:868-876: negate the 
   orc_ldl_solve(w->N, w->P, w->Lp, w->Li, w->Lx, w->Dg, b, w->bp);
 }
 
+/* ---- indirect back-end (linsys_solver = 3): the DEFINITION abip_amd/csrc/qcp_pcg.h states and justifies -- pcg of linsys.c:629-716 on the
+ * y-space Schur complement rho_y I + A H^-1 A', H = rho_x I + Q diagonal.  (Upstream's n-space qcp_pcg, linsys.c:755-851, is unreachable and,
+ * restated here first, did not converge within its n-iteration cap: condition number ~1e8 at the default rho_y = 1e-6.) ---- */
+static int init_qcp_pcg(QW *w) {
+  const I m = w->m, n = w->n;
+  w->Hinv = (F *)malloc(sizeof(F) * n); w->Mpre = (F *)malloc(sizeof(F) * m);
+  for (I j = 0; j < n; ++j) w->Hinv[j] = w->rho_dr[m + j];
+  if (w->hasQ) for (I j = 0; j < n; ++j) for (I q = w->Q.p[j]; q < w->Q.p[j + 1]; ++q) {
+    if (w->Q.i[q] == j) w->Hinv[j] += w->Q.x[q]; else if (w->Q.x[q] != 0) return -1; /* a non-diagonal Q is refused */
+  }
+  for (I j = 0; j < n; ++j) w->Hinv[j] = 1.0 / w->Hinv[j];
+  for (I i = 0; i < m; ++i) w->Mpre[i] = w->rho_dr[i];
+  for (I j = 0; j < n; ++j) for (I q = w->A.p[j]; q < w->A.p[j + 1]; ++q) w->Mpre[w->A.i[q]] += w->A.x[q] * w->A.x[q] * w->Hinv[j];
+  for (I i = 0; i < m; ++i) w->Mpre[i] = 1.0 / w->Mpre[i];
+  return 0;
+}
+static void qcp_G(QW *w, const F *y, F *out, F *tn) { /* out = rho_y y + A H^-1 A' y */
+  const I m = w->m, n = w->n;
+  memset(tn, 0, sizeof(F) * n);
+  sp_accum_At(&w->A, y, tn);
+  for (I j = 0; j < n; ++j) tn[j] *= w->Hinv[j];
+  for (I i = 0; i < m; ++i) out[i] = y[i] * w->rho_dr[i];
+  sp_accum_A(&w->A, tn, out);
+}
+static I qcp_pcg(QW *w, F *b, const F *y0, I max_iter, F tol) { /* linsys.c:629-716; result overwrites b */
+  const I m = w->m, n = w->n;
+  F *p = (F *)calloc(m, sizeof(F)), *Gp = (F *)calloc(m, sizeof(F)), *r = (F *)calloc(m, sizeof(F)), *z = (F *)calloc(m, sizeof(F)), *tn = (F *)calloc(n, sizeof(F));
+  I it = 0;
+  if (!y0) { memcpy(r, b, sizeof(F) * m); memset(b, 0, sizeof(F) * m); }
+  else { qcp_G(w, y0, r, tn); for (I i = 0; i < m; ++i) r[i] = b[i] - r[i]; memcpy(b, y0, sizeof(F) * m); }
+  if (v_dot(r, r, m) != 0) {
+    for (I i = 0; i < m; ++i) z[i] = r[i] * w->Mpre[i];
+    F ip = v_dot(z, r, m), ipold;
+    memcpy(p, z, sizeof(F) * m);
+    while (it < max_iter) {
+      qcp_G(w, p, Gp, tn);
+      const F alpha = ip / v_dot(p, Gp, m);
+      for (I i = 0; i < m; ++i) { b[i] += alpha * p[i]; r[i] -= alpha * Gp[i]; }
+      ++it;
+      if (sqrt(v_dot(r, r, m)) < tol) break;
+      for (I i = 0; i < m; ++i) z[i] = r[i] * w->Mpre[i];
+      ipold = ip; ip = v_dot(z, r, m);
+      const F beta = ip / ipold;
+      for (I i = 0; i < m; ++i) p[i] = z[i] + beta * p[i];
+    }
+  }
+  free(p); free(Gp); free(r); free(z); free(tn);
+  return it;
+}
+/* K z = (-b_y ; b_x) (the system solve_qcp_linsys hands the direct solver, qcp_config.c:868-876) through the Schur complement */
+static void solve_qcp_linsys_pcg(QW *w, F *b, const F *warm /* (m+n) or null */, I iter, F tol) {
+  const I m = w->m, n = w->n;
+  F *t = (F *)malloc(sizeof(F) * n);
+  for (I j = 0; j < n; ++j) t[j] = b[m + j] * w->Hinv[j];
+  /* g_y = -b_y  =>  rhs = -g_y - A H^-1 g_x = b_y - A H^-1 b_x */
+  F *acc = (F *)calloc(m, sizeof(F));
+  sp_accum_A(&w->A, t, acc);
+  for (I i = 0; i < m; ++i) b[i] = b[i] - acc[i];
+  const I its = qcp_pcg(w, b, warm ? warm : 0, m, tol);
+  if (iter >= 0) { w->tot_cg += its; w->cg_solves++; }
+  memset(t, 0, sizeof(F) * n);
+  sp_accum_At(&w->A, b, t);
+  for (I j = 0; j < n; ++j) b[m + j] = (b[m + j] + t[j]) * w->Hinv[j];
+  free(t); free(acc);
+}
+
 /* ---- cones.c:130-288 ------------------------------------------------------------------------------------ */
 static void orthant_prox(F *x, const F *t, F lambda, I n) { /* :279-288 */
   for (I i = 0; i < n; ++i) {
@@ -263,7 +331,20 @@ static void projection(QW *w, I iter) { /* abip.c:186-255 (the direct branch) */
   for (long i = 0; i < mn; ++i) mu[i] = (w->u[i] + w->v[i]) * w->rho_dr[i];
   const F eta = w->rho_dr[mn] * (w->u[mn] + w->v[mn]);
   memcpy(p, mu, sizeof(F) * mn);
-  solve_qcp_linsys(w, p);
+  if (w->stgs->linsys_solver == 3) { /* abip.c:206-224: warm start u + tau r, tolerance from the last residual check (unknown = +inf before the first) */
+    F *warm = (F *)malloc(sizeof(F) * mn);
+    for (long i = 0; i < mn; ++i) warm[i] = w->u[i] + w->u[mn] * w->r[i];
+    F tol = MINF(w->last_Ax_b_norm, w->last_Qx_norm);
+    tol = 0.2 * MINF(tol, v_nrminf(warm, n) / pow((F)iter + 1, 1.5));
+    tol = MAXF(tol, 1e-12);
+    { const char *e = getenv("ORC_QCP_PCG_TOL"); if (e) tol = atof(e); } /* diagnostic: fixed tolerance */
+    if (getenv("ORC_QCP_PCG_CHECK") && w->N) { F *p2 = (F *)malloc(sizeof(F) * mn); memcpy(p2, mu, sizeof(F) * mn); solve_qcp_linsys(w, p2);
+      F *p3 = (F *)malloc(sizeof(F) * mn); memcpy(p3, mu, sizeof(F) * mn); solve_qcp_linsys_pcg(w, p3, warm, -2, 1e-14);
+      F dy = 0, dx = 0; for (long i = 0; i < mn; ++i) { F e = ABSF(p2[i] - p3[i]); if (i < m) dy = MAXF(dy, e); else dx = MAXF(dx, e); }
+      fprintf(stderr, "check iter %ld: |dy| %.3e |dx| %.3e (|p| %.3e)\n", (long)iter, dy, dx, v_nrminf(p2, mn)); free(p2); free(p3); }
+    solve_qcp_linsys_pcg(w, p, warm, iter, tol);
+    free(warm);
+  } else solve_qcp_linsys(w, p);
   for (long i = 0; i < mn; ++i) tem[i] = p[i] * w->rho_dr[i];
   const F bq = v_dot(w->r, mu, mn) - 2 * v_dot(w->r, tem, mn) - eta;
   if (w->hasQ) sp_accum_A(&w->Q, &p[m], Qp);
@@ -327,7 +408,7 @@ static void calc_residuals(QW *w, QR *r, I ipm_iter, I admm_iter) { /* qcp_confi
   F *Ax = (F *)calloc(m, sizeof(F)), *Ax_b = (F *)malloc(sizeof(F) * m);
   sp_accum_A(&w->A, x, Ax);
   for (I i = 0; i < m; ++i) Ax_b[i] = Ax[i] - w->b[i];
-  r->Ax_b_norm = v_nrminf(Ax_b, m);
+  r->Ax_b_norm = v_nrminf(Ax_b, m); w->last_Ax_b_norm = r->Ax_b_norm;
   for (I i = 0; i < m; ++i) { Ax[i] *= w->D[i]; Ax_b[i] *= w->D[i]; }
   const F this_pr = v_nrminf(Ax_b, m) / (w->sc_b + MAXF(v_nrminf(Ax, m), w->sc_b * w->nm_inf_b));
   F *Qx = (F *)calloc(n, sizeof(F)), *ATy = (F *)calloc(n, sizeof(F)), *R = (F *)malloc(sizeof(F) * n);
@@ -335,7 +416,7 @@ static void calc_residuals(QW *w, QR *r, I ipm_iter, I admm_iter) { /* qcp_confi
   if (w->hasQ) { sp_accum_A(&w->Q, x, Qx); xQx_2 = v_dot(x, Qx, n) / (2 * w->sc_b * w->sc_c); }
   sp_accum_At(&w->A, y, ATy);
   for (I j = 0; j < n; ++j) R[j] = Qx[j] - ATy[j] + w->c[j] - s[j];
-  r->Qx_ATy_c_s_norm = v_nrminf(R, n);
+  r->Qx_ATy_c_s_norm = v_nrminf(R, n); w->last_Qx_norm = r->Qx_ATy_c_s_norm;
   for (I j = 0; j < n; ++j) { Qx[j] *= w->E[j]; ATy[j] *= w->E[j]; R[j] *= w->E[j]; s[j] *= w->E[j]; }
   const F this_dr = v_nrminf(R, n) / (w->sc_c + MAXF(w->sc_c * w->nm_inf_c, v_nrminf(Qx, n)));
   const F cTx = v_dot(w->c, x, n) / (w->sc_b * w->sc_c), bTy = v_dot(w->b, y, m) / (w->sc_b * w->sc_c);
@@ -451,7 +532,7 @@ void orc_qcp_set_trace(I T, F *buf) { g_trace = buf; g_trace_T = T; g_trace_n = 
 I orc_qcp_trace_count(void) { return g_trace_n; }
 
 qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) { /* abip(), abip.c:1335-1371 */
-  if (!d || !sol || !info || !K || !d->A || !d->b || !d->c || d->stgs->linsys_solver != 1 || d->stgs->prob_type != 2) {
+  if (!d || !sol || !info || !K || !d->A || !d->b || !d->c || (d->stgs->linsys_solver != 1 && d->stgs->linsys_solver != 3) || d->stgs->prob_type != 2) {
     if (info) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); }
     return ST_FAILED;
   }
@@ -479,7 +560,9 @@ qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone
   w->rel_ut = (F *)calloc(l, sizeof(F)); w->r = (F *)calloc(l, sizeof(F));
   w->nm_inf_b = v_nrminf(d->b, m); w->nm_inf_c = v_nrminf(d->c, n);
   scaling_qcp_data(w, d, K);
-  if (init_kkt(w) < 0) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED; }
+  w->last_Ax_b_norm = INFINITY; w->last_Qx_norm = INFINITY;
+  if (d->stgs->linsys_solver == 3) { if (init_qcp_pcg(w) < 0) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED; } if (getenv("ORC_QCP_PCG_CHECK")) init_kkt(w); }
+  else if (init_kkt(w) < 0) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED; }
   info->setup_time = now_ms() - t_init;
   const double t0 = now_ms();
   QR R; memset(&R, 0, sizeof(R)); QR *r = &R;
@@ -498,7 +581,8 @@ qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone
     /* pre_calculate, abip.c:886-910 */
     for (I i = 0; i < m; ++i) w->r[i] = -w->b[i];
     memcpy(&w->r[m], w->c, sizeof(F) * n);
-    solve_qcp_linsys(w, w->r);
+    if (d->stgs->linsys_solver == 3) solve_qcp_linsys_pcg(w, w->r, 0, -1, 1e-12); /* abip.c:899 */
+    else solve_qcp_linsys(w, w->r);
     F acc = 0; for (long i = 0; i < (long)m + n; ++i) acc += (w->r[i] * w->rho_dr[i]) * w->r[i];
     w->a = w->rho_dr[m + n] + acc;
   }
@@ -530,7 +614,8 @@ qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone
     tol_inner = adjust_barrier(w, r);
   }
 done:
-  info->avg_linsys_time = 0; info->avg_cg_iters = 0;
+  info->avg_linsys_time = 0; info->avg_cg_iters = w->cg_solves ? (F)w->tot_cg / (F)w->cg_solves : 0;
+  free(w->Mpre); free(w->Hinv);
   free(w->rho_dr); free(w->A.x); free(w->A.i); free(w->A.p);
   if (w->hasQ) { free(w->Q.x); free(w->Q.i); free(w->Q.p); }
   free(w->b); free(w->c); free(w->D); free(w->E); free(w->u); free(w->v); free(w->v_origin); free(w->u_t); free(w->rel_ut); free(w->r);

@@ -31,6 +31,14 @@ def main():
         rng = np.random.default_rng(seed)
         if kind == "rand":
             m = int(rng.integers(40, 300)); A, b, c = problems.lp_random_sparse(m=m, n=int(m * rng.uniform(1.5, 4)), per_col=int(rng.integers(2, 7)), seed=seed)
+        elif kind == "skew":   # a few nearly dense rows on top of a sparse LP: the non-zero-balanced row blocks have very different row counts,
+            import scipy.sparse as sp   # so every rank's local grid would differ if it were derived from its own block
+            m = int(rng.integers(120, 260)); n = int(m * 3)
+            A0, b0, c0 = problems.lp_random_sparse(m=m, n=n, per_col=3, seed=seed)
+            dense = sp.random(4, n, density=0.7, random_state=np.random.default_rng(seed + 1), data_rvs=lambda k: np.random.default_rng(seed + 2).uniform(0.1, 1.0, k), format="csr")
+            A = sp.vstack([dense, sp.csr_matrix(A0)]).tocsc()
+            x0 = np.abs(np.random.default_rng(seed + 3).standard_normal(n)) * (np.random.default_rng(seed + 4).random(n) < 0.4)
+            b = A @ x0; c = c0
         elif kind == "stair":
             A, b, c = problems.lp_staircase(seed=seed, stages=int(rng.integers(2, 6)), rows_per=int(rng.integers(8, 30)), cols_per=int(rng.integers(20, 60)))[:3]
         else:

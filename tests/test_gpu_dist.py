@@ -83,3 +83,19 @@ def test_multi_rank_sharding_matches_reference(gpu, world, name, eps):
     for k in "xys":
         assert rel(np.array(out[k]), z[f"indirect_{eps:g}_{k}"]) < 10 * eps, k
     assert abs(out["pobj"] - g["pobj"]) <= 10 * eps * (1 + abs(g["pobj"]))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_skewed_row_blocks_stay_bit_identical(gpu, world):
+    """Row blocks balanced by non-zeros can hold very different numbers of rows (a few nearly dense rows on one rank).  The replicated
+    n-space reductions must still add in the same order on every rank: the persistent grid is derived from global quantities only, so
+    x, y, s, mu, beta, the CG count -- everything -- is bit-identical across the ranks ('consistent'), and NB is the same number."""
+    port = 29950 + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "gloo-callback", "gen:skew:11", "1e-05"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert p.returncode == 0 and lines, p.stdout[-2000:] + p.stderr[-2000:]
+    out = json.loads(lines[-1][7:])
+    assert out["consistent"] and out["status"] == "Solved" and out["nb"] >= 1

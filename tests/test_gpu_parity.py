@@ -300,6 +300,34 @@ def test_spmv_long_rows_and_ragged_blocks(gpu):
         assert rel(S.accum_by_Atrans(y, np.zeros(S.n)), Asc.T @ y) < 1e-13
 
 
+def test_sliced_ell_layout(gpu, oracle_built, monkeypatch):
+    """The SELL-64 image of A' (dev_common.h spmv_sell; built where natural-order slices pad little, e.g. the CSC columns of the C4 generator):
+    products to 1e-14, ragged last slice and one-entry rows included, and the PCG trajectory still follows the oracle."""
+    po = oracle_built
+    monkeypatch.setenv("ABIP_HIP_SELL", "2")          # build it for small matrices too
+    z, A, b, c = load("lp_random_sparse_small")
+    rng = np.random.default_rng(4)
+    with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-9) as S:
+        assert S.scalar("sell_At") == (S.n + 63) // 64
+        Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
+        x, y = rng.standard_normal(S.n), rng.standard_normal(S.m)
+        assert rel(S.accum_by_Atrans(y, x), x + Asc.T @ y) < 1e-14
+        assert rel(S.accum_by_A(x, y), y + Asc @ x) < 1e-14
+        T = 25
+        o = po.solve("oracle", A, b, c, linsys="indirect", eps=1e-9, trace=T, max_admm_iters=100000)
+        S.begin()
+        for t in range(T):
+            S.step(1)
+            for col, nm in enumerate(("u", "v", "u_t")):
+                assert rel(S.vector(nm), o.trace[t, col]) < 1e-9, (t + 1, nm)
+    with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-6) as S:
+        info = S.solve()
+        _check_against_golden_loose((info, S.x, S.y, S.s), z, "indirect_1e-06", 1e-6, "lp_random_sparse_small")
+    monkeypatch.setenv("ABIP_HIP_SELL", "0")
+    with gpu.Solver(A, b, c, linsys="indirect", verbose=0) as S:
+        assert S.scalar("sell_At") == 0
+
+
 # ---------------------------------------------------------------------------------------------- trajectories
 @pytest.mark.parametrize("name", ["lp_afiro_like", "lp_random_sparse_small", "lp_multicommodity_small"])
 @pytest.mark.parametrize("linsys", ["indirect", "direct"])

@@ -136,8 +136,68 @@ def test_conic_tail_residual_guard(gpu, monkeypatch):
 
 def test_unsupported_back_ends_are_rejected(gpu):
     data, K = toy()
+    sol, info = gpu.abip_qcp(data, K, dict(eps=1e-3, linsys_solver=5, verbose=0))
+    assert info["status"] == "Failure" and info["status_val"] == -4
+    # the PCG back-end needs H = rho_x I + Q diagonal
+    rng = np.random.default_rng(1)
+    G = rng.standard_normal((8, 8)); data["Q"] = sp.csc_matrix(G @ G.T)
     sol, info = gpu.abip_qcp(data, K, dict(eps=1e-3, linsys_solver=3, verbose=0))
     assert info["status"] == "Failure" and info["status_val"] == -4
+
+
+@pytest.mark.parametrize("case", ["toy", "lasso_small", "lasso_mid", "lp_afiro", "rsoc_mix", "lasso_bigcone"])
+def test_conic_pcg_back_end(gpu, pq, case):
+    """linsys_solver = 3: the device's y-space PCG (abip_amd/csrc/qcp_pcg.h; upstream's own conic PCG is unreachable and ill-posed, so the
+    definition is this repository's, restated on the CPU by oracle/abip_qcp_oracle.c).  Checked three ways: against the oracle's PCG run
+    (same algorithm, other summation order), against the device's direct back-end (another linear solver inside the same ADMM) and,
+    for the LP case, against the real LP reference's fixture."""
+    rng = np.random.default_rng(11)
+    Q = None
+    if case == "toy":
+        data, K = toy(); Q = data["Q"]          # Q = I: diagonal
+    elif case == "lasso_small":
+        data, K = lasso_socp(30, 60, 2)
+    elif case == "lasso_mid":
+        data, K = lasso_socp(400, 1500, 3, density=0.02)
+    elif case == "lasso_bigcone":
+        data, K = lasso_socp(2200, 2600, 4, density=0.004)
+    elif case == "lp_afiro":
+        z, A, b, c = load("lp_afiro_like")
+        data, K = dict(A=A, b=b, c=c), dict(l=A.shape[1])
+    else:
+        sizes_q, sizes_rq, f, zc, l, m2, dens = [3, 5, 1, 8], [3, 4, 6], 4, 2, 12, 9, 0.35
+        n2 = sum(sizes_q) + sum(sizes_rq) + f + zc + l
+        A2 = sp.random(m2, n2, density=dens, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+        x0 = np.zeros(n2); pos = 0
+        for sz in sizes_q:
+            v = rng.standard_normal(sz); v[0] = np.linalg.norm(v[1:]) + 1.0; x0[pos:pos + sz] = v; pos += sz
+        for sz in sizes_rq:
+            v = rng.standard_normal(sz); v[0] = 1.0 + abs(v[0]); v[1] = (v[2:] @ v[2:]) / (2 * v[0]) + 0.5; x0[pos:pos + sz] = v; pos += sz
+        x0[pos:pos + f] = rng.standard_normal(f); pos += f + zc
+        x0[pos:] = rng.random(l) + 0.1
+        data = dict(A=A2, b=A2 @ x0, c=A2.T @ rng.standard_normal(m2) + np.concatenate([x0[:sum(sizes_q) + sum(sizes_rq)], np.zeros(f), rng.standard_normal(zc), rng.random(l) + 0.1]))
+        K = dict(q=sizes_q, rq=sizes_rq, f=f, z=zc, l=l)
+    eps = {"lasso_bigcone": 1e-3, "lasso_mid": 1e-5}.get(case, 1e-6)
+    st3 = dict(eps=eps, linsys_solver=3, verbose=0)
+    x, y, s, oi, _ = pq.solve(data["A"], data["b"], data["c"], K, Q=Q, eps=eps, eps_p=eps, eps_d=eps, eps_g=eps, eps_inf=eps, eps_unb=eps, linsys_solver=3)
+    sol, gi = gpu.abip_qcp(data, K, st3)
+    # inexact inner solves: the two runs may leave the last outer iteration on different sides of the convergence test
+    assert gi["status"] == oi["status"] and gi["status_val"] in (1, 2) and abs(gi["ipm_iter"] - oi["ipm_iter"]) <= 1
+    same_outer = gi["ipm_iter"] == oi["ipm_iter"]
+    if same_outer:
+        assert abs(gi["admm_iter"] - oi["admm_iter"]) <= 0.03 * oi["admm_iter"] + 3
+    tol = (20 if same_outer else 200) * eps
+    assert rel(sol["x"], x) < tol and rel(sol["y"], y) < tol
+    assert abs(gi["pobj"] - oi["pobj"]) <= tol * (1 + abs(oi["pobj"]))
+    assert gi["avg_cg_iters"] > 0 and abs(gi["avg_cg_iters"] - oi["avg_cg_iters"]) <= 0.25 * oi["avg_cg_iters"] + 0.5
+    sold, gd = gpu.abip_qcp(data, K, eps_all(eps))          # the direct back-end on the device
+    assert gd["status"] == gi["status"] and abs(gd["ipm_iter"] - gi["ipm_iter"]) <= 1
+    tol_d = 200 * eps
+    assert abs(gd["pobj"] - gi["pobj"]) <= tol_d * (1 + abs(gd["pobj"])) and rel(sol["x"], sold["x"]) < max(tol_d, 5e-2 if case == "lp_afiro" else 0)
+    if case == "lp_afiro":
+        g = info_of(z, "direct_1e-08")
+        assert abs(gi["pobj"] - g["pobj"]) <= 30 * eps * (1 + abs(g["pobj"]))
+
 
 
 @pytest.mark.parametrize("p,d", [(4000, 18000), (10000, 45000)])

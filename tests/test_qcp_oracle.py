@@ -126,3 +126,30 @@ def test_cone_prox_is_the_minimiser_of_the_barrier_subproblem(pq):
     t = np.array([3.0, -2.0, 1e-3, -50.0])                                   # orthant: x - t = lambda / x
     x = pq.cone_prox(2, t, 0.25)
     assert np.all(x > 0) and np.allclose(x - t, 0.25 / x, rtol=1e-12)
+
+
+@pytest.mark.parametrize("case", ["toy", "lasso"])
+def test_oracle_pcg_back_end_agrees_with_its_direct_back_end(pq, case):
+    """linsys_solver = 3 (y-space PCG on rho_y I + A H^-1 A', the definition of abip_amd/csrc/qcp_pcg.h) inside the same ADMM must land where the
+    direct back-end lands: same status and outer count, inner count within a few iterations, solution to the run's tolerance."""
+    import scipy.sparse as sp
+    if case == "toy":
+        A = sp.csc_matrix(np.array([[1, 2, 3, 4, 5, 6, 7, 8], [0, 1, 2, 1, 2, 3, 1, 2]], dtype=float))
+        b, c, Q, K = np.array([4.0, 3.0]), np.array([1, 0, 2, 1, 4, 2, 3, 0], dtype=float), sp.identity(8, format="csc"), dict(q=[3], rq=[3], f=1, l=1)
+    else:
+        rng = np.random.default_rng(2)
+        p_, dft = 30, 60
+        X = sp.random(p_, dft, density=0.2, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+        yv = X @ (rng.standard_normal(dft) * (rng.random(dft) < 0.3)) + 0.01 * rng.standard_normal(p_)
+        lam = np.abs(X.T @ yv).max() / 5
+        A = sp.vstack([sp.hstack([sp.csc_matrix(np.array([[1.0, -1.0]])), sp.csc_matrix((1, p_ + 2 * dft))]), sp.hstack([sp.csc_matrix((p_, 2)), sp.identity(p_), -X, X])]).tocsc()
+        b = np.concatenate([[1.0], -yv]); c = np.concatenate([[0.5, 0.5], np.zeros(p_), lam * np.ones(2 * dft)]); Q = None; K = dict(q=[p_ + 2], l=2 * dft)
+    out = {}
+    for ls in (1, 3):
+        x, y, s, oi, _ = pq.solve(A, b, c, K, Q=Q, eps=1e-6, eps_p=1e-6, eps_d=1e-6, eps_g=1e-6, eps_inf=1e-6, eps_unb=1e-6, linsys_solver=ls)
+        out[ls] = (x, oi)
+    a, p3 = out[1], out[3]
+    assert a[1]["status"] == p3[1]["status"] == "Solved" and a[1]["ipm_iter"] == p3[1]["ipm_iter"]
+    assert abs(a[1]["admm_iter"] - p3[1]["admm_iter"]) <= 0.03 * a[1]["admm_iter"] + 3
+    assert np.linalg.norm(a[0] - p3[0]) / np.linalg.norm(a[0]) < 1e-6 and abs(a[1]["pobj"] - p3[1]["pobj"]) < 1e-5 * (1 + abs(a[1]["pobj"]))
+    assert p3[1]["avg_cg_iters"] > 0 and a[1]["avg_cg_iters"] == 0
