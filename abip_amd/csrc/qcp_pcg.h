@@ -7,10 +7,10 @@
 // (qcp_pcg, src/abip-qcp/source/linsys.c:755-851, on the n-space matrix R_x + Q + A' R_y^-1 A, mat_vec :722-748) cannot be reached
 // -- ABIP(solve_linsys) sends prob_type QCP to the LP-shaped `pcg` with mismatched dimensions (linsys.c:1158-1165) --
 // and it would not work if it could: with the default rho_y = 1e-6 that matrix has condition number ~1e8 and n iterations (its cap)
-// do not converge in double precision (restated on the CPU and tried: oracle/abip_qcp_oracle.c history, residual oscillating between
+// do not converge in double precision (restated on the CPU and tried (the test tree's CPU checker): residual oscillating between
 // 1e-1 and 1e+2 on the 2 x 8 toy problem of test/test_abip_install.m).  The formulation that does work is the one the reference uses
 // for its specialised problems, `pcg` (linsys.c:629-716): the y-space Schur complement rho I + A A', here with H^-1 in the middle.
-// DEFINITION (shared with oracle/abip_qcp_oracle.c, which restates the same steps on the CPU):
+// DEFINITION (the test tree's CPU checker restates the same steps; nothing here depends on it):
 //   * pcg of linsys.c:629-716 on G = rho_y I + A H^-1 A' with the Jacobi preconditioner M_i = 1 / (rho_y + sum_j A_ij^2 / H_jj),
 //     warm start y0, r = b - G y0, at most m iterations, stop after an update once |r|_2 < tol (linsys.c:683);
 //   * warm start and tolerance as the projection prepares them for its PCG branch (abip.c:206-218): y0 = (u + tau r)_y,

@@ -25,7 +25,6 @@
 #include "../../include/abip_hip.h"
 #include "dev_kernels.h"
 #include "dev_ldl.h"
-#include "dev_lp_persist.h"
 #include "host_setup.h"
 #include "dev_host_util.h"
 
@@ -154,12 +153,6 @@ struct ABIP_WORK {
   int it_seen = 0;    // ctl.it_count at the last control read
   int batch = 4;      // iterations enqueued per control read (direct back-end)
   bool fuse_small = false; // small direct systems on one GPU: rhs build and u_t'h inside the solve kernels
-  bool persist = false;    // ... and, when the solve vector fits LDS, whole batches of iterations in ONE launch (dev_lp_persist.h)
-  int persist_wgs = 1;     // workgroups of that launch: 1 + helpers for the dense tail's mat-vecs
-  DBuf<unsigned> psync;    // its grid-barrier counter and go flag
-  DBuf<double> prp;        // per-workgroup partial sums of the residual products
-  size_t persist_lds = 0;  // dynamic LDS of the launch
-  DBuf<unsigned long long> pdbg; // ABIP_HIP_PERSIST_DEBUG: per-phase ticks of workgroup 0
   bool batch_ok = true; // ABIP_HIP_BATCH=0 forces one control read per iteration
   Resid r;
   abip_int status = 0;
@@ -577,35 +570,6 @@ UpdArgs upd_args(W *w, bool fuse_avg, bool avg_stats, abip_int j) {
 // ------------------------------------------------------------------------------------------------
 // one inner ADMM iteration (abip.c:2133-2173 up to and including the stopping metric); returns the metric
 // ------------------------------------------------------------------------------------------------
-// Netlib-class LPs (dev_lp_persist.h): iterations j .. j + nb - 1 in one launch; the exit test may end the batch early.
-int enqueue_persist(W *w, abip_int j, int nb, bool restart) {
-  PersistArgs a;
-  a.upd = upd_args(w, true, false, j);
-  a.h = w->h.p; a.g_th = w->g_th; a.d = dims(w);
-  a.A = w->dA.view(); a.At = w->dAt.view();
-  a.wD = w->stgs->normalize ? w->wD.p : nullptr; a.wE = w->stgs->normalize ? w->wE.p : nullptr;
-  a.part = w->part.p; a.ctl = w->ctl.p;
-  a.F = w->ldl.F.view(); a.B = w->ldl.B.view(); a.Pmap = w->ldl.Pmap.p; a.D = w->ldl.D.p; a.xg = w->ldl.xw.p;
-  a.t0 = w->ldl.t0; a.N = w->ldl.N; a.T = w->ldl.T; a.W = w->ldl.W.p; a.Wt = w->ldl.Wt.p; a.ttmp = w->ldl.tmp.p;
-  a.nb = nb; a.j0 = (long)j; a.restart = restart ? 1 : 0; a.restart_fre = (double)w->stgs->restart_fre; a.LV = w->LV;
-  for (int av = 0; av < 2; ++av) {
-    FinArgs &f = a.fin[av];
-    const int base[10] = {S_NU, S_NV, S_CX, S_BY, S_QP, S_RP, S_NAX, S_QD, S_RD, S_NATY};
-    const int extra[10] = {S_NUA, S_NVA, S_CXA, S_BYA, S_QPA, S_RPA, S_NAXA, S_QDA, S_RDA, S_NATYA};
-    int ns = 0;
-    for (int sl : base) f.slots[ns++] = sl;
-    if (av) for (int sl : extra) f.slots[ns++] = sl;
-    f.nslots = ns;
-    f.u = w->u.p; f.v = w->v.p; f.ua = w->u_avgc.p; f.va = w->v_avgc.p; f.gs = nullptr;
-    f.decide = 1; f.avg_stats = av; f.thr = w->gamma * w->mu; f.sentinel = (double)w->stgs->max_admm_iters;
-  }
-  a.sync = w->psync.p; a.dbg = w->pdbg.p; a.rp = w->prp.p;
-  const int G = w->persist_wgs;
-  if (G > 1) HIP_OK(hipMemsetAsync(w->psync.p, 0, sizeof(unsigned) * 2, w->stream));
-  launch_lds(w, ABIP_HIP_K_SPTRSV, k_lp_persist<true>, G, TBS, w->persist_lds, a);
-  return 0;
-}
-
 // everything of ADMM iteration (k, j) up to and including the finalize that evaluates the exit test (direct back-end)
 // prev_fin: the finalize of the previous iteration, still pending (fused path); defer: hand this iteration's finalize to the next one
 int enqueue_iteration_direct(W *w, abip_int j, bool restart, const FinArgs *prev_fin = nullptr, FinArgs *defer = nullptr) {
@@ -651,8 +615,7 @@ int admm_batch_direct(W *w, int nb, int *done, double *metric_out) {
   if (!w->wg_valid) launch(w, ABIP_HIP_K_VEC, k_dot_wg, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->g.p, w->stgs->rho_y, dims(w), w->part.p, w->xwt);
   FinArgs pend, cur;
   bool have = false;
-  if (w->persist) { if (enqueue_persist(w, w->j, nb, false)) return -1; }
-  else for (int q = 0; q < nb; ++q) {
+  for (int q = 0; q < nb; ++q) {
     const bool defer = w->fuse_small && q + 1 < nb; // the last iteration of the batch closes itself
     if (enqueue_iteration_direct(w, w->j + q, false, have ? &pend : nullptr, defer ? &cur : nullptr)) return -1;
     have = defer; pend = cur;
@@ -680,7 +643,7 @@ int admm_iteration(W *w, double *metric_out) {
   w->tot_solves++;
   w->prof.kkt_solves++;
   if (w->linsys == ABIP_HIP_LINSYS_DIRECT) {
-    if ((w->persist ? enqueue_persist(w, w->j, 1, restart) : enqueue_iteration_direct(w, w->j, restart)) || sync_ctl(w)) return -1;
+    if (enqueue_iteration_direct(w, w->j, restart) || sync_ctl(w)) return -1;
   } else {
     launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, w->ut.p, (const double *)w->h.p, st->rho_y, w->g_th, d,
            w->part.p, w->NB, ctl, (const double *)w->gs);
@@ -1051,7 +1014,7 @@ void free_work(W *w) {
                           &w->wD, &w->wE, &w->cg_p, &w->cg_r, &w->cg_Gp, &w->cg_z, &w->cg_M, &w->cg_tmp, &w->cg_pair, &w->a_up, &w->a_vp, &w->a_ut, &w->a_u,
                           &w->a_v, &w->a_utn, &w->a_un, &w->a_vn, &w->part};
   for (auto *b : bufs) b->release();
-  w->ctl.release(); w->ldl.release(); w->T.release(); w->psync.release(); w->pdbg.release(); w->prp.release();
+  w->ctl.release(); w->ldl.release(); w->T.release();
   if (w->hctl) (void)hipHostFree(w->hctl);
   w->stamps.release();
   if (w->hstamps) (void)hipHostFree(w->hstamps);
@@ -1261,28 +1224,6 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
     }
     w->factor_resid = res;
     { const char *e = getenv("ABIP_HIP_FUSE"); w->fuse_small = w->ldl.small && !w->dist && !(e && atoi(e) == 0) && (!w->ldl.xl || w->ldl.allow_lds<LpSolveFuse>()); }
-    { // whole batches of iterations in one launch when the solve vector also fits LDS (every Netlib-class LP)
-      const char *e = getenv("ABIP_HIP_PERSIST");
-      // dynamic LDS: solve vector / mat-vec operand, and (several workgroups) one iterate staged for the residual products
-      w->persist_lds = sizeof(double) * ((size_t)std::max(w->ldl.N, w->ldl.T) + (size_t)w->LV + (size_t)n);
-      // OPT-IN (ABIP_HIP_PERSIST=1): measured on MI355X it LOSES to the launch-per-kernel path (C2 surrogate: ~100 us per iteration against 58 us;
-      // profiles/README.md r02d) -- a dependent phase that crosses workgroups costs 6-8 us here (agent-scope round trips of the operands plus the
-      // grid barrier; the XCDs' L2s are not coherent) against 2.7 us for a kernel boundary, and the phases kept in one workgroup run at global-memory
-      // latency.  Kept because it is correct, tested (test_persistent_iteration_kernel) and the natural starting point for an all-LDS variant.
-      w->persist = w->fuse_small && w->ldl.xl && (e && atoi(e) == 1) && w->persist_lds + 24 * 1024 <= 160 * 1024 &&
-                   hipFuncSetAttribute((const void *)k_lp_persist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->persist_lds) == hipSuccess;
-      if (w->persist) {
-        if (w->psync.alloc(2) || w->prp.alloc(12 * 128) || hipMemsetAsync(w->psync.p, 0, sizeof(unsigned) * 2, w->stream) != hipSuccess) return fail("work memory allocation failure");
-        const int T = w->ldl.T;
-        // workgroups: the dense tail's mat-vecs want the chip's ingest (T^2 doubles each), the grid barriers want few arrivals
-        int G = T <= 0 ? 1 : (T <= 256 ? 8 : (T <= 512 ? 16 : (T < 1024 ? 32 : 64)));
-        const char *g = getenv("ABIP_HIP_PERSIST_WGS");
-        if (g && atoi(g) > 0) G = std::min(atoi(g), 128);
-        w->persist_wgs = T > 0 ? std::max(G, 2) : std::max(1, std::min(G, 128));
-        if (getenv("ABIP_HIP_PERSIST_DEBUG")) { if (w->pdbg.alloc(8) || hipMemsetAsync(w->pdbg.p, 0, 64, w->stream) != hipSuccess) return fail("work memory allocation failure"); }
-        w->NB = 1; // one partial per reduction slot: the kernels outside the persistent launch run on a one-workgroup grid too
-      }
-    }
     const int one = 1; // the post-solve kernels are gated on cg_done: permanently set for the direct back-end
     if (hipMemcpyAsync(&w->ctl.p->cg_done, &one, sizeof(int), hipMemcpyHostToDevice, w->stream) != hipSuccess) return fail("memcpy failure");
   }
@@ -1534,14 +1475,6 @@ abip_int abip_solve(ABIPWork *w, const ABIPData *d, ABIPSolution *sol, ABIPInfo 
 
 void abip_finish(ABIPWork *w) { // abip.c:2301-2337
   if (!w) return;
-  if (w->pdbg.p) { // developer diagnostic
-    unsigned long long t[8];
-    if (hipMemcpy(t, w->pdbg.p, 64, hipMemcpyDeviceToHost) == hipSuccess) {
-      const char *nm[8] = {"rhs", "perm+fwd", "tail(3 barriers)", "D^-1+bwd+perm", "u_t'h", "prox/dual/avg", "residual products", "finalize"};
-      const double its = (double)std::max(1, w->hctl->it_count);
-      for (int q = 0; q < 8; ++q) fprintf(stderr, "persist phase %-18s %8.2f us / iteration\n", nm[q], (double)t[q] * 0.01 / its);
-    }
-  }
   if (w->stgs && w->stgs->normalize && w->A) host::un_normalize_A(w->A, w->stgs, w->D, w->E);
   free_work(w);
 }
@@ -1649,7 +1582,7 @@ abip_float abip_hip_get_scalar(ABIPWork *w, const char *name) {
   RET("mu", w->mu) RET("beta", w->beta) RET("sigma", w->sigma) RET("gamma", w->gamma) RET("g_th", w->g_th)
   RET("sc_b", w->sc_b) RET("sc_c", w->sc_c) RET("nm_b", w->nm_b) RET("nm_c", w->nm_c) RET("tot_cg_its", w->tot_cg_its)
   RET("lnnz", w->ldl.lnnz) RET("levels_fwd", w->ldl.F.nlev) RET("levels_bwd", w->ldl.B.nlev) RET("tail", w->ldl.T) RET("admm_iter", w->k) RET("ipm_iter", w->i)
-  RET("sell_At", w->dAt.nslices) RET("sell_A", w->dA.nslices) RET("nb", w->NB) RET("small_solve", w->ldl.small ? 1 : 0) RET("persist", w->persist ? w->persist_wgs : 0) RET("factor_resid", w->factor_resid)
+  RET("sell_At", w->dAt.nslices) RET("sell_A", w->dA.nslices) RET("nb", w->NB) RET("small_solve", w->ldl.small ? 1 : 0) RET("factor_resid", w->factor_resid)
 #undef RET
   return NAN;
 }

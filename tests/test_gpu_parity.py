@@ -110,53 +110,6 @@ def test_batched_iterations_equal_stepwise(gpu, name, monkeypatch):
             assert np.array_equal(a2, b2)
 
 
-@pytest.mark.parametrize("name", ["lp_afiro_like", "lp_staircase", "lp_random_sparse_small"])
-def test_persistent_iteration_kernel(gpu, name, monkeypatch):
-    """Netlib-class LPs, opt-in (ABIP_HIP_PERSIST=1): whole batches of iterations in one launch (dev_lp_persist.h; with helper workgroups
-    and grid barriers when the factor has a dense tail).  Batched, stepwise and strided use of that launch must be bit-identical; against
-    the default launch-per-kernel path (other reduction geometry) and the reference fixture it must agree like any two correct runs."""
-    z, A, b, c = load(name)
-    monkeypatch.delenv("ABIP_HIP_BATCH", raising=False)
-    runs = {}
-    for mode in ("persist", "persist_stepwise", "persist_strided", "persist_wgs5", "launches"):
-        monkeypatch.setenv("ABIP_HIP_PERSIST", "1"); monkeypatch.delenv("ABIP_HIP_BATCH", raising=False); monkeypatch.delenv("ABIP_HIP_PERSIST_WGS", raising=False)
-        if mode == "launches":
-            monkeypatch.delenv("ABIP_HIP_PERSIST", raising=False)      # the default
-        if mode == "persist_stepwise":
-            monkeypatch.setenv("ABIP_HIP_BATCH", "0")
-        if mode == "persist_wgs5":
-            monkeypatch.setenv("ABIP_HIP_PERSIST_WGS", "5")       # an odd number of workgroups (also for the tail-free factors: helpers for the products only)
-        with gpu.Solver(A, b, c, linsys="direct", verbose=0, eps=1e-6) as S:
-            assert (S.scalar("persist") > 0) == (mode != "launches")
-            if mode != "launches":
-                assert S.scalar("nb") == 1
-                if S.scalar("tail") > 0:
-                    assert S.scalar("persist") >= 2
-            if mode == "persist_strided":
-                S.begin()
-                fin = False
-                while not fin:
-                    fin, done = S.step(13)
-                info = S.end()
-            else:
-                info = S.solve()
-            runs[mode] = (info, S.x.copy(), S.y.copy(), S.s.copy())
-    base = runs["persist"]
-    for mode in ("persist_stepwise", "persist_strided"):
-        r = runs[mode]
-        assert r[0]["admm_iter"] == base[0]["admm_iter"] and r[0]["ipm_iter"] == base[0]["ipm_iter"] and r[0]["pobj"] == base[0]["pobj"], mode
-        for a2, b2 in zip(r[1:], base[1:]):
-            assert np.array_equal(a2, b2), mode
-    for mode in ("launches", "persist_wgs5"):      # another reduction geometry (the residual sums are split over the workgroups): two correct runs
-        r = runs[mode]
-        assert r[0]["status_val"] == base[0]["status_val"] == 1 and r[0]["ipm_iter"] == base[0]["ipm_iter"], mode
-        assert abs(r[0]["admm_iter"] - base[0]["admm_iter"]) <= 0.03 * base[0]["admm_iter"] + 2, mode
-        tol = 1e-3 if name == "lp_staircase" else 1e-5
-        for a2, b2 in zip(r[1:], base[1:]):
-            assert rel(a2, b2) < tol, mode
-    _check_against_golden_loose(base, z, "direct_1e-06", 1e-6, name)
-
-
 @pytest.mark.parametrize("variant", ["default", "origin", "qp", "scale5", "nonorm"])
 def test_host_scaling_matches_the_oracle(gpu, oracle_built, variant):
     """a12: ABIP(_normalize_A) (linsys/common.c:150-565: pc / origin / Ruiz x10 / qp rescaling with their clamps),

@@ -1,3 +1,10 @@
+// EXPERIMENT, NOT PART OF THE LIBRARY (moved out of abip_amd/csrc after measurement; last built in commit 915fa21, where solver.hip
+// still carries the host side `enqueue_persist`).  Result on MI355X: correct and bit-identical between batched / stepwise / strided use
+// (commit 915fa21's tests/test_gpu_parity.py::test_persistent_iteration_kernel), but ~100 us per iteration on the C2 surrogate against 58 us
+// for the launch-per-kernel path (profiles/r02d_*), and the multi-workgroup form became unreliable once the kernel's scratch use grew
+// (960 B per lane after the Csr struct gained the SELL fields: the grid barriers need every workgroup resident, which a scratch-limited
+// dispatch does not guarantee -- it deadlocked).  Kept as the record of what was tried and as a starting point for an all-LDS variant.
+//
 // dev_lp_persist.h -- Netlib-class LPs on the direct back-end: a whole batch of inner ADMM iterations in ONE launch.
 //
 // When the sparse part of the LDL' solve fits one workgroup (DevLdl::small; every Netlib LP does), an iteration of the launch-per-kernel
