@@ -338,19 +338,20 @@ __device__ __forceinline__ void spmv_sell(const Csr M, ProdF prod, RowF rowf, Pr
     s = sn; base = nbase; len = nlen;
   }
 }
-// the product in whichever layout the matrix carries
-template <int NV, class ProdF, class RowF, class PreF>
+// the product in the layout chosen at COMPILE time (a kernel that carried both paths would pay for the wider one in registers: the
+// stream path fits 64 VGPRs = 8 waves per SIMD = the whole persistent grid resident; host code picks kern<true> when M.nslices > 0)
+template <int NV, bool SELL, class ProdF, class RowF, class PreF>
 __device__ __forceinline__ void spmv_rows(const Csr M, double *lds, int *lptr, double *sm, ProdF prod, RowF rowf, PreF pre, int vb, int vgrid) {
-  if (M.nslices > 0) spmv_sell<NV>(M, prod, rowf, pre, vb, vgrid);
+  if (SELL) spmv_sell<NV>(M, prod, rowf, pre, vb, vgrid);
   else spmv_stream<NV>(M, lds, lptr, sm, prod, rowf, pre, vb, vgrid);
 }
-template <int NV, class ProdF, class RowF, class PreF>
+template <int NV, bool SELL, class ProdF, class RowF, class PreF>
 __device__ __forceinline__ void spmv_rows(const Csr M, double *lds, int *lptr, double *sm, ProdF prod, RowF rowf, PreF pre) {
-  spmv_rows<NV>(M, lds, lptr, sm, prod, rowf, pre, (int)blockIdx.x, (int)gridDim.x);
+  spmv_rows<NV, SELL>(M, lds, lptr, sm, prod, rowf, pre, (int)blockIdx.x, (int)gridDim.x);
 }
-template <int NV, class ProdF, class RowF>
+template <int NV, bool SELL, class ProdF, class RowF>
 __device__ __forceinline__ void spmv_rows(const Csr M, double *lds, int *lptr, double *sm, ProdF prod, RowF rowf) {
-  spmv_rows<NV>(M, lds, lptr, sm, prod, rowf, [] { return true; }, (int)blockIdx.x, (int)gridDim.x);
+  spmv_rows<NV, SELL>(M, lds, lptr, sm, prod, rowf, [] { return true; }, (int)blockIdx.x, (int)gridDim.x);
 }
 
 } // namespace abip

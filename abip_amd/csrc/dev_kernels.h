@@ -91,13 +91,14 @@ __global__ __launch_bounds__(BS) void k_rhs(const double *__restrict__ u, const 
 // 82 us and 4.6x the algorithmic traffic against ~35 us for every other product of the same matrix).  The two sums stay separate,
 // exactly as the reference forms them.  Without a warm start (s == nullptr): r = b, x0 = 0 (indirect.c:347-348), one plain gather.
 // ---------------------------------------------------------------------------------------------
+template <bool SELL>
 __global__ __launch_bounds__(BS) void k_cg_init_At(Csr At /* rows = columns of A */, const double *__restrict__ s, const double *__restrict__ bx,
                                                    double2 *__restrict__ pair, const Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
-  spmv_rows<1>(
+  spmv_rows<1, SELL>(
       At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * s[c]; },
       [&](int row, double(&acc)[1]) { pair[row] = make_double2(bx[row], acc[0]); });
 }
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(BS) void k_cg_init_pair(const double *__restrict__ 
   for (int j = blockIdx.x * BS + threadIdx.x; j < n; j += gridDim.x * BS) pair[j] = make_double2(bx[j], T[j]);
 }
 
-template <bool DIST> // DIST: also the partial of z'z (= ||p||^2 of the first direction) for the sharded path
+template <bool DIST, bool SELL> // DIST: also the partial of z'z (= ||p||^2 of the first direction) for the sharded path
 __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rhs /* l-vector: y in/out (x0), x read */,
                                                   const double2 *__restrict__ pair /* (rhs_x, A's) per column; unused without a warm start */,
                                                   const double *__restrict__ s, const double *__restrict__ Minv, double *__restrict__ r, double *__restrict__ z,
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rh
   const double *bx = rhs + d.MP;
   double acc2[3] = {0.0, 0.0, 0.0};
   if (s) {
-    spmv_rows<2>(
+    spmv_rows<2, SELL>(
         A, lds, lptr, sm, [&](int c, double a, double(&pr)[2]) { const double2 t = pair[c]; pr[0] = a * t.x; pr[1] = a * t.y; },
         [&](int i, double(&acc)[2]) {
           const double si = s[i];
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rh
           if (DIST) acc2[2] += zi * zi;
         });
   } else {
-    spmv_rows<1>(
+    spmv_rows<1, SELL>(
         A, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * bx[c]; },
         [&](int i, double(&acc)[1]) {
           const double ri = rhs[i] + acc[0];
@@ -181,7 +182,8 @@ __device__ __forceinline__ bool cg_converged(Ctl *ctl, const double *part, int n
 // tmp = A' p_new with p_new = z + beta p (indirect.c:386-387 folded into 216).  Gathering two m-vectors per non-zero
 // costs a second pass through the texture path, so the identity A'(z + beta p) = A'z + beta (A'p) is used instead:
 // tmp still holds A'p of the previous iteration (it is rebuilt from scratch, beta = 0, at every solve).
-__global__ __launch_bounds__(BS) void k_cg_spmv_At(Csr At, const double *__restrict__ z,
+template <bool SELL>
+__global__ __launch_bounds__(BS, SELL ? 6 : 8) void k_cg_spmv_At(Csr At, const double *__restrict__ z,
                                                    double *__restrict__ tmp, int max_its, double *part, int nb, Ctl *ctl, Stamp *st) {
   ABIP_GATE_HALT(ctl);
   if (ctl->cg_done) return;
@@ -205,14 +207,15 @@ __global__ __launch_bounds__(BS) void k_cg_spmv_At(Csr At, const double *__restr
     ran = true;
     return true;
   };
-  spmv_rows<1>(
+  spmv_rows<1, SELL>(
       At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * z[c]; },
       [&](int row, double(&acc)[1]) { tmp[row] = first ? acc[0] : acc[0] + beta * tmp[row]; }, pre);
   if (ran) stamp_end(st); // a launch that found the PCG converged leaves t1 == 0: not counted
 }
 
 // p <- z + beta p ; Gp = A tmp + rho p ; S_PG <- p'Gp            (indirect.c:214-219, 371)
-__global__ __launch_bounds__(BS) void k_cg_spmv_A(Csr A, const double *__restrict__ tmp, const double *__restrict__ z,
+template <bool SELL>
+__global__ __launch_bounds__(BS, SELL ? 6 : 8) void k_cg_spmv_A(Csr A, const double *__restrict__ tmp, const double *__restrict__ z,
                                                   double *__restrict__ p, double *__restrict__ Gp, double rho, double *part, const Ctl *ctl, Stamp *st) {
   ABIP_GATE_HALT(ctl);
   if (ctl->cg_done) return;
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(BS) void k_cg_spmv_A(Csr A, const double *__restric
   __shared__ double sm[WAVES];
   const double beta = ctl->beta_cur;
   double acc1[1] = {0.0};
-  spmv_rows<1>(
+  spmv_rows<1, SELL>(
       A, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * tmp[c]; },
       [&](int i, double(&acc)[1]) {
         const double pn = z[i] + beta * p[i];
@@ -286,6 +289,7 @@ __global__ __launch_bounds__(BS) void k_cg_update(double *__restrict__ x, double
 // Post-solve: rhs_x <- A' rhs_y - rhs_x (indirect.c:419-420) and S_DH <- rhs[0:l-1)'h (abip.c:560).
 // Runs only once the CG has converged; re-checks convergence itself because the last update of a
 // chunk has no SpMV behind it.
+template <bool SELL>
 __global__ __launch_bounds__(BS) void k_post_At(Csr At, double *__restrict__ rhs, const double *__restrict__ h, Dims d,
                                                 int max_its, double *part, int nb, Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(BS) void k_post_At(Csr At, double *__restrict__ rhs
   double *bx = rhs + d.MP;
   const double *hx = h + d.MP;
   double acc1[1] = {0.0};
-  spmv_rows<1>(
+  spmv_rows<1, SELL>(
       At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * rhs[c]; },
       [&](int j, double(&acc)[1]) {
         const double v = acc[0] - bx[j];
@@ -450,13 +454,14 @@ __global__ __launch_bounds__(BS) void k_avg_stats(UpdArgs a, Dims d, double *par
 // residuals (abip.c:407-413, 443-449) from ONE pass over each matrix; pr/dr are never stored.
 // ---------------------------------------------------------------------------------------------
 // bodies: (vb, vgrid) = this workgroup's index / count among those working on the product
+template <bool SELL>
 __device__ __forceinline__ void d_q_A(const Csr &A, const double *__restrict__ uu /* l-vector */, const double *__restrict__ b,
                                       const double *__restrict__ wD /* D_i/(sc_b*scale) or null */, const Dims &d, int slot0, double *part,
                                       double *lds, int *lptr, double *sm, int vb, int vgrid) {
   const double *x = uu + d.MP;
   const double tau = uu[d.MP + d.n];
   double acc3[3] = {0.0, 0.0, 0.0};
-  spmv_rows<1>(
+  spmv_rows<1, SELL>(
       A, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
       [&](int i, double(&acc)[1]) {
         const double pri = acc[0], e = pri - b[i] * tau;
@@ -468,13 +473,14 @@ __device__ __forceinline__ void d_q_A(const Csr &A, const double *__restrict__ u
   const int ws[3] = {slot0, slot0 + 1, slot0 + 2};
   write_partials<3>(part, ws, acc3, sm, vb);
 }
+template <bool SELL>
 __device__ __forceinline__ void d_q_At(const Csr &At, const double *__restrict__ uu, const double *__restrict__ vv, const double *__restrict__ c,
                                        const double *__restrict__ wE /* E_j/(sc_c*scale) or null */, const Dims &d, int slot0, double *part,
                                        double *lds, int *lptr, double *sm, int vb, int vgrid) {
   const double *s = vv + d.MP;
   const double tau = uu[d.MP + d.n];
   double acc3[3] = {0.0, 0.0, 0.0};
-  spmv_rows<1>(
+  spmv_rows<1, SELL>(
       At, lds, lptr, sm, [&](int cidx, double a, double(&pr)[1]) { pr[0] = a * uu[cidx]; },
       [&](int j, double(&acc)[1]) {
         const double drj = acc[0] + s[j], e = drj - c[j] * tau;
@@ -486,6 +492,7 @@ __device__ __forceinline__ void d_q_At(const Csr &At, const double *__restrict__
   const int ws[3] = {slot0, slot0 + 1, slot0 + 2};
   write_partials<3>(part, ws, acc3, sm, vb);
 }
+template <bool SELL>
 __global__ __launch_bounds__(BS) void k_q_A(Csr A, const double *__restrict__ uu, const double *__restrict__ b, const double *__restrict__ wD, Dims d, int slot0,
                                             double *part, const Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
@@ -493,8 +500,9 @@ __global__ __launch_bounds__(BS) void k_q_A(Csr A, const double *__restrict__ uu
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[3 * WAVES];
-  d_q_A(A, uu, b, wD, d, slot0, part, lds, lptr, sm, (int)blockIdx.x, (int)gridDim.x);
+  d_q_A<SELL>(A, uu, b, wD, d, slot0, part, lds, lptr, sm, (int)blockIdx.x, (int)gridDim.x);
 }
+template <bool SELL>
 __global__ __launch_bounds__(BS) void k_q_At(Csr At, const double *__restrict__ uu, const double *__restrict__ vv, const double *__restrict__ c,
                                              const double *__restrict__ wE, Dims d, int slot0, double *part, const Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
@@ -502,10 +510,11 @@ __global__ __launch_bounds__(BS) void k_q_At(Csr At, const double *__restrict__ 
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[3 * WAVES];
-  d_q_At(At, uu, vv, c, wE, d, slot0, part, lds, lptr, sm, (int)blockIdx.x, (int)gridDim.x);
+  d_q_At<SELL>(At, uu, vv, c, wE, d, slot0, part, lds, lptr, sm, (int)blockIdx.x, (int)gridDim.x);
 }
 // both residual products of the stopping test in one launch: workgroups [0, nbA) take A u_x, the rest A'u_y (independent products,
 // each with its own nbA partial entries per slot)
+template <bool SELLA, bool SELLT>
 __global__ __launch_bounds__(BS) void k_q_both(Csr A, Csr At, const double *__restrict__ uu, const double *__restrict__ vv, const double *__restrict__ b,
                                                const double *__restrict__ c, const double *__restrict__ wD, const double *__restrict__ wE, Dims d,
                                                int slotA, int slotAt, int nbA, double *part, const Ctl *ctl) {
@@ -514,8 +523,8 @@ __global__ __launch_bounds__(BS) void k_q_both(Csr A, Csr At, const double *__re
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[3 * WAVES];
-  if ((int)blockIdx.x < nbA) d_q_A(A, uu, b, wD, d, slotA, part, lds, lptr, sm, (int)blockIdx.x, nbA);
-  else d_q_At(At, uu, vv, c, wE, d, slotAt, part, lds, lptr, sm, (int)blockIdx.x - nbA, (int)gridDim.x - nbA);
+  if ((int)blockIdx.x < nbA) d_q_A<SELLA>(A, uu, b, wD, d, slotA, part, lds, lptr, sm, (int)blockIdx.x, nbA);
+  else d_q_At<SELLT>(At, uu, vv, c, wE, d, slotAt, part, lds, lptr, sm, (int)blockIdx.x - nbA, (int)gridDim.x - nbA);
 }
 
 // One block: fold the listed slots into ctl->out[slot] and append the tau/kappa entries the host needs.
@@ -715,7 +724,7 @@ __device__ __forceinline__ void fold_slots(const FoldArgs &f, const double *part
 }
 __global__ __launch_bounds__(BS) void k_fold(FoldArgs f, const double *part, int nb, double *gs) { fold_slots(f, part, nb, gs); }
 // out = M x on the rows of this rank; FOLD: the last workgroup also folds the partials of the previous kernel into gs
-template <bool FOLD>
+template <bool FOLD, bool SELL>
 __global__ __launch_bounds__(BS) void k_spmv_set_t(Csr M, const double *__restrict__ x, double *__restrict__ out, int mode, const Ctl *ctl,
                                                    FoldArgs f, const double *part, int nb, double *gs, Stamp *st) {
   ABIP_GATE_HALT(ctl);
@@ -726,11 +735,12 @@ __global__ __launch_bounds__(BS) void k_spmv_set_t(Csr M, const double *__restri
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
-  spmv_rows<1>(
+  spmv_rows<1, SELL>(
       M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
       [&](int row, double(&acc)[1]) { out[row] = acc[0]; });
   stamp_end(st);
 }
+template <bool SELL>
 __global__ __launch_bounds__(BS) void k_spmv_set(Csr M, const double *__restrict__ x, double *__restrict__ out, int mode, const Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
   if (mode == 1 && ctl->cg_done) return;
@@ -738,7 +748,7 @@ __global__ __launch_bounds__(BS) void k_spmv_set(Csr M, const double *__restrict
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
-  spmv_rows<1>(
+  spmv_rows<1, SELL>(
       M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
       [&](int row, double(&acc)[1]) { out[row] = acc[0]; });
 }
@@ -808,11 +818,12 @@ __global__ __launch_bounds__(BS) void k_dist_q(const double *__restrict__ T, con
 }
 
 // plain y += A x for the unit-level ABI and the direct back-end's accumulations
+template <bool SELL>
 __global__ __launch_bounds__(BS) void k_spmv_acc(Csr M, const double *__restrict__ x, double *__restrict__ y) {
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
-  spmv_rows<1>(
+  spmv_rows<1, SELL>(
       M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
       [&](int row, double(&acc)[1]) { y[row] += acc[0]; });
 }

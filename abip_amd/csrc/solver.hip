@@ -273,6 +273,10 @@ int sync_ctl(W *w) { // the once-per-iteration control read
   return 0;
 }
 
+// the kernel instantiation for the layout a matrix carries (dev_common.h spmv_rows)
+#define PICK(kern, M) ((M).nslices > 0 ? kern<true> : kern<false>)
+#define PICK2(kern, T1, M) ((M).nslices > 0 ? kern<T1, true> : kern<T1, false>)
+
 inline Dims dims(const W *w) { return Dims{(int)w->m, (int)w->n, w->MP}; }
 
 // ------------------------------------------------------------------------------------------------
@@ -322,18 +326,18 @@ int enqueue_cg_begin(W *w, double *rhs, const double *warm, abip_int iter) {
   const double *bx = rhs + w->MP;
   double2 *pair = (double2 *)w->cg_pair.p;
   if (!w->dist) {
-    if (warm) launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_At, w->NB, BS, w->dAt.view(), warm, bx, pair, ctl);
-    launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_A<false>, w->NB, BS, w->dA.view(), rhs, (const double2 *)pair, warm, (const double *)w->cg_M.p,
+    if (warm) launch(w, ABIP_HIP_K_CG_EDGE, PICK(k_cg_init_At, w->dAt), w->NB, BS, w->dAt.view(), warm, bx, pair, ctl);
+    launch(w, ABIP_HIP_K_CG_EDGE, PICK2(k_cg_init_A, false, w->dA), w->NB, BS, w->dA.view(), rhs, (const double2 *)pair, warm, (const double *)w->cg_M.p,
            w->cg_r.p, w->cg_z.p, w->cg_p.p, w->stgs->rho_y, cg_tol_factor(w, iter), d, w->part.p, w->NB, w->ctl.p, (const double *)nullptr);
     return 0;
   }
   enqueue_fold(w, {S_BN});
   if (warm) {
-    launch(w, ABIP_HIP_K_CG_EDGE, k_spmv_set, w->NB, BS, w->dAt.view(), warm, w->T.p, 0, ctl);
+    launch(w, ABIP_HIP_K_CG_EDGE, PICK(k_spmv_set, w->dAt), w->NB, BS, w->dAt.view(), warm, w->T.p, 0, ctl);
     if (allreduce_vec_and_scalars(w)) return -1;
     launch(w, ABIP_HIP_K_VEC, k_cg_init_pair, w->NB, BS, (const double *)w->T.p, bx, pair, (int)w->n, ctl);
   } else if (allreduce_scalars(w)) return -1;
-  launch(w, ABIP_HIP_K_CG_EDGE, k_cg_init_A<true>, w->NB, BS, w->dA.view(), rhs, (const double2 *)pair, warm, (const double *)w->cg_M.p,
+  launch(w, ABIP_HIP_K_CG_EDGE, PICK2(k_cg_init_A, true, w->dA), w->NB, BS, w->dA.view(), rhs, (const double2 *)pair, warm, (const double *)w->cg_M.p,
          w->cg_r.p, w->cg_z.p, w->cg_p.p, w->stgs->rho_y, cg_tol_factor(w, iter), d, w->part.p, w->NB, w->ctl.p, (const double *)w->gs);
   return 0;
 }
@@ -343,17 +347,17 @@ int enqueue_cg_chunk(W *w, double *rhs, int its) {
   for (int q = 0; q < its; ++q) {
     w->ev_tag = w->cg_enq++;
     if (!w->dist) {
-      launch(w, ABIP_HIP_K_SPMV_AT, k_cg_spmv_At, w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, w->cg_tmp.p,
+      launch(w, ABIP_HIP_K_SPMV_AT, PICK(k_cg_spmv_At, w->dAt), w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, w->cg_tmp.p,
              max_its, w->part.p, w->NB, w->ctl.p, next_stamp(w, ABIP_HIP_K_SPMV_AT));
     } else {
       FoldArgs fo; fo.nslots = 0;
       for (int sl : {S_RR0, S_RR1, S_ZR0, S_ZR1, S_ZZ, S_ZP}) fo.slots[fo.nslots++] = sl;
-      launch(w, ABIP_HIP_K_SPMV_AT, k_spmv_set_t<true>, w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, w->T.p, 1, (const Ctl *)w->ctl.p,
+      launch(w, ABIP_HIP_K_SPMV_AT, PICK2(k_spmv_set_t, true, w->dAt), w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, w->T.p, 1, (const Ctl *)w->ctl.p,
              fo, (const double *)w->part.p, w->NB, w->gs, next_stamp(w, ABIP_HIP_K_SPMV_AT));
       if (allreduce_vec_and_scalars(w)) return -1;
       launch(w, ABIP_HIP_K_CG_VEC, k_dist_cg_step, w->NB, BS, (const double *)w->T.p, w->cg_tmp.p, (int)w->n, max_its, 1, (const double *)w->gs, w->part.p, w->ctl.p);
     }
-    launch(w, ABIP_HIP_K_SPMV_A, k_cg_spmv_A, w->NB, BS, w->dA.view(), (const double *)w->cg_tmp.p, (const double *)w->cg_z.p, w->cg_p.p,
+    launch(w, ABIP_HIP_K_SPMV_A, PICK(k_cg_spmv_A, w->dA), w->NB, BS, w->dA.view(), (const double *)w->cg_tmp.p, (const double *)w->cg_z.p, w->cg_p.p,
            w->cg_Gp.p, w->stgs->rho_y, w->part.p, (const Ctl *)w->ctl.p, next_stamp(w, ABIP_HIP_K_SPMV_A));
     // sharded: p'Gp = rho ||p||^2 + ||A'p||^2 needs no collective of its own (k_dist_cg_step left both pieces behind)
     if (w->dist)
@@ -368,14 +372,14 @@ int enqueue_cg_chunk(W *w, double *rhs, int its) {
 }
 int enqueue_cg_post(W *w, double *rhs) {
   if (!w->dist) {
-    launch(w, ABIP_HIP_K_CG_EDGE, k_post_At, w->NB, BS, w->dAt.view(), rhs, (const double *)w->h.p, dims(w), (int)w->m_glob, w->part.p, w->NB, w->ctl.p);
+    launch(w, ABIP_HIP_K_CG_EDGE, PICK(k_post_At, w->dAt), w->NB, BS, w->dAt.view(), rhs, (const double *)w->h.p, dims(w), (int)w->m_glob, w->part.p, w->NB, w->ctl.p);
     return 0;
   }
   // late convergence decision on the summed ||r||^2, then (only if converged) the back-substitution A'y
   enqueue_fold(w, {S_RR0, S_RR1, S_ZR0, S_ZR1});
   if (allreduce_scalars(w)) return -1;
   launch(w, ABIP_HIP_K_CG_VEC, k_dist_cg_step, 1, BS, (const double *)w->T.p, w->cg_tmp.p, (int)w->n, (int)w->m_glob, 0, (const double *)w->gs, w->part.p, w->ctl.p);
-  launch(w, ABIP_HIP_K_CG_EDGE, k_spmv_set, w->NB, BS, w->dAt.view(), (const double *)rhs, w->T.p, 2, (const Ctl *)w->ctl.p);
+  launch(w, ABIP_HIP_K_CG_EDGE, PICK(k_spmv_set, w->dAt), w->NB, BS, w->dAt.view(), (const double *)rhs, w->T.p, 2, (const Ctl *)w->ctl.p);
   if (allreduce_vec_and_scalars(w)) return -1;
   launch(w, ABIP_HIP_K_CG_EDGE, k_dist_post, w->NB, BS, (const double *)w->T.p, rhs, (const double *)w->h.p, dims(w), w->xwt, w->part.p, (const Ctl *)w->ctl.p);
   enqueue_fold(w, {S_DH});
@@ -517,12 +521,12 @@ int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty, bool decide =
   const int extra[] = {S_NUA, S_NVA, S_CXA, S_BYA, S_QPA, S_RPA, S_NAXA, S_QDA, S_RDA, S_NATYA};
   for (int s : base) f.slots[ns++] = s;
   if (!w->dist) {
-    launch(w, ABIP_HIP_K_QNORM, k_q_both, 2 * w->NB, BS, w->dA.view(), w->dAt.view(), (const double *)w->u.p, (const double *)w->v.p, (const double *)w->b.p,
+    launch(w, ABIP_HIP_K_QNORM, (w->dA.nslices > 0 ? (w->dAt.nslices > 0 ? k_q_both<true, true> : k_q_both<true, false>) : (w->dAt.nslices > 0 ? k_q_both<false, true> : k_q_both<false, false>)), 2 * w->NB, BS, w->dA.view(), w->dAt.view(), (const double *)w->u.p, (const double *)w->v.p, (const double *)w->b.p,
            (const double *)w->c.p, wD, wE, d, (int)S_QP, (int)S_QD, w->NB, w->part.p, ctl);
   } else {
-    launch(w, ABIP_HIP_K_QNORM, k_q_A, w->NB, BS, w->dA.view(), (const double *)w->u.p, (const double *)w->b.p, wD, d, (int)S_QP, w->part.p, ctl);
+    launch(w, ABIP_HIP_K_QNORM, PICK(k_q_A, w->dA), w->NB, BS, w->dA.view(), (const double *)w->u.p, (const double *)w->b.p, wD, d, (int)S_QP, w->part.p, ctl);
     if (!T_holds_Aty) { // A'u_y differs from the A'u_t,y the back-substitution left in T (v_y != 0): one more partial + all-reduce
-      launch(w, ABIP_HIP_K_QNORM, k_spmv_set, w->NB, BS, w->dAt.view(), (const double *)w->u.p, w->T.p, 2, ctl);
+      launch(w, ABIP_HIP_K_QNORM, PICK(k_spmv_set, w->dAt), w->NB, BS, w->dAt.view(), (const double *)w->u.p, w->T.p, 2, ctl);
       if (allreduce_vec_and_scalars(w)) return -1;
     }
     launch(w, ABIP_HIP_K_QNORM, k_dist_q, w->NB, BS, (const double *)w->T.p, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->c.p, wE, d,
@@ -530,11 +534,11 @@ int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty, bool decide =
   }
   if (avg_stats) {
     if (!w->dist) {
-      launch(w, ABIP_HIP_K_QNORM, k_q_both, 2 * w->NB, BS, w->dA.view(), w->dAt.view(), (const double *)w->u_avgc.p, (const double *)w->v_avgc.p, (const double *)w->b.p,
+      launch(w, ABIP_HIP_K_QNORM, (w->dA.nslices > 0 ? (w->dAt.nslices > 0 ? k_q_both<true, true> : k_q_both<true, false>) : (w->dAt.nslices > 0 ? k_q_both<false, true> : k_q_both<false, false>)), 2 * w->NB, BS, w->dA.view(), w->dAt.view(), (const double *)w->u_avgc.p, (const double *)w->v_avgc.p, (const double *)w->b.p,
              (const double *)w->c.p, wD, wE, d, (int)S_QPA, (int)S_QDA, w->NB, w->part.p, ctl);
     } else {
-      launch(w, ABIP_HIP_K_QNORM, k_q_A, w->NB, BS, w->dA.view(), (const double *)w->u_avgc.p, (const double *)w->b.p, wD, d, (int)S_QPA, w->part.p, ctl);
-      launch(w, ABIP_HIP_K_QNORM, k_spmv_set, w->NB, BS, w->dAt.view(), (const double *)w->u_avgc.p, w->T.p, 2, ctl);
+      launch(w, ABIP_HIP_K_QNORM, PICK(k_q_A, w->dA), w->NB, BS, w->dA.view(), (const double *)w->u_avgc.p, (const double *)w->b.p, wD, d, (int)S_QPA, w->part.p, ctl);
+      launch(w, ABIP_HIP_K_QNORM, PICK(k_spmv_set, w->dAt), w->NB, BS, w->dAt.view(), (const double *)w->u_avgc.p, w->T.p, 2, ctl);
       if (allreduce_vec_and_scalars(w)) return -1;
       launch(w, ABIP_HIP_K_QNORM, k_dist_q, w->NB, BS, (const double *)w->T.p, (const double *)w->u_avgc.p, (const double *)w->v_avgc.p, (const double *)w->c.p, wE, d,
              (int)S_QDA, w->xwt, w->part.p, ctl);
@@ -1507,7 +1511,7 @@ abip_int abip_hip_accum_by_A(ABIPWork *w, const abip_float *x, abip_float *y) { 
   if (dx.alloc(w->n) || dy.alloc(w->m)) return -1;
   HIP_OK(hipMemcpyAsync(dx.p, x, sizeof(double) * w->n, hipMemcpyHostToDevice, w->stream));
   HIP_OK(hipMemcpyAsync(dy.p, y, sizeof(double) * w->m, hipMemcpyHostToDevice, w->stream));
-  launch(w, ABIP_HIP_K_SPMV_A, k_spmv_acc, w->NB, BS, w->dA.view(), (const double *)dx.p, dy.p);
+  launch(w, ABIP_HIP_K_SPMV_A, PICK(k_spmv_acc, w->dA), w->NB, BS, w->dA.view(), (const double *)dx.p, dy.p);
   HIP_OK(hipMemcpyAsync(y, dy.p, sizeof(double) * w->m, hipMemcpyDeviceToHost, w->stream));
   HIP_OK(hipStreamSynchronize(w->stream));
   harvest_events(w);
@@ -1520,7 +1524,7 @@ abip_int abip_hip_accum_by_Atrans(ABIPWork *w, const abip_float *x, abip_float *
   if (dx.alloc(w->m) || dy.alloc(w->n)) return -1;
   HIP_OK(hipMemcpyAsync(dx.p, x, sizeof(double) * w->m, hipMemcpyHostToDevice, w->stream));
   HIP_OK(hipMemcpyAsync(dy.p, y, sizeof(double) * w->n, hipMemcpyHostToDevice, w->stream));
-  launch(w, ABIP_HIP_K_SPMV_AT, k_spmv_acc, w->NB, BS, w->dAt.view(), (const double *)dx.p, dy.p);
+  launch(w, ABIP_HIP_K_SPMV_AT, PICK(k_spmv_acc, w->dAt), w->NB, BS, w->dAt.view(), (const double *)dx.p, dy.p);
   HIP_OK(hipMemcpyAsync(y, dy.p, sizeof(double) * w->n, hipMemcpyDeviceToHost, w->stream));
   HIP_OK(hipStreamSynchronize(w->stream));
   harvest_events(w);

@@ -170,7 +170,8 @@ def bench_c5(args, rank, world, dist, torch):
     from abip_amd import problems, qcp
     p, d = 10_000, 45_000
     data, K = problems.qcp_lasso_socp(p, d)
-    stg = dict(eps=1e-3, linsys_solver=1, verbose=0)     # eps 1e-3: the reference's LASSO protocol (scripts/bench-qcp/test_lasso.m:11)
+    pcg = args.linsys == "indirect"                      # --linsys indirect: the conic PCG back-end (linsys_solver 3, abip_amd/csrc/qcp_pcg.h)
+    stg = dict(eps=1e-3, linsys_solver=3 if pcg else 1, verbose=0)     # eps 1e-3: the reference's LASSO protocol (scripts/bench-qcp/test_lasso.m:11)
     sol, info0 = qcp.abip_qcp(data, K, stg)               # warm-up: pages the library in, JIT-free but first-touch allocations
     if dist is not None:
         dist.barrier()
@@ -192,6 +193,14 @@ def bench_c5(args, rank, world, dist, torch):
                 kernel="KKT solve of the conic projection: k_perm_in, k_tri_wide (L21 stream), k_tail_mv x2 (dense inv(L22), inv(L22)'), k_dscale, k_tri_wide, k_perm_out",
                 avg_launch_us=avg_ms * 1e3, launches=f["solves_timed"], algorithmic_bytes_per_launch=bytes_solve, lnnz=lnnz, dense_tail=T,
                 streamed_bytes_per_solve=8 * T * (T + 1) + 12 * f["head_nnz"], levels=f["levels"])
+    if pcg:   # one solve = prep + (warm set-up pair) + avg_cg_iters x (A'z, A tn, update) + back-substitution: 2 + 2 + 2 cg + 1 products of the matrix
+        nnzA = int(data["A"].nnz); mA, nA = data["A"].shape
+        cg = float(info["avg_cg_iters"])
+        bytes_solve = (3 + 2 * cg + 2) * (b_spmv(mA, nA, nnzA) + b_spmv(nA, mA, nnzA)) / 2 + cg * 8 * 8 * mA
+        ach = bytes_solve / max(avg_ms * 1e-3, 1e-12) / 1e9
+        roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+                    kernel="KKT solve of the conic projection by y-space PCG: kq_pcg_prep, kq_pcg_Aty/_Gp (set-up), {kq_pcg_Aty, kq_pcg_Gp, kq_pcg_update} x cg, kq_pcg_post; one host round trip per solve",
+                    avg_launch_us=avg_ms * 1e3, launches=f["solves_timed"], algorithmic_bytes_per_launch=bytes_solve, avg_cg_iters=cg)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         # the conic reference needs MKL headers (unbuildable here) and the scalar oracle's LDL' of the full-size KKT matrix takes
@@ -207,8 +216,8 @@ def bench_c5(args, rank, world, dist, torch):
         emit(({
             "metric": "ADMM iterations/s", "value": world * steps / elapsed, "unit": "ADMM iterations/s", "n_gpus": world, "steps": steps, "warmup": int(info0["admm_iter"]),
             "ms_per_step": 1e3 * elapsed / max(steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"LASSO-as-SOCP p={p} d={d} density 0.005 (BASELINE configs[4]): n={p + 2 + 2 * d}, m={p + 1}, K.q=[{p + 2}], K.l={2 * d}; conic path, direct LDL'",
-                       "linsys": "direct", "eps": 1e-3,
+            "config": {"workload": f"LASSO-as-SOCP p={p} d={d} density 0.005 (BASELINE configs[4]): n={p + 2 + 2 * d}, m={p + 1}, K.q=[{p + 2}], K.l={2 * d}; conic path, " + ("y-space PCG" if pcg else "direct LDL'"),
+                       "linsys": "indirect (PCG, linsys_solver 3)" if pcg else "direct", "eps": 1e-3,
                        "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (the direct back-end does not shard)"},
             "roofline": roof, "cpu_baseline": cpu,
             "time_to_tol": dict(seconds=info["runtime"], setup_s=info["setup_time"], solve_s=info["solve_time"], status=info["status"], admm_iter=steps,
