@@ -92,7 +92,7 @@ __global__ __launch_bounds__(BS) void k_rhs(const double *__restrict__ u, const 
 // exactly as the reference forms them.  Without a warm start (s == nullptr): r = b, x0 = 0 (indirect.c:347-348), one plain gather.
 // ---------------------------------------------------------------------------------------------
 template <bool SELL>
-__global__ __launch_bounds__(BS) void k_cg_init_At(Csr At /* rows = columns of A */, const double *__restrict__ s, const double *__restrict__ bx,
+__global__ __launch_bounds__(BS, SELL ? 6 : 8) void k_cg_init_At(Csr At /* rows = columns of A */, const double *__restrict__ s, const double *__restrict__ bx,
                                                    double2 *__restrict__ pair, const Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
   __shared__ double lds[CHUNK];
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(BS) void k_cg_init_pair(const double *__restrict__ 
 }
 
 template <bool DIST, bool SELL> // DIST: also the partial of z'z (= ||p||^2 of the first direction) for the sharded path
-__global__ __launch_bounds__(BS) void k_cg_init_A(Csr A, double *__restrict__ rhs /* l-vector: y in/out (x0), x read */,
+__global__ __launch_bounds__(BS, SELL ? 5 : 8) void k_cg_init_A(Csr A, double *__restrict__ rhs /* l-vector: y in/out (x0), x read */,
                                                   const double2 *__restrict__ pair /* (rhs_x, A's) per column; unused without a warm start */,
                                                   const double *__restrict__ s, const double *__restrict__ Minv, double *__restrict__ r, double *__restrict__ z,
                                                   double *__restrict__ p, double rho, double tol_factor, Dims d,
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(BS) void k_cg_update(double *__restrict__ x, double
 // Runs only once the CG has converged; re-checks convergence itself because the last update of a
 // chunk has no SpMV behind it.
 template <bool SELL>
-__global__ __launch_bounds__(BS) void k_post_At(Csr At, double *__restrict__ rhs, const double *__restrict__ h, Dims d,
+__global__ __launch_bounds__(BS, SELL ? 6 : 8) void k_post_At(Csr At, double *__restrict__ rhs, const double *__restrict__ h, Dims d,
                                                 int max_its, double *part, int nb, Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
   __shared__ double lds[CHUNK];
@@ -493,7 +493,7 @@ __device__ __forceinline__ void d_q_At(const Csr &At, const double *__restrict__
   write_partials<3>(part, ws, acc3, sm, vb);
 }
 template <bool SELL>
-__global__ __launch_bounds__(BS) void k_q_A(Csr A, const double *__restrict__ uu, const double *__restrict__ b, const double *__restrict__ wD, Dims d, int slot0,
+__global__ __launch_bounds__(BS, SELL ? 6 : 8) void k_q_A(Csr A, const double *__restrict__ uu, const double *__restrict__ b, const double *__restrict__ wD, Dims d, int slot0,
                                             double *part, const Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
   if (!ctl->cg_done) return;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(BS) void k_q_A(Csr A, const double *__restrict__ uu
   d_q_A<SELL>(A, uu, b, wD, d, slot0, part, lds, lptr, sm, (int)blockIdx.x, (int)gridDim.x);
 }
 template <bool SELL>
-__global__ __launch_bounds__(BS) void k_q_At(Csr At, const double *__restrict__ uu, const double *__restrict__ vv, const double *__restrict__ c,
+__global__ __launch_bounds__(BS, SELL ? 6 : 8) void k_q_At(Csr At, const double *__restrict__ uu, const double *__restrict__ vv, const double *__restrict__ c,
                                              const double *__restrict__ wE, Dims d, int slot0, double *part, const Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
   if (!ctl->cg_done) return;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(BS) void k_q_At(Csr At, const double *__restrict__ 
 // both residual products of the stopping test in one launch: workgroups [0, nbA) take A u_x, the rest A'u_y (independent products,
 // each with its own nbA partial entries per slot)
 template <bool SELLA, bool SELLT>
-__global__ __launch_bounds__(BS) void k_q_both(Csr A, Csr At, const double *__restrict__ uu, const double *__restrict__ vv, const double *__restrict__ b,
+__global__ __launch_bounds__(BS, (SELLA || SELLT) ? 6 : 8) void k_q_both(Csr A, Csr At, const double *__restrict__ uu, const double *__restrict__ vv, const double *__restrict__ b,
                                                const double *__restrict__ c, const double *__restrict__ wD, const double *__restrict__ wE, Dims d,
                                                int slotA, int slotAt, int nbA, double *part, const Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
@@ -706,18 +706,21 @@ struct FoldArgs { int nslots; int slots[40]; };
 // partials -> one number per slot in gs (the packed scalars that ride along with an all-reduce); one wavefront per slot
 __device__ __forceinline__ void fold_slots(const FoldArgs &f, const double *part, int nb, double *gs) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  constexpr int PER = MAXNB / 64;
+  constexpr int PER = MAXNB / 64, GRP = 8; // eight loads in flight per lane at a time: the fold rides inside an SpMV kernel and must not set its register count
   for (int s = wave; s < f.nslots; s += WAVES) {
     const int slot = f.slots[s];
-    double t[PER];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int i = lane + u * 64;
-      t[u] = (i < nb) ? part[slot * MAXNB + i] : 0.0;
-    }
     double acc = 0.0;
+#pragma unroll 1
+    for (int u0 = 0; u0 < PER; u0 += GRP) {
+      double t[GRP];
 #pragma unroll
-    for (int u = 0; u < PER; ++u) acc += t[u];
+      for (int u = 0; u < GRP; ++u) {
+        const int i = lane + (u0 + u) * 64;
+        t[u] = (i < nb) ? part[slot * MAXNB + i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) acc += t[u];
+    }
     acc = wave_sum(acc);
     if (lane == 0) gs[slot] = acc;
   }
@@ -725,7 +728,7 @@ __device__ __forceinline__ void fold_slots(const FoldArgs &f, const double *part
 __global__ __launch_bounds__(BS) void k_fold(FoldArgs f, const double *part, int nb, double *gs) { fold_slots(f, part, nb, gs); }
 // out = M x on the rows of this rank; FOLD: the last workgroup also folds the partials of the previous kernel into gs
 template <bool FOLD, bool SELL>
-__global__ __launch_bounds__(BS) void k_spmv_set_t(Csr M, const double *__restrict__ x, double *__restrict__ out, int mode, const Ctl *ctl,
+__global__ __launch_bounds__(BS, SELL ? 6 : 8) void k_spmv_set_t(Csr M, const double *__restrict__ x, double *__restrict__ out, int mode, const Ctl *ctl,
                                                    FoldArgs f, const double *part, int nb, double *gs, Stamp *st) {
   ABIP_GATE_HALT(ctl);
   if (FOLD && blockIdx.x == gridDim.x - 1) fold_slots(f, part, nb, gs); // (before the gates: the convergence test needs the sums)
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(BS) void k_spmv_set_t(Csr M, const double *__restri
   stamp_end(st);
 }
 template <bool SELL>
-__global__ __launch_bounds__(BS) void k_spmv_set(Csr M, const double *__restrict__ x, double *__restrict__ out, int mode, const Ctl *ctl) {
+__global__ __launch_bounds__(BS, SELL ? 6 : 8) void k_spmv_set(Csr M, const double *__restrict__ x, double *__restrict__ out, int mode, const Ctl *ctl) {
   ABIP_GATE_HALT(ctl);
   if (mode == 1 && ctl->cg_done) return;
   if (mode == 2 && !ctl->cg_done) return;
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(BS) void k_dist_q(const double *__restrict__ T, con
 
 // plain y += A x for the unit-level ABI and the direct back-end's accumulations
 template <bool SELL>
-__global__ __launch_bounds__(BS) void k_spmv_acc(Csr M, const double *__restrict__ x, double *__restrict__ y) {
+__global__ __launch_bounds__(BS, SELL ? 6 : 8) void k_spmv_acc(Csr M, const double *__restrict__ x, double *__restrict__ y) {
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
