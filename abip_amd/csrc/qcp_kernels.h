@@ -15,13 +15,14 @@
 
 namespace abip {
 
-struct QDims { int m, n, MP; };
+struct QDims { int m, n, MP; int norm_u; }; // norm_u: the inner test normalises by |u| (lasso_config.c:343-345) instead of |Qu| (qcp_config.c:549-551)
 
 enum QSlot : int { // reuse of the partials table; *_MAX slots are reduced with max
   Q_T0 = 0, Q_T1, Q_PG,                       // r'mu, r'(rho o p), p_x'Qp
   Q_D1, Q_D2, Q_D3, Q_E1, Q_E2, Q_E3,         // inner test: u'Mu, u_y'b, u_x'c, |Qu - v_o|^2, |Qu|^2, |v_o|^2 (tau entry added by the host)
   Q_S0, Q_S1, Q_S2, Q_S3, Q_S4, Q_S5,         // |D o Ax|^2, b'u_y, c'u_x, u_x'Qx, |E o Qx|^2, |E o (A'y + v_o)|^2
   Q_M0, Q_M1, Q_M2, Q_M3, Q_M4, Q_M5,         // max slots: |Ax/t-b|, D|Ax/t-b|, D|Ax/t|, |R|, E|R|, E|Qx/t|
+  Q_L0, Q_L1, Q_L2, Q_L3, Q_L4, Q_L5,         // LASSO residuals (kq_resid_lasso): |pr|^2, |dr|^2, x'x, 1'(beta+ + beta-), z'z, y'z
   Q_COUNT
 };
 __host__ __device__ inline bool qslot_is_max(int s) { return s >= Q_M0 && s <= Q_M5; }
@@ -257,7 +258,7 @@ __device__ __forceinline__ void dq_inner_A(const Csr &A, const double *__restric
       [&](int i, double(&acc)[1]) {
         const double mu = acc[0], qu = mu + (-tau) * b[i], dv = qu - vo[i];
         Ax[i] = mu;
-        a5[0] += u[i] * mu; a5[1] += u[i] * b[i]; a5[2] += dv * dv; a5[3] += qu * qu; a5[4] += vo[i] * vo[i];
+        a5[0] += u[i] * mu; a5[1] += u[i] * b[i]; a5[2] += dv * dv; a5[3] += d.norm_u ? u[i] * u[i] : qu * qu; a5[4] += vo[i] * vo[i];
       },
       [] { return true; }, vb, vgrid);
   const int ws[5] = {Q_D1, Q_D2, Q_E1, Q_E2, Q_E3};
@@ -276,7 +277,7 @@ __device__ __forceinline__ void dq_inner_At(const Csr &At, const double *__restr
           const int q = d.MP + j;
           const double mu = -acc[0], qu = mu + tau * c[j], dv = qu - vo[q];
           Qx[j] = 0.0;
-          a5[0] += u[q] * mu; a5[1] += u[q] * c[j]; a5[2] += dv * dv; a5[3] += qu * qu; a5[4] += vo[q] * vo[q];
+          a5[0] += u[q] * mu; a5[1] += u[q] * c[j]; a5[2] += dv * dv; a5[3] += d.norm_u ? u[q] * u[q] : qu * qu; a5[4] += vo[q] * vo[q];
         }
       },
       [] { return true; }, vb, vgrid);
@@ -368,12 +369,41 @@ __global__ __launch_bounds__(BS) void kq_resid(const double *__restrict__ u, con
   write_partials_max<6>(part, wm, m6, sm);
 }
 
+// ---- residuals of the LASSO reformulation (lasso_config.c:358-460) from the stored products of the scaled operator ----
+// With X~ = D X E the scaled data block: X (E o u_b) = D^-1 (X~ u_b) and X'(D o u_y) = E^-1 (X~' u_y), so the products with the caller's
+// un-scaled X that the reference forms are the stored A u_x (rows 1..dm) and A'u_y (the beta columns) divided by D resp. E:
+//   pr_i = (A u_x)_{1+i} / (D_i tau sc_b) - y_i,   dr_j = (v_j + (A'u_y)_j) / (E_j tau sc_c) - lambda   (both beta blocks),
+//   x = sqrt(sc_cone2) u_z / (tau sc_b),  beta+- = E o u_b / (tau sc_b),  z = D o u_y[1:] / (tau sc_c).
+struct QLasso { int dm, dn; double sqrt_sc2, sc_b, sc_c, lambda; const double *D, *E, *y; };
+__global__ __launch_bounds__(BS) void kq_resid_lasso(const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ Ax,
+                                                     const double *__restrict__ ATy, QLasso L, QDims d, double *part) {
+  __shared__ double sm[6 * WAVES];
+  const double tau = u[d.MP + d.n], ib = 1.0 / (tau * L.sc_b), ic = 1.0 / (tau * L.sc_c);
+  double s6[6] = {0, 0, 0, 0, 0, 0};
+  const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
+  const double *ux = u + d.MP, *vx = v + d.MP;
+  for (int i = t0; i < L.dm; i += stride) {
+    const double Di = L.D[i], yi = L.y[i];
+    const double pr = Ax[1 + i] / Di * ib - yi, x = ux[2 + i] * (L.sqrt_sc2 * ib), z = u[1 + i] * (Di * ic);
+    s6[0] += pr * pr; s6[2] += x * x; s6[4] += z * z; s6[5] += yi * z;
+  }
+  for (int e = t0; e < 2 * L.dn; e += stride) {
+    const int q = L.dm + 2 + e;
+    const double Ej = L.E[e < L.dn ? e : e - L.dn];
+    const double dr = (vx[q] + ATy[q]) / Ej * ic - L.lambda;
+    s6[1] += dr * dr; s6[3] += ux[q] * (Ej * ib);
+  }
+  const int ws[6] = {Q_L0, Q_L1, Q_L2, Q_L3, Q_L4, Q_L5};
+  write_partials<6>(part, ws, s6, sm);
+}
+
 // one block: partials (both halves of the table) -> ctl->out
 struct QFin {
   int nslots; int slots[24]; int second_half[24];
   // decide = 1 (the finalize that closes an inner iteration): complete the inner stopping metric with the tau entries, count the
   // iteration and raise the halt flag when the metric is below tol_inner, so that iterations enqueued behind it fall through
   int decide = 0;
+  int norm_u = 0; // as QDims::norm_u
   double tol_inner = 0.0;
   const double *u_tau = nullptr, *vo_tau = nullptr;
 };
@@ -405,7 +435,8 @@ __global__ __launch_bounds__(1024) void kq_finalize(QFin f, const double *part, 
     const double tau = *f.u_tau, vot = *f.vo_tau;
     const double qut = -o[Q_D1] / tau + o[Q_D2] - o[Q_D3];
     const double dq = qut - vot;
-    const double e1 = __dadd_rn(o[Q_E1], __dmul_rn(dq, dq)), e2 = __dadd_rn(o[Q_E2], __dmul_rn(qut, qut)), e3 = o[Q_E3];
+    const double t2 = f.norm_u ? tau : qut;
+    const double e1 = __dadd_rn(o[Q_E1], __dmul_rn(dq, dq)), e2 = __dadd_rn(o[Q_E2], __dmul_rn(t2, t2)), e3 = o[Q_E3];
     const double err = sqrt(e1) / (1 + sqrt(e2) + sqrt(e3));
     ctl->err_inner = err; ctl->it_count = ctl->it_count + 1;
     if (err < f.tol_inner) { hc->halt = 1; ctl->halted = 1; }

@@ -40,7 +40,18 @@ struct QResid { // struct ABIP_RESIDUALS, abip.h:182-207
          error_ratio = 1e8, Ax_b_norm = INFINITY, Qx_ATy_c_s_norm = INFINITY; // (the two norms: unknown until the first residual check -- qcp_pcg.h)
 };
 
+// The LASSO reformulation (lasso_config.c): what the front end keeps of the caller's data and of its own scaling
+struct LassoForm {
+  int dm = 0, dn = 0; // rows (samples) and columns (features) of the data matrix X
+  double lambda = 0, sc = 1, sc_b = 1, sc_c = 1, sc_cone1 = 1, sc_cone2 = 1;
+  std::vector<double> D, E, y;
+  DBuf<double> Dd, Ed, yd;
+};
+
 struct QWk {
+  int kind = 2; // enum problem_type as abip() maps settings.prob_type (abip.c:1341-1348): 0 LASSO, 2 generic QCP
+  LassoForm ls;
+  double kkt_rho_x = 1; // the rho_x the KKT system is assembled with (the LASSO solve hard-codes 1, lasso_config.c:652-708)
   int m = 0, n = 0, MP = 0, LV = 0, NB = 1;
   const QCPSettings *st = nullptr;
   bool hasQ = false;
@@ -75,6 +86,7 @@ void release(QWk *w) {
   if (w->ev_b) (void)hipEventDestroy(w->ev_b);
   w->ev_a = w->ev_b = nullptr;
   w->dA.release(); w->dAt.release(); w->dQ.release();
+  w->ls.Dd.release(); w->ls.Ed.release(); w->ls.yd.release();
   DBuf<double> *bufs[] = {&w->u, &w->v, &w->vo, &w->ut, &w->rel, &w->r, &w->p, &w->bd, &w->cd, &w->Dd, &w->Ed, &w->Ax, &w->ATy, &w->Qx, &w->part};
   for (auto *b : bufs) b->release();
   w->xkind.release(); w->c_off.release(); w->c_len.release(); w->c_kind.release(); w->ctl.release();
@@ -163,6 +175,85 @@ void scale_data(QWk *w, const QCPData *d, const QCPCone *k) {
   for (int j = 0; j < n; ++j) w->c[j] *= w->sc_c * w->st->scale;
 }
 
+// ---- LASSO front end: init_lasso + scaling_lasso_data, lasso_config.c:8-260 -----------------------------------------------
+// min 1/2 |X beta - y|^2 + lambda |beta|_1 as the conic problem over (x0, x1, z (dm), beta+ (dn), beta- (dn)):
+//   row 0: x0 = 1; rows 1..dm: z + X beta+ - X beta- = y; (x0, x1, z) in one rotated cone; beta+- >= 0; cost 2 x1 + lambda 1'(beta+ + beta-).
+// The reference applies this operator matrix-free (lasso_A_times / lasso_AT_times, :99-128) and solves the KKT system through a reduced
+// dm x dm or dn x dn system (:506-556, 652-708); here the scaled operator is materialised once as a sparse matrix (nnz = 1 + dm + 2 nnz(X))
+// and handed to the conic path's own kernels and KKT back-ends -- the same linear maps, one code path on the device.
+void build_lasso(QWk *w, const QCPData *d) {
+  LassoForm &L = w->ls;
+  const int dm = d->m, dn = d->n;
+  L.dm = dm; L.dn = dn; L.lambda = d->lambda;
+  const int p = dm + 1, q = 2 + 2 * dn + dm;
+  const QCPMatrix *X = d->A;
+  const int xnnz = X->p[dn];
+  w->sparsity = (((double)xnnz / ((double)dm * (double)dn)) < 0.1); // :21
+  if (w->sparsity) { // :36-51
+    L.sc = 2; L.sc_c = 1 / L.lambda; L.sc_cone2 = L.lambda / dm * 80; L.sc_cone1 = 0.8 / L.sc_c / L.sc_cone2; L.sc_b = L.sc_c * 300 * L.lambda / dm;
+  } else {
+    L.sc = dm < dn ? 4 : 1; L.sc_c = 1 / L.lambda; L.sc_b = L.sc_c; L.sc_cone2 = 0.8; L.sc_cone1 = 1 / L.sc_c;
+  }
+  std::vector<double> xs(X->x, X->x + xnnz);
+  std::vector<double> &E = L.E, &D = L.D;
+  E.assign(dn, 0.0); D.assign(dm, 0.0);
+  const double sqm = std::sqrt((double)dm);
+  if (w->st->scale_E) { // :156-210
+    if (w->sparsity) {
+      double avg = 0, avg1 = 0;
+      for (int i = 0; i < dn; ++i) { for (int j = X->p[i]; j < X->p[i + 1]; ++j) E[i] += xs[j] * xs[j]; avg += std::sqrt(E[i]); }
+      avg /= dn;
+      for (int i = 0; i < dn; ++i) {
+        E[i] = avg / std::sqrt(E[i] + 1e-4) / L.sc;
+        if (E[i] > 1000 * sqm) E[i] = 1000 * sqm;
+        if (E[i] < 0.001 * sqm) E[i] = 1;
+        if (E[i] > 50) E[i] = 50;
+        avg1 += E[i];
+      }
+      avg1 /= dn;
+      for (int i = 0; i < dn; ++i) E[i] = avg1 / E[i] / L.sc;
+    } else {
+      for (int i = 0; i < dn; ++i) {
+        for (int j = X->p[i]; j < X->p[i + 1]; ++j) E[i] += xs[j] * xs[j];
+        E[i] = std::sqrt(E[i]);
+        if (E[i] > 1000 * sqm) E[i] = 1000 * sqm;
+        if (E[i] < 0.001 * sqm) E[i] = 1;
+        if (E[i] > 7) E[i] = 7;
+        E[i] = 1 / (E[i] * L.sc);
+      }
+    }
+    for (int i = 0; i < dn; ++i) for (int j = X->p[i]; j < X->p[i + 1]; ++j) xs[j] *= E[i];
+  }
+  for (int k = 0; k < xnnz; ++k) D[X->i[k]] += xs[k] * xs[k]; // :212-230
+  double avg = 0;
+  for (int i = 0; i < dm; ++i) avg += std::sqrt(2 * D[i] + L.sc_cone2);
+  avg /= dm;
+  for (int i = 0; i < dm; ++i) D[i] = avg / std::sqrt(2 * D[i] + L.sc_cone2);
+  for (int k = 0; k < xnnz; ++k) xs[k] *= D[X->i[k]];
+  L.y.assign(d->b, d->b + dm);
+  w->b.assign(p, 0.0); w->c.assign(q, 0.0); // :232-250
+  w->b[0] = L.sc_cone1;
+  for (int i = 0; i < dm; ++i) w->b[1 + i] = d->b[i] * D[i];
+  for (double &t : w->b) t *= L.sc_b;
+  w->c[1] = L.sc_cone1 * L.sc_cone2;
+  for (int i = 0; i < dn; ++i) { w->c[dm + 2 + i] = E[i] * L.lambda; w->c[dm + 2 + dn + i] = E[i] * L.lambda; }
+  for (double &t : w->c) t *= L.sc_c;
+  // the operator of lasso_A_times (:99-110) as a p x q CSC matrix
+  HMat &A = w->A;
+  A.m = p; A.n = q; A.p.assign(q + 1, 0); A.i.clear(); A.x.clear();
+  A.i.reserve((size_t)1 + dm + 2 * (size_t)xnnz); A.x.reserve(A.i.capacity());
+  const double sq2 = std::sqrt(L.sc_cone2);
+  A.i.push_back(0); A.x.push_back(1.0); A.p[1] = 1; // column 0
+  A.p[2] = 1;                                         // column 1 is empty
+  for (int i = 0; i < dm; ++i) { A.i.push_back(1 + i); A.x.push_back(D[i] * sq2); A.p[3 + i] = (int)A.i.size(); }
+  for (int sign = 0; sign < 2; ++sign)
+    for (int j = 0; j < dn; ++j) {
+      for (int k = X->p[j]; k < X->p[j + 1]; ++k) { A.i.push_back(1 + X->i[k]); A.x.push_back(sign ? -xs[k] : xs[k]); }
+      A.p[dm + 2 + sign * dn + j + 1] = (int)A.i.size();
+    }
+  w->D.assign(p, 1.0); w->E.assign(q, 1.0); w->sc_b = 1; w->sc_c = 1; // (neutral for the generic sums kq_resid still provides: certificates)
+}
+
 void hcsr_from(const HMat &M, host::HostCsr &out, bool transpose_to_rows) {
   // transpose_to_rows = false: CSC read as CSR of M' (ncols rows); true: explicit CSR of M (nrows rows)
   const int nnz = M.p[M.n];
@@ -186,7 +277,7 @@ void enqueue_solve(QWk *w, double *rhs) { // _ldl_solve, linsys.c:309-316
 // norms of the last check); otherwise y0 = 0 and tol as given (the set-up solve, abip.c:899).  Synchronises with the host once per chunk
 // of iterations.  Returns the CG iterations used, < 0 on a device error.
 int solve_pcg(QWk *w, double *rhs, bool warm, int iter, double tol_host) {
-  const QDims d{w->m, w->n, w->MP};
+  const QDims d{w->m, w->n, w->MP, w->kind == 0 ? 1 : 0};
   const QCPSettings *st = w->st;
   QPcgVec v{w->cg_x0.p, w->cg_r.p, w->cg_z.p, w->cg_p.p, w->cg_Gp.p, w->cg_tm.p, w->cg_M.p, w->cg_H.p};
   Ctl *hc = w->lp_ctl;
@@ -233,6 +324,7 @@ int read_ctl(QWk *w) {
 void finalize(QWk *w, std::initializer_list<int> slots, std::initializer_list<int> both_halves, double tol_inner = -1.0) {
   QFin f; f.nslots = 0;
   for (int s : slots) { f.slots[f.nslots] = s; f.second_half[f.nslots] = 0; for (int bsl : both_halves) if (bsl == s) f.second_half[f.nslots] = 1; ++f.nslots; }
+  f.norm_u = w->kind == 0 ? 1 : 0;
   if (tol_inner >= 0) { f.decide = 1; f.tol_inner = tol_inner; f.u_tau = w->u.p + w->MP + w->n; f.vo_tau = w->vo.p + w->MP + w->n; }
   QLAUNCH(w, kq_finalize, 1, 1024, f, (const double *)w->part.p, w->NB, w->ctl.p, w->lp_ctl);
 }
@@ -280,16 +372,40 @@ int has_converged(const QWk *w, const QResid &r, int ipm_iter, int admm_iter) { 
 int calc_residuals(QWk *w, QResid &r, int ipm_iter, int admm_iter) { // qcp_config.c:562-691 (sums from kq_resid)
   if (admm_iter && r.last_admm_iter == admm_iter) return 0;
   r.last_ipm_iter = ipm_iter; r.last_admm_iter = admm_iter;
-  const QDims d{w->m, w->n, w->MP};
+  const QDims d{w->m, w->n, w->MP, w->kind == 0 ? 1 : 0};
   QLAUNCH(w, kq_resid, w->NB, BS, (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->bd.p, (const double *)w->cd.p,
           (const double *)w->Dd.p, (const double *)w->Ed.p, (const double *)w->Ax.p, (const double *)w->ATy.p, (const double *)w->Qx.p, d, w->part.p);
   finalize(w, {Q_S0, Q_S1, Q_S2, Q_S3, Q_S4, Q_S5, Q_M0, Q_M1, Q_M2, Q_M3, Q_M4, Q_M5}, {});
+  if (w->kind == 0) {
+    const LassoForm &L = w->ls;
+    QLasso ql{L.dm, L.dn, std::sqrt(L.sc_cone2), L.sc_b, L.sc_c, L.lambda, L.Dd.p, L.Ed.p, L.yd.p};
+    QLAUNCH(w, kq_resid_lasso, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->Ax.p, (const double *)w->ATy.p, ql, d, w->part.p);
+    finalize(w, {Q_L0, Q_L1, Q_L2, Q_L3, Q_L4, Q_L5}, {});
+  }
   double tails[2];
   HIP_OK(hipMemcpyAsync(&tails[0], w->u.p + w->MP + w->n, sizeof(double), hipMemcpyDeviceToHost, w->stream));
   HIP_OK(hipMemcpyAsync(&tails[1], w->vo.p + w->MP + w->n, sizeof(double), hipMemcpyDeviceToHost, w->stream));
   if (read_ctl(w)) return -1;
   const double *o = w->hctl->out;
   const QCPSettings *st = w->st;
+  if (w->kind == 0) { // calc_lasso_residuals, lasso_config.c:358-503
+    const LassoForm &L = w->ls;
+    r.tau = tails[0];
+    r.Ax_b_norm = o[Q_M0]; r.Qx_ATy_c_s_norm = o[Q_M3]; // (for the PCG tolerance of abip.c:213-217 only)
+    double ny = 0; for (double t : L.y) ny += t * t;
+    const double this_pr = std::sqrt(o[Q_L0]) / std::max(std::sqrt(ny), 1.0);
+    const double this_dr = std::sqrt(o[Q_L1]) / (std::sqrt((double)(2 * L.dn)) * L.lambda);
+    const double P = 0.5 * o[Q_L2] + L.lambda * o[Q_L3];
+    const double this_gap = std::fabs(P + 0.5 * o[Q_L4] - o[Q_L5]) / (1 + std::fabs(P));
+    r.dobj = -0.5 * o[Q_L4] + o[Q_L5]; r.pobj = P;
+    r.res_dif = std::max(std::max(std::fabs(this_pr - r.res_pri), std::fabs(this_dr - r.res_dual)), std::fabs(this_gap - r.rel_gap));
+    r.res_pri = this_pr; r.res_dual = this_dr; r.rel_gap = this_gap;
+    r.error_ratio = std::max(r.res_pri / st->eps_p, std::max(r.res_dual / st->eps_d, r.rel_gap / st->eps_g));
+    const double ctu = o[Q_S2], btu = o[Q_S1]; // c'u_x, b'u_y; |A u_x|_2 and |A'u_y + v_o|_2 from the generic sums (D = E = 1 here)
+    r.res_unbdd = ctu < 0 ? std::sqrt(o[Q_S0]) / (-ctu) : INFINITY;
+    r.res_infeas = btu > 0 ? std::sqrt(o[Q_S5]) / btu : INFINITY;
+    return 0;
+  }
   r.tau = std::fabs(tails[0]);
   r.kap = std::fabs(tails[1]) / (st->normalize ? (st->scale * w->sc_c * w->sc_b) : 1);
   r.Ax_b_norm = o[Q_M0];
@@ -352,11 +468,20 @@ void abip_qcp_set_default_settings(QCPData *d) { // util.c:203-255
 
 qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) {
   if (!d || !sol || !info || !K) return fail(info, "ABIP_NULL input");
-  if (!d->A || !d->b || !d->c) return fail(info, "the device path needs A, b and c");
-  if (d->stgs->prob_type != 2) return fail(info, "only the generic QCP formulation (prob_type 2) is served");
+  if (!d->stgs) return fail(info, "ABIP_NULL input");
+  const int kind = d->stgs->prob_type; // abip.c:1341-1348: 0 LASSO, 1 SVM, 2 QCP, 3 SVMQP
+  if (kind != 2 && kind != 0) return fail(info, "served formulations: the generic QCP (prob_type 2) and LASSO (prob_type 0)");
+  if (!d->A || !d->b || (kind == 2 && !d->c)) return fail(info, "the device path needs A, b and c");
   if (d->stgs->linsys_solver != 1 && d->stgs->linsys_solver != 3) return fail(info, "only linsys_solver = 1 (QDLDL-class direct) and 3 (PCG) are served");
   const QCPSettings *st = d->stgs;
-  const int m = d->m, n = d->n;
+  if (kind == 0) { // LASSO: data = (X, y, lambda) as abip_ml_mex.c:117-160 hands them over
+    if (d->m <= 0 || d->n <= 0 || !(d->lambda > 0)) return fail(info, "LASSO needs a non-empty X and lambda > 0");
+    // the reference scales the data whatever `normalize` says and un-scales only when it is set, and divides by E = 0 when scale_E = 0
+    // (lasso_config.c:147-156, 300-310; abip.c:580-582): neither combination returns a usable beta
+    if (!st->normalize || !st->scale_E) return fail(info, "the LASSO formulation needs normalize = 1 and scale_E = 1");
+    if ((long long)2 + 2LL * d->n + d->m > 2147483647LL) return fail(info, "problem too large for 32-bit indices");
+  }
+  const int m = kind == 0 ? d->m + 1 : d->m, n = kind == 0 ? 2 + 2 * d->n + d->m : d->n;
   { // validate, abip.c:779-832 ; cones.c:37-81
     long dims = (long)K->l + K->z + K->f;
     for (int i = 0; K->q && i < K->qsize; ++i) dims += K->q[i];
@@ -372,14 +497,18 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) { printf("ERROR: no usable HIP device: libabip_hip has no CPU fallback\n"); return fail(info, "could not initialize work"); }
   const double t_init = now_ms();
   QWk W; QWk *w = &W;
-  w->m = m; w->n = n; w->st = st; w->hasQ = d->Q != nullptr;
-  // integer division, qcp_config.c:22 -- taken in 64 bits: the reference's 32-bit m * n overflows from m * n = 2^31 on (and divides by
-  // zero at m = 32768, n = 131072); for every size the reference can run, the quotient below is the same number
-  w->sparsity = (((long long)d->A->p[n] / std::max(1LL, (long long)m * (long long)n)) < 0.05);
-  copy_in(w->A, d->A);
-  if (w->hasQ) copy_in(w->Q, d->Q);
-  w->nm_inf_b = vnrminf(d->b, m); w->nm_inf_c = vnrminf(d->c, n);
-  scale_data(w, d, K);
+  w->kind = kind; w->m = m; w->n = n; w->st = st; w->hasQ = kind == 2 && d->Q != nullptr;
+  w->kkt_rho_x = kind == 0 ? 1.0 : st->rho_x;
+  if (kind == 0) build_lasso(w, d);
+  else {
+    // integer division, qcp_config.c:22 -- taken in 64 bits: the reference's 32-bit m * n overflows from m * n = 2^31 on (and divides by
+    // zero at m = 32768, n = 131072); for every size the reference can run, the quotient below is the same number
+    w->sparsity = (((long long)d->A->p[n] / std::max(1LL, (long long)m * (long long)n)) < 0.05);
+    copy_in(w->A, d->A);
+    if (w->hasQ) copy_in(w->Q, d->Q);
+    w->nm_inf_b = vnrminf(d->b, m); w->nm_inf_c = vnrminf(d->c, n);
+    scale_data(w, d, K);
+  }
   w->MP = ((m + 31) / 32) * 32;
   w->LV = ((w->MP + n + 1 + 31) / 32) * 32;
   auto bail = [&](const char *msg) { release(w); return fail(info, msg); };
@@ -396,7 +525,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   }
   w->pcg = st->linsys_solver == 3;
   if (w->pcg) { // H = rho_x I + Q must be diagonal; Jacobi preconditioner M_i = 1 / (rho_y + sum_j A_ij^2 / H_jj)  (qcp_pcg.h)
-    std::vector<double> Hinv(n, st->rho_x), M(m, st->rho_y);
+    std::vector<double> Hinv(n, w->kkt_rho_x), M(m, st->rho_y);
     if (w->hasQ) for (int j = 0; j < n; ++j) for (int q = w->Q.p[j]; q < w->Q.p[j + 1]; ++q) {
       if (w->Q.i[q] == j) Hinv[j] += w->Q.x[q];
       else if (w->Q.x[q] != 0.0) return bail("linsys_solver = 3 (PCG) needs Q absent or diagonal; use linsys_solver = 1");
@@ -411,7 +540,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     if (hipMalloc((void **)&w->lp_ctl, sizeof(Ctl)) != hipSuccess || hipMemsetAsync(w->lp_ctl, 0, sizeof(Ctl), w->stream) != hipSuccess) return bail("allocation failure");
   } else { // KKT upper triangle (qcp_config.c:699-748) -> LDL' -> level-scheduled device factors
     const int N = m + n;
-    const double rho_y = st->rho_y, rho_x = st->rho_x;
+    const double rho_y = st->rho_y, rho_x = w->kkt_rho_x;
     std::vector<int> Kp(N + 1), Ki; std::vector<double> Kx;
     Ki.reserve(N + w->A.p[n] + (w->hasQ ? w->Q.p[n] : 0)); Kx.reserve(Ki.capacity());
     for (int i = 0; i < m; ++i) { Kp[i] = (int)Ki.size(); Ki.push_back(i); Kx.push_back(-rho_y); }
@@ -473,6 +602,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   if (w->bd.upload(w->b, w->stream) || w->cd.upload(w->c, w->stream) || w->Dd.upload(w->D, w->stream) || w->Ed.upload(w->E, w->stream) || w->Ax.alloc(m) ||
       w->ATy.alloc(n) || w->Qx.alloc(n) || w->part.alloc((size_t)2 * Q_COUNT * MAXNB) || w->ctl.alloc(1))
     return bail("work memory allocation failure");
+  if (kind == 0 && (w->ls.Dd.upload(w->ls.D, w->stream) || w->ls.Ed.upload(w->ls.E, w->stream) || w->ls.yd.upload(w->ls.y, w->stream))) return bail("work memory allocation failure");
   if (hipMemsetAsync(w->part.p, 0, sizeof(double) * 2 * Q_COUNT * MAXNB, w->stream) != hipSuccess || hipMemsetAsync(w->Qx.p, 0, sizeof(double) * n, w->stream) != hipSuccess ||
       hipMemsetAsync(w->ctl.p, 0, sizeof(QCtl), w->stream) != hipSuccess || hipHostMalloc((void **)&w->hctl, sizeof(QCtl), hipHostMallocDefault) != hipSuccess)
     return bail("work memory allocation failure");
@@ -543,7 +673,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   QResid r;
   info->status_val = 0;
   double tol_inner = 4 * std::pow(w->mu, st->psi);
-  const QDims dm{m, n, w->MP};
+  const QDims dm{m, n, w->MP, w->kind == 0 ? 1 : 0};
   int i = 0, j = 0, k = 0;
   bool finished = false;
   auto get_solution = [&](int ipm_iter, int admm_iter) -> int { // abip.c:559-587
@@ -551,6 +681,26 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     if (hipMemcpyAsync(hu2.data(), w->u.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
         hipMemcpyAsync(hv2.data(), w->v.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess)
       return -1;
+    std::vector<double> lx;
+    if (kind == 0) { // LASSO hands back beta only (un_scaling_lasso_sol, lasso_config.c:296-311): the conic (x, y, s) stay inside
+      const LassoForm &L = w->ls;
+      lx.resize(n);
+      for (int q = 0; q < n; ++q) lx[q] = hu2[w->MP + q];
+      const int sv = info->status_val;
+      double scx = 1.0;
+      if (sv == 0 || sv == 1 || sv == 2) { scx = safediv_pos(1.0, r.tau); if (sv == 0 || sv == 2) { strcpy(info->status, "Solved/Inaccurate"); info->status_val = 2; } else { strcpy(info->status, "Solved"); info->status_val = 1; } }
+      else if (sv == -2 || sv == -7) { scx = NAN; strcpy(info->status, "Infeasible"); info->status_val = -2; }
+      else { scx = -1 / (r.pobj * r.tau); strcpy(info->status, "Unbounded"); info->status_val = -1; }
+      if (!sol->x) sol->x = (qcp_float *)malloc(sizeof(qcp_float) * L.dn);
+      for (int jx = 0; jx < L.dn; ++jx) sol->x[jx] = (lx[L.dm + 2 + jx] * scx + (-1) * (lx[L.dm + L.dn + 2 + jx] * scx)) * L.E[jx] * (1 / L.sc_b);
+      info->ipm_iter = ipm_iter + 1; info->admm_iter = admm_iter;
+      info->res_infeas = r.res_infeas; info->res_unbdd = r.res_unbdd;
+      if (info->status_val == 1 || info->status_val == 2) { info->rel_gap = r.rel_gap; info->res_pri = r.res_pri; info->res_dual = r.res_dual; info->pobj = r.pobj; info->dobj = r.dobj; }
+      else if (info->status_val == -1) { info->rel_gap = info->res_pri = info->res_dual = NAN; info->pobj = info->dobj = -INFINITY; }
+      else { info->rel_gap = info->res_pri = info->res_dual = NAN; info->pobj = info->dobj = INFINITY; }
+      info->solve_time = now_ms() - t0;
+      return 0;
+    }
     if (!sol->x) sol->x = (qcp_float *)malloc(sizeof(qcp_float) * n);
     if (!sol->y) sol->y = (qcp_float *)malloc(sizeof(qcp_float) * m);
     if (!sol->s) sol->s = (qcp_float *)malloc(sizeof(qcp_float) * n);

@@ -116,6 +116,54 @@ def abip_qcp(data, cones, settings: dict):
     return dict(x=x, y=y, s=s), out
 
 
+def abip_ml(data, settings: dict):
+    """[sol, info] = abip_ml(data, settings)   (src/abip-qcp/mex/abip_ml_mex.c:90-449): the machine-learning front end.
+    data: X (sparse), y (dense), lambda; settings.prob_type is mandatory (:266-276).  Served: prob_type 0 (LASSO,
+    min 1/2 |X beta - y|^2 + lambda |beta|_1; sol = {x: beta}).  The gateway builds the cone itself (:315-331)."""
+    L = _bind()
+    X, y, lam = _get(data, "X"), _get(data, "y"), _get(data, "lambda")
+    if X is None:
+        raise ValueError("ABIPData struct must contain a `X` entry.")
+    if not sp.issparse(X):
+        raise ValueError("Input matrix X must be in sparse format (pass in sparse(X))")
+    if y is None:
+        raise ValueError("ABIPData struct must contain a `y` entry.")
+    if sp.issparse(y):
+        raise ValueError("Input vector y must be in dense format (pass in full(y))")
+    if lam is None:
+        raise ValueError("ABIPData struct must contain a `lambda` entry.")
+    if "prob_type" not in settings:
+        raise ValueError("Please input the machine learning problem type")
+    prob_type = int(settings["prob_type"])
+    if prob_type not in (0, 1, 3):
+        raise ValueError("Invalid problem type")
+    if prob_type != 0:
+        raise NotImplementedError("This type of machine learning problem is not supported yet")  # SVM (1), SVM-QP (3): not built
+    (keep, Xm) = _csc(X)
+    m, n = Xm.m, Xm.n
+    y = np.array(y, dtype=np.float64, copy=True).ravel()
+    stgs = QCPSettings()
+    d = QCPData(m, n, C.pointer(Xm), None, y.ctypes.data_as(PF), None, float(lam), C.pointer(stgs))
+    L.abip_qcp_set_default_settings(C.byref(d))
+    if "eps" in settings:                       # abip_ml_mex.c:176-184
+        for k in ("eps", "eps_p", "eps_d", "eps_g", "eps_inf", "eps_unb"):
+            setattr(stgs, k, settings["eps"])
+    for k, v in settings.items():
+        if k != "eps" and hasattr(stgs, k):
+            setattr(stgs, k, int(v) if isinstance(getattr(stgs, k), int) else float(v))
+    rq = np.array([2 + m], dtype=np.int32)      # :328-331
+    K = QCPCone(None, 0, rq.ctypes.data_as(PI), 1, 0, 0, 2 * n)
+    beta = np.full(n, np.nan)
+    sol = QCPSolution(beta.ctypes.data_as(PF), None, None)
+    info = QCPInfo()
+    L.abip_qcp(C.byref(d), C.byref(sol), C.byref(info), C.byref(K))
+    out = dict(ipm_iter=info.ipm_iter, admm_iter=info.admm_iter, status=info.status.decode(), pobj=info.pobj, dobj=info.dobj,
+               res_pri=info.res_pri, res_dual=info.res_dual, gap=info.rel_gap, status_val=info.status_val,
+               setup_time=info.setup_time / 1e3, solve_time=info.solve_time / 1e3, runtime=(info.setup_time + info.solve_time) / 1e3,
+               lin_sys_time_per_iter=info.avg_linsys_time / 1e3, avg_cg_iters=info.avg_cg_iters)
+    return dict(x=beta), out
+
+
 def cone_prox(kind: int, tmp, lam: float, x_prev=None):
     """One SOC (kind 0) / rotated-SOC (kind 1) barrier prox on the device (kq_cones); unit-level mirror of cones.c:130-248."""
     L = _bind()

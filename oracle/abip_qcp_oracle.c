@@ -66,7 +66,10 @@ static void sp_accum_At(const QCPMatrix *A, const F *x, F *y) { /* y += A' x, li
 }
 
 /* ---- work ---------------------------------------------------------------------------------------------- */
+struct OrcLasso;
 typedef struct {
+  int kind;               /* 2: generic QCP (qcp_config.c); 0: the LASSO reformulation (lasso_config.c) */
+  struct OrcLasso *ls;
   I m, n;
   const QCPSettings *stgs;
   QCPMatrix A, Q; int hasQ;
@@ -262,6 +265,165 @@ static void solve_qcp_linsys_pcg(QW *w, F *b, const F *warm /* (m+n) or null */,
   free(t); free(acc);
 }
 
+/* ==== LASSO reformulation, lasso_config.c ===================================================================================
+ * data: X (dm x dn), y (dm), lambda.  Conic form (init_lasso, :8-94): p = dm + 1 rows, q = 2 + dm + 2 dn columns,
+ *   x = (x0, x1, z (dm), beta+ (dn), beta- (dn)),  (x0, x1, z) in one rotated cone of dm + 2, beta+- >= 0,
+ *   row 0: x0 = 1;  rows 1..dm: z + X beta+ - X beta- = y;  objective 2 x1 + lambda 1'(beta+ + beta-)   [x0 x1 >= |z|^2 / 2].
+ * The operator is applied matrix-free (:99-128), the KKT solve goes through the reduced dm x dm / dn x dn system (:506-556, 652-708);
+ * the reference factorises that system with QDLDL / CSparse / MKL, this restatement with a dense Cholesky (test sizes only). */
+typedef struct OrcLasso {
+  I dm, dn; F lambda, sc, sc_b, sc_c, sc_cone1, sc_cone2;
+  QCPMatrix X;                 /* scaled copy of the data matrix */
+  const QCPMatrix *X0; const F *y0;
+  F *D, *E, *D_hat, *data_b;
+  I cn; F *chol;               /* lower Cholesky factor (cn x cn, row-major) of the reduced system */
+} OrcLasso;
+
+static void lasso_A_times(QW *w, const F *x, F *y) { /* :99-110 */
+  OrcLasso *s = w->ls; const I m = s->dm, n = s->dn;
+  y[0] += x[0];
+  for (I i = 1; i < m + 1; ++i) y[i] += s->D[i - 1] * sqrt(s->sc_cone2) * x[i + 1];
+  sp_accum_A(&s->X, &x[m + 2], &y[1]);
+  for (I i = 0; i < m; ++i) y[1 + i] *= -1;
+  sp_accum_A(&s->X, &x[m + n + 2], &y[1]);
+  for (I i = 0; i < m; ++i) y[1 + i] *= -1;
+}
+static void lasso_AT_times(QW *w, const F *x, F *y) { /* :116-128 */
+  OrcLasso *s = w->ls; const I m = s->dm, n = s->dn;
+  y[0] += x[0];
+  for (I i = 2; i < m + 2; ++i) y[i] += x[i - 1] * s->D[i - 2] * sqrt(s->sc_cone2);
+  sp_accum_At(&s->X, &x[1], &y[m + 2]);
+  for (I j = 0; j < n; ++j) y[m + 2 + n + j] *= -1;
+  sp_accum_At(&s->X, &x[1], &y[m + 2 + n]);
+  for (I j = 0; j < n; ++j) y[m + 2 + n + j] *= -1;
+}
+static void init_lasso(QW *w, const QCPData *d) { /* :8-94 */
+  OrcLasso *s = (OrcLasso *)calloc(1, sizeof(OrcLasso));
+  w->ls = s; w->kind = 0;
+  s->dm = d->m; s->dn = d->n; s->lambda = d->lambda; s->X0 = d->A; s->y0 = d->b;
+  w->m = d->m + 1; w->n = 2 + 2 * d->n + d->m;
+  w->sparsity = (((F)d->A->p[d->n] / ((F)d->m * d->n)) < 0.1);
+  if (w->sparsity) {
+    s->sc = 2; s->sc_c = 1 / s->lambda; s->sc_cone2 = s->lambda / d->m * 80;
+    s->sc_cone1 = 0.8 / s->sc_c / s->sc_cone2; s->sc_b = s->sc_c * 300 * s->lambda / d->m;
+  } else {
+    s->sc = d->m < d->n ? 4 : 1;
+    s->sc_c = 1 / s->lambda; s->sc_b = s->sc_c; s->sc_cone2 = 0.8; s->sc_cone1 = 1 / s->sc_c;
+  }
+  s->data_b = (F *)malloc(sizeof(F) * w->m);
+  s->data_b[0] = 1; memcpy(&s->data_b[1], d->b, sizeof(F) * d->m);
+  s->D = (F *)calloc(d->m, sizeof(F)); s->E = (F *)calloc(d->n, sizeof(F)); s->D_hat = (F *)malloc(sizeof(F) * d->m);
+}
+static void scaling_lasso_data(QW *w) { /* :133-260 */
+  OrcLasso *s = w->ls; const I m = s->dm, n = s->dn;
+  copy_mat(&s->X, s->X0);
+  QCPMatrix *A = &s->X; F *E = s->E, *D = s->D;
+  F avg = 0, avg1 = 0;
+  if (w->stgs->scale_E) {
+    if (w->sparsity) {
+      for (I i = 0; i < n; ++i) { for (I j = A->p[i]; j < A->p[i + 1]; ++j) E[i] += A->x[j] * A->x[j]; avg += sqrt(E[i]); }
+      avg /= n;
+      for (I i = 0; i < n; ++i) {
+        E[i] = avg / sqrt(E[i] + 1e-4) / s->sc;
+        if (E[i] > 1000 * sqrt((F)m)) E[i] = 1000 * sqrt((F)m);
+        if (E[i] < 0.001 * sqrt((F)m)) E[i] = 1;
+        if (E[i] > 50) E[i] = 50;
+        avg1 += E[i];
+      }
+      avg1 /= n;
+      for (I i = 0; i < n; ++i) E[i] = avg1 / E[i] / s->sc;
+    } else {
+      for (I i = 0; i < n; ++i) {
+        for (I j = A->p[i]; j < A->p[i + 1]; ++j) E[i] += A->x[j] * A->x[j];
+        E[i] = sqrt(E[i]);
+        if (E[i] > 1000 * sqrt((F)m)) E[i] = 1000 * sqrt((F)m);
+        if (E[i] < 0.001 * sqrt((F)m)) E[i] = 1;
+        if (E[i] > 7) E[i] = 7;
+        E[i] = 1 / (E[i] * s->sc);
+      }
+    }
+    for (I i = 0; i < n; ++i) for (I j = A->p[i]; j < A->p[i + 1]; ++j) A->x[j] *= E[i];
+  }
+  for (I q = 0; q < A->p[n]; ++q) D[A->i[q]] += A->x[q] * A->x[q];
+  avg = 0;
+  for (I i = 0; i < m; ++i) avg += sqrt(2 * D[i] + s->sc_cone2);
+  avg /= m;
+  for (I i = 0; i < m; ++i) D[i] = avg / sqrt(2 * D[i] + s->sc_cone2);
+  for (I q = 0; q < A->p[n]; ++q) A->x[q] *= D[A->i[q]];
+  memcpy(w->b, s->data_b, sizeof(F) * w->m);
+  w->b[0] = s->sc_cone1;
+  for (I i = 1; i < m + 1; ++i) w->b[i] *= D[i - 1];
+  for (I i = 0; i < w->m; ++i) w->b[i] *= s->sc_b;
+  w->c[0] = 0; w->c[1] = s->sc_cone1 * s->sc_cone2;
+  memset(&w->c[2], 0, sizeof(F) * m);
+  for (I i = 0; i < n; ++i) { w->c[i + m + 2] = E[i] * s->lambda; w->c[i + m + 2 + n] = E[i] * s->lambda; }
+  for (I j = 0; j < w->n; ++j) w->c[j] *= s->sc_c;
+  for (I i = 0; i < m; ++i) s->D_hat[i] = D[i] * D[i] * s->sc_cone2 + w->stgs->rho_y;
+}
+/* form_lasso_kkt (:506-556) as a dense matrix + Cholesky: dm > dn: I/2 + X' D_hat^-1 X (dn x dn), else D_hat + 2 X X' (dm x dm) */
+static int init_lasso_linsys(QW *w) {
+  OrcLasso *s = w->ls; const I m = s->dm, n = s->dn; const QCPMatrix *A = &s->X;
+  const I cn = m > n ? n : m; s->cn = cn;
+  F *Xd = (F *)calloc((size_t)m * n, sizeof(F)), *G = (F *)calloc((size_t)cn * cn, sizeof(F));
+  for (I j = 0; j < n; ++j) for (I q = A->p[j]; q < A->p[j + 1]; ++q) Xd[(size_t)A->i[q] * n + j] = A->x[q];
+  if (m > n) {
+    for (I i = 0; i < m; ++i) { const F *row = &Xd[(size_t)i * n]; const F dinv = 1 / s->D_hat[i];
+      for (I a = 0; a < n; ++a) { if (row[a] == 0) continue; const F t = row[a] * dinv; for (I bq = 0; bq <= a; ++bq) G[(size_t)a * cn + bq] += t * row[bq]; } }
+    for (I a = 0; a < n; ++a) G[(size_t)a * cn + a] += 0.5;
+  } else {
+    for (I a = 0; a < m; ++a) for (I bq = 0; bq <= a; ++bq) { F t = 0; const F *ra = &Xd[(size_t)a * n], *rb = &Xd[(size_t)bq * n]; for (I j = 0; j < n; ++j) t += ra[j] * rb[j]; G[(size_t)a * cn + bq] = 2 * t; }
+    for (I a = 0; a < m; ++a) G[(size_t)a * cn + a] += s->D_hat[a];
+  }
+  for (I a = 0; a < cn; ++a) { /* in-place lower Cholesky */
+    for (I bq = 0; bq <= a; ++bq) {
+      F t = G[(size_t)a * cn + bq];
+      for (I k = 0; k < bq; ++k) t -= G[(size_t)a * cn + k] * G[(size_t)bq * cn + k];
+      if (a == bq) { if (t <= 0) { free(Xd); free(G); return -1; } G[(size_t)a * cn + a] = sqrt(t); }
+      else G[(size_t)a * cn + bq] = t / G[(size_t)bq * cn + bq];
+    }
+  }
+  s->chol = G; free(Xd);
+  return 0;
+}
+static void lasso_chol_solve(const OrcLasso *s, F *b) {
+  const I cn = s->cn; const F *G = s->chol;
+  for (I a = 0; a < cn; ++a) { F t = b[a]; for (I k = 0; k < a; ++k) t -= G[(size_t)a * cn + k] * b[k]; b[a] = t / G[(size_t)a * cn + a]; }
+  for (I a = cn - 1; a >= 0; --a) { F t = b[a]; for (I k = a + 1; k < cn; ++k) t -= G[(size_t)k * cn + a] * b[k]; b[a] = t / G[(size_t)a * cn + a]; }
+}
+static void solve_lasso_linsys(QW *w, F *b) { /* :652-708, the direct branch */
+  OrcLasso *s = w->ls; const I m = s->dm, n = s->dn, p = w->m, q = w->n;
+  for (I j = 0; j < q; ++j) b[p + j] *= -1;
+  F *b2 = (F *)malloc(sizeof(F) * p);
+  memcpy(b2, b, sizeof(F) * p);
+  lasso_A_times(w, &b[p], b2);
+  b[0] = b2[0] / (1 + w->stgs->rho_y);
+  if (m > n) {
+    for (I i = 0; i < m; ++i) { b2[i + 1] /= s->D_hat[i]; b[i + 1] = b2[i + 1]; }
+    F *tmp = (F *)calloc(n, sizeof(F)), *tmp2 = (F *)calloc(m, sizeof(F));
+    sp_accum_At(&s->X, &b2[1], tmp);
+    lasso_chol_solve(s, tmp);
+    sp_accum_A(&s->X, tmp, tmp2);
+    for (I i = 0; i < m; ++i) { tmp2[i] /= s->D_hat[i]; b[1 + i] += -tmp2[i]; }
+    free(tmp); free(tmp2);
+  } else {
+    memcpy(&b[1], &b2[1], sizeof(F) * m);
+    lasso_chol_solve(s, &b[1]);
+  }
+  free(b2);
+  for (I j = 0; j < q; ++j) b[p + j] *= -1;
+  lasso_AT_times(w, b, &b[p]);
+}
+static void free_lasso(QW *w) {
+  OrcLasso *s = w->ls; if (!s) return;
+  free(s->X.x); free(s->X.i); free(s->X.p); free(s->D); free(s->E); free(s->D_hat); free(s->data_b); free(s->chol); free(s);
+  w->ls = 0;
+}
+
+/* operator and KKT solve of the formulation in use */
+static void op_A(QW *w, const F *x, F *y) { if (w->kind == 0) lasso_A_times(w, x, y); else sp_accum_A(&w->A, x, y); }
+static void op_At(QW *w, const F *x, F *y) { if (w->kind == 0) lasso_AT_times(w, x, y); else sp_accum_At(&w->A, x, y); }
+static void solve_spe_linsys(QW *w, F *b) { if (w->kind == 0) solve_lasso_linsys(w, b); else solve_qcp_linsys(w, b); }
+
 /* ---- cones.c:130-288 ------------------------------------------------------------------------------------ */
 static void orthant_prox(F *x, const F *t, F lambda, I n) { /* :279-288 */
   for (I i = 0; i < n; ++i) {
@@ -344,7 +506,7 @@ static void projection(QW *w, I iter) { /* abip.c:186-255 (the direct branch) */
       fprintf(stderr, "check iter %ld: |dy| %.3e |dx| %.3e (|p| %.3e)\n", (long)iter, dy, dx, v_nrminf(p2, mn)); free(p2); free(p3); }
     solve_qcp_linsys_pcg(w, p, warm, iter, tol);
     free(warm);
-  } else solve_qcp_linsys(w, p);
+  } else solve_spe_linsys(w, p);
   for (long i = 0; i < mn; ++i) tem[i] = p[i] * w->rho_dr[i];
   const F bq = v_dot(w->r, mu, mn) - 2 * v_dot(w->r, tem, mn) - eta;
   if (w->hasQ) sp_accum_A(&w->Q, &p[m], Qp);
@@ -379,11 +541,11 @@ static void solve_barrier_subproblem(QW *w, const QCPCone *c) { /* abip.c:326-41
   if (c->z) { for (I i = 0; i < c->z; ++i) w->u[m + count + i] = 0; count += c->z; }
   if (c->l) { orthant_prox(&w->u[m + count], &tmp[m + count], lambda / w->rho_dr[m + count], c->l); count += c->l; }
 }
-static F inner_conv_check(QW *w) { /* qcp_config.c:518-557 */
+static F inner_conv_check(QW *w) { /* qcp_config.c:518-557, lasso_config.c:312-353 */
   const I m = w->m, n = w->n; const long mn = (long)m + n;
   F *Qu = (F *)malloc(sizeof(F) * (mn + 1)), *Mu = (F *)calloc(mn, sizeof(F));
-  sp_accum_A(&w->A, &w->u[m], Mu);
-  sp_accum_At(&w->A, w->u, &Mu[m]);
+  op_A(w, &w->u[m], Mu);
+  op_At(w, w->u, &Mu[m]);
   for (I j = 0; j < n; ++j) Mu[m + j] *= -1;
   if (w->hasQ) sp_accum_A(&w->Q, &w->u[m], &Mu[m]);
   memcpy(Qu, Mu, sizeof(F) * mn);
@@ -392,11 +554,52 @@ static F inner_conv_check(QW *w) { /* qcp_config.c:518-557 */
   Qu[mn] = -v_dot(w->u, Mu, mn) / w->u[mn] + v_dot(w->u, w->b, m) - v_dot(&w->u[m], w->c, n);
   F num = 0;
   for (long i = 0; i <= mn; ++i) { F t = Qu[i] - w->v_origin[i]; num += t * t; }
-  const F err = sqrt(num) / (1 + v_nrm2(Qu, mn + 1) + v_nrm2(w->v_origin, mn + 1));
+  /* qcp_config.c:549-551 normalises by |Qu|, lasso_config.c:343-345 by |u| */
+  const F err = sqrt(num) / (1 + v_nrm2(w->kind == 0 ? w->u : Qu, mn + 1) + v_nrm2(w->v_origin, mn + 1));
   free(Qu); free(Mu);
   return err;
 }
+static void calc_lasso_residuals(QW *w, QR *r, I ipm_iter, I admm_iter) { /* lasso_config.c:358-503 */
+  OrcLasso *s = w->ls; const I p = w->m, q = w->n, m = s->dm, n = s->dn;
+  r->tau = w->u[p + q];
+  const F tau = r->tau;
+  F *x = (F *)malloc(sizeof(F) * m), *bp = (F *)malloc(sizeof(F) * n), *bm = (F *)malloc(sizeof(F) * n), *z = (F *)malloc(sizeof(F) * m);
+  F *s1 = (F *)malloc(sizeof(F) * n), *s2 = (F *)malloc(sizeof(F) * n), *pr = (F *)malloc(sizeof(F) * m), *dr1 = (F *)malloc(sizeof(F) * n), *dr2 = (F *)malloc(sizeof(F) * n);
+  for (I i = 0; i < m; ++i) x[i] = w->u[m + 3 + i] * (sqrt(s->sc_cone2) / (tau * s->sc_b));
+  for (I j = 0; j < n; ++j) { bp[j] = w->u[2 * m + 3 + j] * (s->E[j] / (tau * s->sc_b)); bm[j] = w->u[2 * m + 3 + n + j] * (s->E[j] / (tau * s->sc_b)); }
+  for (I i = 0; i < m; ++i) z[i] = w->u[1 + i] * (s->D[i] / (tau * s->sc_c));
+  for (I j = 0; j < n; ++j) { s1[j] = w->v[2 * m + 3 + j] / (s->E[j] * tau * s->sc_c); s2[j] = w->v[2 * m + n + 3 + j] / (s->E[j] * tau * s->sc_c); }
+  memcpy(pr, x, sizeof(F) * m);
+  sp_accum_A(s->X0, bp, pr);
+  for (I i = 0; i < m; ++i) pr[i] *= -1;
+  sp_accum_A(s->X0, bm, pr);
+  for (I i = 0; i < m; ++i) pr[i] = -pr[i] - s->y0[i];
+  const F this_pr = v_nrm2(pr, m) / MAXF(v_nrm2(s->y0, m), 1);
+  memcpy(dr1, s1, sizeof(F) * n);
+  sp_accum_At(s->X0, z, dr1);
+  for (I j = 0; j < n; ++j) dr1[j] -= s->lambda;
+  for (I j = 0; j < n; ++j) dr2[j] = -s2[j];
+  sp_accum_At(s->X0, z, dr2);
+  for (I j = 0; j < n; ++j) dr2[j] = -dr2[j] - s->lambda;
+  const F this_dr = sqrt(v_nrm2sq(dr1, n) + v_nrm2sq(dr2, n)) / (sqrt((F)(2 * n)) * s->lambda);
+  F sp = 0, sm = 0;
+  for (I j = 0; j < n; ++j) { sp += s->lambda * bp[j]; sm += s->lambda * bm[j]; }
+  const F P = 0.5 * v_dot(x, x, m) + sp + sm, zz = v_dot(z, z, m), yz = v_dot(s->y0, z, m);
+  const F this_gap = ABSF(P + 0.5 * zz - yz) / (1 + ABSF(P));
+  r->last_ipm_iter = ipm_iter; r->last_admm_iter = admm_iter;
+  r->dobj = -0.5 * zz + yz; r->pobj = P;
+  r->res_dif = MAXF(MAXF(ABSF(this_pr - r->res_pri), ABSF(this_dr - r->res_dual)), ABSF(this_gap - r->rel_gap));
+  r->res_pri = this_pr; r->res_dual = this_dr; r->rel_gap = this_gap;
+  r->error_ratio = MAXF(r->res_pri / w->stgs->eps_p, MAXF(r->res_dual / w->stgs->eps_d, r->rel_gap / w->stgs->eps_g));
+  const F ctu = v_dot(w->c, &w->u[p], q), btu = v_dot(w->b, w->u, p);
+  if (ctu < 0) { F *Ax = (F *)calloc(p, sizeof(F)); lasso_A_times(w, &w->u[p], Ax); r->res_unbdd = v_nrm2(Ax, p) / (-ctu); free(Ax); }
+  else r->res_unbdd = INFINITY;
+  if (btu > 0) { F *t = (F *)calloc(q, sizeof(F)); lasso_AT_times(w, w->u, t); for (I j = 0; j < q; ++j) t[j] += w->v_origin[p + j]; r->res_infeas = v_nrm2(t, q) / btu; free(t); }
+  else r->res_infeas = INFINITY;
+  free(x); free(bp); free(bm); free(z); free(s1); free(s2); free(pr); free(dr1); free(dr2);
+}
 static void calc_residuals(QW *w, QR *r, I ipm_iter, I admm_iter) { /* qcp_config.c:562-691 */
+  if (w->kind == 0) { calc_lasso_residuals(w, r, ipm_iter, admm_iter); return; }
   const I n = w->n, m = w->m;
   if (admm_iter && r->last_admm_iter == admm_iter) return;
   r->last_ipm_iter = ipm_iter; r->last_admm_iter = admm_iter;
@@ -499,7 +702,13 @@ static void get_solution(QW *w, QCPSolution *sol, QCPInfo *info, const QR *r, I 
     for (I i = 0; i < m; ++i) sol->y[i] = NAN;
     strcpy(info->status, "Unbounded"); info->status_val = ST_UNBOUNDED;
   }
-  if (w->stgs->normalize) { /* un_scaling_qcp_sol, qcp_config.c:496-513 */
+  if (w->stgs->normalize && w->kind == 0) { /* un_scaling_lasso_sol, lasso_config.c:296-311: beta = E o (beta+ - beta-) / sc_b replaces x (y and s are dropped) */
+    const OrcLasso *ls = w->ls;
+    F *beta = (F *)malloc(sizeof(F) * ls->dn);
+    for (I j = 0; j < ls->dn; ++j) beta[j] = (sol->x[ls->dm + 2 + j] + (-1) * sol->x[ls->dm + ls->dn + 2 + j]) * ls->E[j] * (1 / ls->sc_b);
+    memcpy(sol->x, beta, sizeof(F) * ls->dn);
+    free(beta);
+  } else if (w->stgs->normalize) { /* un_scaling_qcp_sol, qcp_config.c:496-513 */
     for (I j = 0; j < n; ++j) sol->x[j] /= (w->E[j] * w->sc_b);
     for (I i = 0; i < m; ++i) sol->y[i] /= (w->D[i] * w->sc_c);
     for (I j = 0; j < n; ++j) sol->s[j] *= w->E[j] / (w->sc_c * w->stgs->scale);
@@ -532,14 +741,18 @@ void orc_qcp_set_trace(I T, F *buf) { g_trace = buf; g_trace_T = T; g_trace_n = 
 I orc_qcp_trace_count(void) { return g_trace_n; }
 
 qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) { /* abip(), abip.c:1335-1371 */
-  if (!d || !sol || !info || !K || !d->A || !d->b || !d->c || (d->stgs->linsys_solver != 1 && d->stgs->linsys_solver != 3) || d->stgs->prob_type != 2) {
+  const int lasso = d && d->stgs && d->stgs->prob_type == 0; /* abip.c:1341-1348: 0 LASSO, 1 SVM, 2 QCP, 3 SVMQP */
+  if (!d || !sol || !info || !K || !d->A || !d->b || (!lasso && !d->c) || (d->stgs->linsys_solver != 1 && d->stgs->linsys_solver != 3) ||
+      (d->stgs->prob_type != 2 && !lasso) || (lasso && (d->stgs->linsys_solver != 1 || !(d->lambda > 0)))) {
     if (info) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); }
     return ST_FAILED;
   }
   const double t_init = now_ms();
   QW W; memset(&W, 0, sizeof(W)); QW *w = &W;
-  const I m = d->m, n = d->n; const long l = (long)m + n + 1;
-  w->m = m; w->n = n; w->stgs = d->stgs; w->hasQ = d->Q != 0;
+  w->kind = 2; w->stgs = d->stgs;
+  if (lasso) init_lasso(w, d); else { w->m = d->m; w->n = d->n; }
+  const I m = w->m, n = w->n; const long l = (long)m + n + 1;
+  w->hasQ = !lasso && d->Q != 0;
   { /* validate, abip.c:779-832 + cones.c:37-81 */
     long dims = K->l + K->z + K->f;
     for (I i = 0; K->q && i < K->qsize; ++i) dims += K->q[i];
@@ -550,19 +763,20 @@ qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone
       info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED;
     }
   }
-  w->sparsity = ((d->A->p[n] / (m * n)) < 0.05); /* integer division, qcp_config.c:22 */
+  if (!lasso) w->sparsity = ((d->A->p[n] / (m * n)) < 0.05); /* integer division, qcp_config.c:22 */
   w->rho_dr = (F *)malloc(sizeof(F) * l);
   for (long i = 0; i < l; ++i) w->rho_dr[i] = i < m ? d->stgs->rho_y : (i < m + n ? d->stgs->rho_x : d->stgs->rho_tau);
-  copy_mat(&w->A, d->A); if (w->hasQ) copy_mat(&w->Q, d->Q);
+  if (!lasso) copy_mat(&w->A, d->A);
+  if (w->hasQ) copy_mat(&w->Q, d->Q);
   w->b = (F *)malloc(sizeof(F) * m); w->c = (F *)malloc(sizeof(F) * n); w->D = (F *)malloc(sizeof(F) * m); w->E = (F *)malloc(sizeof(F) * n);
   w->mu = 1.0; w->beta = 1.0;
   w->u = (F *)calloc(l, sizeof(F)); w->v = (F *)calloc(l, sizeof(F)); w->v_origin = (F *)calloc(l, sizeof(F)); w->u_t = (F *)calloc(l, sizeof(F));
   w->rel_ut = (F *)calloc(l, sizeof(F)); w->r = (F *)calloc(l, sizeof(F));
-  w->nm_inf_b = v_nrminf(d->b, m); w->nm_inf_c = v_nrminf(d->c, n);
-  scaling_qcp_data(w, d, K);
+  if (lasso) scaling_lasso_data(w); /* (nm_inf_b / nm_inf_c, abip.c:875-876, are not used by the LASSO residuals) */
+  else { w->nm_inf_b = v_nrminf(d->b, m); w->nm_inf_c = v_nrminf(d->c, n); scaling_qcp_data(w, d, K); }
   w->last_Ax_b_norm = INFINITY; w->last_Qx_norm = INFINITY;
   if (d->stgs->linsys_solver == 3) { if (init_qcp_pcg(w) < 0) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED; } if (getenv("ORC_QCP_PCG_CHECK")) init_kkt(w); }
-  else if (init_kkt(w) < 0) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED; }
+  else if ((lasso ? init_lasso_linsys(w) : init_kkt(w)) < 0) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED; }
   info->setup_time = now_ms() - t_init;
   const double t0 = now_ms();
   QR R; memset(&R, 0, sizeof(R)); QR *r = &R;
@@ -582,7 +796,7 @@ qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone
     for (I i = 0; i < m; ++i) w->r[i] = -w->b[i];
     memcpy(&w->r[m], w->c, sizeof(F) * n);
     if (d->stgs->linsys_solver == 3) solve_qcp_linsys_pcg(w, w->r, 0, -1, 1e-12); /* abip.c:899 */
-    else solve_qcp_linsys(w, w->r);
+    else solve_spe_linsys(w, w->r);
     F acc = 0; for (long i = 0; i < (long)m + n; ++i) acc += (w->r[i] * w->rho_dr[i]) * w->r[i];
     w->a = w->rho_dr[m + n] + acc;
   }
@@ -616,6 +830,7 @@ qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone
 done:
   info->avg_linsys_time = 0; info->avg_cg_iters = w->cg_solves ? (F)w->tot_cg / (F)w->cg_solves : 0;
   free(w->Mpre); free(w->Hinv);
+  free_lasso(w);
   free(w->rho_dr); free(w->A.x); free(w->A.i); free(w->A.p);
   if (w->hasQ) { free(w->Q.x); free(w->Q.i); free(w->Q.p); }
   free(w->b); free(w->c); free(w->D); free(w->E); free(w->u); free(w->v); free(w->v_origin); free(w->u_t); free(w->rel_ut); free(w->r);

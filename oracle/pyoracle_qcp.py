@@ -121,6 +121,23 @@ def solve(A, b, c, K, Q=None, trace: int = 0, **settings):
     return P.x.copy(), P.y.copy(), P.s.copy(), P.info_dict(), tr
 
 
+def solve_lasso(X, y, lam: float, **settings):
+    """min 1/2 |X beta - y|^2 + lam |beta|_1 through the LASSO reformulation (prob_type 0, lasso_config.c); returns (beta, info).
+    The caller hands over what abip_ml_mex.c:117-160,322-331 does: X, y, lambda, the cone {rq: [m + 2], l: 2 n}, no c."""
+    L = lib()
+    X = sp.csc_matrix(X)
+    m, n = X.shape
+    P = Problem(X, y, np.zeros(n), {"rq": [m + 2], "l": 2 * n}, set_defaults=L.orc_qcp_set_default_settings, verbose=0, **settings)
+    P.stgs.prob_type = 0
+    P.data.lambda_ = float(lam)
+    P.data.c = None
+    q, p_ = 2 + 2 * n + m, m + 1
+    P.x = np.full(q, np.nan); P.y = np.full(p_, np.nan); P.s = np.full(q, np.nan)
+    P.sol = QCPSolution(P.x.ctypes.data_as(PF), P.y.ctypes.data_as(PF), P.s.ctypes.data_as(PF))
+    L.orc_qcp_solve(C.byref(P.data), C.byref(P.sol), C.byref(P.info), C.byref(P.cone))
+    return P.x[:n].copy(), P.info_dict()
+
+
 def cone_prox(kind: int, tmp, lam: float, x_prev=None):
     """Barrier prox of one cone (cones.c:130-288): kind 0 SOC, 1 rotated SOC, 2 orthant."""
     L = lib()
