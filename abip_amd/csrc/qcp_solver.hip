@@ -48,8 +48,12 @@ struct LassoForm {
   DBuf<double> Dd, Ed, yd;
 };
 
+// The SVM reformulations (svm_qp_config.c; svm_config.c): data dimensions and what the un-scaling needs
+struct SvmForm { int dm = 0, dn = 0; double lambda = 0; };
+
 struct QWk {
-  int kind = 2; // enum problem_type as abip() maps settings.prob_type (abip.c:1341-1348): 0 LASSO, 2 generic QCP
+  SvmForm sv;
+  int kind = 2; // enum problem_type as abip() maps settings.prob_type (abip.c:1341-1348): 0 LASSO, 2 generic QCP, 3 SVM as a QP
   LassoForm ls;
   double kkt_rho_x = 1; // the rho_x the KKT system is assembled with (the LASSO solve hard-codes 1, lasso_config.c:652-708)
   int m = 0, n = 0, MP = 0, LV = 0, NB = 1;
@@ -123,10 +127,11 @@ void apply_pass(QWk *w, std::vector<double> &Dp, std::vector<double> &Ep) { // :
   for (int i = 0; i < n; ++i) w->E[i] *= Ep[i];
   for (int i = 0; i < m; ++i) w->D[i] *= Dp[i];
 }
-void scale_data(QWk *w, const QCPData *d, const QCPCone *k) {
+// the ruiz / origin / pc passes over (A, Q) of a view of w->m rows and w->n columns; D_hat and E_hat accumulate in w->D, w->E
+// (qcp_config.c:130-460; svm_qp_config.c:199-556 runs the same passes over its first dn + 1 columns)
+void scale_passes(QWk *w, const QCPCone *k) {
   const int m = w->m, n = w->n;
   HMat &A = w->A, &Q = w->Q;
-  w->b.assign(d->b, d->b + m); w->c.assign(d->c, d->c + n);
   w->D.assign(m, 1.0); w->E.assign(n, 1.0);
   std::vector<double> Ep(n), E1(n), E2(n), Dp(m);
   auto col_inf = [](const HMat &M, int j) { double mx = 0; for (int q = M.p[j]; q < M.p[j + 1]; ++q) { const double t = std::fabs(M.x[q]); if (t >= mx) mx = t; } return mx; };
@@ -162,6 +167,11 @@ void scale_data(QWk *w, const QCPData *d, const QCPCone *k) {
     for (int i = 0; i < m; ++i) Dp[i] = std::sqrt(Dp[i]);
     apply_pass(w, Dp, Ep);
   }
+}
+void scale_data(QWk *w, const QCPData *d, const QCPCone *k) {
+  const int m = w->m, n = w->n;
+  w->b.assign(d->b, d->b + m); w->c.assign(d->c, d->c + n);
+  scale_passes(w, k);
   double ss = 0;
   for (double t : w->c) ss += t * t;
   double sb = 0;
@@ -252,6 +262,47 @@ void build_lasso(QWk *w, const QCPData *d) {
       A.p[dm + 2 + sign * dn + j + 1] = (int)A.i.size();
     }
   w->D.assign(p, 1.0); w->E.assign(q, 1.0); w->sc_b = 1; w->sc_c = 1; // (neutral for the generic sums kq_resid still provides: certificates)
+}
+
+// ---- SVM-QP front end: init_svmqp + scaling_svmqp_data, svm_qp_config.c:8-124, 195-590 -------------------------------------
+// x = (w (dn), b, xi (dm), t (dm)); w, b free, xi, t >= 0;  min 1/2 |w|^2 + 1/(dm lambda) 1'xi  s.t.  diag(y) (X w + b) + xi - t = 1.
+// The reference keeps the data block B~ = D^-1 diag(y) [X, 1] E^-1 and applies the +-D^-1 identity columns on the fly (:129-147); here the
+// whole dm x q operator [B~, D^-1, -D^-1] is materialised and the generic conic path (kernels, KKT back-ends, residuals) runs on it.
+// The caller's X is left untouched (the reference folds the labels into it in place, :84-86).
+void build_svmqp(QWk *w, const QCPData *d, const QCPCone *k) {
+  SvmForm &V = w->sv;
+  const int dm = d->m, dn = d->n, q = 1 + dn + 2 * dm, n1 = dn + 1;
+  V.dm = dm; V.dn = dn; V.lambda = d->lambda;
+  const QCPMatrix *X = d->A;
+  const int xnnz = X->p[dn];
+  w->sparsity = (((double)xnnz / ((double)dm * (double)dn)) < 0.05); // :37
+  HMat &B = w->A, &Q = w->Q;
+  B.m = dm; B.n = n1; B.p.assign(X->p, X->p + dn + 1); B.p.push_back(xnnz + dm);
+  B.i.assign(X->i, X->i + xnnz); B.x.resize((size_t)xnnz + dm);
+  for (int t = 0; t < xnnz; ++t) B.x[t] = X->x[t] * d->b[X->i[t]];
+  for (int i = 0; i < dm; ++i) { B.i.push_back(i); B.x[xnnz + i] = d->b[i]; }
+  Q.m = q; Q.n = q; Q.p.assign(q + 1, dn); Q.i.resize(dn); Q.x.assign(dn, 1.0); // :19-35
+  for (int i = 0; i < dn; ++i) { Q.i[i] = i; Q.p[i] = i; }
+  w->b.assign(dm, 1.0); w->c.assign(q, 0.0);
+  for (int i = 0; i < dm; ++i) w->c[dn + 1 + i] = 1.0 / (dm * V.lambda);
+  w->nm_inf_b = vnrminf(w->b.data(), dm); w->nm_inf_c = vnrminf(w->c.data(), q); // abip.c:875-876
+  w->n = n1; scale_passes(w, k); w->n = q; // (the passes see the data block only)
+  w->E.resize(q, 1.0);                      // :107-110
+  double ss = 0, sb = 0;
+  for (double t : w->c) ss += t * t;
+  for (double t : w->b) sb += t * t;
+  double sc = std::sqrt(std::sqrt(ss + sb)); // :549-550
+  for (int i = 0; i < dm; ++i) w->b[i] /= w->D[i];
+  for (int j = 0; j < n1; ++j) w->c[j] /= w->E[j];
+  if (sc < kMinScale) sc = 1; else if (sc > kMaxScale) sc = kMaxScale;
+  w->sc_b = 1 / sc; w->sc_c = 1 / sc;
+  for (double &t : w->b) t *= w->sc_b * w->st->scale;
+  for (double &t : w->c) t *= w->sc_c * w->st->scale;
+  // [B~, D^-1, -D^-1]
+  B.n = q; B.p.resize(q + 1);
+  B.i.reserve(B.i.size() + 2 * (size_t)dm); B.x.reserve(B.x.size() + 2 * (size_t)dm);
+  for (int sign = 0; sign < 2; ++sign)
+    for (int i = 0; i < dm; ++i) { B.i.push_back(i); B.x.push_back((sign ? -1.0 : 1.0) * (1 / w->D[i])); B.p[n1 + sign * dm + i + 1] = (int)B.i.size(); }
 }
 
 void hcsr_from(const HMat &M, host::HostCsr &out, bool transpose_to_rows) {
@@ -470,7 +521,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   if (!d || !sol || !info || !K) return fail(info, "ABIP_NULL input");
   if (!d->stgs) return fail(info, "ABIP_NULL input");
   const int kind = d->stgs->prob_type; // abip.c:1341-1348: 0 LASSO, 1 SVM, 2 QCP, 3 SVMQP
-  if (kind != 2 && kind != 0) return fail(info, "served formulations: the generic QCP (prob_type 2) and LASSO (prob_type 0)");
+  if (kind != 2 && kind != 0 && kind != 3) return fail(info, "served formulations: the generic QCP (prob_type 2), LASSO (prob_type 0) and SVM as a QP (prob_type 3)");
   if (!d->A || !d->b || (kind == 2 && !d->c)) return fail(info, "the device path needs A, b and c");
   if (d->stgs->linsys_solver != 1 && d->stgs->linsys_solver != 3) return fail(info, "only linsys_solver = 1 (QDLDL-class direct) and 3 (PCG) are served");
   const QCPSettings *st = d->stgs;
@@ -481,7 +532,12 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     if (!st->normalize || !st->scale_E) return fail(info, "the LASSO formulation needs normalize = 1 and scale_E = 1");
     if ((long long)2 + 2LL * d->n + d->m > 2147483647LL) return fail(info, "problem too large for 32-bit indices");
   }
-  const int m = kind == 0 ? d->m + 1 : d->m, n = kind == 0 ? 2 + 2 * d->n + d->m : d->n;
+  if (kind == 3) { // SVM-QP: data = (X, labels y, lambda) as abip_ml_mex.c:117-160 hands them over
+    if (d->m <= 0 || d->n <= 0 || !(d->lambda > 0)) return fail(info, "SVM needs a non-empty X and lambda > 0");
+    if (!st->normalize) return fail(info, "the SVM formulation needs normalize = 1"); // (as for LASSO: scaled unconditionally, un-scaled only when set)
+    if ((long long)1 + d->n + 2LL * d->m > 2147483647LL) return fail(info, "problem too large for 32-bit indices");
+  }
+  const int m = kind == 0 ? d->m + 1 : d->m, n = kind == 0 ? 2 + 2 * d->n + d->m : (kind == 3 ? 1 + d->n + 2 * d->m : d->n);
   { // validate, abip.c:779-832 ; cones.c:37-81
     long dims = (long)K->l + K->z + K->f;
     for (int i = 0; K->q && i < K->qsize; ++i) dims += K->q[i];
@@ -497,9 +553,10 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) { printf("ERROR: no usable HIP device: libabip_hip has no CPU fallback\n"); return fail(info, "could not initialize work"); }
   const double t_init = now_ms();
   QWk W; QWk *w = &W;
-  w->kind = kind; w->m = m; w->n = n; w->st = st; w->hasQ = kind == 2 && d->Q != nullptr;
+  w->kind = kind; w->m = m; w->n = n; w->st = st; w->hasQ = kind == 3 || (kind == 2 && d->Q != nullptr);
   w->kkt_rho_x = kind == 0 ? 1.0 : st->rho_x;
   if (kind == 0) build_lasso(w, d);
+  else if (kind == 3) build_svmqp(w, d, K);
   else {
     // integer division, qcp_config.c:22 -- taken in 64 bits: the reference's 32-bit m * n overflows from m * n = 2^31 on (and divides by
     // zero at m = 32768, n = 131072); for every size the reference can run, the quotient below is the same number
@@ -681,52 +738,51 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     if (hipMemcpyAsync(hu2.data(), w->u.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
         hipMemcpyAsync(hv2.data(), w->v.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess)
       return -1;
-    std::vector<double> lx;
-    if (kind == 0) { // LASSO hands back beta only (un_scaling_lasso_sol, lasso_config.c:296-311): the conic (x, y, s) stay inside
-      const LassoForm &L = w->ls;
-      lx.resize(n);
-      for (int q = 0; q < n; ++q) lx[q] = hu2[w->MP + q];
-      const int sv = info->status_val;
-      double scx = 1.0;
-      if (sv == 0 || sv == 1 || sv == 2) { scx = safediv_pos(1.0, r.tau); if (sv == 0 || sv == 2) { strcpy(info->status, "Solved/Inaccurate"); info->status_val = 2; } else { strcpy(info->status, "Solved"); info->status_val = 1; } }
-      else if (sv == -2 || sv == -7) { scx = NAN; strcpy(info->status, "Infeasible"); info->status_val = -2; }
-      else { scx = -1 / (r.pobj * r.tau); strcpy(info->status, "Unbounded"); info->status_val = -1; }
-      if (!sol->x) sol->x = (qcp_float *)malloc(sizeof(qcp_float) * L.dn);
-      for (int jx = 0; jx < L.dn; ++jx) sol->x[jx] = (lx[L.dm + 2 + jx] * scx + (-1) * (lx[L.dm + L.dn + 2 + jx] * scx)) * L.E[jx] * (1 / L.sc_b);
-      info->ipm_iter = ipm_iter + 1; info->admm_iter = admm_iter;
-      info->res_infeas = r.res_infeas; info->res_unbdd = r.res_unbdd;
-      if (info->status_val == 1 || info->status_val == 2) { info->rel_gap = r.rel_gap; info->res_pri = r.res_pri; info->res_dual = r.res_dual; info->pobj = r.pobj; info->dobj = r.dobj; }
-      else if (info->status_val == -1) { info->rel_gap = info->res_pri = info->res_dual = NAN; info->pobj = info->dobj = -INFINITY; }
-      else { info->rel_gap = info->res_pri = info->res_dual = NAN; info->pobj = info->dobj = INFINITY; }
-      info->solve_time = now_ms() - t0;
-      return 0;
-    }
-    if (!sol->x) sol->x = (qcp_float *)malloc(sizeof(qcp_float) * n);
-    if (!sol->y) sol->y = (qcp_float *)malloc(sizeof(qcp_float) * m);
-    if (!sol->s) sol->s = (qcp_float *)malloc(sizeof(qcp_float) * n);
-    for (int q = 0; q < n; ++q) { sol->x[q] = hu2[w->MP + q]; sol->s[q] = hv2[w->MP + q]; }
-    for (int q = 0; q < m; ++q) sol->y[q] = hu2[q];
+    // the conic (x, y, s) of the formulation; what the caller receives depends on the formulation (below)
+    std::vector<double> X(n), Y(m), S(n);
+    for (int q = 0; q < n; ++q) { X[q] = hu2[w->MP + q]; S[q] = hv2[w->MP + q]; }
+    for (int q = 0; q < m; ++q) Y[q] = hu2[q];
     const int sv = info->status_val;
     if (sv == 0 || sv == 1 || sv == 2) {
       const double sc = safediv_pos(1.0, r.tau);
-      for (int q = 0; q < n; ++q) { sol->x[q] *= sc; sol->s[q] *= sc; }
-      for (int q = 0; q < m; ++q) sol->y[q] *= sc;
+      for (int q = 0; q < n; ++q) { X[q] *= sc; S[q] *= sc; }
+      for (int q = 0; q < m; ++q) Y[q] *= sc;
       if (sv == 0 || sv == 2) { strcpy(info->status, "Solved/Inaccurate"); info->status_val = 2; } else { strcpy(info->status, "Solved"); info->status_val = 1; }
     } else if (sv == -2 || sv == -7) {
       const double bty = r.dobj * r.tau;
-      for (int q = 0; q < m; ++q) sol->y[q] *= 1 / bty;
-      for (int q = 0; q < n; ++q) { sol->s[q] *= 1 / bty; sol->x[q] = NAN; }
+      for (int q = 0; q < m; ++q) Y[q] *= 1 / bty;
+      for (int q = 0; q < n; ++q) { S[q] *= 1 / bty; X[q] = NAN; }
       strcpy(info->status, "Infeasible"); info->status_val = -2;
     } else {
       const double ctx = r.pobj * r.tau;
-      for (int q = 0; q < n; ++q) { sol->x[q] *= -1 / ctx; sol->s[q] = NAN; }
-      for (int q = 0; q < m; ++q) sol->y[q] = NAN;
+      for (int q = 0; q < n; ++q) { X[q] *= -1 / ctx; S[q] = NAN; }
+      for (int q = 0; q < m; ++q) Y[q] = NAN;
       strcpy(info->status, "Unbounded"); info->status_val = -1;
     }
-    if (st->normalize) { // un_scaling_qcp_sol, qcp_config.c:496-513
-      for (int q = 0; q < n; ++q) sol->x[q] /= (w->E[q] * w->sc_b);
-      for (int q = 0; q < m; ++q) sol->y[q] /= (w->D[q] * w->sc_c);
-      for (int q = 0; q < n; ++q) sol->s[q] *= w->E[q] / (w->sc_c * st->scale);
+    if (kind == 0) { // un_scaling_lasso_sol, lasso_config.c:296-311: beta = E o (beta+ - beta-) / sc_b is all the caller gets (x: dn entries)
+      const LassoForm &L = w->ls;
+      if (!sol->x) sol->x = (qcp_float *)malloc(sizeof(qcp_float) * L.dn);
+      for (int jx = 0; jx < L.dn; ++jx) sol->x[jx] = (X[L.dm + 2 + jx] + (-1) * X[L.dm + L.dn + 2 + jx]) * L.E[jx] * (1 / L.sc_b);
+    } else if (kind == 3) { // un_scaling_svmqp_sol, svm_qp_config.c:595-619: x / (E sc_b), then x: w (dn), y: b (1), s: xi (dm)
+      const SvmForm &V = w->sv;
+      for (int q = 0; q < n; ++q) X[q] /= (w->E[q] * w->sc_b);
+      if (!sol->x) sol->x = (qcp_float *)malloc(sizeof(qcp_float) * V.dn);
+      if (!sol->y) sol->y = (qcp_float *)malloc(sizeof(qcp_float));
+      if (!sol->s) sol->s = (qcp_float *)malloc(sizeof(qcp_float) * V.dm);
+      for (int q = 0; q < V.dn; ++q) sol->x[q] = X[q];
+      sol->y[0] = X[V.dn];
+      for (int q = 0; q < V.dm; ++q) sol->s[q] = X[V.dn + 1 + q];
+    } else {
+      if (st->normalize) { // un_scaling_qcp_sol, qcp_config.c:496-513
+        for (int q = 0; q < n; ++q) X[q] /= (w->E[q] * w->sc_b);
+        for (int q = 0; q < m; ++q) Y[q] /= (w->D[q] * w->sc_c);
+        for (int q = 0; q < n; ++q) S[q] *= w->E[q] / (w->sc_c * st->scale);
+      }
+      if (!sol->x) sol->x = (qcp_float *)malloc(sizeof(qcp_float) * n);
+      if (!sol->y) sol->y = (qcp_float *)malloc(sizeof(qcp_float) * m);
+      if (!sol->s) sol->s = (qcp_float *)malloc(sizeof(qcp_float) * n);
+      for (int q = 0; q < n; ++q) { sol->x[q] = X[q]; sol->s[q] = S[q]; }
+      for (int q = 0; q < m; ++q) sol->y[q] = Y[q];
     }
     info->ipm_iter = ipm_iter + 1; info->admm_iter = admm_iter;
     info->res_infeas = r.res_infeas; info->res_unbdd = r.res_unbdd;

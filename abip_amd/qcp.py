@@ -119,7 +119,8 @@ def abip_qcp(data, cones, settings: dict):
 def abip_ml(data, settings: dict):
     """[sol, info] = abip_ml(data, settings)   (src/abip-qcp/mex/abip_ml_mex.c:90-449): the machine-learning front end.
     data: X (sparse), y (dense), lambda; settings.prob_type is mandatory (:266-276).  Served: prob_type 0 (LASSO,
-    min 1/2 |X beta - y|^2 + lambda |beta|_1; sol = {x: beta}).  The gateway builds the cone itself (:315-331)."""
+    min 1/2 |X beta - y|^2 + lambda |beta|_1; sol = {x: beta}) and prob_type 3 (soft-margin SVM as a QP,
+    min 1/2 |w|^2 + 1/(m lambda) sum xi; labels in y).  The gateway builds the cone itself (:315-342)."""
     L = _bind()
     X, y, lam = _get(data, "X"), _get(data, "y"), _get(data, "lambda")
     if X is None:
@@ -137,8 +138,8 @@ def abip_ml(data, settings: dict):
     prob_type = int(settings["prob_type"])
     if prob_type not in (0, 1, 3):
         raise ValueError("Invalid problem type")
-    if prob_type != 0:
-        raise NotImplementedError("This type of machine learning problem is not supported yet")  # SVM (1), SVM-QP (3): not built
+    if prob_type == 1:
+        raise NotImplementedError("This type of machine learning problem is not supported yet")  # SVM as an SOCP (svm_config.c): not built
     (keep, Xm) = _csc(X)
     m, n = Xm.m, Xm.n
     y = np.array(y, dtype=np.float64, copy=True).ravel()
@@ -151,17 +152,26 @@ def abip_ml(data, settings: dict):
     for k, v in settings.items():
         if k != "eps" and hasattr(stgs, k):
             setattr(stgs, k, int(v) if isinstance(getattr(stgs, k), int) else float(v))
-    rq = np.array([2 + m], dtype=np.int32)      # :328-331
-    K = QCPCone(None, 0, rq.ctypes.data_as(PI), 1, 0, 0, 2 * n)
-    beta = np.full(n, np.nan)
-    sol = QCPSolution(beta.ctypes.data_as(PF), None, None)
+    stgs.prob_type = prob_type
+    rq = np.array([2 + m], dtype=np.int32)
+    beta = np.full(n, np.nan); b0 = np.full(1, np.nan); xi = np.full(m, np.nan)
+    if prob_type == 0:                          # :328-331
+        K = QCPCone(None, 0, rq.ctypes.data_as(PI), 1, 0, 0, 2 * n)
+        sol = QCPSolution(beta.ctypes.data_as(PF), None, None)
+    else:                                       # SVM-QP, :338-342
+        K = QCPCone(None, 0, None, 0, n + 1, 0, 2 * m)
+        sol = QCPSolution(beta.ctypes.data_as(PF), b0.ctypes.data_as(PF), xi.ctypes.data_as(PF))
     info = QCPInfo()
     L.abip_qcp(C.byref(d), C.byref(sol), C.byref(info), C.byref(K))
     out = dict(ipm_iter=info.ipm_iter, admm_iter=info.admm_iter, status=info.status.decode(), pobj=info.pobj, dobj=info.dobj,
                res_pri=info.res_pri, res_dual=info.res_dual, gap=info.rel_gap, status_val=info.status_val,
                setup_time=info.setup_time / 1e3, solve_time=info.solve_time / 1e3, runtime=(info.setup_time + info.solve_time) / 1e3,
                lin_sys_time_per_iter=info.avg_linsys_time / 1e3, avg_cg_iters=info.avg_cg_iters)
-    return dict(x=beta), out
+    if prob_type == 0:
+        return dict(x=beta), out
+    # (the gateway's own output switch tests prob_type against 2 and 4, abip_ml_mex.c:362, so Matlab receives {x: w} for SVM too;
+    #  the C entry point hands back all three, un_scaling_svmqp_sol svm_qp_config.c:595-619)
+    return dict(x=beta, w=beta, b=float(b0[0]), xi=xi), out
 
 
 def cone_prox(kind: int, tmp, lam: float, x_prev=None):

@@ -66,10 +66,10 @@ static void sp_accum_At(const QCPMatrix *A, const F *x, F *y) { /* y += A' x, li
 }
 
 /* ---- work ---------------------------------------------------------------------------------------------- */
-struct OrcLasso;
+struct OrcLasso; struct OrcSvmqp;
 typedef struct {
-  int kind;               /* 2: generic QCP (qcp_config.c); 0: the LASSO reformulation (lasso_config.c) */
-  struct OrcLasso *ls;
+  int kind;               /* enum problem_type as abip() maps prob_type (abip.c:1341-1348): 0 LASSO (lasso_config.c), 2 generic QCP (qcp_config.c), 3 SVM-QP (svm_qp_config.c) */
+  struct OrcLasso *ls; struct OrcSvmqp *sq;
   I m, n;
   const QCPSettings *stgs;
   QCPMatrix A, Q; int hasQ;
@@ -119,10 +119,11 @@ static void apply_pass(QW *w, F *D, F *E, F min_row, F max_row, F min_col, F max
   for (I i = 0; i < m; ++i) w->D[i] *= D[i];
 }
 
-static void scaling_qcp_data(QW *w, const QCPData *d, const QCPCone *k) { /* qcp_config.c:91-491 */
+/* the ruiz / origin / pc passes over (A, Q) of a view with w->m rows and w->n columns; D_hat, E_hat accumulate in w->D, w->E
+ * (qcp_config.c:130-460; svm_qp_config.c:199-556 runs the same passes over its first n + 1 columns) */
+static void scaling_passes(QW *w, const QCPCone *k) {
   const I m = w->m, n = w->n; QCPMatrix *A = &w->A, *Q = &w->Q;
   const F min_row = MIN_SCALE * sqrt((F)n), max_row = MAX_SCALE * sqrt((F)n), min_col = MIN_SCALE * sqrt((F)m), max_col = MAX_SCALE * sqrt((F)m);
-  memcpy(w->b, d->b, sizeof(F) * m); memcpy(w->c, d->c, sizeof(F) * n);
   for (I i = 0; i < n; ++i) w->E[i] = 1;
   for (I i = 0; i < m; ++i) w->D[i] = 1;
   F *E = (F *)calloc(n, sizeof(F)), *E1 = (F *)calloc(n, sizeof(F)), *E2 = (F *)calloc(n, sizeof(F)), *D = (F *)calloc(m, sizeof(F));
@@ -158,6 +159,12 @@ static void scaling_qcp_data(QW *w, const QCPData *d, const QCPCone *k) { /* qcp
     for (I i = 0; i < m; ++i) D[i] = sqrt(pow(D[i], 1.0));
     apply_pass(w, D, E, min_row, max_row, min_col, max_col);
   }
+  free(E); free(E1); free(E2); free(D);
+}
+static void scaling_qcp_data(QW *w, const QCPData *d, const QCPCone *k) { /* qcp_config.c:91-491 */
+  const I m = w->m, n = w->n;
+  memcpy(w->b, d->b, sizeof(F) * m); memcpy(w->c, d->c, sizeof(F) * n);
+  scaling_passes(w, k);
   F sc = sqrt(sqrt(v_nrm2sq(w->c, n) + v_nrm2sq(w->b, m))); /* :462-463 (before the division by D_hat / E_hat) */
   for (I i = 0; i < m; ++i) w->b[i] /= w->D[i];
   for (I i = 0; i < n; ++i) w->c[i] /= w->E[i];
@@ -165,7 +172,6 @@ static void scaling_qcp_data(QW *w, const QCPData *d, const QCPCone *k) { /* qcp
   w->sc_b = 1 / sc; w->sc_c = 1 / sc;
   for (I i = 0; i < m; ++i) w->b[i] *= w->sc_b * w->stgs->scale;
   for (I i = 0; i < n; ++i) w->c[i] *= w->sc_c * w->stgs->scale;
-  free(E); free(E1); free(E2); free(D);
 }
 
 /* K = [[-rho_y I, -A], [., Q_upper + rho_x I]] upper triangle (qcp_config.c:699-748), factorised with orc_ldl.h */
@@ -419,10 +425,114 @@ static void free_lasso(QW *w) {
   w->ls = 0;
 }
 
+/* ==== SVM as a QP, svm_qp_config.c ==========================================================================================
+ * data: X (dm x dn), labels y (+-1), lambda.  QP over x = (w (dn), b, xi (dm), t (dm)), w and b free, xi, t >= 0 (init_svmqp, :8-124):
+ *   min 1/2 |w|^2 + 1/(dm lambda) 1'xi   s.t.  diag(y) (X w + b) + xi - t = 1.
+ * w->A holds the scaled data block B~ = D^-1 diag(y) [X, 1] E^-1 (dm x (dn + 1)); the +-identity columns are applied on the fly (:129-147).
+ * Scaling (:195-590) = the generic passes over the first dn + 1 columns only; residuals and inner test = the generic ones (:150-193, 622-738). */
+typedef struct OrcSvmqp {
+  I dm, dn; F lambda;
+  F *Fd, *H;
+  I cn; F *chol;
+} OrcSvmqp;
+static void svmqp_A_times(QW *w, const F *x, F *y) { /* :129-136 */
+  const OrcSvmqp *s = w->sq; const I m = s->dm, n = s->dn;
+  sp_accum_A(&w->A, x, y);
+  for (I i = 0; i < m; ++i) y[i] += 1 / w->D[i] * (x[n + 1 + i] - x[n + 1 + m + i]);
+}
+static void svmqp_AT_times(QW *w, const F *x, F *y) { /* :141-147 */
+  const OrcSvmqp *s = w->sq; const I m = s->dm, n = s->dn;
+  sp_accum_At(&w->A, x, y);
+  for (I i = 0; i < m; ++i) { y[n + 1 + i] += 1 / w->D[i] * x[i]; y[n + 1 + m + i] -= 1 / w->D[i] * x[i]; }
+}
+static void init_svmqp(QW *w, const QCPData *d, F *data_b, F *data_c) { /* :8-124 (the caller's X is not modified here; the reference folds the labels into it in place, :84-86) */
+  OrcSvmqp *s = (OrcSvmqp *)calloc(1, sizeof(OrcSvmqp));
+  const I m = d->m, n = d->n, q = 1 + n + 2 * m, nnz = d->A->p[n];
+  w->sq = s; w->kind = 3; s->dm = m; s->dn = n; s->lambda = d->lambda;
+  w->m = m; w->n = q;
+  w->sparsity = (((F)nnz / ((F)m * n)) < 0.05);
+  w->hasQ = 1;
+  w->Q.m = q; w->Q.n = q; w->Q.i = (I *)malloc(sizeof(I) * n); w->Q.x = (F *)malloc(sizeof(F) * n); w->Q.p = (I *)malloc(sizeof(I) * (q + 1));
+  for (I i = 0; i < n; ++i) { w->Q.i[i] = i; w->Q.p[i] = i; w->Q.x[i] = 1; }
+  for (I i = n; i <= q; ++i) w->Q.p[i] = n;
+  for (I i = 0; i < m; ++i) data_b[i] = 1;
+  memset(data_c, 0, sizeof(F) * q);
+  for (I i = 0; i < m; ++i) data_c[i + n + 1] = 1.0 / (m * s->lambda);
+  QCPMatrix *B = &w->A;
+  B->m = m; B->n = n + 1; B->p = (I *)malloc(sizeof(I) * (n + 2)); B->i = (I *)malloc(sizeof(I) * (nnz + m)); B->x = (F *)malloc(sizeof(F) * (nnz + m));
+  memcpy(B->p, d->A->p, sizeof(I) * (n + 1)); B->p[n + 1] = nnz + m;
+  memcpy(B->i, d->A->i, sizeof(I) * nnz);
+  for (I k = 0; k < nnz; ++k) B->x[k] = d->A->x[k] * d->b[d->A->i[k]];
+  for (I i = 0; i < m; ++i) { B->i[nnz + i] = i; B->x[nnz + i] = d->b[i]; }
+  s->Fd = (F *)malloc(sizeof(F) * m); s->H = (F *)malloc(sizeof(F) * q);
+}
+static void scaling_svmqp_data(QW *w, const F *data_b, const F *data_c, const QCPCone *k) { /* :195-590 */
+  OrcSvmqp *s = w->sq; const I m = s->dm, n1 = s->dn + 1, q = w->n;
+  memcpy(w->b, data_b, sizeof(F) * m); memcpy(w->c, data_c, sizeof(F) * q);
+  for (I i = 0; i < q; ++i) w->E[i] = 1.0; /* :107-110 */
+  w->n = n1; scaling_passes(w, k); w->n = q;
+  F sc = sqrt(sqrt(v_nrm2sq(w->c, q) + v_nrm2sq(w->b, m)));
+  for (I i = 0; i < m; ++i) w->b[i] /= w->D[i];
+  for (I i = 0; i < n1; ++i) w->c[i] /= w->E[i];
+  if (sc < MIN_SCALE) sc = 1; else if (sc > MAX_SCALE) sc = MAX_SCALE;
+  w->sc_b = 1 / sc; w->sc_c = 1 / sc;
+  for (I i = 0; i < m; ++i) w->b[i] *= w->sc_b * w->stgs->scale;
+  for (I i = 0; i < q; ++i) w->c[i] *= w->sc_c * w->stgs->scale;
+  for (I i = 0; i < m; ++i) s->Fd[i] = w->stgs->rho_y + 2 / w->stgs->rho_x / pow(w->D[i], 2);
+  for (I i = 0; i < q; ++i) s->H[i] = i < s->dn ? w->stgs->rho_x + w->Q.x[i] : w->stgs->rho_x;
+}
+/* form_svmqp_kkt (:743-806) dense: dm > dn + 1: diag(H[0:dn+1]) + B~' F^-1 B~, else F + B~ H^-1 B~' */
+static int init_svmqp_linsys(QW *w) {
+  OrcSvmqp *s = w->sq; const I m = s->dm, n1 = s->dn + 1; const QCPMatrix *B = &w->A;
+  const I cn = m > n1 ? n1 : m; s->cn = cn;
+  F *Bd = (F *)calloc((size_t)m * n1, sizeof(F)), *G = (F *)calloc((size_t)cn * cn, sizeof(F));
+  for (I j = 0; j < n1; ++j) for (I t = B->p[j]; t < B->p[j + 1]; ++t) Bd[(size_t)B->i[t] * n1 + j] = B->x[t];
+  if (m > n1) {
+    for (I i = 0; i < m; ++i) { const F *row = &Bd[(size_t)i * n1]; const F fi = 1 / s->Fd[i];
+      for (I a = 0; a < n1; ++a) { if (row[a] == 0) continue; const F t = row[a] * fi; for (I c2 = 0; c2 <= a; ++c2) G[(size_t)a * cn + c2] += t * row[c2]; } }
+    for (I a = 0; a < n1; ++a) G[(size_t)a * cn + a] += s->H[a];
+  } else {
+    for (I a = 0; a < m; ++a) for (I c2 = 0; c2 <= a; ++c2) { F t = 0; const F *ra = &Bd[(size_t)a * n1], *rb = &Bd[(size_t)c2 * n1]; for (I j = 0; j < n1; ++j) t += ra[j] * rb[j] / s->H[j]; G[(size_t)a * cn + c2] = t; }
+    for (I a = 0; a < m; ++a) G[(size_t)a * cn + a] += s->Fd[a];
+  }
+  for (I a = 0; a < cn; ++a) for (I c2 = 0; c2 <= a; ++c2) {
+    F t = G[(size_t)a * cn + c2];
+    for (I kk = 0; kk < c2; ++kk) t -= G[(size_t)a * cn + kk] * G[(size_t)c2 * cn + kk];
+    if (a == c2) { if (t <= 0) { free(Bd); free(G); return -1; } G[(size_t)a * cn + a] = sqrt(t); } else G[(size_t)a * cn + c2] = t / G[(size_t)c2 * cn + c2];
+  }
+  s->chol = G; free(Bd);
+  return 0;
+}
+static void dense_chol_solve(I cn, const F *G, F *b) {
+  for (I a = 0; a < cn; ++a) { F t = b[a]; for (I k = 0; k < a; ++k) t -= G[(size_t)a * cn + k] * b[k]; b[a] = t / G[(size_t)a * cn + a]; }
+  for (I a = cn - 1; a >= 0; --a) { F t = b[a]; for (I k = a + 1; k < cn; ++k) t -= G[(size_t)k * cn + a] * b[k]; b[a] = t / G[(size_t)a * cn + a]; }
+}
+static void solve_svmqp_linsys(QW *w, F *b) { /* :878-973, the direct branch */
+  OrcSvmqp *s = w->sq; const I m = s->dm, n1 = s->dn + 1, p = w->m, q = w->n;
+  F *b2 = (F *)malloc(sizeof(F) * p), *tmp = (F *)malloc(sizeof(F) * q);
+  memcpy(b2, b, sizeof(F) * p);
+  for (I i = 0; i < q; ++i) tmp[i] = b[p + i] / -s->H[i];
+  svmqp_A_times(w, tmp, b2);
+  if (m > n1) {
+    for (I i = 0; i < p; ++i) b2[i] /= s->Fd[i];
+    F *t1 = (F *)calloc(n1, sizeof(F)), *t2 = (F *)calloc(m, sizeof(F));
+    sp_accum_At(&w->A, b2, t1);
+    dense_chol_solve(s->cn, s->chol, t1);
+    sp_accum_A(&w->A, t1, t2);
+    for (I i = 0; i < m; ++i) { t2[i] /= s->Fd[i]; b2[i] += -t2[i]; }
+    free(t1); free(t2);
+  } else dense_chol_solve(s->cn, s->chol, b2);
+  memcpy(b, b2, sizeof(F) * m);
+  free(b2); free(tmp);
+  svmqp_AT_times(w, b, &b[p]);
+  for (I i = 0; i < q; ++i) b[p + i] /= s->H[i];
+}
+static void free_svmqp(QW *w) { OrcSvmqp *s = w->sq; if (!s) return; free(s->Fd); free(s->H); free(s->chol); free(s); w->sq = 0; }
+
 /* operator and KKT solve of the formulation in use */
-static void op_A(QW *w, const F *x, F *y) { if (w->kind == 0) lasso_A_times(w, x, y); else sp_accum_A(&w->A, x, y); }
-static void op_At(QW *w, const F *x, F *y) { if (w->kind == 0) lasso_AT_times(w, x, y); else sp_accum_At(&w->A, x, y); }
-static void solve_spe_linsys(QW *w, F *b) { if (w->kind == 0) solve_lasso_linsys(w, b); else solve_qcp_linsys(w, b); }
+static void op_A(QW *w, const F *x, F *y) { if (w->kind == 0) lasso_A_times(w, x, y); else if (w->kind == 3) svmqp_A_times(w, x, y); else sp_accum_A(&w->A, x, y); }
+static void op_At(QW *w, const F *x, F *y) { if (w->kind == 0) lasso_AT_times(w, x, y); else if (w->kind == 3) svmqp_AT_times(w, x, y); else sp_accum_At(&w->A, x, y); }
+static void solve_spe_linsys(QW *w, F *b) { if (w->kind == 0) solve_lasso_linsys(w, b); else if (w->kind == 3) solve_svmqp_linsys(w, b); else solve_qcp_linsys(w, b); }
 
 /* ---- cones.c:130-288 ------------------------------------------------------------------------------------ */
 static void orthant_prox(F *x, const F *t, F lambda, I n) { /* :279-288 */
@@ -609,7 +719,7 @@ static void calc_residuals(QW *w, QR *r, I ipm_iter, I admm_iter) { /* qcp_confi
   for (I i = 0; i < m; ++i) y[i] = w->u[i] * (1 / r->tau);
   for (I j = 0; j < n; ++j) { x[j] = w->u[m + j] * (1 / r->tau); s[j] = w->v_origin[m + j] * (1 / r->tau); }
   F *Ax = (F *)calloc(m, sizeof(F)), *Ax_b = (F *)malloc(sizeof(F) * m);
-  sp_accum_A(&w->A, x, Ax);
+  op_A(w, x, Ax);
   for (I i = 0; i < m; ++i) Ax_b[i] = Ax[i] - w->b[i];
   r->Ax_b_norm = v_nrminf(Ax_b, m); w->last_Ax_b_norm = r->Ax_b_norm;
   for (I i = 0; i < m; ++i) { Ax[i] *= w->D[i]; Ax_b[i] *= w->D[i]; }
@@ -617,7 +727,7 @@ static void calc_residuals(QW *w, QR *r, I ipm_iter, I admm_iter) { /* qcp_confi
   F *Qx = (F *)calloc(n, sizeof(F)), *ATy = (F *)calloc(n, sizeof(F)), *R = (F *)malloc(sizeof(F) * n);
   F xQx_2 = 0;
   if (w->hasQ) { sp_accum_A(&w->Q, x, Qx); xQx_2 = v_dot(x, Qx, n) / (2 * w->sc_b * w->sc_c); }
-  sp_accum_At(&w->A, y, ATy);
+  op_At(w, y, ATy);
   for (I j = 0; j < n; ++j) R[j] = Qx[j] - ATy[j] + w->c[j] - s[j];
   r->Qx_ATy_c_s_norm = v_nrminf(R, n); w->last_Qx_norm = r->Qx_ATy_c_s_norm;
   for (I j = 0; j < n; ++j) { Qx[j] *= w->E[j]; ATy[j] *= w->E[j]; R[j] *= w->E[j]; s[j] *= w->E[j]; }
@@ -708,6 +818,11 @@ static void get_solution(QW *w, QCPSolution *sol, QCPInfo *info, const QR *r, I 
     for (I j = 0; j < ls->dn; ++j) beta[j] = (sol->x[ls->dm + 2 + j] + (-1) * sol->x[ls->dm + ls->dn + 2 + j]) * ls->E[j] * (1 / ls->sc_b);
     memcpy(sol->x, beta, sizeof(F) * ls->dn);
     free(beta);
+  } else if (w->stgs->normalize && w->kind == 3) { /* un_scaling_svmqp_sol, svm_qp_config.c:595-619: x / (E sc_b) -> w = x[0:dn], b = x[dn], xi = x[dn+1 : dn+1+dm] */
+    const OrcSvmqp *sq = w->sq;
+    for (I j = 0; j < n; ++j) sol->x[j] /= (w->E[j] * w->sc_b);
+    sol->y[0] = sol->x[sq->dn];
+    memcpy(sol->s, &sol->x[sq->dn + 1], sizeof(F) * sq->dm);
   } else if (w->stgs->normalize) { /* un_scaling_qcp_sol, qcp_config.c:496-513 */
     for (I j = 0; j < n; ++j) sol->x[j] /= (w->E[j] * w->sc_b);
     for (I i = 0; i < m; ++i) sol->y[i] /= (w->D[i] * w->sc_c);
@@ -742,17 +857,22 @@ I orc_qcp_trace_count(void) { return g_trace_n; }
 
 qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) { /* abip(), abip.c:1335-1371 */
   const int lasso = d && d->stgs && d->stgs->prob_type == 0; /* abip.c:1341-1348: 0 LASSO, 1 SVM, 2 QCP, 3 SVMQP */
-  if (!d || !sol || !info || !K || !d->A || !d->b || (!lasso && !d->c) || (d->stgs->linsys_solver != 1 && d->stgs->linsys_solver != 3) ||
-      (d->stgs->prob_type != 2 && !lasso) || (lasso && (d->stgs->linsys_solver != 1 || !(d->lambda > 0)))) {
+  const int svmqp = d && d->stgs && d->stgs->prob_type == 3;
+  const int ml = lasso || svmqp;
+  if (!d || !sol || !info || !K || !d->A || !d->b || (!ml && !d->c) || (d->stgs->linsys_solver != 1 && d->stgs->linsys_solver != 3) ||
+      (d->stgs->prob_type != 2 && !ml) || (ml && (d->stgs->linsys_solver != 1 || !(d->lambda > 0)))) {
     if (info) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); }
     return ST_FAILED;
   }
   const double t_init = now_ms();
   QW W; memset(&W, 0, sizeof(W)); QW *w = &W;
   w->kind = 2; w->stgs = d->stgs;
-  if (lasso) init_lasso(w, d); else { w->m = d->m; w->n = d->n; }
+  F *sq_b = 0, *sq_c = 0;
+  if (lasso) init_lasso(w, d);
+  else if (svmqp) { sq_b = (F *)malloc(sizeof(F) * d->m); sq_c = (F *)malloc(sizeof(F) * (1 + d->n + 2 * d->m)); init_svmqp(w, d, sq_b, sq_c); }
+  else { w->m = d->m; w->n = d->n; }
   const I m = w->m, n = w->n; const long l = (long)m + n + 1;
-  w->hasQ = !lasso && d->Q != 0;
+  if (!ml) w->hasQ = d->Q != 0;
   { /* validate, abip.c:779-832 + cones.c:37-81 */
     long dims = K->l + K->z + K->f;
     for (I i = 0; K->q && i < K->qsize; ++i) dims += K->q[i];
@@ -763,20 +883,21 @@ qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone
       info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED;
     }
   }
-  if (!lasso) w->sparsity = ((d->A->p[n] / (m * n)) < 0.05); /* integer division, qcp_config.c:22 */
+  if (!ml) w->sparsity = ((d->A->p[n] / (m * n)) < 0.05); /* integer division, qcp_config.c:22 */
   w->rho_dr = (F *)malloc(sizeof(F) * l);
   for (long i = 0; i < l; ++i) w->rho_dr[i] = i < m ? d->stgs->rho_y : (i < m + n ? d->stgs->rho_x : d->stgs->rho_tau);
-  if (!lasso) copy_mat(&w->A, d->A);
-  if (w->hasQ) copy_mat(&w->Q, d->Q);
+  if (!ml) copy_mat(&w->A, d->A);
+  if (w->hasQ && !ml) copy_mat(&w->Q, d->Q);
   w->b = (F *)malloc(sizeof(F) * m); w->c = (F *)malloc(sizeof(F) * n); w->D = (F *)malloc(sizeof(F) * m); w->E = (F *)malloc(sizeof(F) * n);
   w->mu = 1.0; w->beta = 1.0;
   w->u = (F *)calloc(l, sizeof(F)); w->v = (F *)calloc(l, sizeof(F)); w->v_origin = (F *)calloc(l, sizeof(F)); w->u_t = (F *)calloc(l, sizeof(F));
   w->rel_ut = (F *)calloc(l, sizeof(F)); w->r = (F *)calloc(l, sizeof(F));
   if (lasso) scaling_lasso_data(w); /* (nm_inf_b / nm_inf_c, abip.c:875-876, are not used by the LASSO residuals) */
+  else if (svmqp) { w->nm_inf_b = v_nrminf(sq_b, m); w->nm_inf_c = v_nrminf(sq_c, n); scaling_svmqp_data(w, sq_b, sq_c, K); free(sq_b); free(sq_c); }
   else { w->nm_inf_b = v_nrminf(d->b, m); w->nm_inf_c = v_nrminf(d->c, n); scaling_qcp_data(w, d, K); }
   w->last_Ax_b_norm = INFINITY; w->last_Qx_norm = INFINITY;
   if (d->stgs->linsys_solver == 3) { if (init_qcp_pcg(w) < 0) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED; } if (getenv("ORC_QCP_PCG_CHECK")) init_kkt(w); }
-  else if ((lasso ? init_lasso_linsys(w) : init_kkt(w)) < 0) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED; }
+  else if ((lasso ? init_lasso_linsys(w) : svmqp ? init_svmqp_linsys(w) : init_kkt(w)) < 0) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED; }
   info->setup_time = now_ms() - t_init;
   const double t0 = now_ms();
   QR R; memset(&R, 0, sizeof(R)); QR *r = &R;
@@ -830,7 +951,7 @@ qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone
 done:
   info->avg_linsys_time = 0; info->avg_cg_iters = w->cg_solves ? (F)w->tot_cg / (F)w->cg_solves : 0;
   free(w->Mpre); free(w->Hinv);
-  free_lasso(w);
+  free_lasso(w); free_svmqp(w);
   free(w->rho_dr); free(w->A.x); free(w->A.i); free(w->A.p);
   if (w->hasQ) { free(w->Q.x); free(w->Q.i); free(w->Q.p); }
   free(w->b); free(w->c); free(w->D); free(w->E); free(w->u); free(w->v); free(w->v_origin); free(w->u_t); free(w->rel_ut); free(w->r);

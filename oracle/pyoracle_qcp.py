@@ -127,6 +127,7 @@ def solve_lasso(X, y, lam: float, **settings):
     L = lib()
     X = sp.csc_matrix(X)
     m, n = X.shape
+    settings.setdefault("linsys_solver", 1)  # (the default rule of util.c:237-243 picks 5, dense Cholesky, for dense data)
     P = Problem(X, y, np.zeros(n), {"rq": [m + 2], "l": 2 * n}, set_defaults=L.orc_qcp_set_default_settings, verbose=0, **settings)
     P.stgs.prob_type = 0
     P.data.lambda_ = float(lam)
@@ -136,6 +137,24 @@ def solve_lasso(X, y, lam: float, **settings):
     P.sol = QCPSolution(P.x.ctypes.data_as(PF), P.y.ctypes.data_as(PF), P.s.ctypes.data_as(PF))
     L.orc_qcp_solve(C.byref(P.data), C.byref(P.sol), C.byref(P.info), C.byref(P.cone))
     return P.x[:n].copy(), P.info_dict()
+
+
+def solve_svmqp(X, y, lam: float, **settings):
+    """Soft-margin SVM min 1/2 |w|^2 + 1/(m lam) sum xi, y_i (x_i'w + b) >= 1 - xi_i, through the QP reformulation
+    (prob_type 3, svm_qp_config.c); returns (w, b, xi, info).  Cone as abip_ml_mex.c:338-342: f = n + 1, l = 2 m."""
+    L = lib()
+    X = sp.csc_matrix(X)
+    m, n = X.shape
+    settings.setdefault("linsys_solver", 1)
+    P = Problem(X, y, np.zeros(n), {"f": n + 1, "l": 2 * m}, set_defaults=L.orc_qcp_set_default_settings, verbose=0, **settings)
+    P.stgs.prob_type = 3
+    P.data.lambda_ = float(lam)
+    P.data.c = None
+    q = 1 + n + 2 * m
+    P.x = np.full(q, np.nan); P.y = np.full(m, np.nan); P.s = np.full(q, np.nan)
+    P.sol = QCPSolution(P.x.ctypes.data_as(PF), P.y.ctypes.data_as(PF), P.s.ctypes.data_as(PF))
+    L.orc_qcp_solve(C.byref(P.data), C.byref(P.sol), C.byref(P.info), C.byref(P.cone))
+    return P.x[:n].copy(), float(P.y[0]), P.s[:m].copy(), P.info_dict()
 
 
 def cone_prox(kind: int, tmp, lam: float, x_prev=None):
