@@ -15,14 +15,14 @@
 
 namespace abip {
 
-struct QDims { int m, n, MP; int norm_u; }; // norm_u: the inner test normalises by |u| (lasso_config.c:343-345) instead of |Qu| (qcp_config.c:549-551)
+struct QDims { int m, n, MP; int norm_u; }; // norm_u: the inner test normalises by 1 + |u| + |v_o| (1: lasso_config.c:343-345) or 1 + |(u, v_o)| (2: svm_config.c:266-268) instead of 1 + |Qu| + |v_o| (0: qcp_config.c:549-551)
 
 enum QSlot : int { // reuse of the partials table; *_MAX slots are reduced with max
   Q_T0 = 0, Q_T1, Q_PG,                       // r'mu, r'(rho o p), p_x'Qp
   Q_D1, Q_D2, Q_D3, Q_E1, Q_E2, Q_E3,         // inner test: u'Mu, u_y'b, u_x'c, |Qu - v_o|^2, |Qu|^2, |v_o|^2 (tau entry added by the host)
   Q_S0, Q_S1, Q_S2, Q_S3, Q_S4, Q_S5,         // |D o Ax|^2, b'u_y, c'u_x, u_x'Qx, |E o Qx|^2, |E o (A'y + v_o)|^2
   Q_M0, Q_M1, Q_M2, Q_M3, Q_M4, Q_M5,         // max slots: |Ax/t-b|, D|Ax/t-b|, D|Ax/t|, |R|, E|R|, E|Qx/t|
-  Q_L0, Q_L1, Q_L2, Q_L3, Q_L4, Q_L5,         // LASSO residuals (kq_resid_lasso): |pr|^2, |dr|^2, x'x, 1'(beta+ + beta-), z'z, y'z
+  Q_L0, Q_L1, Q_L2, Q_L3, Q_L4, Q_L5,         // LASSO residuals (kq_resid_lasso): |pr|^2, |dr|^2, x'x, 1'(beta+ + beta-), z'z, y'z;  SVM (kq_resid_svm): |pr|^2, |dr|^2, 1'y, 1'xi, |w|^2, |B'y|^2
   Q_COUNT
 };
 __host__ __device__ inline bool qslot_is_max(int s) { return s >= Q_M0 && s <= Q_M5; }
@@ -397,6 +397,36 @@ __global__ __launch_bounds__(BS) void kq_resid_lasso(const double *__restrict__ 
   write_partials<6>(part, ws, s6, sm);
 }
 
+// ---- residuals of the SVM-SOCP reformulation (svm_config.c:445-561) from the stored products of the scaled operator ----
+// x-block layout: x0, x1, r (dn), w+ (dn), b+, w- (dn), b-, xi (dm), t (dm).  With A~ = D [diag(y) X, y] E the scaled data block:
+//   pr_i = (A u_x)_{1+i} / (D_i tau sc_b) - 1            (= xi + data_A (w, b) - t - 1: the xi and t columns carry D / sc and -D),
+//   (B'y)_j = ((A'u_y)_{w+_j} + wE_j u_y[1+dm+j]) / (E_j tau sc_c),   y = D o u_y[1:1+dm] / (tau sc_c),
+//   dr = (y - s2 ; y + s1 - C) with s1, s2 the duals of xi, t;  w = E o (u_w+ - u_w-) / (tau sc_b);  xi = u_xi / (tau sc sc_b).
+struct QSvm { int dm, dn; double sc, sc_b, sc_c, C; const double *D, *E, *wE; };
+__global__ __launch_bounds__(BS) void kq_resid_svm(const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ Ax,
+                                                   const double *__restrict__ ATy, QSvm V, QDims d, double *part) {
+  __shared__ double sm[6 * WAVES];
+  const double tau = u[d.MP + d.n], ib = 1.0 / (tau * V.sc_b), ic = 1.0 / (tau * V.sc_c);
+  double s6[6] = {0, 0, 0, 0, 0, 0};
+  const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
+  const double *ux = u + d.MP, *vx = v + d.MP;
+  const int o_xi = 3 * V.dn + 4, o_t = o_xi + V.dm;
+  for (int i = t0; i < V.dm; i += stride) {
+    const double Di = V.D[i];
+    const double pr = Ax[1 + i] / Di * ib - 1.0, y = u[1 + i] * (Di * ic), s2 = vx[o_t + i] * ic, s1 = vx[o_xi + i] * (V.sc * ic);
+    const double a = y - s2, b = y + s1 - V.C;
+    s6[0] += pr * pr; s6[1] += a * a + b * b; s6[2] += y; s6[3] += ux[o_xi + i] * (ib / V.sc);
+  }
+  for (int j = t0; j < V.dn; j += stride) {
+    const double Ej = V.E[j];
+    const double wj = (ux[V.dn + 2 + j] - ux[2 * V.dn + 3 + j]) * (Ej * ib);
+    const double bty = (ATy[V.dn + 2 + j] + V.wE[j] * u[1 + V.dm + j]) / Ej * ic;
+    s6[4] += wj * wj; s6[5] += bty * bty;
+  }
+  const int ws[6] = {Q_L0, Q_L1, Q_L2, Q_L3, Q_L4, Q_L5};
+  write_partials<6>(part, ws, s6, sm);
+}
+
 // one block: partials (both halves of the table) -> ctl->out
 struct QFin {
   int nslots; int slots[24]; int second_half[24];
@@ -437,7 +467,7 @@ __global__ __launch_bounds__(1024) void kq_finalize(QFin f, const double *part, 
     const double dq = qut - vot;
     const double t2 = f.norm_u ? tau : qut;
     const double e1 = __dadd_rn(o[Q_E1], __dmul_rn(dq, dq)), e2 = __dadd_rn(o[Q_E2], __dmul_rn(t2, t2)), e3 = o[Q_E3];
-    const double err = sqrt(e1) / (1 + sqrt(e2) + sqrt(e3));
+    const double err = f.norm_u == 2 ? sqrt(e1) / (1 + sqrt(e2 + e3)) : sqrt(e1) / (1 + sqrt(e2) + sqrt(e3));
     ctl->err_inner = err; ctl->it_count = ctl->it_count + 1;
     if (err < f.tol_inner) { hc->halt = 1; ctl->halted = 1; }
   }

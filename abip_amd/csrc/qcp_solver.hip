@@ -49,11 +49,16 @@ struct LassoForm {
 };
 
 // The SVM reformulations (svm_qp_config.c; svm_config.c): data dimensions and what the un-scaling needs
-struct SvmForm { int dm = 0, dn = 0; double lambda = 0; };
+struct SvmForm {
+  int dm = 0, dn = 0; double lambda = 0;
+  double sc = 1, sc_b = 1, sc_c = 1, sc_cone1 = 1, sc_cone2 = 1; // SVM-SOCP only (svm_config.c:63-107)
+  std::vector<double> D, E, wE;
+  DBuf<double> Dd, Ed, wEd;
+};
 
 struct QWk {
   SvmForm sv;
-  int kind = 2; // enum problem_type as abip() maps settings.prob_type (abip.c:1341-1348): 0 LASSO, 2 generic QCP, 3 SVM as a QP
+  int kind = 2; // enum problem_type as abip() maps settings.prob_type (abip.c:1341-1348): 0 LASSO, 1 SVM as an SOCP, 2 generic QCP, 3 SVM as a QP
   LassoForm ls;
   double kkt_rho_x = 1; // the rho_x the KKT system is assembled with (the LASSO solve hard-codes 1, lasso_config.c:652-708)
   int m = 0, n = 0, MP = 0, LV = 0, NB = 1;
@@ -91,6 +96,7 @@ void release(QWk *w) {
   w->ev_a = w->ev_b = nullptr;
   w->dA.release(); w->dAt.release(); w->dQ.release();
   w->ls.Dd.release(); w->ls.Ed.release(); w->ls.yd.release();
+  w->sv.Dd.release(); w->sv.Ed.release(); w->sv.wEd.release();
   DBuf<double> *bufs[] = {&w->u, &w->v, &w->vo, &w->ut, &w->rel, &w->r, &w->p, &w->bd, &w->cd, &w->Dd, &w->Ed, &w->Ax, &w->ATy, &w->Qx, &w->part};
   for (auto *b : bufs) b->release();
   w->xkind.release(); w->c_off.release(); w->c_len.release(); w->c_kind.release(); w->ctl.release();
@@ -264,6 +270,97 @@ void build_lasso(QWk *w, const QCPData *d) {
   w->D.assign(p, 1.0); w->E.assign(q, 1.0); w->sc_b = 1; w->sc_c = 1; // (neutral for the generic sums kq_resid still provides: certificates)
 }
 
+// ---- SVM-SOCP front end: init_svm + scaling_svm_data, svm_config.c:8-171, 281-391 -------------------------------------------------
+// x = (x0, x1, r (dn), w+ (dn), b+, w- (dn), b-, xi (dm), t (dm)); (x0, x1, r) in one rotated cone, the rest >= 0; dm + dn + 1 rows:
+//   row 0: x0 = const;  rows 1..dm: diag(y)(X (w+ - w-) + (b+ - b-)) + xi - t = 1;  rows dm+1..: r tied to w+ - w-;  cost x1 + C 1'xi.
+// As for LASSO the operator of svm_A_times (:177-199) is materialised (nnz = 1 + 3 dn + 2 dm + 2 (nnz(X) + dm)) and the conic path's own
+// KKT back-ends replace the block elimination of :725-806 (same linear system, rho_x = 1 as hard-coded there).
+// The scale constants are a table of heuristics in (dm, dn, lambda); the reference leaves them uninitialised when dm == 10 dn or
+// 10 dm == dn (no branch taken, :63-107) and never assigns sc_cone2 when dm > 10 dn with dn < 10 (:85-89): the boundaries are closed
+// towards the outer branches here and sc_cone2 starts from sc_cone1 in that corner.
+void svm_constants(int m, int n, double lambda, SvmForm &V) {
+  const double l2 = std::log(2 * lambda) / std::log(10.0), l5 = std::log(5 * lambda) / std::log(10.0);
+  V.sc = 1; V.sc_b = 1;
+  if (((long long)m < 10LL * n) && (10LL * m > (long long)n)) {
+    V.sc_c = std::max(0.45, std::pow(7.5, -l2) * 2); V.sc_cone1 = std::max(3.0, l2 * 4 + 4); V.sc_cone2 = V.sc_cone1;
+  } else if (10LL * m <= (long long)n) {
+    V.sc_cone2 = std::max(3.0, l2 * 2 + 2);
+    if (lambda >= 1) { V.sc_c = std::max(0.2, std::pow(0.2, l2) * 7.5); V.sc_cone1 = V.sc_cone2; }
+    else { V.sc_c = std::pow(0.3, l2) * 3; V.sc_cone1 = std::max(0.4, l2 * 0.2 + 0.8); }
+  } else {
+    if (n < 10) {
+      V.sc_c = 1 / lambda; V.sc_cone1 = 6; V.sc_cone2 = 6;
+      if (lambda < 0.002) V.sc_cone2 = V.sc_cone2 - 3 * std::log(lambda * 500) / std::log(10.0);
+    } else if (lambda >= 1) { V.sc_c = 1 / lambda; V.sc_cone1 = 6; V.sc_cone2 = lambda; }
+    else {
+      V.sc_c = std::min(std::pow(5, -l5) * 4, 300.0); V.sc_b = std::max(0.1, l5 * 0.2 + 0.9); V.sc_cone1 = std::max(0.05, l5 * 0.3 + 0.7); V.sc_cone2 = -l5 * 2 + 6;
+      if (lambda < 0.002) V.sc_cone2 = V.sc_cone2 - 3 * std::log(lambda * 500) / std::log(10.0);
+    }
+  }
+}
+void build_svm(QWk *w, const QCPData *d) {
+  SvmForm &V = w->sv;
+  const int dm = d->m, dn = d->n, n1 = dn + 1, p = dm + dn + 1, q = 4 + 3 * dn + 2 * dm;
+  V.dm = dm; V.dn = dn; V.lambda = d->lambda;
+  const QCPMatrix *X = d->A;
+  const int xnnz = X->p[dn];
+  w->sparsity = (((double)xnnz / ((double)dm * (double)dn)) < 0.05); // :20
+  svm_constants(dm, dn, V.lambda, V);
+  // data_A = [diag(y) X, y] (:109-133), then column and row equilibration (:300-341)
+  std::vector<double> xs((size_t)xnnz + dm);
+  for (int t = 0; t < xnnz; ++t) xs[t] = X->x[t] * d->b[X->i[t]];
+  for (int i = 0; i < dm; ++i) xs[xnnz + i] = d->b[i];
+  auto col_lo = [&](int j) { return j < dn ? X->p[j] : xnnz; };
+  auto col_hi = [&](int j) { return j < dn ? X->p[j + 1] : xnnz + dm; };
+  auto row_of = [&](int t) { return t < xnnz ? X->i[t] : t - xnnz; };
+  std::vector<double> &E = V.E, &D = V.D;
+  E.assign(n1, 0.0); D.assign(dm, 0.0);
+  double avg = 0;
+  if (w->st->scale_E) {
+    for (int j = 0; j < n1; ++j) { for (int t = col_lo(j); t < col_hi(j); ++t) E[j] += xs[t] * xs[t]; E[j] = std::sqrt(E[j]); avg += E[j]; }
+    avg /= n1;
+    for (int j = 0; j < n1; ++j) E[j] = avg / E[j];
+    for (int j = 0; j < n1; ++j) for (int t = col_lo(j); t < col_hi(j); ++t) xs[t] *= E[j];
+  }
+  for (int t = 0; t < xnnz + dm; ++t) D[row_of(t)] += xs[t] * xs[t];
+  avg = 0;
+  for (int i = 0; i < dm; ++i) avg += std::sqrt(D[i]);
+  avg /= dm;
+  for (int i = 0; i < dm; ++i) D[i] = avg / std::sqrt(D[i]);
+  for (int t = 0; t < xnnz + dm; ++t) xs[t] *= D[row_of(t)];
+  std::vector<double> wD(dn), &wE = V.wE;
+  wE.assign(dn, 0.0);
+  for (int j = 0; j < dn; ++j) { const double F = 1 / std::sqrt(1 + 2 * E[j] * E[j]); wD[j] = F * -std::sqrt(V.sc_cone1); wE[j] = E[j] * F; } // :343-345, 374-380
+  w->b.assign(p, 0.0); w->c.assign(q, 0.0); // :347-364
+  w->b[0] = V.sc_cone2;
+  for (int i = 0; i < dm; ++i) w->b[1 + i] = D[i];
+  for (double &t : w->b) t *= V.sc_b;
+  w->c[1] = V.sc_c * V.sc_cone1 * V.sc_cone2;
+  for (int i = 0; i < dm; ++i) w->c[3 * dn + 4 + i] = V.lambda * V.sc_c / V.sc;
+  // the operator of svm_A_times (:177-199) as a p x q CSC matrix
+  HMat &A = w->A;
+  A.m = p; A.n = q; A.p.assign(q + 1, 0); A.i.clear(); A.x.clear();
+  A.i.reserve((size_t)1 + 3 * dn + 2 * dm + 2 * ((size_t)xnnz + dm)); A.x.reserve(A.i.capacity());
+  int col = 0;
+  auto close = [&]() { A.p[++col] = (int)A.i.size(); };
+  A.i.push_back(0); A.x.push_back(1.0); close(); // x0
+  close();                                        // x1: empty
+  for (int j = 0; j < dn; ++j) { A.i.push_back(1 + dm + j); A.x.push_back(wD[j]); close(); } // r
+  for (int sign = 0; sign < 2; ++sign) {
+    const double sg = sign ? -1.0 : 1.0;
+    for (int j = 0; j < dn; ++j) { // w+ / w-
+      for (int t = X->p[j]; t < X->p[j + 1]; ++t) { A.i.push_back(1 + X->i[t]); A.x.push_back(sg * xs[t]); }
+      A.i.push_back(1 + dm + j); A.x.push_back(-sg * wE[j]);
+      close();
+    }
+    for (int i = 0; i < dm; ++i) { A.i.push_back(1 + i); A.x.push_back(sg * xs[xnnz + i]); } // b+ / b-
+    close();
+  }
+  for (int i = 0; i < dm; ++i) { A.i.push_back(1 + i); A.x.push_back(D[i] * (1 / V.sc)); close(); } // xi
+  for (int i = 0; i < dm; ++i) { A.i.push_back(1 + i); A.x.push_back(-D[i]); close(); }             // t
+  w->D.assign(p, 1.0); w->E.assign(q, 1.0); w->sc_b = 1; w->sc_c = 1; // (neutral for the generic sums kq_resid still provides: certificates)
+}
+
 // ---- SVM-QP front end: init_svmqp + scaling_svmqp_data, svm_qp_config.c:8-124, 195-590 -------------------------------------
 // x = (w (dn), b, xi (dm), t (dm)); w, b free, xi, t >= 0;  min 1/2 |w|^2 + 1/(dm lambda) 1'xi  s.t.  diag(y) (X w + b) + xi - t = 1.
 // The reference keeps the data block B~ = D^-1 diag(y) [X, 1] E^-1 and applies the +-D^-1 identity columns on the fly (:129-147); here the
@@ -328,7 +425,7 @@ void enqueue_solve(QWk *w, double *rhs) { // _ldl_solve, linsys.c:309-316
 // norms of the last check); otherwise y0 = 0 and tol as given (the set-up solve, abip.c:899).  Synchronises with the host once per chunk
 // of iterations.  Returns the CG iterations used, < 0 on a device error.
 int solve_pcg(QWk *w, double *rhs, bool warm, int iter, double tol_host) {
-  const QDims d{w->m, w->n, w->MP, w->kind == 0 ? 1 : 0};
+  const QDims d{w->m, w->n, w->MP, w->kind == 0 ? 1 : (w->kind == 1 ? 2 : 0)};
   const QCPSettings *st = w->st;
   QPcgVec v{w->cg_x0.p, w->cg_r.p, w->cg_z.p, w->cg_p.p, w->cg_Gp.p, w->cg_tm.p, w->cg_M.p, w->cg_H.p};
   Ctl *hc = w->lp_ctl;
@@ -375,7 +472,7 @@ int read_ctl(QWk *w) {
 void finalize(QWk *w, std::initializer_list<int> slots, std::initializer_list<int> both_halves, double tol_inner = -1.0) {
   QFin f; f.nslots = 0;
   for (int s : slots) { f.slots[f.nslots] = s; f.second_half[f.nslots] = 0; for (int bsl : both_halves) if (bsl == s) f.second_half[f.nslots] = 1; ++f.nslots; }
-  f.norm_u = w->kind == 0 ? 1 : 0;
+  f.norm_u = w->kind == 0 ? 1 : (w->kind == 1 ? 2 : 0);
   if (tol_inner >= 0) { f.decide = 1; f.tol_inner = tol_inner; f.u_tau = w->u.p + w->MP + w->n; f.vo_tau = w->vo.p + w->MP + w->n; }
   QLAUNCH(w, kq_finalize, 1, 1024, f, (const double *)w->part.p, w->NB, w->ctl.p, w->lp_ctl);
 }
@@ -423,7 +520,7 @@ int has_converged(const QWk *w, const QResid &r, int ipm_iter, int admm_iter) { 
 int calc_residuals(QWk *w, QResid &r, int ipm_iter, int admm_iter) { // qcp_config.c:562-691 (sums from kq_resid)
   if (admm_iter && r.last_admm_iter == admm_iter) return 0;
   r.last_ipm_iter = ipm_iter; r.last_admm_iter = admm_iter;
-  const QDims d{w->m, w->n, w->MP, w->kind == 0 ? 1 : 0};
+  const QDims d{w->m, w->n, w->MP, w->kind == 0 ? 1 : (w->kind == 1 ? 2 : 0)};
   QLAUNCH(w, kq_resid, w->NB, BS, (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->bd.p, (const double *)w->cd.p,
           (const double *)w->Dd.p, (const double *)w->Ed.p, (const double *)w->Ax.p, (const double *)w->ATy.p, (const double *)w->Qx.p, d, w->part.p);
   finalize(w, {Q_S0, Q_S1, Q_S2, Q_S3, Q_S4, Q_S5, Q_M0, Q_M1, Q_M2, Q_M3, Q_M4, Q_M5}, {});
@@ -431,6 +528,12 @@ int calc_residuals(QWk *w, QResid &r, int ipm_iter, int admm_iter) { // qcp_conf
     const LassoForm &L = w->ls;
     QLasso ql{L.dm, L.dn, std::sqrt(L.sc_cone2), L.sc_b, L.sc_c, L.lambda, L.Dd.p, L.Ed.p, L.yd.p};
     QLAUNCH(w, kq_resid_lasso, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->Ax.p, (const double *)w->ATy.p, ql, d, w->part.p);
+    finalize(w, {Q_L0, Q_L1, Q_L2, Q_L3, Q_L4, Q_L5}, {});
+  }
+  if (w->kind == 1) {
+    const SvmForm &V = w->sv;
+    QSvm qs{V.dm, V.dn, V.sc, V.sc_b, V.sc_c, V.lambda, V.Dd.p, V.Ed.p, V.wEd.p};
+    QLAUNCH(w, kq_resid_svm, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->Ax.p, (const double *)w->ATy.p, qs, d, w->part.p);
     finalize(w, {Q_L0, Q_L1, Q_L2, Q_L3, Q_L4, Q_L5}, {});
   }
   double tails[2];
@@ -453,6 +556,23 @@ int calc_residuals(QWk *w, QResid &r, int ipm_iter, int admm_iter) { // qcp_conf
     r.res_pri = this_pr; r.res_dual = this_dr; r.rel_gap = this_gap;
     r.error_ratio = std::max(r.res_pri / st->eps_p, std::max(r.res_dual / st->eps_d, r.rel_gap / st->eps_g));
     const double ctu = o[Q_S2], btu = o[Q_S1]; // c'u_x, b'u_y; |A u_x|_2 and |A'u_y + v_o|_2 from the generic sums (D = E = 1 here)
+    r.res_unbdd = ctu < 0 ? std::sqrt(o[Q_S0]) / (-ctu) : INFINITY;
+    r.res_infeas = btu > 0 ? std::sqrt(o[Q_S5]) / btu : INFINITY;
+    return 0;
+  }
+  if (w->kind == 1) { // calc_svm_residuals, svm_config.c:445-561
+    const SvmForm &V = w->sv;
+    const double C = V.lambda;
+    r.tau = tails[0];
+    r.Ax_b_norm = o[Q_M0]; r.Qx_ATy_c_s_norm = o[Q_M3]; // (for the PCG tolerance of abip.c:213-217 only)
+    const double this_pr = std::sqrt(o[Q_L0]) / std::sqrt((double)V.dm);
+    const double this_dr = std::sqrt(o[Q_L1]) / (std::sqrt((double)V.dm) * C);
+    r.dobj = o[Q_L2] - 0.5 * o[Q_L5]; r.pobj = C * o[Q_L3] + 0.5 * o[Q_L4];
+    const double this_gap = std::fabs(r.dobj - r.pobj) / (1 + std::fabs(r.pobj));
+    r.res_dif = std::max(std::max(std::fabs(this_pr - r.res_pri), std::fabs(this_dr - r.res_dual)), std::fabs(this_gap - r.rel_gap));
+    r.res_pri = this_pr; r.res_dual = this_dr; r.rel_gap = this_gap;
+    r.error_ratio = std::max(r.res_pri / st->eps_p, std::max(r.res_dual / st->eps_d, r.rel_gap / st->eps_g));
+    const double ctu = o[Q_S2], btu = o[Q_S1];
     r.res_unbdd = ctu < 0 ? std::sqrt(o[Q_S0]) / (-ctu) : INFINITY;
     r.res_infeas = btu > 0 ? std::sqrt(o[Q_S5]) / btu : INFINITY;
     return 0;
@@ -521,7 +641,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   if (!d || !sol || !info || !K) return fail(info, "ABIP_NULL input");
   if (!d->stgs) return fail(info, "ABIP_NULL input");
   const int kind = d->stgs->prob_type; // abip.c:1341-1348: 0 LASSO, 1 SVM, 2 QCP, 3 SVMQP
-  if (kind != 2 && kind != 0 && kind != 3) return fail(info, "served formulations: the generic QCP (prob_type 2), LASSO (prob_type 0) and SVM as a QP (prob_type 3)");
+  if (kind < 0 || kind > 3) return fail(info, "prob_type must be 0 (LASSO), 1 (SVM as an SOCP), 2 (generic QCP) or 3 (SVM as a QP)");
   if (!d->A || !d->b || (kind == 2 && !d->c)) return fail(info, "the device path needs A, b and c");
   if (d->stgs->linsys_solver != 1 && d->stgs->linsys_solver != 3) return fail(info, "only linsys_solver = 1 (QDLDL-class direct) and 3 (PCG) are served");
   const QCPSettings *st = d->stgs;
@@ -532,12 +652,14 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     if (!st->normalize || !st->scale_E) return fail(info, "the LASSO formulation needs normalize = 1 and scale_E = 1");
     if ((long long)2 + 2LL * d->n + d->m > 2147483647LL) return fail(info, "problem too large for 32-bit indices");
   }
-  if (kind == 3) { // SVM-QP: data = (X, labels y, lambda) as abip_ml_mex.c:117-160 hands them over
+  if (kind == 3 || kind == 1) { // SVM: data = (X, labels y, lambda) as abip_ml_mex.c:117-160 hands them over
     if (d->m <= 0 || d->n <= 0 || !(d->lambda > 0)) return fail(info, "SVM needs a non-empty X and lambda > 0");
     if (!st->normalize) return fail(info, "the SVM formulation needs normalize = 1"); // (as for LASSO: scaled unconditionally, un-scaled only when set)
-    if ((long long)1 + d->n + 2LL * d->m > 2147483647LL) return fail(info, "problem too large for 32-bit indices");
+    if (kind == 1 && !st->scale_E) return fail(info, "the SVM-SOCP formulation needs scale_E = 1"); // (E = 0 otherwise, svm_config.c:296-316)
+    if ((long long)4 + 3LL * d->n + 2LL * d->m > 2147483647LL) return fail(info, "problem too large for 32-bit indices");
   }
-  const int m = kind == 0 ? d->m + 1 : d->m, n = kind == 0 ? 2 + 2 * d->n + d->m : (kind == 3 ? 1 + d->n + 2 * d->m : d->n);
+  const int m = kind == 0 ? d->m + 1 : (kind == 1 ? d->m + d->n + 1 : d->m);
+  const int n = kind == 0 ? 2 + 2 * d->n + d->m : (kind == 1 ? 4 + 3 * d->n + 2 * d->m : (kind == 3 ? 1 + d->n + 2 * d->m : d->n));
   { // validate, abip.c:779-832 ; cones.c:37-81
     long dims = (long)K->l + K->z + K->f;
     for (int i = 0; K->q && i < K->qsize; ++i) dims += K->q[i];
@@ -554,8 +676,9 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   const double t_init = now_ms();
   QWk W; QWk *w = &W;
   w->kind = kind; w->m = m; w->n = n; w->st = st; w->hasQ = kind == 3 || (kind == 2 && d->Q != nullptr);
-  w->kkt_rho_x = kind == 0 ? 1.0 : st->rho_x;
+  w->kkt_rho_x = (kind == 0 || kind == 1) ? 1.0 : st->rho_x; // (lasso_config.c:652-708 and svm_config.c:725-806 hard-code rho_x = 1 in the solve)
   if (kind == 0) build_lasso(w, d);
+  else if (kind == 1) build_svm(w, d);
   else if (kind == 3) build_svmqp(w, d, K);
   else {
     // integer division, qcp_config.c:22 -- taken in 64 bits: the reference's 32-bit m * n overflows from m * n = 2^31 on (and divides by
@@ -659,6 +782,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   if (w->bd.upload(w->b, w->stream) || w->cd.upload(w->c, w->stream) || w->Dd.upload(w->D, w->stream) || w->Ed.upload(w->E, w->stream) || w->Ax.alloc(m) ||
       w->ATy.alloc(n) || w->Qx.alloc(n) || w->part.alloc((size_t)2 * Q_COUNT * MAXNB) || w->ctl.alloc(1))
     return bail("work memory allocation failure");
+  if (kind == 1 && (w->sv.Dd.upload(w->sv.D, w->stream) || w->sv.Ed.upload(w->sv.E, w->stream) || w->sv.wEd.upload(w->sv.wE, w->stream))) return bail("work memory allocation failure");
   if (kind == 0 && (w->ls.Dd.upload(w->ls.D, w->stream) || w->ls.Ed.upload(w->ls.E, w->stream) || w->ls.yd.upload(w->ls.y, w->stream))) return bail("work memory allocation failure");
   if (hipMemsetAsync(w->part.p, 0, sizeof(double) * 2 * Q_COUNT * MAXNB, w->stream) != hipSuccess || hipMemsetAsync(w->Qx.p, 0, sizeof(double) * n, w->stream) != hipSuccess ||
       hipMemsetAsync(w->ctl.p, 0, sizeof(QCtl), w->stream) != hipSuccess || hipHostMalloc((void **)&w->hctl, sizeof(QCtl), hipHostMallocDefault) != hipSuccess)
@@ -730,7 +854,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   QResid r;
   info->status_val = 0;
   double tol_inner = 4 * std::pow(w->mu, st->psi);
-  const QDims dm{m, n, w->MP, w->kind == 0 ? 1 : 0};
+  const QDims dm{m, n, w->MP, w->kind == 0 ? 1 : (w->kind == 1 ? 2 : 0)};
   int i = 0, j = 0, k = 0;
   bool finished = false;
   auto get_solution = [&](int ipm_iter, int admm_iter) -> int { // abip.c:559-587
@@ -763,6 +887,14 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       const LassoForm &L = w->ls;
       if (!sol->x) sol->x = (qcp_float *)malloc(sizeof(qcp_float) * L.dn);
       for (int jx = 0; jx < L.dn; ++jx) sol->x[jx] = (X[L.dm + 2 + jx] + (-1) * X[L.dm + L.dn + 2 + jx]) * L.E[jx] * (1 / L.sc_b);
+    } else if (kind == 1) { // un_scaling_svm_sol, svm_config.c:410-440: x: w (dn), y: b (1), s: xi (dm)
+      const SvmForm &V = w->sv;
+      if (!sol->x) sol->x = (qcp_float *)malloc(sizeof(qcp_float) * V.dn);
+      if (!sol->y) sol->y = (qcp_float *)malloc(sizeof(qcp_float));
+      if (!sol->s) sol->s = (qcp_float *)malloc(sizeof(qcp_float) * V.dm);
+      for (int q = 0; q < V.dn; ++q) sol->x[q] = (X[V.dn + 2 + q] + (-1) * X[2 * V.dn + 3 + q]) * V.E[q] * (1 / V.sc_b);
+      sol->y[0] = (X[2 * V.dn + 2] - X[3 * V.dn + 3]) * V.E[V.dn] / V.sc_b;
+      for (int q = 0; q < V.dm; ++q) sol->s[q] = X[3 * V.dn + 4 + q] * (1 / (V.sc_b * V.sc_c));
     } else if (kind == 3) { // un_scaling_svmqp_sol, svm_qp_config.c:595-619: x / (E sc_b), then x: w (dn), y: b (1), s: xi (dm)
       const SvmForm &V = w->sv;
       for (int q = 0; q < n; ++q) X[q] /= (w->E[q] * w->sc_b);

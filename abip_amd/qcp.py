@@ -119,8 +119,8 @@ def abip_qcp(data, cones, settings: dict):
 def abip_ml(data, settings: dict):
     """[sol, info] = abip_ml(data, settings)   (src/abip-qcp/mex/abip_ml_mex.c:90-449): the machine-learning front end.
     data: X (sparse), y (dense), lambda; settings.prob_type is mandatory (:266-276).  Served: prob_type 0 (LASSO,
-    min 1/2 |X beta - y|^2 + lambda |beta|_1; sol = {x: beta}) and prob_type 3 (soft-margin SVM as a QP,
-    min 1/2 |w|^2 + 1/(m lambda) sum xi; labels in y).  The gateway builds the cone itself (:315-342)."""
+    min 1/2 |X beta - y|^2 + lambda |beta|_1; sol = {x: beta}), prob_type 1 (soft-margin SVM as an SOCP, min 1/2 |w|^2 + lambda sum xi;
+    labels in y) and prob_type 3 (the same SVM as a QP with C = 1 / (m lambda)).  The gateway builds the cone itself (:315-342)."""
     L = _bind()
     X, y, lam = _get(data, "X"), _get(data, "y"), _get(data, "lambda")
     if X is None:
@@ -138,8 +138,6 @@ def abip_ml(data, settings: dict):
     prob_type = int(settings["prob_type"])
     if prob_type not in (0, 1, 3):
         raise ValueError("Invalid problem type")
-    if prob_type == 1:
-        raise NotImplementedError("This type of machine learning problem is not supported yet")  # SVM as an SOCP (svm_config.c): not built
     (keep, Xm) = _csc(X)
     m, n = Xm.m, Xm.n
     y = np.array(y, dtype=np.float64, copy=True).ravel()
@@ -158,6 +156,10 @@ def abip_ml(data, settings: dict):
     if prob_type == 0:                          # :328-331
         K = QCPCone(None, 0, rq.ctypes.data_as(PI), 1, 0, 0, 2 * n)
         sol = QCPSolution(beta.ctypes.data_as(PF), None, None)
+    elif prob_type == 1:                        # SVM-SOCP, :333-336
+        rq[0] = 2 + n
+        K = QCPCone(None, 0, rq.ctypes.data_as(PI), 1, 0, 0, 2 + 2 * m + 2 * n)
+        sol = QCPSolution(beta.ctypes.data_as(PF), b0.ctypes.data_as(PF), xi.ctypes.data_as(PF))
     else:                                       # SVM-QP, :338-342
         K = QCPCone(None, 0, None, 0, n + 1, 0, 2 * m)
         sol = QCPSolution(beta.ctypes.data_as(PF), b0.ctypes.data_as(PF), xi.ctypes.data_as(PF))

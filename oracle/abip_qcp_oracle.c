@@ -66,10 +66,10 @@ static void sp_accum_At(const QCPMatrix *A, const F *x, F *y) { /* y += A' x, li
 }
 
 /* ---- work ---------------------------------------------------------------------------------------------- */
-struct OrcLasso; struct OrcSvmqp;
+struct OrcLasso; struct OrcSvmqp; struct OrcSvm;
 typedef struct {
-  int kind;               /* enum problem_type as abip() maps prob_type (abip.c:1341-1348): 0 LASSO (lasso_config.c), 2 generic QCP (qcp_config.c), 3 SVM-QP (svm_qp_config.c) */
-  struct OrcLasso *ls; struct OrcSvmqp *sq;
+  int kind;               /* enum problem_type as abip() maps prob_type (abip.c:1341-1348): 0 LASSO (lasso_config.c), 1 SVM-SOCP (svm_config.c), 2 generic QCP (qcp_config.c), 3 SVM-QP (svm_qp_config.c) */
+  struct OrcLasso *ls; struct OrcSvmqp *sq; struct OrcSvm *sv;
   I m, n;
   const QCPSettings *stgs;
   QCPMatrix A, Q; int hasQ;
@@ -529,10 +529,181 @@ static void solve_svmqp_linsys(QW *w, F *b) { /* :878-973, the direct branch */
 }
 static void free_svmqp(QW *w) { OrcSvmqp *s = w->sq; if (!s) return; free(s->Fd); free(s->H); free(s->chol); free(s); w->sq = 0; }
 
+/* ==== SVM as an SOCP, svm_config.c ===========================================================================================
+ * data: X (dm x dn), labels y, lambda (= C).  x = (x0, x1, r (dn), w+ (dn), b+, w- (dn), b-, xi (dm), t (dm)); (x0, x1, r) in one rotated
+ * cone of dn + 2, the rest >= 0; p = dm + dn + 1 rows (init_svm, :8-171):
+ *   row 0: x0 = const;  rows 1..dm: diag(y)(X (w+ - w-) + (b+ - b-)) + xi - t = 1;  rows dm+1..: r tied to w+ - w-;  cost x1 + C 1'xi.
+ * Operator matrix-free (:177-229); KKT solve by the block elimination of :736-800 with a dense Cholesky for its reduced system.
+ * The scale constants of :63-107 are a table of heuristics in (dm, dn, lambda); two of its corners read uninitialised memory in the
+ * reference (dm == 10 dn or 10 dm == dn: no branch taken; dm > 10 dn with dn < 10: sc_cone2 never assigned) -- see svm_constants. */
+typedef struct OrcSvm {
+  I dm, dn; F lambda, sc, sc_b, sc_c, sc_cone1, sc_cone2;
+  QCPMatrix A0;          /* data_A = [diag(y) X, y], dm x (dn + 1), un-scaled (:109-133) */
+  QCPMatrix A;           /* its scaled copy */
+  QCPMatrix wX;          /* first dn columns of A, column i times -2 wE_i (:384-390) */
+  F *sc_D, *sc_E, *sc_F, *wy, *wB, *wC, *wD, *wE, *wF, *wG, *wH;
+  I cn; F *chol;
+} OrcSvm;
+static void svm_constants(I m, I n, F lambda, F *sc, F *sc_b, F *sc_c, F *sc_cone1, F *sc_cone2) { /* :63-107 */
+  const F l2 = log(2 * lambda) / log(10), l5 = log(5 * lambda) / log(10);
+  *sc = 1; *sc_b = 1;
+  if ((m < 10 * n) && (10 * m > n)) {
+    *sc_c = MAXF(0.45, pow(7.5, -l2) * 2); *sc_cone1 = MAXF(3, l2 * 4 + 4); *sc_cone2 = *sc_cone1;
+  } else if (10 * m <= n) { /* (reference: 10 m < n; equality is left undefined there) */
+    *sc_cone2 = MAXF(3, l2 * 2 + 2);
+    if (lambda >= 1) { *sc_c = MAXF(0.2, pow(0.2, l2) * 7.5); *sc_cone1 = *sc_cone2; }
+    else { *sc_c = pow(0.3, l2) * 3; *sc_cone1 = MAXF(0.4, l2 * 0.2 + 0.8); }
+  } else { /* m >= 10 n (reference: m > 10 n) */
+    if (n < 10) {
+      *sc_c = 1 / lambda; *sc_cone1 = 6; *sc_cone2 = 6; /* (sc_cone2 is read before it is ever written in the reference, :85-89: taken as sc_cone1) */
+      if (lambda < 0.002) *sc_cone2 = *sc_cone2 - 3 * log(lambda * 500) / log(10);
+    } else if (lambda >= 1) { *sc_c = 1 / lambda; *sc_cone1 = 6; *sc_cone2 = lambda; }
+    else {
+      *sc_c = MINF(pow(5, -l5) * 4, 300); *sc_b = MAXF(0.1, l5 * 0.2 + 0.9); *sc_cone1 = MAXF(0.05, l5 * 0.3 + 0.7); *sc_cone2 = -l5 * 2 + 6;
+      if (lambda < 0.002) *sc_cone2 = *sc_cone2 - 3 * log(lambda * 500) / log(10);
+    }
+  }
+}
+static void svm_A_times(QW *w, const F *x, F *y) { /* :177-199 */
+  const OrcSvm *s = w->sv; const I m = s->dm, n = s->dn;
+  y[0] += x[0];
+  F *tmp = (F *)malloc(sizeof(F) * (n + 1));
+  for (I i = 0; i < n; ++i) tmp[i] = x[n + 2 + i] + (-1) * x[2 * n + 3 + i];
+  tmp[n] = 0;
+  { QCPMatrix wA = s->A; wA.n = n; sp_accum_A(&wA, tmp, &y[1]); }
+  const F db = x[2 * n + 2] - x[3 * n + 3];
+  for (I i = 0; i < m; ++i) y[1 + i] += db * s->wy[i];
+  for (I i = 0; i < m; ++i) y[i + 1] += (s->wB[i] * x[i + 3 * n + 4] - s->wC[i] * x[i + 3 * n + 4 + m]);
+  for (I i = 0; i < n; ++i) y[i + 1 + m] += (s->wD[i] * x[i + 2] - s->wE[i] * tmp[i]);
+  free(tmp);
+}
+static void svm_AT_times(QW *w, const F *x, F *y) { /* :205-229 */
+  const OrcSvm *s = w->sv; const I m = s->dm, n = s->dn;
+  y[0] += x[0];
+  for (I i = 0; i < n; ++i) y[i + 2] += s->wD[i] * x[i + m + 1];
+  F *tmp = (F *)malloc(sizeof(F) * n);
+  for (I i = 0; i < n; ++i) tmp[i] = -s->wE[i] * x[i + m + 1];
+  { QCPMatrix wA = s->A; wA.n = n; sp_accum_At(&wA, &x[1], tmp); }
+  for (I i = 0; i < n; ++i) { y[n + 2 + i] += tmp[i]; y[2 * n + 3 + i] += -tmp[i]; }
+  const F dt = v_dot(s->wy, &x[1], m);
+  y[2 * n + 2] += dt; y[3 * n + 3] -= dt;
+  for (I i = 0; i < m; ++i) { y[i + 3 * n + 4] += s->wB[i] * x[i + 1]; y[i + 3 * n + 4 + m] -= s->wC[i] * x[i + 1]; }
+  free(tmp);
+}
+static void init_svm(QW *w, const QCPData *d) { /* :8-171 */
+  OrcSvm *s = (OrcSvm *)calloc(1, sizeof(OrcSvm));
+  const I m = d->m, n = d->n, nnz = d->A->p[n];
+  w->sv = s; w->kind = 1; s->dm = m; s->dn = n; s->lambda = d->lambda;
+  w->m = m + n + 1; w->n = 4 + 3 * n + 2 * m;
+  w->sparsity = (((F)nnz / ((F)m * n)) < 0.05);
+  svm_constants(m, n, s->lambda, &s->sc, &s->sc_b, &s->sc_c, &s->sc_cone1, &s->sc_cone2);
+  QCPMatrix *B = &s->A0;
+  B->m = m; B->n = n + 1; B->p = (I *)malloc(sizeof(I) * (n + 2)); B->i = (I *)malloc(sizeof(I) * (nnz + m)); B->x = (F *)malloc(sizeof(F) * (nnz + m));
+  memcpy(B->p, d->A->p, sizeof(I) * (n + 1)); B->p[n + 1] = nnz + m;
+  memcpy(B->i, d->A->i, sizeof(I) * nnz);
+  for (I k = 0; k < nnz; ++k) B->x[k] = d->A->x[k] * d->b[d->A->i[k]];
+  for (I i = 0; i < m; ++i) { B->i[nnz + i] = i; B->x[nnz + i] = d->b[i]; }
+  s->sc_D = (F *)calloc(m, sizeof(F)); s->sc_E = (F *)calloc(n + 1, sizeof(F)); s->sc_F = (F *)calloc(n, sizeof(F));
+  s->wy = (F *)malloc(sizeof(F) * m); s->wB = (F *)malloc(sizeof(F) * m); s->wC = (F *)malloc(sizeof(F) * m); s->wF = (F *)malloc(sizeof(F) * m);
+  s->wD = (F *)malloc(sizeof(F) * n); s->wE = (F *)malloc(sizeof(F) * n); s->wG = (F *)malloc(sizeof(F) * n); s->wH = (F *)malloc(sizeof(F) * (n + 1));
+}
+static void scaling_svm_data(QW *w) { /* :281-391 */
+  OrcSvm *s = w->sv; const I m = s->dm, n1 = s->dn + 1, n = s->dn;
+  copy_mat(&s->A, &s->A0);
+  QCPMatrix *A = &s->A; F *E = s->sc_E, *D = s->sc_D;
+  F avg = 0;
+  if (w->stgs->scale_E) {
+    for (I i = 0; i < n1; ++i) { for (I j = A->p[i]; j < A->p[i + 1]; ++j) E[i] += A->x[j] * A->x[j]; E[i] = sqrt(E[i]); avg += E[i]; }
+    avg /= n1;
+    for (I i = 0; i < n1; ++i) E[i] = avg / E[i];
+    for (I i = 0; i < n1; ++i) for (I j = A->p[i]; j < A->p[i + 1]; ++j) A->x[j] *= E[i];
+  }
+  for (I q = 0; q < A->p[n1]; ++q) D[A->i[q]] += A->x[q] * A->x[q];
+  avg = 0;
+  for (I i = 0; i < m; ++i) avg += sqrt(D[i]);
+  avg /= m;
+  for (I i = 0; i < m; ++i) D[i] = avg / sqrt(D[i]);
+  for (I q = 0; q < A->p[n1]; ++q) A->x[q] *= D[A->i[q]];
+  for (I i = 0; i < n; ++i) s->sc_F[i] = 1 / sqrt(1 + 2 * E[i] * E[i]);
+  memset(w->b, 0, sizeof(F) * w->m);
+  w->b[0] = s->sc_cone2;
+  for (I i = 1; i < m + 1; ++i) w->b[i] = D[i - 1];
+  for (I i = 0; i < w->m; ++i) w->b[i] *= s->sc_b;
+  memset(w->c, 0, sizeof(F) * w->n);
+  w->c[1] = s->sc_c * s->sc_cone1 * s->sc_cone2;
+  for (I i = 0; i < m; ++i) w->c[i + 4 + 3 * n] = s->lambda * s->sc_c / s->sc;
+  memcpy(s->wy, &A->x[A->p[n]], sizeof(F) * m); /* the label column: dense, rows 0..dm-1 in order */
+  for (I i = 0; i < m; ++i) { s->wB[i] = D[i] * (1 / s->sc); s->wC[i] = D[i]; }
+  for (I i = 0; i < n; ++i) { s->wD[i] = s->sc_F[i] * -sqrt(s->sc_cone1); s->wE[i] = E[i] * s->sc_F[i]; }
+  for (I i = 0; i < m; ++i) s->wF[i] = s->wB[i] * s->wB[i] + s->wC[i] * s->wC[i] + w->stgs->rho_y;
+  for (I i = 0; i < n; ++i) s->wG[i] = s->wD[i] * s->wD[i] + 2 * s->wE[i] * s->wE[i] + w->stgs->rho_y;
+  for (I i = 0; i < n; ++i) s->wH[i] = 2 - 4 / s->wG[i] * s->wE[i] * s->wE[i];
+  s->wH[n] = 2;
+  copy_mat(&s->wX, &s->A); s->wX.n = n;
+  for (I i = 0; i < n; ++i) for (I j = s->wX.p[i]; j < s->wX.p[i + 1]; ++j) s->wX.x[j] *= (-2 * s->wE[i]);
+}
+/* form_svm_kkt (:566-634) dense: dm > dn + 1: diag(1 / wH) + A' wF^-1 A ((dn+1)^2), else wF + A diag(wH) A' (dm^2) */
+static int init_svm_linsys(QW *w) {
+  OrcSvm *s = w->sv; const I m = s->dm, n1 = s->dn + 1; const QCPMatrix *A = &s->A;
+  const I cn = m > n1 ? n1 : m; s->cn = cn;
+  F *Ad = (F *)calloc((size_t)m * n1, sizeof(F)), *G = (F *)calloc((size_t)cn * cn, sizeof(F));
+  for (I j = 0; j < n1; ++j) for (I t = A->p[j]; t < A->p[j + 1]; ++t) Ad[(size_t)A->i[t] * n1 + j] = A->x[t];
+  if (m > n1) {
+    for (I i = 0; i < m; ++i) { const F *row = &Ad[(size_t)i * n1]; const F fi = 1 / s->wF[i];
+      for (I a = 0; a < n1; ++a) { if (row[a] == 0) continue; const F t = row[a] * fi; for (I c2 = 0; c2 <= a; ++c2) G[(size_t)a * cn + c2] += t * row[c2]; } }
+    for (I a = 0; a < n1; ++a) G[(size_t)a * cn + a] += 1 / s->wH[a];
+  } else {
+    for (I a = 0; a < m; ++a) for (I c2 = 0; c2 <= a; ++c2) { F t = 0; const F *ra = &Ad[(size_t)a * n1], *rb = &Ad[(size_t)c2 * n1]; for (I j = 0; j < n1; ++j) t += ra[j] * s->wH[j] * rb[j]; G[(size_t)a * cn + c2] = t; }
+    for (I a = 0; a < m; ++a) G[(size_t)a * cn + a] += s->wF[a];
+  }
+  for (I a = 0; a < cn; ++a) for (I c2 = 0; c2 <= a; ++c2) {
+    F t = G[(size_t)a * cn + c2];
+    for (I kk = 0; kk < c2; ++kk) t -= G[(size_t)a * cn + kk] * G[(size_t)c2 * cn + kk];
+    if (a == c2) { if (t <= 0) { free(Ad); free(G); return -1; } G[(size_t)a * cn + a] = sqrt(t); } else G[(size_t)a * cn + c2] = t / G[(size_t)c2 * cn + c2];
+  }
+  s->chol = G; free(Ad);
+  return 0;
+}
+static void solve_svm_linsys(QW *w, F *b) { /* :725-806, the direct branch */
+  OrcSvm *s = w->sv; const I m = s->dm, n = s->dn, p = w->m, q = w->n;
+  for (I j = 0; j < q; ++j) b[p + j] *= -1;
+  F *b2 = (F *)malloc(sizeof(F) * p), *b3 = (F *)malloc(sizeof(F) * m), *tmp = (F *)malloc(sizeof(F) * (n + 1));
+  memcpy(b2, b, sizeof(F) * p);
+  svm_A_times(w, &b[p], b2);
+  b[0] = b2[0] / (1 + w->stgs->rho_y);
+  for (I i = 0; i < n; ++i) b[i + m + 1] = b2[i + m + 1] / s->wG[i];
+  for (I i = 0; i < m; ++i) b3[i] = -b2[1 + i];
+  sp_accum_A(&s->wX, &b[m + 1], b3);
+  for (I i = 0; i < m; ++i) b3[i] *= -1;
+  if (m > n + 1) {
+    for (I i = 0; i < m; ++i) b3[i] /= s->wF[i];
+    memset(tmp, 0, sizeof(F) * (n + 1));
+    sp_accum_At(&s->A, b3, tmp);
+    dense_chol_solve(s->cn, s->chol, tmp);
+    F *t2 = (F *)calloc(m, sizeof(F));
+    sp_accum_A(&s->A, tmp, t2);
+    for (I i = 0; i < m; ++i) { t2[i] /= s->wF[i]; b[1 + i] = b3[i] + (-1) * t2[i]; }
+    free(t2);
+  } else { dense_chol_solve(s->cn, s->chol, b3); memcpy(&b[1], b3, sizeof(F) * m); }
+  memset(tmp, 0, sizeof(F) * (n + 1));
+  sp_accum_At(&s->wX, &b[1], tmp);
+  for (I i = 0; i < n; ++i) { tmp[i] /= s->wG[i]; b[m + 1 + i] += -tmp[i]; }
+  free(b2); free(b3); free(tmp);
+  for (I j = 0; j < q; ++j) b[p + j] *= -1;
+  svm_AT_times(w, b, &b[p]);
+}
+static void free_mat(QCPMatrix *M) { free(M->x); free(M->i); free(M->p); M->x = 0; M->i = 0; M->p = 0; }
+static void free_svm(QW *w) {
+  OrcSvm *s = w->sv; if (!s) return;
+  free_mat(&s->A0); free_mat(&s->A); free_mat(&s->wX);
+  free(s->sc_D); free(s->sc_E); free(s->sc_F); free(s->wy); free(s->wB); free(s->wC); free(s->wD); free(s->wE); free(s->wF); free(s->wG); free(s->wH); free(s->chol); free(s);
+  w->sv = 0;
+}
+
 /* operator and KKT solve of the formulation in use */
-static void op_A(QW *w, const F *x, F *y) { if (w->kind == 0) lasso_A_times(w, x, y); else if (w->kind == 3) svmqp_A_times(w, x, y); else sp_accum_A(&w->A, x, y); }
-static void op_At(QW *w, const F *x, F *y) { if (w->kind == 0) lasso_AT_times(w, x, y); else if (w->kind == 3) svmqp_AT_times(w, x, y); else sp_accum_At(&w->A, x, y); }
-static void solve_spe_linsys(QW *w, F *b) { if (w->kind == 0) solve_lasso_linsys(w, b); else if (w->kind == 3) solve_svmqp_linsys(w, b); else solve_qcp_linsys(w, b); }
+static void op_A(QW *w, const F *x, F *y) { if (w->kind == 0) lasso_A_times(w, x, y); else if (w->kind == 1) svm_A_times(w, x, y); else if (w->kind == 3) svmqp_A_times(w, x, y); else sp_accum_A(&w->A, x, y); }
+static void op_At(QW *w, const F *x, F *y) { if (w->kind == 0) lasso_AT_times(w, x, y); else if (w->kind == 1) svm_AT_times(w, x, y); else if (w->kind == 3) svmqp_AT_times(w, x, y); else sp_accum_At(&w->A, x, y); }
+static void solve_spe_linsys(QW *w, F *b) { if (w->kind == 0) solve_lasso_linsys(w, b); else if (w->kind == 1) solve_svm_linsys(w, b); else if (w->kind == 3) solve_svmqp_linsys(w, b); else solve_qcp_linsys(w, b); }
 
 /* ---- cones.c:130-288 ------------------------------------------------------------------------------------ */
 static void orthant_prox(F *x, const F *t, F lambda, I n) { /* :279-288 */
@@ -651,7 +822,23 @@ static void solve_barrier_subproblem(QW *w, const QCPCone *c) { /* abip.c:326-41
   if (c->z) { for (I i = 0; i < c->z; ++i) w->u[m + count + i] = 0; count += c->z; }
   if (c->l) { orthant_prox(&w->u[m + count], &tmp[m + count], lambda / w->rho_dr[m + count], c->l); count += c->l; }
 }
+static F svm_inner_conv_check(QW *w) { /* svm_config.c:234-276 */
+  const I m = w->m, n = w->n; const long l = (long)m + n + 1;
+  const F *y = w->u, *x = &w->u[m], *sv = &w->v_origin[m];
+  const F tau = w->u[l - 1], kap = w->v_origin[l - 1];
+  F *row1 = (F *)malloc(sizeof(F) * m), *row2 = (F *)malloc(sizeof(F) * n);
+  for (I i = 0; i < m; ++i) row1[i] = w->b[i] * -tau;
+  svm_A_times(w, x, row1);
+  for (I j = 0; j < n; ++j) row2[j] = sv[j] + (-tau) * w->c[j];
+  svm_AT_times(w, y, row2);
+  for (I j = 0; j < n; ++j) row2[j] *= -1;
+  const F last = v_dot(w->b, y, m) - v_dot(w->c, x, n) - kap;
+  const F err = sqrt(v_nrm2sq(row1, m) + v_nrm2sq(row2, n) + last * last) / (1 + sqrt(v_nrm2sq(w->u, l) + v_nrm2sq(w->v_origin, l)));
+  free(row1); free(row2);
+  return err;
+}
 static F inner_conv_check(QW *w) { /* qcp_config.c:518-557, lasso_config.c:312-353 */
+  if (w->kind == 1) return svm_inner_conv_check(w);
   const I m = w->m, n = w->n; const long mn = (long)m + n;
   F *Qu = (F *)malloc(sizeof(F) * (mn + 1)), *Mu = (F *)calloc(mn, sizeof(F));
   op_A(w, &w->u[m], Mu);
@@ -708,8 +895,49 @@ static void calc_lasso_residuals(QW *w, QR *r, I ipm_iter, I admm_iter) { /* las
   else r->res_infeas = INFINITY;
   free(x); free(bp); free(bm); free(z); free(s1); free(s2); free(pr); free(dr1); free(dr2);
 }
+static void calc_svm_residuals(QW *w, QR *r, I ipm_iter, I admm_iter) { /* svm_config.c:445-561 */
+  OrcSvm *s = w->sv; const I p = w->m, q = w->n, m = s->dm, n = s->dn; const F C = s->lambda;
+  r->tau = w->u[p + q];
+  const F tau = r->tau;
+  F *w1 = (F *)malloc(sizeof(F) * (n + 1)), *xi = (F *)malloc(sizeof(F) * m), *t = (F *)malloc(sizeof(F) * m), *y = (F *)malloc(sizeof(F) * m);
+  F *s1 = (F *)malloc(sizeof(F) * m), *s2 = (F *)malloc(sizeof(F) * m), *pr = (F *)malloc(sizeof(F) * m), *BTy = (F *)calloc(n, sizeof(F));
+  for (I i = 0; i < n; ++i) w1[i] = (w->u[m + 2 * n + 3 + i] + (-1) * w->u[m + 3 * n + 4 + i]) * (s->sc_E[i] / (tau * s->sc_b));
+  w1[n] = (w->u[m + 3 * n + 3] - w->u[m + 4 * n + 4]) / tau * s->sc_E[n] / s->sc_b;
+  for (I i = 0; i < m; ++i) {
+    xi[i] = w->u[m + 4 * n + 5 + i] * (1 / (tau * s->sc * s->sc_b));
+    t[i] = w->u[2 * m + 4 * n + 5 + i] * (1 / (tau * s->sc_b));
+    y[i] = w->u[1 + i] / tau * s->sc_D[i] / s->sc_c;
+    s2[i] = w->v[2 * m + 4 * n + 5 + i] * (1 / (tau * s->sc_c));
+    s1[i] = w->v[m + 4 * n + 5 + i] * (s->sc / (tau * s->sc_c));
+  }
+  memcpy(pr, xi, sizeof(F) * m);
+  sp_accum_A(&s->A0, w1, pr);
+  for (I i = 0; i < m; ++i) pr[i] -= (t[i] + 1);
+  const F this_pr = v_nrm2(pr, m) / sqrt((F)m);
+  F drs = 0;
+  for (I i = 0; i < m; ++i) { const F a = y[i] - s2[i], b2 = y[i] + s1[i] - C; drs += a * a; (void)b2; }
+  for (I i = 0; i < m; ++i) { const F b2 = y[i] + s1[i] - C; drs += b2 * b2; }
+  const F this_dr = sqrt(drs) / (sqrt((F)m) * C);
+  { QCPMatrix B = s->A0; B.n = n; sp_accum_At(&B, y, BTy); }
+  r->dobj = 0; r->pobj = 0;
+  for (I i = 0; i < m; ++i) { r->dobj += y[i]; r->pobj += C * xi[i]; }
+  r->pobj += 0.5 * v_dot(w1, w1, n);
+  r->dobj -= 0.5 * v_dot(BTy, BTy, n);
+  const F this_gap = ABSF(r->dobj - r->pobj) / (1 + ABSF(r->pobj));
+  r->last_ipm_iter = ipm_iter; r->last_admm_iter = admm_iter;
+  r->res_dif = MAXF(MAXF(ABSF(this_pr - r->res_pri), ABSF(this_dr - r->res_dual)), ABSF(this_gap - r->rel_gap));
+  r->res_pri = this_pr; r->res_dual = this_dr; r->rel_gap = this_gap;
+  r->error_ratio = MAXF(r->res_pri / w->stgs->eps_p, MAXF(r->res_dual / w->stgs->eps_d, r->rel_gap / w->stgs->eps_g));
+  const F ctu = v_dot(w->c, &w->u[p], q), btu = v_dot(w->b, w->u, p);
+  if (ctu < 0) { F *Ax = (F *)calloc(p, sizeof(F)); svm_A_times(w, &w->u[p], Ax); r->res_unbdd = v_nrm2(Ax, p) / (-ctu); free(Ax); }
+  else r->res_unbdd = INFINITY;
+  if (btu > 0) { F *tq = (F *)calloc(q, sizeof(F)); svm_AT_times(w, w->u, tq); for (I j = 0; j < q; ++j) tq[j] += w->v_origin[p + j]; r->res_infeas = v_nrm2(tq, q) / btu; free(tq); }
+  else r->res_infeas = INFINITY;
+  free(w1); free(xi); free(t); free(y); free(s1); free(s2); free(pr); free(BTy);
+}
 static void calc_residuals(QW *w, QR *r, I ipm_iter, I admm_iter) { /* qcp_config.c:562-691 */
   if (w->kind == 0) { calc_lasso_residuals(w, r, ipm_iter, admm_iter); return; }
+  if (w->kind == 1) { calc_svm_residuals(w, r, ipm_iter, admm_iter); return; }
   const I n = w->n, m = w->m;
   if (admm_iter && r->last_admm_iter == admm_iter) return;
   r->last_ipm_iter = ipm_iter; r->last_admm_iter = admm_iter;
@@ -818,6 +1046,14 @@ static void get_solution(QW *w, QCPSolution *sol, QCPInfo *info, const QR *r, I 
     for (I j = 0; j < ls->dn; ++j) beta[j] = (sol->x[ls->dm + 2 + j] + (-1) * sol->x[ls->dm + ls->dn + 2 + j]) * ls->E[j] * (1 / ls->sc_b);
     memcpy(sol->x, beta, sizeof(F) * ls->dn);
     free(beta);
+  } else if (w->stgs->normalize && w->kind == 1) { /* un_scaling_svm_sol, svm_config.c:410-440 */
+    const OrcSvm *sv = w->sv; const I dn = sv->dn, dm = sv->dm;
+    F *wv = (F *)malloc(sizeof(F) * dn), *xi = (F *)malloc(sizeof(F) * dm);
+    for (I j = 0; j < dn; ++j) wv[j] = (sol->x[dn + 2 + j] + (-1) * sol->x[2 * dn + 3 + j]) * sv->sc_E[j] * (1 / sv->sc_b);
+    const F bb = (sol->x[2 * dn + 2] - sol->x[3 * dn + 3]) * sv->sc_E[dn] / sv->sc_b;
+    for (I i = 0; i < dm; ++i) xi[i] = sol->x[3 * dn + 4 + i] * (1 / (sv->sc_b * sv->sc_c));
+    memcpy(sol->x, wv, sizeof(F) * dn); sol->y[0] = bb; memcpy(sol->s, xi, sizeof(F) * dm);
+    free(wv); free(xi);
   } else if (w->stgs->normalize && w->kind == 3) { /* un_scaling_svmqp_sol, svm_qp_config.c:595-619: x / (E sc_b) -> w = x[0:dn], b = x[dn], xi = x[dn+1 : dn+1+dm] */
     const OrcSvmqp *sq = w->sq;
     for (I j = 0; j < n; ++j) sol->x[j] /= (w->E[j] * w->sc_b);
@@ -857,8 +1093,8 @@ I orc_qcp_trace_count(void) { return g_trace_n; }
 
 qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) { /* abip(), abip.c:1335-1371 */
   const int lasso = d && d->stgs && d->stgs->prob_type == 0; /* abip.c:1341-1348: 0 LASSO, 1 SVM, 2 QCP, 3 SVMQP */
-  const int svmqp = d && d->stgs && d->stgs->prob_type == 3;
-  const int ml = lasso || svmqp;
+  const int svmqp = d && d->stgs && d->stgs->prob_type == 3, svm = d && d->stgs && d->stgs->prob_type == 1;
+  const int ml = lasso || svmqp || svm;
   if (!d || !sol || !info || !K || !d->A || !d->b || (!ml && !d->c) || (d->stgs->linsys_solver != 1 && d->stgs->linsys_solver != 3) ||
       (d->stgs->prob_type != 2 && !ml) || (ml && (d->stgs->linsys_solver != 1 || !(d->lambda > 0)))) {
     if (info) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); }
@@ -869,6 +1105,7 @@ qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone
   w->kind = 2; w->stgs = d->stgs;
   F *sq_b = 0, *sq_c = 0;
   if (lasso) init_lasso(w, d);
+  else if (svm) init_svm(w, d);
   else if (svmqp) { sq_b = (F *)malloc(sizeof(F) * d->m); sq_c = (F *)malloc(sizeof(F) * (1 + d->n + 2 * d->m)); init_svmqp(w, d, sq_b, sq_c); }
   else { w->m = d->m; w->n = d->n; }
   const I m = w->m, n = w->n; const long l = (long)m + n + 1;
@@ -893,11 +1130,12 @@ qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone
   w->u = (F *)calloc(l, sizeof(F)); w->v = (F *)calloc(l, sizeof(F)); w->v_origin = (F *)calloc(l, sizeof(F)); w->u_t = (F *)calloc(l, sizeof(F));
   w->rel_ut = (F *)calloc(l, sizeof(F)); w->r = (F *)calloc(l, sizeof(F));
   if (lasso) scaling_lasso_data(w); /* (nm_inf_b / nm_inf_c, abip.c:875-876, are not used by the LASSO residuals) */
+  else if (svm) scaling_svm_data(w);
   else if (svmqp) { w->nm_inf_b = v_nrminf(sq_b, m); w->nm_inf_c = v_nrminf(sq_c, n); scaling_svmqp_data(w, sq_b, sq_c, K); free(sq_b); free(sq_c); }
   else { w->nm_inf_b = v_nrminf(d->b, m); w->nm_inf_c = v_nrminf(d->c, n); scaling_qcp_data(w, d, K); }
   w->last_Ax_b_norm = INFINITY; w->last_Qx_norm = INFINITY;
   if (d->stgs->linsys_solver == 3) { if (init_qcp_pcg(w) < 0) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED; } if (getenv("ORC_QCP_PCG_CHECK")) init_kkt(w); }
-  else if ((lasso ? init_lasso_linsys(w) : svmqp ? init_svmqp_linsys(w) : init_kkt(w)) < 0) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED; }
+  else if ((lasso ? init_lasso_linsys(w) : svm ? init_svm_linsys(w) : svmqp ? init_svmqp_linsys(w) : init_kkt(w)) < 0) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED; }
   info->setup_time = now_ms() - t_init;
   const double t0 = now_ms();
   QR R; memset(&R, 0, sizeof(R)); QR *r = &R;
@@ -951,7 +1189,7 @@ qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone
 done:
   info->avg_linsys_time = 0; info->avg_cg_iters = w->cg_solves ? (F)w->tot_cg / (F)w->cg_solves : 0;
   free(w->Mpre); free(w->Hinv);
-  free_lasso(w); free_svmqp(w);
+  free_lasso(w); free_svmqp(w); free_svm(w);
   free(w->rho_dr); free(w->A.x); free(w->A.i); free(w->A.p);
   if (w->hasQ) { free(w->Q.x); free(w->Q.i); free(w->Q.p); }
   free(w->b); free(w->c); free(w->D); free(w->E); free(w->u); free(w->v); free(w->v_origin); free(w->u_t); free(w->rel_ut); free(w->r);

@@ -157,6 +157,24 @@ def solve_svmqp(X, y, lam: float, **settings):
     return P.x[:n].copy(), float(P.y[0]), P.s[:m].copy(), P.info_dict()
 
 
+def solve_svm(X, y, C_: float, **settings):
+    """Soft-margin SVM min 1/2 |w|^2 + C sum xi through the SOCP reformulation (prob_type 1, svm_config.c; data.lambda = C,
+    scripts/bench-qcp/test_svm.m:95-102); returns (w, b, xi, info).  Cone as abip_ml_mex.c:333-336: rq = [n + 2], l = 2 + 2 m + 2 n."""
+    L = lib()
+    X = sp.csc_matrix(X)
+    m, n = X.shape
+    settings.setdefault("linsys_solver", 1)
+    P = Problem(X, y, np.zeros(n), {"rq": [n + 2], "l": 2 + 2 * m + 2 * n}, set_defaults=L.orc_qcp_set_default_settings, verbose=0, **settings)
+    P.stgs.prob_type = 1
+    P.data.lambda_ = float(C_)
+    P.data.c = None
+    q, p_ = 4 + 3 * n + 2 * m, m + n + 1
+    P.x = np.full(q, np.nan); P.y = np.full(p_, np.nan); P.s = np.full(q, np.nan)
+    P.sol = QCPSolution(P.x.ctypes.data_as(PF), P.y.ctypes.data_as(PF), P.s.ctypes.data_as(PF))
+    L.orc_qcp_solve(C.byref(P.data), C.byref(P.sol), C.byref(P.info), C.byref(P.cone))
+    return P.x[:n].copy(), float(P.y[0]), P.s[:m].copy(), P.info_dict()
+
+
 def cone_prox(kind: int, tmp, lam: float, x_prev=None):
     """Barrier prox of one cone (cones.c:130-288): kind 0 SOC, 1 rotated SOC, 2 orthant."""
     L = lib()
