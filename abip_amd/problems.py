@@ -171,17 +171,34 @@ def lp_random_sparse(m: int = 200_000, n: int = 500_000, per_col: int = 16, seed
     return A, np.ascontiguousarray(b), np.ascontiguousarray(c)
 
 
+def lasso_data(p: int = 10_000, d: int = 45_000, density: float = 0.005, seed: int = 5):
+    """(X, y, lambda) of config C5: scripts/bench-qcp/get_lasso_simu_data.m:3-14 (sparse Gaussian X, v_i ~ N(0, 1/d) w.p. 1/2,
+    y = X v + noise, lambda = ||X'y||_inf / 5) -- what the LASSO front end (abip_ml, prob_type 0) takes as it stands."""
+    rng = np.random.default_rng(seed)
+    X = sp.random(p, d, density=density, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+    v = rng.standard_normal(d) / np.sqrt(d) * (rng.random(d) < 0.5)
+    y = X @ v + 0.01 * rng.standard_normal(p)
+    return X, y, float(np.abs(X.T @ y).max() / 5)
+
+
+def lasso_protocol_data(m: int = 5000, n: int = 15000, seed: int = 1, density: float = 0.15):
+    """(X, y, lambda) of the reference's own LASSO benchmark (scripts/bench-qcp/test_lasso.m:39-44 sizes 1000..5000 x 5000..15000,
+    get_lasso_simu_data.m:3-14): sprandn-like X of density 0.15, v_i ~ N(0, 1/n) w.p. 1/2, y = X v + N(0, 1), lambda = |X'y|_inf / 5.
+    (Matlab's rng stream is not reproducible here: numpy default_rng(seed).)"""
+    rng = np.random.default_rng(seed)
+    X = sp.random(m, n, density=density, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+    v = np.where(rng.random(n) > 0.5, rng.standard_normal(n) / n, 0.0)
+    y = X @ v + rng.standard_normal(m)
+    return X, y, float(np.abs(X.T @ y).max() / 5)
+
+
 def qcp_lasso_socp(p: int = 10_000, d: int = 45_000, density: float = 0.005, seed: int = 5):
     """Config C5: LASSO  min 1/2 ||X beta - y||^2 + lam ||beta||_1  as an SOCP for the conic path.
     Data as scripts/bench-qcp/get_lasso_simu_data.m:3-14 (sparse Gaussian X, v_i ~ N(0, 1/d) w.p. 1/2, y = X v + noise,
     lam = ||X'y||_inf / 5).  Variables (q0, q1, z) in SOC(p+2) then (beta+, beta-) >= 0:
         q0 - q1 = 1,   z - X beta+ + X beta- = -y,   minimise 1/2 (q0 + q1) + lam 1'(beta+ + beta-)
     (q0^2 - q1^2 = q0 + q1 >= ||z||^2).  Returns (data dict, cone dict): n = p + 2 + 2d, m = p + 1."""
-    rng = np.random.default_rng(seed)
-    X = sp.random(p, d, density=density, random_state=rng, data_rvs=rng.standard_normal, format="csc")
-    v = rng.standard_normal(d) / np.sqrt(d) * (rng.random(d) < 0.5)
-    y = X @ v + 0.01 * rng.standard_normal(p)
-    lam = float(np.abs(X.T @ y).max() / 5)
+    X, y, lam = lasso_data(p, d, density, seed)
     r1 = sp.hstack([sp.csc_matrix(np.array([[1.0, -1.0]])), sp.csc_matrix((1, p + 2 * d))])
     r2 = sp.hstack([sp.csc_matrix((p, 2)), sp.identity(p), -X, X])
     A = canonical_csc(sp.vstack([r1, r2]))

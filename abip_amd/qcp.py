@@ -169,6 +169,10 @@ def abip_ml(data, settings: dict):
                res_pri=info.res_pri, res_dual=info.res_dual, gap=info.rel_gap, status_val=info.status_val,
                setup_time=info.setup_time / 1e3, solve_time=info.solve_time / 1e3, runtime=(info.setup_time + info.solve_time) / 1e3,
                lin_sys_time_per_iter=info.avg_linsys_time / 1e3, avg_cg_iters=info.avg_cg_iters)
+    st = (C.c_double * 8)()
+    L.abip_hip_qcp_last_stats(st)
+    out["factor"] = dict(N=int(st[0]), dense_tail=int(st[1]), lnnz=int(st[2]), levels=[int(st[3]), int(st[4])], solves_timed=int(st[5]),
+                         solve_ms_total=float(st[6]), head_nnz=int(st[7]))
     if prob_type == 0:
         return dict(x=beta), out
     # (the gateway's own output switch tests prob_type against 2 and 4, abip_ml_mex.c:362, so Matlab receives {x: w} for SVM too;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- ADMM iterations/s of the MI355X-native ABIP-LP hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c4|c2|c3|c5] [--no-to-tol] [--no-cpu] [--no-extra]
+    python bench.py --gpus N --steps K --warmup W [--workload c4|c2|c3|c5|lasso] [--no-to-tol] [--no-cpu] [--no-extra]
 
 One "step" = one inner ADMM iteration of the real solver trajectory (KKT solve incl. all its PCG
 iterations, barrier prox, dual update, averages, stopping test; outer-iteration work -- residuals,
@@ -25,6 +25,8 @@ structure-matched surrogates, labelled as such):
     c5  LASSO-as-SOCP through the conic path (abip_qcp, p=10000 samples, d=45000 features, n=100002), direct LDL' with a dense tail;
         abip_qcp() is one call (the reference's conic entry point has no stepping form), so a step count cannot be imposed:
         one untimed full solve warms up, a second one is timed and `steps` is the number of ADMM iterations it took
+    lasso  the reference's own LASSO benchmark (scripts/bench-qcp/test_lasso.m: 5000 x 15000, density 0.15, eps 1e-3) through the LASSO
+        front end (abip_ml, prob_type 0; lasso_config.c's formulation and scaling) on the conic device path; y-space PCG unless --linsys direct
 On one GPU the default (c4) line also carries short c2 and c3 records under extra.configs (each with its own roofline and cpu_baseline).
 
 Prints ONE JSON line (rank 0).
@@ -168,15 +170,26 @@ def bench_c5(args, rank, world, dist, torch):
     """BASELINE configs[4]: the conic path on LASSO-as-SOCP.  The direct back-end does not shard: N > 1 = N replicas."""
     import numpy as np
     from abip_amd import problems, qcp
-    p, d = 10_000, 45_000
-    data, K = problems.qcp_lasso_socp(p, d)
-    pcg = args.linsys == "indirect"                      # --linsys indirect: the conic PCG back-end (linsys_solver 3, abip_amd/csrc/qcp_pcg.h)
-    stg = dict(eps=1e-3, linsys_solver=3 if pcg else 1, verbose=0)     # eps 1e-3: the reference's LASSO protocol (scripts/bench-qcp/test_lasso.m:11)
-    sol, info0 = qcp.abip_qcp(data, K, stg)               # warm-up: pages the library in, JIT-free but first-touch allocations
+    ml = args.workload == "lasso"                         # the reference's own LASSO benchmark through the LASSO front end (abip_ml, prob_type 0)
+    if ml:
+        p, d = 5000, 15000                                # the largest size of scripts/bench-qcp/test_lasso.m:39-40
+        X, yv, lam = problems.lasso_protocol_data(p, d)
+        pcg = args.linsys != "direct"                     # PCG unless --linsys direct: the direct back-end spends ~13 s in the host LDL' of this KKT matrix
+        stg = dict(prob_type=0, eps=1e-3, linsys_solver=3 if pcg else 1, verbose=0)
+        run = lambda: qcp.abip_ml(dict(X=X, y=yv, **{"lambda": lam}), stg)
+        nnz_op, m_op, n_op = 1 + p + 2 * int(X.nnz), p + 1, 2 + p + 2 * d
+    else:
+        p, d = 10_000, 45_000
+        data, K = problems.qcp_lasso_socp(p, d)
+        pcg = args.linsys == "indirect"                  # --linsys indirect: the conic PCG back-end (linsys_solver 3, abip_amd/csrc/qcp_pcg.h)
+        stg = dict(eps=1e-3, linsys_solver=3 if pcg else 1, verbose=0)     # eps 1e-3: the reference's LASSO protocol (scripts/bench-qcp/test_lasso.m:11)
+        run = lambda: qcp.abip_qcp(data, K, stg)
+        nnz_op = int(data["A"].nnz); m_op, n_op = data["A"].shape
+    sol, info0 = run()                                    # warm-up: pages the library in, JIT-free but first-touch allocations
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    sol, info = qcp.abip_qcp(data, K, stg)
+    sol, info = run()
     torch.cuda.synchronize()
     elapsed = info["solve_time"]                          # seconds inside abip_qcp between set-up (data resident) and get_solution
     if dist is not None:
@@ -194,7 +207,7 @@ def bench_c5(args, rank, world, dist, torch):
                 avg_launch_us=avg_ms * 1e3, launches=f["solves_timed"], algorithmic_bytes_per_launch=bytes_solve, lnnz=lnnz, dense_tail=T,
                 streamed_bytes_per_solve=8 * T * (T + 1) + 12 * f["head_nnz"], levels=f["levels"])
     if pcg:   # one solve = prep + (warm set-up pair) + avg_cg_iters x (A'z, A tn, update) + back-substitution: 2 + 2 + 2 cg + 1 products of the matrix
-        nnzA = int(data["A"].nnz); mA, nA = data["A"].shape
+        nnzA, mA, nA = nnz_op, m_op, n_op
         cg = float(info["avg_cg_iters"])
         bytes_solve = (3 + 2 * cg + 2) * (b_spmv(mA, nA, nnzA) + b_spmv(nA, mA, nnzA)) / 2 + cg * 8 * 8 * mA
         ach = bytes_solve / max(avg_ms * 1e-3, 1e-12) / 1e9
@@ -202,7 +215,15 @@ def bench_c5(args, rank, world, dist, torch):
                     kernel="KKT solve of the conic projection by y-space PCG: kq_pcg_prep, kq_pcg_Aty/_Gp (set-up), {kq_pcg_Aty, kq_pcg_Gp, kq_pcg_update} x cg, kq_pcg_post; one host round trip per solve",
                     avg_launch_us=avg_ms * 1e3, launches=f["solves_timed"], algorithmic_bytes_per_launch=bytes_solve, avg_cg_iters=cg)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and ml:
+        # the oracle's LASSO restatement solves the reduced system with a dense Cholesky (test sizes): the CPU leg runs the same generator at 1000 x 3000
+        from oracle import pyoracle_qcp as pq
+        Xs, ys, ls_ = problems.lasso_protocol_data(1000, 3000)
+        _, oi = pq.solve_lasso(Xs, ys, ls_, eps=1e-3, eps_p=1e-3, eps_d=1e-3, eps_g=1e-3)
+        cpu = dict(value=oi["admm_iter"] / max(oi["solve_time"] / 1e3, 1e-9), unit="ADMM iterations/s", cores=1, kind="port", host_cores=host_cores(),
+                   sample=f"REDUCED instance 1000 x 3000 of the same generator: {oi['admm_iter']} iterations in {oi['solve_time'] / 1e3:.2f} s "
+                          f"(+ {oi['setup_time'] / 1e3:.1f} s set-up), oracle/abip_qcp_oracle.c (LASSO restatement, dense reduced Cholesky), single thread, gcc -O2")
+    elif rank == 0 and world == 1 and not args.no_cpu:
         # the conic reference needs MKL headers (unbuildable here) and the scalar oracle's LDL' of the full-size KKT matrix takes
         # hours, so the CPU leg runs the oracle on the same generator at p=1000, d=4500 and says so
         from oracle import pyoracle_qcp as pq
@@ -212,17 +233,19 @@ def bench_c5(args, rank, world, dist, torch):
                    sample=f"REDUCED instance p=1000, d=4500 (n=10002) of the same generator: {oi['admm_iter']} iterations in {oi['solve_time'] / 1e3:.2f} s "
                           f"(+ {oi['setup_time'] / 1e3:.1f} s set-up), oracle/abip_qcp_oracle.c, single thread, gcc -O2")
     if rank == 0:
-        beta = sol["x"][p + 2:p + 2 + d] - sol["x"][p + 2 + d:]
+        beta = sol["x"] if ml else sol["x"][p + 2:p + 2 + d] - sol["x"][p + 2 + d:]
+        wl = (f"LASSO {p} x {d}, density 0.15 (scripts/bench-qcp/test_lasso.m largest size) through the LASSO front end (prob_type 0): conic n={n_op}, m={m_op}, K.rq=[{p + 2}], K.l={2 * d}; "
+              if ml else f"LASSO-as-SOCP p={p} d={d} density 0.005 (BASELINE configs[4]): n={p + 2 + 2 * d}, m={p + 1}, K.q=[{p + 2}], K.l={2 * d}; conic path, ")
         emit(({
             "metric": "ADMM iterations/s", "value": world * steps / elapsed, "unit": "ADMM iterations/s", "n_gpus": world, "steps": steps, "warmup": int(info0["admm_iter"]),
             "ms_per_step": 1e3 * elapsed / max(steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"LASSO-as-SOCP p={p} d={d} density 0.005 (BASELINE configs[4]): n={p + 2 + 2 * d}, m={p + 1}, K.q=[{p + 2}], K.l={2 * d}; conic path, " + ("y-space PCG" if pcg else "direct LDL'"),
+            "config": {"workload": wl + ("y-space PCG" if pcg else "direct LDL'"),
                        "linsys": "indirect (PCG, linsys_solver 3)" if pcg else "direct", "eps": 1e-3,
                        "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (the direct back-end does not shard)"},
             "roofline": roof, "cpu_baseline": cpu,
             "time_to_tol": dict(seconds=info["runtime"], setup_s=info["setup_time"], solve_s=info["solve_time"], status=info["status"], admm_iter=steps,
                                 ipm_iter=info["ipm_iter"], res_pri=info["res_pri"], res_dual=info["res_dual"], rel_gap=info["gap"]),
-            "extra": {"nnz": int(data["A"].nnz), "nonzero_coefficients": int(np.sum(np.abs(beta) > 1e-6)), "pobj": info["pobj"]},
+            "extra": {"nnz": nnz_op, "nonzero_coefficients": int(np.sum(np.abs(beta) > 1e-6)), "pobj": info["pobj"]},
         }))
     if dist is not None:
         dist.destroy_process_group()
@@ -373,7 +396,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5"])
+    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "c3", "c5", "lasso"])
     ap.add_argument("--linsys", default=None, choices=["direct", "indirect"], help="override the workload's KKT back-end (c2/c3/c4)")
     ap.add_argument("--to-tol", action="store_true", help="(default on one GPU) also run a full solve to eps=1e-6 and report wall-clock")
     ap.add_argument("--no-to-tol", action="store_true", help="skip the full solve to eps=1e-6 (the second half of BASELINE.json's metric)")
@@ -411,7 +434,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     try:
-        if args.workload == "c5":
+        if args.workload in ("c5", "lasso"):
             return bench_c5(args, rank, world, dist, torch)
         steps = args.steps if args.steps is not None else {"c4": 200, "c2": 2000, "c3": 500}[args.workload]
         warmup = args.warmup if args.warmup is not None else {"c4": 20, "c2": 200, "c3": 50}[args.workload]

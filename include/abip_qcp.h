@@ -10,7 +10,19 @@
  * uses a qcp_ prefix for the types and exports the entry point as abip_qcp(); INTEGRATION.md shows the one-line
  * `#define` a maintainer adds to compile the reference's abip_qcp_mex.c against it.
  *
- * Served: the generic QCP formulation (enum QCP, prob_type 2) with the QDLDL-class direct solver (linsys_solver 1) and with a
+ * Served formulations (settings.prob_type as abip() maps it, source/abip.c:1341-1348):
+ *   2  generic QCP (qcp_config.c): data = (A, Q, b, c), cone K from the caller; sol = (x, y, s).
+ *   0  LASSO (lasso_config.c):  min 1/2 |X beta - y|^2 + lambda |beta|_1.   d->A = X (m x n), d->b = y, d->lambda, d->c ignored;
+ *      K = {rq: [m + 2], l: 2 n} (as abip_ml_mex.c:328-331 builds it).  sol->x = beta (n entries); sol->y, sol->s are not touched
+ *      (the reference frees them and leaves the pointers dangling, lasso_config.c:296-311).
+ *   1  soft-margin SVM as an SOCP (svm_config.c):  min 1/2 |w|^2 + lambda sum xi,  y_i (x_i'w + b) >= 1 - xi_i.  d->A = X, d->b = labels,
+ *      K = {rq: [n + 2], l: 2 + 2 m + 2 n}.  sol->x = w (n), sol->y = b (1), sol->s = xi (m)  (un_scaling_svm_sol, svm_config.c:410-440).
+ *   3  the same SVM as a QP (svm_qp_config.c) with weight 1 / (m lambda) on sum xi; K = {f: n + 1, l: 2 m}; same outputs.
+ *   For 0, 1 and 3 the library builds the conic problem (formulation, the formulation's own scaling rule, residual definitions, stopping
+ *   test, un-scaling) as the reference's spe_problem vtable does (include/abip.h:27-60), materialises its operator as one sparse matrix and
+ *   runs the same device path; the caller's X is never modified (the reference folds the SVM labels into it in place).  They need
+ *   normalize = 1 (0 and 1 also scale_E = 1): the reference scales unconditionally and un-scales only under `normalize`.
+ * Back-ends: the QDLDL-class direct solver (linsys_solver 1) and a
  * device PCG (linsys_solver 3).  The reference's own PCG for this formulation is unreachable through abip() and ill-posed
  * (abip_amd/csrc/qcp_pcg.h), so linsys_solver 3 is defined here: Jacobi-PCG on the y-space Schur
  * complement rho_y I + A (rho_x I + Q)^-1 A' (the reference's `pcg` of linsys.c:629-716 with H^-1 in the middle; Q absent or
@@ -75,7 +87,7 @@ typedef struct { /* struct ABIP_SETTINGS, abip.h:93-131 */
 
   qcp_int verbose;
   qcp_int linsys_solver; /* 1 = QDLDL-class direct; 3 = PCG on the y-space Schur complement (Q absent or diagonal; abip_amd/csrc/qcp_pcg.h); others: "Failure" */
-  qcp_int prob_type;     /* 2 = generic QCP (what the mex sets, abip_qcp_mex.c:436) */
+  qcp_int prob_type;     /* 0 LASSO, 1 SVM-SOCP, 2 generic QCP (what abip_qcp_mex.c:436 sets), 3 SVM-QP -- see the header comment */
   qcp_float time_limit;  /* seconds */
   qcp_float psi;
 
@@ -115,7 +127,7 @@ typedef struct { /* struct ABIP_INFO, abip.h:140-158 */
   qcp_float avg_cg_iters;
 } QCPInfo;
 
-/* abip(d, sol, info, K) of the reference (source/abip.c:1335-1371).  sol->x/y/s are malloc'ed when NULL. */
+/* abip(d, sol, info, K) of the reference (source/abip.c:1335-1371).  sol->x/y/s are malloc'ed when NULL (sizes per formulation above). */
 qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K);
 /* ABIP(set_default_settings), source/util.c:203-255 (prob_type is left at the mex's value 2 = QCP). */
 void abip_qcp_set_default_settings(QCPData *d);
