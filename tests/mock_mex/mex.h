@@ -1,4 +1,4 @@
-/* TEST INFRASTRUCTURE: the slice of Matlab's mex.h / matrix.h that the LP gateways use (mex/abip_hip_mex.c and the reference's
+/* TEST INFRASTRUCTURE: the slice of Matlab's mex.h / matrix.h that the gateways use (mex/abip_hip_mex.c, mex/abip_hip_qcp_mex.c and the reference's
  * src/abip-lp/mexfile/abip_mex.c), so that they can be compiled AND EXECUTED where no Matlab exists.  The functions are
  * implemented by mock_mex_runtime.c (a few plain-C containers); nothing here ships with the product. */
 #ifndef MOCK_MEX_H
@@ -16,6 +16,10 @@ double *mxGetPr(const mxArray *a);
 int mxIsSparse(const mxArray *a);
 size_t mxGetNumberOfElements(const mxArray *a);
 const mwSize *mxGetDimensions(const mxArray *a);
+mwSize mxGetNumberOfDimensions(const mxArray *a);
+size_t mxGetM(const mxArray *a);
+size_t mxGetN(const mxArray *a);
+int mxIsEmpty(const mxArray *a);
 mwIndex *mxGetJc(const mxArray *a);
 mwIndex *mxGetIr(const mxArray *a);
 void *mxMalloc(size_t n);

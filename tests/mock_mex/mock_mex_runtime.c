@@ -45,6 +45,10 @@ double *mxGetPr(const mxArray *a) { return a ? a->pr : NULL; }
 int mxIsSparse(const mxArray *a) { return a && a->kind == K_SPARSE; }
 size_t mxGetNumberOfElements(const mxArray *a) { return a ? a->dims[0] * a->dims[1] : 0; }
 const mwSize *mxGetDimensions(const mxArray *a) { return a->dims; }
+mwSize mxGetNumberOfDimensions(const mxArray *a) { (void)a; return 2; }
+size_t mxGetM(const mxArray *a) { return a ? a->dims[0] : 0; }
+size_t mxGetN(const mxArray *a) { return a ? a->dims[1] : 0; }
+int mxIsEmpty(const mxArray *a) { return !a || a->dims[0] * a->dims[1] == 0; }
 mwIndex *mxGetJc(const mxArray *a) { return a->jc; }
 mwIndex *mxGetIr(const mxArray *a) { return a->ir; }
 mxArray *mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity c) {
@@ -108,6 +112,15 @@ int mock_call(int nlhs, mxArray **plhs, const mxArray *data, const mxArray *sett
   if (setjmp(g_jmp)) { g_jmp_armed = 0; return 1; }
   g_jmp_armed = 1;
   mexFunction(nlhs, plhs, 2, prhs);
+  g_jmp_armed = 0;
+  return 0;
+}
+/* the same for a gateway of three inputs ([sol, info] = abip_qcp(data, cones, settings)); the gateway checks nrhs itself */
+int mock_calln(int nlhs, mxArray **plhs, int nrhs, const mxArray **prhs) {
+  g_err[0] = 0;
+  if (setjmp(g_jmp)) { g_jmp_armed = 0; return 1; }
+  g_jmp_armed = 1;
+  mexFunction(nlhs, plhs, nrhs, prhs);
   g_jmp_armed = 0;
   return 0;
 }

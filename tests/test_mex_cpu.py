@@ -23,3 +23,23 @@ def test_gateway_field_names_are_the_references():
     assert read == set(_MEX_FIELDS)                       # the Python mirror and the C gateway read the same names
     for f in ("status", "ipm_iter", "admm_iter", "mu", "pobj", "dobj", "resPri", "resDual", "relGap", "resInfeas", "resUnbdd", "setupTime", "solveTime"):
         assert '"%s"' % f in src                           # abip_mex.c:101-102
+
+
+def test_conic_gateways_compile(tmp_path):
+    """mex/abip_hip_qcp_mex.c: [sol, info] = abip_qcp(data, cones, settings) and, with -DABIP_HIP_ML, [sol, info] = abip_ml(data, settings)."""
+    src = os.path.join(ROOT, "mex", "abip_hip_qcp_mex.c")
+    for extra in ([], ["-DABIP_HIP_ML"]):
+        out = tmp_path / ("qgw%d.o" % len(extra))
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-c", src, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "mock_mex"),
+                        "-o", str(out)] + extra, check=True)
+        syms = subprocess.run(["nm", str(out)], capture_output=True, text=True, check=True).stdout
+        assert " T mexFunction" in syms and " U abip_qcp" in syms and " U abip_qcp_set_default_settings" in syms
+    text = open(src).read()
+    # every settings field the reference's gateways read (abip_qcp_mex.c:296-434) and every info field they return (:121-124)
+    for f in ("alpha", "cg_rate", "eps_p", "eps_d", "eps_g", "eps_inf", "eps_unb", "max_admm_iters", "max_ipm_iters", "normalize", "rho_y", "rho_x", "rho_tau",
+              "scale_bc", "scale_E", "use_indirect", "verbose", "linsys_solver", "inner_check_period", "outer_check_period", "err_dif", "time_limit", "psi",
+              "origin_scaling", "ruiz_scaling", "pc_scaling"):
+        assert re.search(r"(FLT|INT)\(%s\)" % f, text), f
+    for f in ("ipm_iter", "admm_iter", "status", "pobj", "dobj", "res_pri", "res_dual", "gap", "status_val", "setup_time", "solve_time", "runtime",
+              "lin_sys_time_per_iter", "avg_cg_iters"):
+        assert '"%s"' % f in text
