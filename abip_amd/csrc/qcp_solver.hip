@@ -298,7 +298,12 @@ void svm_constants(int m, int n, double lambda, SvmForm &V) {
     }
   }
 }
-void build_svm(QWk *w, const QCPData *d) {
+bool build_svm(QWk *w, const QCPData *d) { // false: a feature column of X is identically zero
+  for (int j = 0; j < d->n; ++j) { // the scaling divides by every column's 2-norm (svm_config.c:300-308): the reference goes on with inf / NaN and never converges
+    bool nz = false;
+    for (int t = d->A->p[j]; t < d->A->p[j + 1] && !nz; ++t) nz = d->A->x[t] * d->b[d->A->i[t]] != 0.0;
+    if (!nz) return false;
+  }
   SvmForm &V = w->sv;
   const int dm = d->m, dn = d->n, n1 = dn + 1, p = dm + dn + 1, q = 4 + 3 * dn + 2 * dm;
   V.dm = dm; V.dn = dn; V.lambda = d->lambda;
@@ -359,6 +364,7 @@ void build_svm(QWk *w, const QCPData *d) {
   for (int i = 0; i < dm; ++i) { A.i.push_back(1 + i); A.x.push_back(D[i] * (1 / V.sc)); close(); } // xi
   for (int i = 0; i < dm; ++i) { A.i.push_back(1 + i); A.x.push_back(-D[i]); close(); }             // t
   w->D.assign(p, 1.0); w->E.assign(q, 1.0); w->sc_b = 1; w->sc_c = 1; // (neutral for the generic sums kq_resid still provides: certificates)
+  return true;
 }
 
 // ---- SVM-QP front end: init_svmqp + scaling_svmqp_data, svm_qp_config.c:8-124, 195-590 -------------------------------------
@@ -678,7 +684,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   w->kind = kind; w->m = m; w->n = n; w->st = st; w->hasQ = kind == 3 || (kind == 2 && d->Q != nullptr);
   w->kkt_rho_x = (kind == 0 || kind == 1) ? 1.0 : st->rho_x; // (lasso_config.c:652-708 and svm_config.c:725-806 hard-code rho_x = 1 in the solve)
   if (kind == 0) build_lasso(w, d);
-  else if (kind == 1) build_svm(w, d);
+  else if (kind == 1) { if (!build_svm(w, d)) return fail(info, "SVM-SOCP: X has an all-zero feature column (or only zero-label entries in it); drop it or use prob_type 3"); }
   else if (kind == 3) build_svmqp(w, d, K);
   else {
     // integer division, qcp_config.c:22 -- taken in 64 bits: the reference's 32-bit m * n overflows from m * n = 2^31 on (and divides by

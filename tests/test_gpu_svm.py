@@ -93,3 +93,15 @@ def test_svm_socp_reaches_the_minimiser(gpu, linsys):
     f, fs = hinge_objective(X, y, C, sol["w"], sol["b"]), hinge_objective(X, y, C, ws, bs)
     assert abs(f - fs) <= 2e-4 * max(1.0, abs(fs))
     assert np.max(np.abs(sol["w"] - ws)) <= 1e-2 * max(1.0, np.abs(ws).max())
+
+
+def test_svm_socp_refuses_an_all_zero_feature(gpu):
+    """svm_config.c:300-308 divides by every column norm; the reference then iterates on NaN to its iteration caps.  The device path says so at set-up;
+    the QP formulation (generic scaling: norms below the floor are left alone) solves the same data."""
+    import scipy.sparse as sp
+    X, y = gen("tall")
+    X = sp.csc_matrix(sp.hstack([X[:, :3], sp.csc_matrix((X.shape[0], 1)), X[:, 3:]]))
+    sol, info = gpu.abip_ml(dict(X=X, y=y, **{"lambda": 1.0}), dict(prob_type=1, linsys_solver=1, verbose=0))
+    assert info["status"] == "Failure" and info["status_val"] == -4
+    sol, info = gpu.abip_ml(dict(X=X, y=y, **{"lambda": 1e-2}), dict(prob_type=3, linsys_solver=1, verbose=0))
+    assert info["status"] == "Solved" and sol["w"][3] == 0.0
