@@ -123,6 +123,37 @@ static __global__ __launch_bounds__(256) void k_dldl_update(double *S, int ld, i
     for (int j = 0; j < 4; ++j) S[(i0 + ty * 4 + i) * ld + j0 + tx * 4 + j] -= acc[i][j];
 }
 
+// (0) when the host leaves the product to the device (LdlHost::dev_schur): S -= L21 D1 L21' by dense panels of L21.
+// Panel fill: P[r][c - c0] = L21[r, c] and PD = P D1 for the head columns [c0, c0 + kc); one wavefront per column (the panels are zeroed first).
+static __global__ __launch_bounds__(256) void k_l21_panel(const long *__restrict__ ptr, const int *__restrict__ row, const double *__restrict__ val,
+                                                          const double *__restrict__ Dh, int c0, int kc, int ldp, double *__restrict__ P, double *__restrict__ PD) {
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (col >= kc) return;
+  const int c = c0 + col;
+  const double d = Dh[c];
+  for (long q = ptr[c] + lane; q < ptr[c + 1]; q += 64) { const long o = (long)row[q] * ldp + col; const double v = val[q]; P[o] = v; PD[o] = v * d; }
+}
+// rank-kc update of the lower tile pairs: S[i, j] -= PD[i, :] P[j, :]'
+static __global__ __launch_bounds__(256) void k_schur_sub(double *S, int ld, const double *__restrict__ PD, const double *__restrict__ P, int ldp, int kc) {
+  __shared__ double As[DB][DH + 1], Bs[DB * (DH + 1)];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  int bi = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((long)(bi + 1) * (bi + 2) / 2 <= (long)blockIdx.x) ++bi;
+  while ((long)bi * (bi + 1) / 2 > (long)blockIdx.x) --bi;
+  const int bj = blockIdx.x - bi * (bi + 1) / 2;
+  const long i0 = (long)bi * DB, j0 = (long)bj * DB;
+  double acc[4][4] = {};
+  for (int q0 = 0; q0 < kc; q0 += DH) {
+    __syncthreads();
+    load_rows_slice(As, PD + i0 * ldp, ldp, q0, tid);
+    load_rows_slice((double(*)[DH + 1])Bs, P + j0 * ldp, ldp, q0, tid);
+    __syncthreads();
+    tile_mac<true>(acc, As, Bs, ty, tx);
+  }
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) S[(i0 + ty * 4 + i) * ld + j0 + tx * 4 + j] -= acc[i][j];
+}
+
 // (4) block row kb of W = inv(L22):  W[kb, j] = -inv(L_kb,kb) * sum_{i=j}^{kb-1} L[kb, i] W[i, j],  W[kb, kb] = inv(L_kb,kb)
 static __global__ __launch_bounds__(256) void k_dtri_inv_row(const double *L, int ld, int kb, const double *Linv_all, double *W) {
   constexpr int NA = DB * (DH + 1), NC = DB * (DB + 1);
@@ -348,6 +379,21 @@ struct DevLdl {
     if (Wt.upload(H.S, s) || W.alloc((size_t)T * T) || tmp.alloc(T) || Linv.alloc((size_t)nt * DB * DB) || LD.alloc((size_t)T * DB) || flag.upload(zero, s)) return -1;
     if (hipMemsetAsync(W.p, 0, sizeof(double) * (size_t)T * T, s) != hipSuccess) return -1;
     double *S = Wt.p, *Dt = D.p + t0;
+    if (H.dev_schur) { // S arrived as K22: subtract L21 D1 L21' here, a panel of head columns at a time
+      constexpr int KC = 2048;
+      DBuf<long> lp; DBuf<int> lr; DBuf<double> lv, P, PD;
+      auto drop = [&]() { lp.release(); lr.release(); lv.release(); P.release(); PD.release(); };
+      if (lp.upload(H.l21_ptr, s) || lr.upload(H.l21_row, s) || lv.upload(H.l21_val, s) || P.alloc((size_t)T * KC) || PD.alloc((size_t)T * KC)) { drop(); return -1; }
+      for (int c0 = 0; c0 < t0; c0 += KC) {
+        const int kc = std::min(KC, t0 - c0), kcp = (kc + DH - 1) / DH * DH;
+        if (H.l21_ptr[c0 + kc] == H.l21_ptr[c0]) continue; // no tail entries in these columns
+        if (hipMemsetAsync(P.p, 0, sizeof(double) * (size_t)T * KC, s) != hipSuccess || hipMemsetAsync(PD.p, 0, sizeof(double) * (size_t)T * KC, s) != hipSuccess) { drop(); return -1; }
+        hipLaunchKernelGGL(k_l21_panel, dim3((kc + 3) / 4), dim3(256), 0, s, (const long *)lp.p, (const int *)lr.p, (const double *)lv.p, (const double *)D.p, c0, kc, KC, P.p, PD.p);
+        hipLaunchKernelGGL(k_schur_sub, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, S, T, (const double *)PD.p, (const double *)P.p, KC, kcp);
+      }
+      if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { drop(); return -1; }
+      drop();
+    }
     for (int kb = 0; kb < nt; ++kb) {
       const int k0 = kb * DB, rem = nt - kb - 1;
       hipLaunchKernelGGL(k_dldl_diag, dim3(1), dim3(256), 0, s, S, T, k0, Dt, Linv.p + (size_t)kb * DB * DB, flag.p);

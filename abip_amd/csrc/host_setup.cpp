@@ -389,6 +389,7 @@ int host_solve(const LdlHost &F, std::vector<double> &b) {
   std::vector<double> D(F.D);
   if (T > 0) { // dense LDL' of the Schur complement, then the two triangular solves of the tail (the device applies inv(L22) instead)
     std::vector<double> S(F.S);
+    if (F.dev_schur) { LdlHost G; G.t0 = t0; G.T = T; G.D = F.D; G.S.swap(S); G.l21_ptr = F.l21_ptr; G.l21_row = F.l21_row; G.l21_val = F.l21_val; complete_schur_on_host(G); S.swap(G.S); }
     for (int c = 0; c < T; ++c) {
       const double d = S[(size_t)c * T + c];
       if (d == 0.0) return -2;
@@ -447,6 +448,27 @@ void guard_rhs(int N, std::vector<double> &rhs) {
   rhs.resize(N);
   unsigned long long st = 0x9E3779B97F4A7C15ull;
   for (int i = 0; i < N; ++i) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; rhs[i] = (double)(st >> 11) / 9007199254740992.0 * 2.0 - 1.0; }
+}
+
+namespace { int g_dev_schur_req = -1; }
+void set_dev_schur_request(int v) { g_dev_schur_req = v; }
+static int dev_schur_request() {
+  if (g_dev_schur_req >= 0) return g_dev_schur_req;
+  const char *e = getenv("ABIP_HIP_DEV_SCHUR");
+  return e ? atoi(e) : -1;
+}
+void complete_schur_on_host(LdlHost &F) {
+  const int t0 = F.t0, T = F.T;
+  if ((long)F.l21_ptr.size() == (long)t0 + 1)
+    for (int c = 0; c < t0; ++c) {
+      const double d = F.D[c];
+      for (long a = F.l21_ptr[c]; a < F.l21_ptr[c + 1]; ++a) {
+        const double la = F.l21_val[a] * d;
+        double *Srow = F.S.data() + (size_t)F.l21_row[a] * T;
+        for (long b = F.l21_ptr[c]; b <= a; ++b) Srow[F.l21_row[b]] -= la * F.l21_val[b];
+      }
+    }
+  F.dev_schur = false;
 }
 
 int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, const std::vector<double> &Kx, LdlHost &out) {
@@ -531,8 +553,9 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
   std::vector<double> Lx(std::max<long>(Lhead, 1));
   out.D.assign(N, 0.0);
   std::vector<double> Y(N, 0.0);
-  std::vector<int> stack(N), pat(N), fill(N, 0);
+  std::vector<int> stack(N), pat(N), fill(N, 0), hfill;
   std::fill(flag.begin(), flag.end(), -1);
+  if (t0 == 0) hfill = fill;
   for (int k = 0; k < N; ++k) {
     int top = N; flag[k] = k;
     double dk = 0.0;
@@ -544,15 +567,20 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
       while (flag[r] != k) { pat[len++] = r; flag[r] = k; r = parent[r]; }
       while (len > 0) stack[--top] = pat[--len];
     }
+    if (k == t0) hfill = fill; // from here on only tail rows arrive: a head column's first hfill entries are its head rows
+    const bool tail_row = k >= t0;
     for (; top < N; ++top) {
       const int c = stack[top];
       if (c >= t0) continue;       // tail column: its contribution is applied on the device
       const double yc = Y[c];
       Y[c] = 0.0;
       const long e = Lp[c] + fill[c];
-      for (long q = Lp[c]; q < e; ++q) Y[Li[q]] -= Lx[q] * yc;
+      // a tail row needs the head rows of column c only: the products of its tail entries are the Schur complement's L21 D1 L21',
+      // accumulated afterwards (complete_schur_on_host, or the device)
+      const long eu = tail_row ? Lp[c] + hfill[c] : e;
+      for (long q = Lp[c]; q < eu; ++q) Y[Li[q]] -= Lx[q] * yc;
       const double lkc = yc / out.D[c];
-      dk -= lkc * yc;
+      if (!tail_row) dk -= lkc * yc;
       Li[e] = k; Lx[e] = lkc; fill[c]++;
     }
     if (k >= t0) {
@@ -564,7 +592,28 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
     out.D[k] = dk;
     if (dk == 0.0) return -1;
   }
-  if (tm) { printf("[setup] numeric (head + Schur complement, T = %d) %.3f s\n", T, clk() - tq); tq = clk(); }
+  if (tm) { printf("[setup] numeric (head + L21, T = %d) %.3f s\n", T, clk() - tq); tq = clk(); }
+  out.dev_schur = false; out.l21_ptr.clear(); out.l21_row.clear(); out.l21_val.clear();
+  if (T > 0) { // L21 by head column, and who multiplies it out
+    if ((int)hfill.size() != N) hfill = fill;
+    out.l21_ptr.assign(t0 + 1, 0);
+    double cost = 0.0;
+    for (int c = 0; c < t0; ++c) { const long kc = fill[c] - hfill[c]; out.l21_ptr[c + 1] = out.l21_ptr[c] + kc; cost += 0.5 * (double)kc * (double)(kc + 1); }
+    out.l21_row.resize(out.l21_ptr[t0]); out.l21_val.resize(out.l21_ptr[t0]);
+    for (int c = 0; c < t0; ++c) {
+      long dst = out.l21_ptr[c];
+      for (long q = Lp[c] + hfill[c]; q < Lp[c] + fill[c]; ++q, ++dst) { out.l21_row[dst] = Li[q] - t0; out.l21_val[dst] = Lx[q]; }
+    }
+    // who multiplies it out: the host's scattered updates of S run at ~2.4e8 multiply-adds per second (measured: 1.17e8 in 0.49 s on C5's
+    // KKT matrix), the device's dense panels at ~3 TFLOP/s over T^2 x (head columns that reach the tail) whatever their sparsity
+    long ncol = 0;
+    for (int c = 0; c < t0; ++c) ncol += out.l21_ptr[c + 1] > out.l21_ptr[c];
+    const double host_s = cost / 2.4e8, dev_s = 0.02 + (double)T * (double)T * (double)ncol / 3.0e12;
+    const int req = dev_schur_request();
+    out.dev_schur = req == 1 || (req < 0 && host_s > 0.1 && dev_s < host_s);
+    if (!out.dev_schur) complete_schur_on_host(out);
+    if (tm) { printf("[setup] Schur complement L21 D L21' (%.2e multiply-adds): %s %.3f s\n", cost, out.dev_schur ? "left to the device" : "host", clk() - tq); tq = clk(); }
+  }
   // backward form = CSC of the head columns of L (all rows); forward form = CSR of [L11; L21]
   out.bwd.ptr.assign(N + 1, 0);
   for (int j = 0; j <= N; ++j) out.bwd.ptr[j] = (int)Lp[std::min(j, t0)];
@@ -577,6 +626,7 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
   for (int j = 0; j < t0; ++j) for (long q = Lp[j]; q < Lp[j + 1]; ++q) { const int dst = rpos[Li[q]]++; out.fwd.idx[dst] = j; out.fwd.val[dst] = Lx[q]; }
   level_sets(N, out.fwd, false);
   level_sets(N, out.bwd, true);
+  if (tm) printf("[setup] forward / backward forms + level sets %.3f s\n", clk() - tq);
   return 0;
 }
 

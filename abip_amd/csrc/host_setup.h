@@ -51,7 +51,19 @@ struct LdlHost {
   TriHost fwd, bwd;      // sparse part: columns < t0 of L (rows of the tail included)
   int t0 = 0, T = 0;     // head size, dense-tail size (T % 64 == 0, t0 + T = N)
   std::vector<double> S; // T x T row-major, lower triangle: Schur complement of the head onto the tail
+  // dev_schur: S holds K22 only and the product L21 D1 L21' is still to be subtracted -- by the device (dev_ldl.h: dense panels of
+  // L21 + a tiled rank-k update), which takes over when its dense panels beat the host's sparse accumulation (dense data
+  // blocks: 35 000 head columns with 750 tail entries each = 10^10 multiply-adds, 11 s on one host thread, 0.2 s on the device).
+  // L21 by head column for that purpose: column c owns [l21_ptr[c], l21_ptr[c+1]) of (l21_row = tail row - t0, l21_val), rows ascending.
+  bool dev_schur = false;
+  std::vector<long> l21_ptr;
+  std::vector<int> l21_row;
+  std::vector<double> l21_val;
 };
+// S -= L21 D1 L21' on the host (what the device does when dev_schur is set); clears dev_schur.  For host_solve and as the fallback.
+void complete_schur_on_host(LdlHost &F);
+// -1: decide by cost (default); 0: always accumulate on the host; 1: always leave it to the device (tests).  Also env ABIP_HIP_DEV_SCHUR.
+void set_dev_schur_request(int v);
 // override the tail choice (tests): -2 = environment / automatic, -1 automatic, 0 none, T > 0 forced
 void set_tail_request(int t);
 // Host-only reference solve with a factor as the device would use it (level-ordered head, Schur complement factored densely on

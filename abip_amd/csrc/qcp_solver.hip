@@ -750,7 +750,10 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       host::set_tail_request(-2);
       if (rc < 0) return -2;
       for (int q = 0; q < N; ++q) pmap[q] = F.P[q] < m ? F.P[q] : w->MP + (F.P[q] - m);
-      return w->ldl.setup(F, pmap, w->stream) ? -1 : 0;
+      const double td = now_ms();
+      const int rd = w->ldl.setup(F, pmap, w->stream) ? -1 : 0;
+      if (getenv("ABIP_HIP_SETUP_TIMES")) printf("[setup] device part (uploads, Schur panels, dense LDL' + inverse of the tail) %.3f s\n", (now_ms() - td) / 1e3);
+      return rd;
     };
     if (hipMalloc((void **)&w->lp_ctl, sizeof(Ctl)) != hipSuccess || hipMemsetAsync(w->lp_ctl, 0, sizeof(Ctl), w->stream) != hipSuccess) return bail("allocation failure");
     // set-up guard (see solver.hip: abip_init): one known right-hand side through the factor, ||K z - rhs|| checked on the host
