@@ -16,397 +16,17 @@
 #include "dev_ldl.h"
 #include "qcp_kernels.h"
 #include "qcp_pcg.h"
+#include "qcp_work.h"
+#include "qcp_formulations.h"
 
 using namespace abip;
 using namespace abip::hostutil;
+using namespace abip::qcp;
 
 namespace {
 
-constexpr double kMinScale = 1e-3, kMaxScale = 1e3; // qcp_config.c:2-3
 constexpr double EPS_TOL = 1E-18;
 inline double safediv_pos(double x, double y) { return y < EPS_TOL ? x / EPS_TOL : x / y; }
-
-struct HMat { int m = 0, n = 0; std::vector<int> p, i; std::vector<double> x; };
-void copy_in(HMat &dst, const QCPMatrix *src) {
-  dst.m = src->m; dst.n = src->n;
-  const int nnz = src->p[src->n];
-  dst.p.assign(src->p, src->p + src->n + 1); dst.i.assign(src->i, src->i + nnz); dst.x.assign(src->x, src->x + nnz);
-}
-double vnrminf(const double *a, long n) { double mx = 0; for (long k = 0; k < n; ++k) { const double t = std::fabs(a[k]); if (t >= mx) mx = t; } return mx; }
-
-struct QResid { // struct ABIP_RESIDUALS, abip.h:182-207
-  int last_ipm_iter = -1, last_admm_iter = -1;
-  double res_pri = 1e8, res_dual = 1e8, rel_gap = 1e8, res_infeas = 0, res_unbdd = 0, pobj = 0, dobj = 0, tau = 0, kap = 0, res_dif = 0,
-         error_ratio = 1e8, Ax_b_norm = INFINITY, Qx_ATy_c_s_norm = INFINITY; // (the two norms: unknown until the first residual check -- qcp_pcg.h)
-};
-
-// The LASSO reformulation (lasso_config.c): what the front end keeps of the caller's data and of its own scaling
-struct LassoForm {
-  int dm = 0, dn = 0; // rows (samples) and columns (features) of the data matrix X
-  double lambda = 0, sc = 1, sc_b = 1, sc_c = 1, sc_cone1 = 1, sc_cone2 = 1;
-  std::vector<double> D, E, y;
-  DBuf<double> Dd, Ed, yd;
-};
-
-// The SVM reformulations (svm_qp_config.c; svm_config.c): data dimensions and what the un-scaling needs
-struct SvmForm {
-  int dm = 0, dn = 0; double lambda = 0;
-  double sc = 1, sc_b = 1, sc_c = 1, sc_cone1 = 1, sc_cone2 = 1; // SVM-SOCP only (svm_config.c:63-107)
-  std::vector<double> D, E, wE;
-  DBuf<double> Dd, Ed, wEd;
-};
-
-struct QWk {
-  SvmForm sv;
-  int kind = 2; // enum problem_type as abip() maps settings.prob_type (abip.c:1341-1348): 0 LASSO, 1 SVM as an SOCP, 2 generic QCP, 3 SVM as a QP
-  LassoForm ls;
-  double kkt_rho_x = 1; // the rho_x the KKT system is assembled with (the LASSO solve hard-codes 1, lasso_config.c:652-708)
-  int m = 0, n = 0, MP = 0, LV = 0, NB = 1;
-  const QCPSettings *st = nullptr;
-  bool hasQ = false;
-  int sparsity = 0;
-  HMat A, Q;
-  std::vector<double> D, E, b, c;
-  double sc_b = 1, sc_c = 1, nm_inf_b = 0, nm_inf_c = 0, a_quad = 0, mu = 1, beta = 1;
-  hipStream_t stream = nullptr;
-  DevCsr dA, dAt, dQ;
-  DBuf<double> u, v, vo, ut, rel, r, p, bd, cd, Dd, Ed, Ax, ATy, Qx, part;
-  DBuf<int> xkind, c_off, c_len, c_kind;
-  DBuf<QCtl> ctl;
-  QCtl *hctl = nullptr;
-  DevLdl ldl;
-  hipEvent_t ev_a = nullptr, ev_b = nullptr; // bracket of the KKT solve of the current iteration (avg_linsys_time)
-  double lin_ms = 0; long lin_n = 0;
-  int ncones = 0, nsmall = 0; // cone table: the nsmall cones of <= QC_BIG entries first
-  Ctl *lp_ctl = nullptr; // dev_sptrsv kernels are gated on an LP-style control block (halt flag): a zeroed one
-  // indirect back-end (linsys_solver = 3, qcp_pcg.h)
-  bool pcg = false;
-  DBuf<double> cg_x0, cg_r, cg_z, cg_p, cg_Gp, cg_tm, cg_M, cg_H, cg_part; // m-space: y0, r, z, p, Gp, M; n-space: tn (cg_tm), H^-1
-  Ctl *hlp = nullptr;    // pinned mirror of lp_ctl
-  int last_cg = 8; long tot_cg = 0, cg_solves = 0;
-};
-
-#define QLAUNCH(w, kern, grid, block, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (w)->stream, __VA_ARGS__)
-
-double g_stats[8] = {0};
-
-void release(QWk *w) {
-  if (w->ev_a) (void)hipEventDestroy(w->ev_a);
-  if (w->ev_b) (void)hipEventDestroy(w->ev_b);
-  w->ev_a = w->ev_b = nullptr;
-  w->dA.release(); w->dAt.release(); w->dQ.release();
-  w->ls.Dd.release(); w->ls.Ed.release(); w->ls.yd.release();
-  w->sv.Dd.release(); w->sv.Ed.release(); w->sv.wEd.release();
-  DBuf<double> *bufs[] = {&w->u, &w->v, &w->vo, &w->ut, &w->rel, &w->r, &w->p, &w->bd, &w->cd, &w->Dd, &w->Ed, &w->Ax, &w->ATy, &w->Qx, &w->part};
-  for (auto *b : bufs) b->release();
-  w->xkind.release(); w->c_off.release(); w->c_len.release(); w->c_kind.release(); w->ctl.release();
-  w->ldl.release();
-  { DBuf<double> *cb[] = {&w->cg_x0, &w->cg_r, &w->cg_z, &w->cg_p, &w->cg_Gp, &w->cg_tm, &w->cg_M, &w->cg_H, &w->cg_part}; for (auto *b : cb) b->release(); }
-  if (w->hlp) (void)hipHostFree(w->hlp);
-  if (w->lp_ctl) (void)hipFree(w->lp_ctl);
-  if (w->hctl) (void)hipHostFree(w->hctl);
-  if (w->stream) (void)hipStreamDestroy(w->stream);
-}
-
-// ---- scaling, qcp_config.c:91-491 -----------------------------------------------------------------------------
-void cone_average(std::vector<double> &E, const QCPCone *k) { // :194-212
-  int count = 0;
-  auto avg = [&](int len) { double y = 0; for (int j = 0; j < len; ++j) y += E[count + j]; y /= len; for (int j = 0; j < len; ++j) E[count + j] = y; count += len; };
-  if (k->q) for (int i = 0; i < k->qsize; ++i) avg(k->q[i]);
-  if (k->rq) for (int i = 0; i < k->rqsize; ++i) avg(k->rq[i]);
-}
-void apply_pass(QWk *w, std::vector<double> &Dp, std::vector<double> &Ep) { // :214-262
-  const int m = w->m, n = w->n;
-  const double min_row = kMinScale * std::sqrt((double)n), max_row = kMaxScale * std::sqrt((double)n);
-  const double min_col = kMinScale * std::sqrt((double)m), max_col = kMaxScale * std::sqrt((double)m);
-  HMat &A = w->A, &Q = w->Q;
-  for (int i = 0; i < m; ++i) { if (Dp[i] < min_row) Dp[i] = 1; else if (Dp[i] > max_row) Dp[i] = max_row; }
-  for (int i = 0; i < n; ++i) {
-    if (Ep[i] < min_col) Ep[i] = 1; else if (Ep[i] > max_col) Ep[i] = max_col;
-    for (int j = A.p[i]; j < A.p[i + 1]; ++j) A.x[j] /= Ep[i];
-  }
-  if (w->hasQ) {
-    for (int i = 0; i < n; ++i) for (int j = Q.p[i]; j < Q.p[i + 1]; ++j) Q.x[j] /= Ep[i];
-    for (int q = 0; q < Q.p[n]; ++q) Q.x[q] /= Ep[Q.i[q]];
-  }
-  for (int q = 0; q < A.p[n]; ++q) A.x[q] /= Dp[A.i[q]];
-  for (int i = 0; i < n; ++i) w->E[i] *= Ep[i];
-  for (int i = 0; i < m; ++i) w->D[i] *= Dp[i];
-}
-// the ruiz / origin / pc passes over (A, Q) of a view of w->m rows and w->n columns; D_hat and E_hat accumulate in w->D, w->E
-// (qcp_config.c:130-460; svm_qp_config.c:199-556 runs the same passes over its first dn + 1 columns)
-void scale_passes(QWk *w, const QCPCone *k) {
-  const int m = w->m, n = w->n;
-  HMat &A = w->A, &Q = w->Q;
-  w->D.assign(m, 1.0); w->E.assign(n, 1.0);
-  std::vector<double> Ep(n), E1(n), E2(n), Dp(m);
-  auto col_inf = [](const HMat &M, int j) { double mx = 0; for (int q = M.p[j]; q < M.p[j + 1]; ++q) { const double t = std::fabs(M.x[q]); if (t >= mx) mx = t; } return mx; };
-  if (w->st->ruiz_scaling) {
-    for (int it = 0; it < 10; ++it) {
-      std::fill(E2.begin(), E2.end(), 0.0); std::fill(Dp.begin(), Dp.end(), 0.0);
-      for (int j = 0; j < n; ++j) E1[j] = (A.p[j] == A.p[j + 1]) ? 0 : std::sqrt(col_inf(A, j));
-      if (w->hasQ) for (int j = 0; j < n; ++j) E2[j] = (Q.p[j] == Q.p[j + 1]) ? 0 : std::sqrt(col_inf(Q, j));
-      for (int j = 0; j < n; ++j) Ep[j] = E1[j] < E2[j] ? E2[j] : E1[j];
-      cone_average(Ep, k);
-      for (int q = 0; q < A.p[n]; ++q) if (Dp[A.i[q]] < std::fabs(A.x[q])) Dp[A.i[q]] = std::fabs(A.x[q]);
-      for (int i = 0; i < m; ++i) Dp[i] = std::sqrt(Dp[i]);
-      apply_pass(w, Dp, Ep);
-    }
-  }
-  if (w->st->origin_scaling) {
-    std::fill(E1.begin(), E1.end(), 0.0); std::fill(E2.begin(), E2.end(), 0.0); std::fill(Dp.begin(), Dp.end(), 0.0);
-    for (int j = 0; j < n; ++j) { for (int q = A.p[j]; q < A.p[j + 1]; ++q) E1[j] += A.x[q] * A.x[q]; E1[j] = std::sqrt(E1[j]); }
-    if (w->hasQ) for (int j = 0; j < n; ++j) { for (int q = Q.p[j]; q < Q.p[j + 1]; ++q) E2[j] += Q.x[q] * Q.x[q]; E2[j] = std::sqrt(E2[j]); }
-    for (int j = 0; j < n; ++j) Ep[j] = std::sqrt(E1[j] < E2[j] ? E2[j] : E1[j]);
-    cone_average(Ep, k);
-    for (int q = 0; q < A.p[n]; ++q) Dp[A.i[q]] += A.x[q] * A.x[q];
-    for (int i = 0; i < m; ++i) Dp[i] = std::sqrt(std::sqrt(Dp[i]));
-    apply_pass(w, Dp, Ep);
-  }
-  if (w->st->pc_scaling) {
-    std::fill(E1.begin(), E1.end(), 0.0); std::fill(E2.begin(), E2.end(), 0.0); std::fill(Dp.begin(), Dp.end(), 0.0);
-    for (int j = 0; j < n; ++j) { for (int q = A.p[j]; q < A.p[j + 1]; ++q) E1[j] += std::fabs(A.x[q]); E1[j] = std::sqrt(E1[j]); }
-    if (w->hasQ) for (int j = 0; j < n; ++j) { for (int q = Q.p[j]; q < Q.p[j + 1]; ++q) E2[j] += std::fabs(Q.x[q]); E2[j] = std::sqrt(E2[j]); }
-    for (int j = 0; j < n; ++j) Ep[j] = E1[j] < E2[j] ? E2[j] : E1[j];
-    cone_average(Ep, k);
-    for (int q = 0; q < A.p[n]; ++q) Dp[A.i[q]] += std::fabs(A.x[q]);
-    for (int i = 0; i < m; ++i) Dp[i] = std::sqrt(Dp[i]);
-    apply_pass(w, Dp, Ep);
-  }
-}
-void scale_data(QWk *w, const QCPData *d, const QCPCone *k) {
-  const int m = w->m, n = w->n;
-  w->b.assign(d->b, d->b + m); w->c.assign(d->c, d->c + n);
-  scale_passes(w, k);
-  double ss = 0;
-  for (double t : w->c) ss += t * t;
-  double sb = 0;
-  for (double t : w->b) sb += t * t;
-  double sc = std::sqrt(std::sqrt(ss + sb)); // :462-463
-  for (int i = 0; i < m; ++i) w->b[i] /= w->D[i];
-  for (int j = 0; j < n; ++j) w->c[j] /= w->E[j];
-  if (sc < kMinScale) sc = 1; else if (sc > kMaxScale) sc = kMaxScale;
-  w->sc_b = 1 / sc; w->sc_c = 1 / sc;
-  for (int i = 0; i < m; ++i) w->b[i] *= w->sc_b * w->st->scale;
-  for (int j = 0; j < n; ++j) w->c[j] *= w->sc_c * w->st->scale;
-}
-
-// ---- LASSO front end: init_lasso + scaling_lasso_data, lasso_config.c:8-260 -----------------------------------------------
-// min 1/2 |X beta - y|^2 + lambda |beta|_1 as the conic problem over (x0, x1, z (dm), beta+ (dn), beta- (dn)):
-//   row 0: x0 = 1; rows 1..dm: z + X beta+ - X beta- = y; (x0, x1, z) in one rotated cone; beta+- >= 0; cost 2 x1 + lambda 1'(beta+ + beta-).
-// The reference applies this operator matrix-free (lasso_A_times / lasso_AT_times, :99-128) and solves the KKT system through a reduced
-// dm x dm or dn x dn system (:506-556, 652-708); here the scaled operator is materialised once as a sparse matrix (nnz = 1 + dm + 2 nnz(X))
-// and handed to the conic path's own kernels and KKT back-ends -- the same linear maps, one code path on the device.
-void build_lasso(QWk *w, const QCPData *d) {
-  LassoForm &L = w->ls;
-  const int dm = d->m, dn = d->n;
-  L.dm = dm; L.dn = dn; L.lambda = d->lambda;
-  const int p = dm + 1, q = 2 + 2 * dn + dm;
-  const QCPMatrix *X = d->A;
-  const int xnnz = X->p[dn];
-  w->sparsity = (((double)xnnz / ((double)dm * (double)dn)) < 0.1); // :21
-  if (w->sparsity) { // :36-51
-    L.sc = 2; L.sc_c = 1 / L.lambda; L.sc_cone2 = L.lambda / dm * 80; L.sc_cone1 = 0.8 / L.sc_c / L.sc_cone2; L.sc_b = L.sc_c * 300 * L.lambda / dm;
-  } else {
-    L.sc = dm < dn ? 4 : 1; L.sc_c = 1 / L.lambda; L.sc_b = L.sc_c; L.sc_cone2 = 0.8; L.sc_cone1 = 1 / L.sc_c;
-  }
-  std::vector<double> xs(X->x, X->x + xnnz);
-  std::vector<double> &E = L.E, &D = L.D;
-  E.assign(dn, 0.0); D.assign(dm, 0.0);
-  const double sqm = std::sqrt((double)dm);
-  if (w->st->scale_E) { // :156-210
-    if (w->sparsity) {
-      double avg = 0, avg1 = 0;
-      for (int i = 0; i < dn; ++i) { for (int j = X->p[i]; j < X->p[i + 1]; ++j) E[i] += xs[j] * xs[j]; avg += std::sqrt(E[i]); }
-      avg /= dn;
-      for (int i = 0; i < dn; ++i) {
-        E[i] = avg / std::sqrt(E[i] + 1e-4) / L.sc;
-        if (E[i] > 1000 * sqm) E[i] = 1000 * sqm;
-        if (E[i] < 0.001 * sqm) E[i] = 1;
-        if (E[i] > 50) E[i] = 50;
-        avg1 += E[i];
-      }
-      avg1 /= dn;
-      for (int i = 0; i < dn; ++i) E[i] = avg1 / E[i] / L.sc;
-    } else {
-      for (int i = 0; i < dn; ++i) {
-        for (int j = X->p[i]; j < X->p[i + 1]; ++j) E[i] += xs[j] * xs[j];
-        E[i] = std::sqrt(E[i]);
-        if (E[i] > 1000 * sqm) E[i] = 1000 * sqm;
-        if (E[i] < 0.001 * sqm) E[i] = 1;
-        if (E[i] > 7) E[i] = 7;
-        E[i] = 1 / (E[i] * L.sc);
-      }
-    }
-    for (int i = 0; i < dn; ++i) for (int j = X->p[i]; j < X->p[i + 1]; ++j) xs[j] *= E[i];
-  }
-  for (int k = 0; k < xnnz; ++k) D[X->i[k]] += xs[k] * xs[k]; // :212-230
-  double avg = 0;
-  for (int i = 0; i < dm; ++i) avg += std::sqrt(2 * D[i] + L.sc_cone2);
-  avg /= dm;
-  for (int i = 0; i < dm; ++i) D[i] = avg / std::sqrt(2 * D[i] + L.sc_cone2);
-  for (int k = 0; k < xnnz; ++k) xs[k] *= D[X->i[k]];
-  L.y.assign(d->b, d->b + dm);
-  w->b.assign(p, 0.0); w->c.assign(q, 0.0); // :232-250
-  w->b[0] = L.sc_cone1;
-  for (int i = 0; i < dm; ++i) w->b[1 + i] = d->b[i] * D[i];
-  for (double &t : w->b) t *= L.sc_b;
-  w->c[1] = L.sc_cone1 * L.sc_cone2;
-  for (int i = 0; i < dn; ++i) { w->c[dm + 2 + i] = E[i] * L.lambda; w->c[dm + 2 + dn + i] = E[i] * L.lambda; }
-  for (double &t : w->c) t *= L.sc_c;
-  // the operator of lasso_A_times (:99-110) as a p x q CSC matrix
-  HMat &A = w->A;
-  A.m = p; A.n = q; A.p.assign(q + 1, 0); A.i.clear(); A.x.clear();
-  A.i.reserve((size_t)1 + dm + 2 * (size_t)xnnz); A.x.reserve(A.i.capacity());
-  const double sq2 = std::sqrt(L.sc_cone2);
-  A.i.push_back(0); A.x.push_back(1.0); A.p[1] = 1; // column 0
-  A.p[2] = 1;                                         // column 1 is empty
-  for (int i = 0; i < dm; ++i) { A.i.push_back(1 + i); A.x.push_back(D[i] * sq2); A.p[3 + i] = (int)A.i.size(); }
-  for (int sign = 0; sign < 2; ++sign)
-    for (int j = 0; j < dn; ++j) {
-      for (int k = X->p[j]; k < X->p[j + 1]; ++k) { A.i.push_back(1 + X->i[k]); A.x.push_back(sign ? -xs[k] : xs[k]); }
-      A.p[dm + 2 + sign * dn + j + 1] = (int)A.i.size();
-    }
-  w->D.assign(p, 1.0); w->E.assign(q, 1.0); w->sc_b = 1; w->sc_c = 1; // (neutral for the generic sums kq_resid still provides: certificates)
-}
-
-// ---- SVM-SOCP front end: init_svm + scaling_svm_data, svm_config.c:8-171, 281-391 -------------------------------------------------
-// x = (x0, x1, r (dn), w+ (dn), b+, w- (dn), b-, xi (dm), t (dm)); (x0, x1, r) in one rotated cone, the rest >= 0; dm + dn + 1 rows:
-//   row 0: x0 = const;  rows 1..dm: diag(y)(X (w+ - w-) + (b+ - b-)) + xi - t = 1;  rows dm+1..: r tied to w+ - w-;  cost x1 + C 1'xi.
-// As for LASSO the operator of svm_A_times (:177-199) is materialised (nnz = 1 + 3 dn + 2 dm + 2 (nnz(X) + dm)) and the conic path's own
-// KKT back-ends replace the block elimination of :725-806 (same linear system, rho_x = 1 as hard-coded there).
-// The scale constants are a table of heuristics in (dm, dn, lambda); the reference leaves them uninitialised when dm == 10 dn or
-// 10 dm == dn (no branch taken, :63-107) and never assigns sc_cone2 when dm > 10 dn with dn < 10 (:85-89): the boundaries are closed
-// towards the outer branches here and sc_cone2 starts from sc_cone1 in that corner.
-void svm_constants(int m, int n, double lambda, SvmForm &V) {
-  const double l2 = std::log(2 * lambda) / std::log(10.0), l5 = std::log(5 * lambda) / std::log(10.0);
-  V.sc = 1; V.sc_b = 1;
-  if (((long long)m < 10LL * n) && (10LL * m > (long long)n)) {
-    V.sc_c = std::max(0.45, std::pow(7.5, -l2) * 2); V.sc_cone1 = std::max(3.0, l2 * 4 + 4); V.sc_cone2 = V.sc_cone1;
-  } else if (10LL * m <= (long long)n) {
-    V.sc_cone2 = std::max(3.0, l2 * 2 + 2);
-    if (lambda >= 1) { V.sc_c = std::max(0.2, std::pow(0.2, l2) * 7.5); V.sc_cone1 = V.sc_cone2; }
-    else { V.sc_c = std::pow(0.3, l2) * 3; V.sc_cone1 = std::max(0.4, l2 * 0.2 + 0.8); }
-  } else {
-    if (n < 10) {
-      V.sc_c = 1 / lambda; V.sc_cone1 = 6; V.sc_cone2 = 6;
-      if (lambda < 0.002) V.sc_cone2 = V.sc_cone2 - 3 * std::log(lambda * 500) / std::log(10.0);
-    } else if (lambda >= 1) { V.sc_c = 1 / lambda; V.sc_cone1 = 6; V.sc_cone2 = lambda; }
-    else {
-      V.sc_c = std::min(std::pow(5, -l5) * 4, 300.0); V.sc_b = std::max(0.1, l5 * 0.2 + 0.9); V.sc_cone1 = std::max(0.05, l5 * 0.3 + 0.7); V.sc_cone2 = -l5 * 2 + 6;
-      if (lambda < 0.002) V.sc_cone2 = V.sc_cone2 - 3 * std::log(lambda * 500) / std::log(10.0);
-    }
-  }
-}
-bool build_svm(QWk *w, const QCPData *d) { // false: a feature column of X is identically zero
-  for (int j = 0; j < d->n; ++j) { // the scaling divides by every column's 2-norm (svm_config.c:300-308): the reference goes on with inf / NaN and never converges
-    bool nz = false;
-    for (int t = d->A->p[j]; t < d->A->p[j + 1] && !nz; ++t) nz = d->A->x[t] * d->b[d->A->i[t]] != 0.0;
-    if (!nz) return false;
-  }
-  SvmForm &V = w->sv;
-  const int dm = d->m, dn = d->n, n1 = dn + 1, p = dm + dn + 1, q = 4 + 3 * dn + 2 * dm;
-  V.dm = dm; V.dn = dn; V.lambda = d->lambda;
-  const QCPMatrix *X = d->A;
-  const int xnnz = X->p[dn];
-  w->sparsity = (((double)xnnz / ((double)dm * (double)dn)) < 0.05); // :20
-  svm_constants(dm, dn, V.lambda, V);
-  // data_A = [diag(y) X, y] (:109-133), then column and row equilibration (:300-341)
-  std::vector<double> xs((size_t)xnnz + dm);
-  for (int t = 0; t < xnnz; ++t) xs[t] = X->x[t] * d->b[X->i[t]];
-  for (int i = 0; i < dm; ++i) xs[xnnz + i] = d->b[i];
-  auto col_lo = [&](int j) { return j < dn ? X->p[j] : xnnz; };
-  auto col_hi = [&](int j) { return j < dn ? X->p[j + 1] : xnnz + dm; };
-  auto row_of = [&](int t) { return t < xnnz ? X->i[t] : t - xnnz; };
-  std::vector<double> &E = V.E, &D = V.D;
-  E.assign(n1, 0.0); D.assign(dm, 0.0);
-  double avg = 0;
-  if (w->st->scale_E) {
-    for (int j = 0; j < n1; ++j) { for (int t = col_lo(j); t < col_hi(j); ++t) E[j] += xs[t] * xs[t]; E[j] = std::sqrt(E[j]); avg += E[j]; }
-    avg /= n1;
-    for (int j = 0; j < n1; ++j) E[j] = avg / E[j];
-    for (int j = 0; j < n1; ++j) for (int t = col_lo(j); t < col_hi(j); ++t) xs[t] *= E[j];
-  }
-  for (int t = 0; t < xnnz + dm; ++t) D[row_of(t)] += xs[t] * xs[t];
-  avg = 0;
-  for (int i = 0; i < dm; ++i) avg += std::sqrt(D[i]);
-  avg /= dm;
-  for (int i = 0; i < dm; ++i) D[i] = avg / std::sqrt(D[i]);
-  for (int t = 0; t < xnnz + dm; ++t) xs[t] *= D[row_of(t)];
-  std::vector<double> wD(dn), &wE = V.wE;
-  wE.assign(dn, 0.0);
-  for (int j = 0; j < dn; ++j) { const double F = 1 / std::sqrt(1 + 2 * E[j] * E[j]); wD[j] = F * -std::sqrt(V.sc_cone1); wE[j] = E[j] * F; } // :343-345, 374-380
-  w->b.assign(p, 0.0); w->c.assign(q, 0.0); // :347-364
-  w->b[0] = V.sc_cone2;
-  for (int i = 0; i < dm; ++i) w->b[1 + i] = D[i];
-  for (double &t : w->b) t *= V.sc_b;
-  w->c[1] = V.sc_c * V.sc_cone1 * V.sc_cone2;
-  for (int i = 0; i < dm; ++i) w->c[3 * dn + 4 + i] = V.lambda * V.sc_c / V.sc;
-  // the operator of svm_A_times (:177-199) as a p x q CSC matrix
-  HMat &A = w->A;
-  A.m = p; A.n = q; A.p.assign(q + 1, 0); A.i.clear(); A.x.clear();
-  A.i.reserve((size_t)1 + 3 * dn + 2 * dm + 2 * ((size_t)xnnz + dm)); A.x.reserve(A.i.capacity());
-  int col = 0;
-  auto close = [&]() { A.p[++col] = (int)A.i.size(); };
-  A.i.push_back(0); A.x.push_back(1.0); close(); // x0
-  close();                                        // x1: empty
-  for (int j = 0; j < dn; ++j) { A.i.push_back(1 + dm + j); A.x.push_back(wD[j]); close(); } // r
-  for (int sign = 0; sign < 2; ++sign) {
-    const double sg = sign ? -1.0 : 1.0;
-    for (int j = 0; j < dn; ++j) { // w+ / w-
-      for (int t = X->p[j]; t < X->p[j + 1]; ++t) { A.i.push_back(1 + X->i[t]); A.x.push_back(sg * xs[t]); }
-      A.i.push_back(1 + dm + j); A.x.push_back(-sg * wE[j]);
-      close();
-    }
-    for (int i = 0; i < dm; ++i) { A.i.push_back(1 + i); A.x.push_back(sg * xs[xnnz + i]); } // b+ / b-
-    close();
-  }
-  for (int i = 0; i < dm; ++i) { A.i.push_back(1 + i); A.x.push_back(D[i] * (1 / V.sc)); close(); } // xi
-  for (int i = 0; i < dm; ++i) { A.i.push_back(1 + i); A.x.push_back(-D[i]); close(); }             // t
-  w->D.assign(p, 1.0); w->E.assign(q, 1.0); w->sc_b = 1; w->sc_c = 1; // (neutral for the generic sums kq_resid still provides: certificates)
-  return true;
-}
-
-// ---- SVM-QP front end: init_svmqp + scaling_svmqp_data, svm_qp_config.c:8-124, 195-590 -------------------------------------
-// x = (w (dn), b, xi (dm), t (dm)); w, b free, xi, t >= 0;  min 1/2 |w|^2 + 1/(dm lambda) 1'xi  s.t.  diag(y) (X w + b) + xi - t = 1.
-// The reference keeps the data block B~ = D^-1 diag(y) [X, 1] E^-1 and applies the +-D^-1 identity columns on the fly (:129-147); here the
-// whole dm x q operator [B~, D^-1, -D^-1] is materialised and the generic conic path (kernels, KKT back-ends, residuals) runs on it.
-// The caller's X is left untouched (the reference folds the labels into it in place, :84-86).
-void build_svmqp(QWk *w, const QCPData *d, const QCPCone *k) {
-  SvmForm &V = w->sv;
-  const int dm = d->m, dn = d->n, q = 1 + dn + 2 * dm, n1 = dn + 1;
-  V.dm = dm; V.dn = dn; V.lambda = d->lambda;
-  const QCPMatrix *X = d->A;
-  const int xnnz = X->p[dn];
-  w->sparsity = (((double)xnnz / ((double)dm * (double)dn)) < 0.05); // :37
-  HMat &B = w->A, &Q = w->Q;
-  B.m = dm; B.n = n1; B.p.assign(X->p, X->p + dn + 1); B.p.push_back(xnnz + dm);
-  B.i.assign(X->i, X->i + xnnz); B.x.resize((size_t)xnnz + dm);
-  for (int t = 0; t < xnnz; ++t) B.x[t] = X->x[t] * d->b[X->i[t]];
-  for (int i = 0; i < dm; ++i) { B.i.push_back(i); B.x[xnnz + i] = d->b[i]; }
-  Q.m = q; Q.n = q; Q.p.assign(q + 1, dn); Q.i.resize(dn); Q.x.assign(dn, 1.0); // :19-35
-  for (int i = 0; i < dn; ++i) { Q.i[i] = i; Q.p[i] = i; }
-  w->b.assign(dm, 1.0); w->c.assign(q, 0.0);
-  for (int i = 0; i < dm; ++i) w->c[dn + 1 + i] = 1.0 / (dm * V.lambda);
-  w->nm_inf_b = vnrminf(w->b.data(), dm); w->nm_inf_c = vnrminf(w->c.data(), q); // abip.c:875-876
-  w->n = n1; scale_passes(w, k); w->n = q; // (the passes see the data block only)
-  w->E.resize(q, 1.0);                      // :107-110
-  double ss = 0, sb = 0;
-  for (double t : w->c) ss += t * t;
-  for (double t : w->b) sb += t * t;
-  double sc = std::sqrt(std::sqrt(ss + sb)); // :549-550
-  for (int i = 0; i < dm; ++i) w->b[i] /= w->D[i];
-  for (int j = 0; j < n1; ++j) w->c[j] /= w->E[j];
-  if (sc < kMinScale) sc = 1; else if (sc > kMaxScale) sc = kMaxScale;
-  w->sc_b = 1 / sc; w->sc_c = 1 / sc;
-  for (double &t : w->b) t *= w->sc_b * w->st->scale;
-  for (double &t : w->c) t *= w->sc_c * w->st->scale;
-  // [B~, D^-1, -D^-1]
-  B.n = q; B.p.resize(q + 1);
-  B.i.reserve(B.i.size() + 2 * (size_t)dm); B.x.reserve(B.x.size() + 2 * (size_t)dm);
-  for (int sign = 0; sign < 2; ++sign)
-    for (int i = 0; i < dm; ++i) { B.i.push_back(i); B.x.push_back((sign ? -1.0 : 1.0) * (1 / w->D[i])); B.p[n1 + sign * dm + i + 1] = (int)B.i.size(); }
-}
 
 void hcsr_from(const HMat &M, host::HostCsr &out, bool transpose_to_rows) {
   // transpose_to_rows = false: CSC read as CSR of M' (ncols rows); true: explicit CSR of M (nrows rows)
@@ -656,13 +276,14 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     // the reference scales the data whatever `normalize` says and un-scales only when it is set, and divides by E = 0 when scale_E = 0
     // (lasso_config.c:147-156, 300-310; abip.c:580-582): neither combination returns a usable beta
     if (!st->normalize || !st->scale_E) return fail(info, "the LASSO formulation needs normalize = 1 and scale_E = 1");
-    if ((long long)2 + 2LL * d->n + d->m > 2147483647LL) return fail(info, "problem too large for 32-bit indices");
+    if ((long long)2 + 2LL * d->n + d->m > 2147483647LL || 1LL + d->m + 2LL * d->A->p[d->n] > 2147483647LL) return fail(info, "problem too large for 32-bit indices");
   }
   if (kind == 3 || kind == 1) { // SVM: data = (X, labels y, lambda) as abip_ml_mex.c:117-160 hands them over
     if (d->m <= 0 || d->n <= 0 || !(d->lambda > 0)) return fail(info, "SVM needs a non-empty X and lambda > 0");
     if (!st->normalize) return fail(info, "the SVM formulation needs normalize = 1"); // (as for LASSO: scaled unconditionally, un-scaled only when set)
     if (kind == 1 && !st->scale_E) return fail(info, "the SVM-SOCP formulation needs scale_E = 1"); // (E = 0 otherwise, svm_config.c:296-316)
-    if ((long long)4 + 3LL * d->n + 2LL * d->m > 2147483647LL) return fail(info, "problem too large for 32-bit indices");
+    if ((long long)4 + 3LL * d->n + 2LL * d->m > 2147483647LL || 1LL + 3LL * d->n + 4LL * d->m + 2LL * d->A->p[d->n] > 2147483647LL)
+      return fail(info, "problem too large for 32-bit indices"); // (columns / non-zeros of the materialised operator)
   }
   const int m = kind == 0 ? d->m + 1 : (kind == 1 ? d->m + d->n + 1 : d->m);
   const int n = kind == 0 ? 2 + 2 * d->n + d->m : (kind == 1 ? 4 + 3 * d->n + 2 * d->m : (kind == 3 ? 1 + d->n + 2 * d->m : d->n));
