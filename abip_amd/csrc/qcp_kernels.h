@@ -15,7 +15,8 @@
 
 namespace abip {
 
-struct QDims { int m, n, MP; int norm_u; }; // norm_u: the inner test normalises by 1 + |u| + |v_o| (1: lasso_config.c:343-345) or 1 + |(u, v_o)| (2: svm_config.c:266-268) instead of 1 + |Qu| + |v_o| (0: qcp_config.c:549-551)
+struct QDims { int m, n, MP; int norm_u; double wy; }; // norm_u: the inner test normalises by 1 + |u| + |v_o| (1: lasso_config.c:343-345) or 1 + |(u, v_o)| (2: svm_config.c:266-268) instead of 1 + |Qu| + |v_o| (0: qcp_config.c:549-551);
+// wy: weight of the sums over the y block -- 1 on a single GPU; with the columns sharded over several (qcp_dist.h) the y block is replicated and only rank 0 counts it
 
 enum QSlot : int { // reuse of the partials table; *_MAX slots are reduced with max
   Q_T0 = 0, Q_T1, Q_PG,                       // r'mu, r'(rho o p), p_x'Qp
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(BS) void kq_rhs(const double *__restrict__ u, const
   double acc[1] = {0.0};
   const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
   for (int i = t0; i < d.m; i += stride) { const double mu = (u[i] + v[i]) * rho_y; p[i] = -mu; acc[0] += r[i] * mu; }
+  acc[0] *= d.wy;
   for (int j = t0; j < d.n; j += stride) { const int q = d.MP + j; const double mu = (u[q] + v[q]) * rho_x; p[q] = mu; acc[0] += r[q] * mu; }
   const int ws[1] = {Q_T0};
   write_partials<1>(part, ws, acc, sm);
@@ -80,6 +82,7 @@ __global__ __launch_bounds__(BS) void kq_dots(const double *__restrict__ r, cons
   double acc[1] = {0.0};
   const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
   for (int i = t0; i < d.m; i += stride) acc[0] += r[i] * (p[i] * rho_y);
+  acc[0] *= d.wy;
   for (int j = t0; j < d.n; j += stride) acc[0] += r[d.MP + j] * (p[d.MP + j] * rho_x);
   const int ws[1] = {Q_T1};
   write_partials<1>(part, ws, acc, sm);
@@ -114,12 +117,14 @@ struct QProxArgs {
   int iter_pos; // iter > 0
   int hasQ;
 };
-__global__ __launch_bounds__(BS) void kq_ut_prox(QProxArgs a, QDims d, const double *part, int nb, QCtl *ctl, const Ctl *hc) {
+// gsc: null on a single GPU (the three sums are re-reduced from the partials); with sharded columns the table of all-reduced sums (ctl->out)
+__global__ __launch_bounds__(BS) void kq_ut_prox(QProxArgs a, QDims d, const double *part, int nb, QCtl *ctl, const Ctl *hc, const double *gsc) {
   if (hc->halt) return;
   __shared__ double sm[3 * WAVES];
   double s3[3];
   const int rs[3] = {Q_T0, Q_T1, Q_PG};
-  read_partials<3>(part, rs, nb, s3, sm);
+  if (gsc) { s3[0] = gsc[Q_T0]; s3[1] = gsc[Q_T1]; s3[2] = gsc[Q_PG]; }
+  else read_partials<3>(part, rs, nb, s3, sm);
   const int tail = d.MP + d.n;
   const double eta = a.rho_tau * (a.u[tail] + a.v[tail]);
   const double bq = s3[0] - 2 * s3[1] - eta;               // abip.c:229-230
@@ -282,7 +287,7 @@ __device__ __forceinline__ void dq_inner_At(const Csr &At, const double *__restr
       },
       [] { return true; }, vb, vgrid);
   if (finish) {
-    if (vb == 0 && threadIdx.x == 0) { const double t = vo[d.MP + d.n]; a5[4] += t * t; }
+    if (vb == 0 && threadIdx.x == 0) { const double t = vo[d.MP + d.n]; a5[4] += t * t * d.wy; }
     const int ws[5] = {Q_D1 + 0, Q_D3, Q_E1, Q_E2, Q_E3};
     // the y rows already own slots D1, E1..E3: use the second half of the table (offset Q_COUNT) for the x rows
     double *part2 = part + (size_t)Q_COUNT * MAXNB;
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(BS) void kq_inner_Q(Csr Q, const double *__restrict
         const double mu = -ATy[j] + acc[0], qu = mu + tau * c[j], dv = qu - vo[q];
         a5[0] += u[q] * mu; a5[1] += u[q] * c[j]; a5[2] += dv * dv; a5[3] += qu * qu; a5[4] += vo[q] * vo[q];
       });
-  if (blockIdx.x == 0 && threadIdx.x == 0) { const double t = vo[d.MP + d.n]; a5[4] += t * t; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { const double t = vo[d.MP + d.n]; a5[4] += t * t * d.wy; }
   const int ws[5] = {Q_D1 + 0, Q_D3, Q_E1, Q_E2, Q_E3};
   double *part2 = part + (size_t)Q_COUNT * MAXNB;
   write_partials<5>(part2, ws, a5, sm);
@@ -354,6 +359,7 @@ __global__ __launch_bounds__(BS) void kq_resid(const double *__restrict__ u, con
     const double dax = Di * Ax[i];
     s6[0] += dax * dax; s6[1] += b[i] * u[i];
   }
+  s6[0] *= d.wy; s6[1] *= d.wy;
   for (int j = t0; j < d.n; j += stride) {
     const int q = d.MP + j;
     const double qx = Qx[j] * it, aty = ATy[j] * it, s = vo[q] * it, Ej = Ev[j];
@@ -437,6 +443,18 @@ struct QFin {
   double tol_inner = 0.0;
   const double *u_tau = nullptr, *vo_tau = nullptr;
 };
+// complete the inner stopping metric with the tau entries, count the iteration, raise the halt flag (one thread)
+__device__ __forceinline__ void q_decide(const QFin &f, QCtl *ctl, Ctl *hc) { // un-fused arithmetic: the host code this replaces was compiled without FMA contraction
+  const double *o = ctl->out;
+  const double tau = *f.u_tau, vot = *f.vo_tau;
+  const double qut = -o[Q_D1] / tau + o[Q_D2] - o[Q_D3];
+  const double dq = qut - vot;
+  const double t2 = f.norm_u ? tau : qut;
+  const double e1 = __dadd_rn(o[Q_E1], __dmul_rn(dq, dq)), e2 = __dadd_rn(o[Q_E2], __dmul_rn(t2, t2)), e3 = o[Q_E3];
+  const double err = f.norm_u == 2 ? sqrt(e1) / (1 + sqrt(e2 + e3)) : sqrt(e1) / (1 + sqrt(e2) + sqrt(e3));
+  ctl->err_inner = err; ctl->it_count = ctl->it_count + 1;
+  if (err < f.tol_inner) { hc->halt = 1; ctl->halted = 1; }
+}
 __global__ __launch_bounds__(1024) void kq_finalize(QFin f, const double *part, int nb, QCtl *ctl, Ctl *hc) {
   if (f.decide && hc->halt) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
@@ -460,17 +478,12 @@ __global__ __launch_bounds__(1024) void kq_finalize(QFin f, const double *part, 
   }
   if (!f.decide) return;
   __syncthreads();
-  if (threadIdx.x == 0) { // un-fused arithmetic: the host code this replaces was compiled without FMA contraction
-    const double *o = ctl->out;
-    const double tau = *f.u_tau, vot = *f.vo_tau;
-    const double qut = -o[Q_D1] / tau + o[Q_D2] - o[Q_D3];
-    const double dq = qut - vot;
-    const double t2 = f.norm_u ? tau : qut;
-    const double e1 = __dadd_rn(o[Q_E1], __dmul_rn(dq, dq)), e2 = __dadd_rn(o[Q_E2], __dmul_rn(t2, t2)), e3 = o[Q_E3];
-    const double err = f.norm_u == 2 ? sqrt(e1) / (1 + sqrt(e2 + e3)) : sqrt(e1) / (1 + sqrt(e2) + sqrt(e3));
-    ctl->err_inner = err; ctl->it_count = ctl->it_count + 1;
-    if (err < f.tol_inner) { hc->halt = 1; ctl->halted = 1; }
-  }
+  if (threadIdx.x == 0) q_decide(f, ctl, hc);
+}
+// sharded columns: the sums were reduced locally (decide = 0), exchanged, and written back to ctl->out; this closes the iteration
+__global__ void kq_decide(QFin f, QCtl *ctl, Ctl *hc) {
+  if (hc->halt) return;
+  if (threadIdx.x == 0 && blockIdx.x == 0) q_decide(f, ctl, hc);
 }
 
 } // namespace abip

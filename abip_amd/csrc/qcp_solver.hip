@@ -16,6 +16,8 @@
 #include "dev_ldl.h"
 #include "qcp_kernels.h"
 #include "qcp_pcg.h"
+#include "qcp_dist.h"
+#include "dist_internal.h"
 #include "qcp_work.h"
 #include "qcp_formulations.h"
 
@@ -47,19 +49,44 @@ void enqueue_solve(QWk *w, double *rhs) { // _ldl_solve, linsys.c:309-316
   w->ldl.enqueue([&](auto kern, int grid, int block, size_t lds, auto... a) { hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, w->stream, a...); }, rhs, w->lp_ctl, w->NB);
 }
 
+// several GPUs: in-place sum over the ranks, on the solver's stream
+int ar(QWk *w, double *buf, size_t count) { w->n_allreduce++; return dist_allreduce(buf, count, w->stream, w->hstage); }
+// the sums kq_finalize (decide = 0) left in ctl->out for `slots`: exchange them, write the totals back
+int exchange_sums(QWk *w, std::initializer_list<int> slots) {
+  QPack pk; pk.n = 0;
+  for (int sl : slots) pk.slots[pk.n++] = sl;
+  double *out = reinterpret_cast<double *>(w->ctl.p); // QCtl::out is its first member
+  QLAUNCH(w, kq_dist_pack, 1, 64, pk, (const double *)out, w->gsbuf.p, (int)Q_COUNT);
+  if (ar(w, w->gsbuf.p, Q_COUNT)) return -1;
+  QLAUNCH(w, kq_dist_unpack, 1, 64, pk, (const double *)w->gsbuf.p, out);
+  return 0;
+}
+
 // K z = rhs by y-space PCG (qcp_pcg.h).  warm: y0 = (u + tau r)_y and the tolerance of abip.c:213-217 (tol_host = min of the two residual
 // norms of the last check); otherwise y0 = 0 and tol as given (the set-up solve, abip.c:899).  Synchronises with the host once per chunk
 // of iterations.  Returns the CG iterations used, < 0 on a device error.
 int solve_pcg(QWk *w, double *rhs, bool warm, int iter, double tol_host) {
-  const QDims d{w->m, w->n, w->MP, w->kind == 0 ? 1 : (w->kind == 1 ? 2 : 0)};
+  const QDims d{w->m, w->n, w->MP, w->kind == 0 ? 1 : (w->kind == 1 ? 2 : 0), w->wy};
   const QCPSettings *st = w->st;
   QPcgVec v{w->cg_x0.p, w->cg_r.p, w->cg_z.p, w->cg_p.p, w->cg_Gp.p, w->cg_tm.p, w->cg_M.p, w->cg_H.p};
   Ctl *hc = w->lp_ctl;
   const int max_its = w->m;
-  QLAUNCH(w, kq_pcg_prep, w->NB, BS, w->dA.view(), rhs, (const double *)w->u.p, (const double *)w->r.p, warm ? 1 : 0, d, v, w->cg_part.p, hc);
+  double *buf = w->arbuf.p; // several GPUs: the exchange area, [0, m) products, [m, m + world) the max lanes of the warm start
+  const double ipow = std::pow((double)iter + 1.0, 1.5);
+  if (w->dist) { // qcp_dist.h: products of the rank's column block, all-reduced, then the element-wise halves on the replicated m-space
+    QLAUNCH(w, kq_prod_A, w->NB, BS, w->dA.view(), (const double *)(rhs + w->MP), (const double *)w->cg_H.p, buf, 0, (const Ctl *)hc);
+    QLAUNCH(w, kq_dist_prep_warm, w->NB, BS, (const double *)w->u.p, (const double *)w->r.p, warm ? 1 : 0, d, w->n0, w->n_glob - w->m, v, w->cg_part.p, hc);
+    QLAUNCH(w, kq_dist_pack_max, 1, BS, (const double *)w->cg_part.p, (int)PQ_WM, 1, w->NB, buf + w->m, w->rank, w->world);
+    if (ar(w, buf, (size_t)w->m + w->world)) return -1;
+    QLAUNCH(w, kq_dist_prep_fin, w->NB, BS, rhs, (const double *)buf, w->m, (const Ctl *)hc);
+  } else QLAUNCH(w, kq_pcg_prep, w->NB, BS, w->dA.view(), rhs, (const double *)w->u.p, (const double *)w->r.p, warm ? 1 : 0, d, v, w->cg_part.p, hc);
   if (warm) {
     QLAUNCH(w, kq_pcg_Aty<true>, w->NB, BS, w->dAt.view(), v, max_its, w->cg_part.p, w->NB, hc);
-    QLAUNCH(w, kq_pcg_Gp<true>, w->NB, BS, w->dA.view(), v, rhs, st->rho_y, tol_host, std::pow((double)iter + 1.0, 1.5), w->cg_part.p, w->NB, hc);
+    if (w->dist) {
+      QLAUNCH(w, kq_prod_A, w->NB, BS, w->dA.view(), (const double *)w->cg_tm.p, (const double *)nullptr, buf, 1, (const Ctl *)hc);
+      if (ar(w, buf, (size_t)w->m)) return -1;
+      QLAUNCH(w, kq_dist_Gp_fin<true>, w->NB, BS, v, rhs, (const double *)buf, st->rho_y, tol_host, ipow, (const double *)(buf + w->m), w->world, w->m, w->cg_part.p, hc);
+    } else QLAUNCH(w, kq_pcg_Gp<true>, w->NB, BS, w->dA.view(), v, rhs, st->rho_y, tol_host, ipow, w->cg_part.p, w->NB, hc);
   } else {
     QLAUNCH(w, kq_pcg_init_cold, w->NB, BS, v, rhs, w->m, tol_host, w->cg_part.p, hc);
   }
@@ -67,7 +94,11 @@ int solve_pcg(QWk *w, double *rhs, bool warm, int iter, double tol_host) {
   for (;;) {
     for (int q = 0; q < chunk; ++q) {
       QLAUNCH(w, kq_pcg_Aty<false>, w->NB, BS, w->dAt.view(), v, max_its, w->cg_part.p, w->NB, hc);
-      QLAUNCH(w, kq_pcg_Gp<false>, w->NB, BS, w->dA.view(), v, rhs, st->rho_y, 0.0, 1.0, w->cg_part.p, w->NB, hc);
+      if (w->dist) {
+        QLAUNCH(w, kq_prod_A, w->NB, BS, w->dA.view(), (const double *)w->cg_tm.p, (const double *)nullptr, buf, 1, (const Ctl *)hc);
+        if (ar(w, buf, (size_t)w->m)) return -1;
+        QLAUNCH(w, kq_dist_Gp_fin<false>, w->NB, BS, v, rhs, (const double *)buf, st->rho_y, 0.0, 1.0, (const double *)(buf + w->m), w->world, w->m, w->cg_part.p, hc);
+      } else QLAUNCH(w, kq_pcg_Gp<false>, w->NB, BS, w->dA.view(), v, rhs, st->rho_y, 0.0, 1.0, w->cg_part.p, w->NB, hc);
       QLAUNCH(w, kq_pcg_update, w->NB, BS, v, rhs, w->m, w->cg_part.p, w->NB, hc);
     }
     QLAUNCH(w, kq_pcg_post, w->NB, BS, w->dAt.view(), rhs, v, max_its, d, w->cg_part.p, w->NB, hc);
@@ -100,6 +131,13 @@ void finalize(QWk *w, std::initializer_list<int> slots, std::initializer_list<in
   for (int s : slots) { f.slots[f.nslots] = s; f.second_half[f.nslots] = 0; for (int bsl : both_halves) if (bsl == s) f.second_half[f.nslots] = 1; ++f.nslots; }
   f.norm_u = w->kind == 0 ? 1 : (w->kind == 1 ? 2 : 0);
   if (tol_inner >= 0) { f.decide = 1; f.tol_inner = tol_inner; f.u_tau = w->u.p + w->MP + w->n; f.vo_tau = w->vo.p + w->MP + w->n; }
+  if (w->dist && f.decide) { // local sums -> exchange -> the decision from the totals (every rank decides alike)
+    QFin g = f; g.decide = 0;
+    QLAUNCH(w, kq_finalize, 1, 1024, g, (const double *)w->part.p, w->NB, w->ctl.p, w->lp_ctl);
+    if (exchange_sums(w, slots)) { w->dist_failed = true; return; }
+    QLAUNCH(w, kq_decide, 1, 64, f, w->ctl.p, w->lp_ctl);
+    return;
+  }
   QLAUNCH(w, kq_finalize, 1, 1024, f, (const double *)w->part.p, w->NB, w->ctl.p, w->lp_ctl);
 }
 
@@ -146,10 +184,17 @@ int has_converged(const QWk *w, const QResid &r, int ipm_iter, int admm_iter) { 
 int calc_residuals(QWk *w, QResid &r, int ipm_iter, int admm_iter) { // qcp_config.c:562-691 (sums from kq_resid)
   if (admm_iter && r.last_admm_iter == admm_iter) return 0;
   r.last_ipm_iter = ipm_iter; r.last_admm_iter = admm_iter;
-  const QDims d{w->m, w->n, w->MP, w->kind == 0 ? 1 : (w->kind == 1 ? 2 : 0)};
+  const QDims d{w->m, w->n, w->MP, w->kind == 0 ? 1 : (w->kind == 1 ? 2 : 0), w->wy};
   QLAUNCH(w, kq_resid, w->NB, BS, (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->bd.p, (const double *)w->cd.p,
           (const double *)w->Dd.p, (const double *)w->Ed.p, (const double *)w->Ax.p, (const double *)w->ATy.p, (const double *)w->Qx.p, d, w->part.p);
   finalize(w, {Q_S0, Q_S1, Q_S2, Q_S3, Q_S4, Q_S5, Q_M0, Q_M1, Q_M2, Q_M3, Q_M4, Q_M5}, {});
+  if (w->dist) { // sums: packed exchange; inf-norms: one lane per rank in a sum exchange, then the maximum over the lanes
+    if (exchange_sums(w, {Q_S0, Q_S1, Q_S2, Q_S3, Q_S4, Q_S5})) return -1;
+    double *mx = w->gsbuf.p + Q_COUNT;
+    QLAUNCH(w, kq_dist_pack_max, 1, BS, (const double *)w->part.p, (int)Q_M0, 6, w->NB, mx, w->rank, w->world);
+    if (ar(w, mx, (size_t)6 * w->world)) return -1;
+    QLAUNCH(w, kq_dist_unpack_max, 1, 64, (const double *)mx, (int)Q_M0, 6, w->world, reinterpret_cast<double *>(w->ctl.p));
+  }
   if (w->kind == 0) {
     const LassoForm &L = w->ls;
     QLasso ql{L.dm, L.dn, std::sqrt(L.sc_cone2), L.sc_b, L.sc_c, L.lambda, L.Dd.p, L.Ed.p, L.yd.p};
@@ -316,42 +361,116 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     w->nm_inf_b = vnrminf(d->b, m); w->nm_inf_c = vnrminf(d->c, n);
     scale_data(w, d, K);
   }
-  w->MP = ((m + 31) / 32) * 32;
-  w->LV = ((w->MP + n + 1 + 31) / 32) * 32;
   auto bail = [&](const char *msg) { release(w); return fail(info, msg); };
+  // ---- several GPUs (dist_internal.h): this rank's column block, cut at cone boundaries (qcp_dist.h).  Served for the generic formulation with
+  // the PCG back-end; everything else runs as independent replicas (the direct back-end does not shard).
+  const DistInfo di = dist_info();
+  QCPCone Kloc = *K;
+  std::vector<int> kq_loc, krq_loc;
+  std::vector<double> Mpre; // the Jacobi preconditioner sums over ALL columns: formed before the block is cut out
+  int nl = n;
+  w->n_glob = n;
+  const long nnz_glob = w->A.p[n];
+  if (di.kind != 0 && kind == 2 && st->linsys_solver == 3) {
+    w->dist = true; w->rank = di.rank; w->world = di.world; w->wy = di.rank == 0 ? 1.0 : 0.0;
+    // allowed cut points: behind every cone, and anywhere inside the free / zero / orthant blocks
+    std::vector<int> cuts, qs, qe, rs, re;
+    int pos = 0;
+    for (int i = 0; K->q && i < K->qsize; ++i) { if (K->q[i] <= 0) continue; qs.push_back(pos); pos += K->q[i]; qe.push_back(pos); cuts.push_back(pos); }
+    for (int i = 0; K->rq && i < K->rqsize; ++i) { if (K->rq[i] < 3) return bail("sharded conic path: rotated cones of fewer than 3 entries are not served"); rs.push_back(pos); pos += K->rq[i]; re.push_back(pos); cuts.push_back(pos); }
+    const int f0 = pos, z0 = f0 + K->f, l0 = z0 + K->z;
+    for (int t = pos + 1; t <= n; ++t) cuts.push_back(t);
+    std::vector<double> Wt(n + 1, 0.0);
+    for (int j = 0; j < n; ++j) Wt[j + 1] = Wt[j] + (double)(w->A.p[j + 1] - w->A.p[j]) + 1.0;
+    std::vector<int> bounds(di.world + 1, 0);
+    bounds[di.world] = n;
+    size_t ci = 0;
+    for (int g = 1; g < di.world; ++g) { // first cut at or beyond the g-th share of the weight, leaving a cut for every rank still to come
+      const double target = Wt[n] * g / di.world;
+      while (ci < cuts.size() && (cuts[ci] <= bounds[g - 1] || (Wt[cuts[ci]] < target && cuts.size() - ci > (size_t)(di.world - g)))) ++ci;
+      if (ci >= cuts.size() || cuts[ci] >= n) return bail("sharded conic path: fewer column blocks (cones, free / zero / orthant entries) than ranks");
+      bounds[g] = cuts[ci++];
+    }
+    const int n0 = bounds[di.rank], n1 = bounds[di.rank + 1];
+    if (n1 <= n0) return bail("sharded conic path: empty column block");
+    w->n0 = n0; nl = n1 - n0;
+    for (size_t q = 0; q < qs.size(); ++q) if (qs[q] >= n0 && qe[q] <= n1) kq_loc.push_back(qe[q] - qs[q]);
+    for (size_t q = 0; q < rs.size(); ++q) if (rs[q] >= n0 && re[q] <= n1) krq_loc.push_back(re[q] - rs[q]);
+    auto overlap = [&](int a, int b) { return std::max(0, std::min(b, n1) - std::max(a, n0)); };
+    Kloc.q = kq_loc.empty() ? nullptr : kq_loc.data(); Kloc.qsize = (int)kq_loc.size();
+    Kloc.rq = krq_loc.empty() ? nullptr : krq_loc.data(); Kloc.rqsize = (int)krq_loc.size();
+    Kloc.f = overlap(f0, z0); Kloc.z = overlap(z0, l0); Kloc.l = overlap(l0, n);
+    // the preconditioner M_i = 1 / (rho_y + sum_j A_ij^2 / H_jj) over all columns (replicated, like every m-space quantity)
+    Mpre.assign(m, st->rho_y);
+    {
+      std::vector<double> Hd(n, w->kkt_rho_x);
+      if (w->hasQ) for (int j = 0; j < n; ++j) for (int q = w->Q.p[j]; q < w->Q.p[j + 1]; ++q) {
+        if (w->Q.i[q] == j) Hd[j] += w->Q.x[q];
+        else if (w->Q.x[q] != 0.0) return bail("linsys_solver = 3 (PCG) needs Q absent or diagonal; use linsys_solver = 1");
+      }
+      for (int j = 0; j < n; ++j) for (int q = w->A.p[j]; q < w->A.p[j + 1]; ++q) Mpre[w->A.i[q]] += w->A.x[q] * w->A.x[q] * (1.0 / Hd[j]);
+      for (int i = 0; i < m; ++i) Mpre[i] = 1.0 / Mpre[i];
+    }
+    // cut the block out: A_g, the diagonal block of Q, c_g, E_g
+    auto cut_cols = [&](HMat &M, bool square) {
+      HMat G; G.m = square ? nl : M.m; G.n = nl; G.p.assign(nl + 1, 0);
+      const int base = M.p[n0];
+      for (int j = 0; j <= nl; ++j) G.p[j] = M.p[n0 + j] - base;
+      G.i.assign(M.i.begin() + base, M.i.begin() + M.p[n1]); G.x.assign(M.x.begin() + base, M.x.begin() + M.p[n1]);
+      if (square) for (int &r : G.i) r -= n0;
+      M = std::move(G);
+    };
+    cut_cols(w->A, false);
+    if (w->hasQ) cut_cols(w->Q, true);
+    w->Efull = w->E;
+    w->c = std::vector<double>(w->c.begin() + n0, w->c.begin() + n1);
+    w->E = std::vector<double>(w->E.begin() + n0, w->E.begin() + n1);
+    w->n = nl;
+  }
+  const QCPCone *KK = &Kloc;
+  w->MP = ((m + 31) / 32) * 32;
+  w->LV = ((w->MP + nl + 1 + 31) / 32) * 32;
   if (hipStreamCreate(&w->stream) != hipSuccess) return bail("hipStreamCreate failed");
   if (hipEventCreate(&w->ev_a) != hipSuccess || hipEventCreate(&w->ev_b) != hipSuccess) return bail("hipEventCreate failed");
   { // matrices
     host::HostCsr hAt, hA, hQ;
     hcsr_from(w->A, hAt, false); hcsr_from(w->A, hA, true);
     if (w->dAt.upload(hAt, w->stream) || w->dA.upload(hA, w->stream)) return bail("device allocation failure");
-    long nrb = std::max<long>(std::max<long>(w->dAt.nrb, w->dA.nrb), (std::max(m, n) + 4 * BS - 1) / (4 * BS));
+    long nrb = std::max<long>(std::max<long>(w->dAt.nrb, w->dA.nrb), (std::max(m, nl) + 4 * BS - 1) / (4 * BS));
     if (w->hasQ) { hcsr_from(w->Q, hQ, false); if (w->dQ.upload(hQ, w->stream)) return bail("device allocation failure"); nrb = std::max<long>(nrb, w->dQ.nrb); }
+    if (w->dist) // the replicated m-space kernels must sum in the same order on every rank: a grid that depends on global quantities only
+      nrb = std::max<long>(((long)nnz_glob / w->world + CHUNK - 1) / CHUNK + 1, (std::max<long>(m, (long)n / w->world + 1) + 4 * BS - 1) / (4 * BS));
     const long per = (nrb + MAXNB - 1) / MAXNB;
     w->NB = (int)std::max<long>(1, (nrb + per - 1) / per);
   }
   w->pcg = st->linsys_solver == 3;
   if (w->pcg) { // H = rho_x I + Q must be diagonal; Jacobi preconditioner M_i = 1 / (rho_y + sum_j A_ij^2 / H_jj)  (qcp_pcg.h)
-    std::vector<double> Hinv(n, w->kkt_rho_x), M(m, st->rho_y);
-    if (w->hasQ) for (int j = 0; j < n; ++j) for (int q = w->Q.p[j]; q < w->Q.p[j + 1]; ++q) {
+    std::vector<double> Hinv(nl, w->kkt_rho_x), M(m, st->rho_y);
+    if (w->hasQ) for (int j = 0; j < nl; ++j) for (int q = w->Q.p[j]; q < w->Q.p[j + 1]; ++q) {
       if (w->Q.i[q] == j) Hinv[j] += w->Q.x[q];
       else if (w->Q.x[q] != 0.0) return bail("linsys_solver = 3 (PCG) needs Q absent or diagonal; use linsys_solver = 1");
     }
-    for (int j = 0; j < n; ++j) Hinv[j] = 1.0 / Hinv[j];
-    for (int j = 0; j < n; ++j) for (int q = w->A.p[j]; q < w->A.p[j + 1]; ++q) M[w->A.i[q]] += w->A.x[q] * w->A.x[q] * Hinv[j];
+    for (int j = 0; j < nl; ++j) Hinv[j] = 1.0 / Hinv[j];
+    for (int j = 0; j < nl; ++j) for (int q = w->A.p[j]; q < w->A.p[j + 1]; ++q) M[w->A.i[q]] += w->A.x[q] * w->A.x[q] * Hinv[j];
     for (int i = 0; i < m; ++i) M[i] = 1.0 / M[i];
+    if (w->dist) { // (the sums above saw this rank's columns only)
+      M = Mpre;
+      if (w->arbuf.alloc((size_t)m + w->world) || w->gsbuf.alloc((size_t)Q_COUNT + 6 * (size_t)w->world) ||
+          hipMemsetAsync(w->arbuf.p, 0, sizeof(double) * ((size_t)m + w->world), w->stream) != hipSuccess)
+        return bail("init_lin_sys_work failure");
+    }
     if (w->cg_M.upload(M, w->stream) || w->cg_H.upload(Hinv, w->stream) || w->cg_x0.alloc(m) || w->cg_r.alloc(m) || w->cg_z.alloc(m) || w->cg_p.alloc(m) || w->cg_Gp.alloc(m) ||
-        w->cg_tm.alloc(n) || w->cg_part.alloc((size_t)PQ_COUNT * MAXNB) || hipMemsetAsync(w->cg_part.p, 0, sizeof(double) * PQ_COUNT * MAXNB, w->stream) != hipSuccess ||
-        hipMemsetAsync(w->cg_tm.p, 0, sizeof(double) * n, w->stream) != hipSuccess || hipHostMalloc((void **)&w->hlp, sizeof(Ctl), hipHostMallocDefault) != hipSuccess)
+        w->cg_tm.alloc(nl) || w->cg_part.alloc((size_t)PQ_COUNT * MAXNB) || hipMemsetAsync(w->cg_part.p, 0, sizeof(double) * PQ_COUNT * MAXNB, w->stream) != hipSuccess ||
+        hipMemsetAsync(w->cg_tm.p, 0, sizeof(double) * nl, w->stream) != hipSuccess || hipHostMalloc((void **)&w->hlp, sizeof(Ctl), hipHostMallocDefault) != hipSuccess)
       return bail("init_lin_sys_work failure");
     if (hipMalloc((void **)&w->lp_ctl, sizeof(Ctl)) != hipSuccess || hipMemsetAsync(w->lp_ctl, 0, sizeof(Ctl), w->stream) != hipSuccess) return bail("allocation failure");
   } else { // KKT upper triangle (qcp_config.c:699-748) -> LDL' -> level-scheduled device factors
-    const int N = m + n;
+    const int N = m + nl;
     const double rho_y = st->rho_y, rho_x = w->kkt_rho_x;
     std::vector<int> Kp(N + 1), Ki; std::vector<double> Kx;
-    Ki.reserve(N + w->A.p[n] + (w->hasQ ? w->Q.p[n] : 0)); Kx.reserve(Ki.capacity());
+    Ki.reserve(N + w->A.p[nl] + (w->hasQ ? w->Q.p[nl] : 0)); Kx.reserve(Ki.capacity());
     for (int i = 0; i < m; ++i) { Kp[i] = (int)Ki.size(); Ki.push_back(i); Kx.push_back(-rho_y); }
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < nl; ++i) {
       Kp[m + i] = (int)Ki.size();
       for (int j = w->A.p[i]; j < w->A.p[i + 1]; ++j) { Ki.push_back(w->A.i[j]); Kx.push_back(-w->A.x[j]); }
       if (!w->hasQ || w->Q.p[i] == w->Q.p[i + 1]) { Ki.push_back(m + i); Kx.push_back(rho_x); }
@@ -410,21 +529,21 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   DBuf<double> *lv[] = {&w->u, &w->v, &w->vo, &w->ut, &w->rel, &w->r, &w->p};
   for (auto *b : lv) { if (b->alloc(w->LV)) return bail("work memory allocation failure"); if (hipMemsetAsync(b->p, 0, sizeof(double) * w->LV, w->stream) != hipSuccess) return bail("memset failure"); }
   if (w->bd.upload(w->b, w->stream) || w->cd.upload(w->c, w->stream) || w->Dd.upload(w->D, w->stream) || w->Ed.upload(w->E, w->stream) || w->Ax.alloc(m) ||
-      w->ATy.alloc(n) || w->Qx.alloc(n) || w->part.alloc((size_t)2 * Q_COUNT * MAXNB) || w->ctl.alloc(1))
+      w->ATy.alloc(nl) || w->Qx.alloc(nl) || w->part.alloc((size_t)2 * Q_COUNT * MAXNB) || w->ctl.alloc(1))
     return bail("work memory allocation failure");
   if (kind == 1 && (w->sv.Dd.upload(w->sv.D, w->stream) || w->sv.Ed.upload(w->sv.E, w->stream) || w->sv.wEd.upload(w->sv.wE, w->stream))) return bail("work memory allocation failure");
   if (kind == 0 && (w->ls.Dd.upload(w->ls.D, w->stream) || w->ls.Ed.upload(w->ls.E, w->stream) || w->ls.yd.upload(w->ls.y, w->stream))) return bail("work memory allocation failure");
-  if (hipMemsetAsync(w->part.p, 0, sizeof(double) * 2 * Q_COUNT * MAXNB, w->stream) != hipSuccess || hipMemsetAsync(w->Qx.p, 0, sizeof(double) * n, w->stream) != hipSuccess ||
+  if (hipMemsetAsync(w->part.p, 0, sizeof(double) * 2 * Q_COUNT * MAXNB, w->stream) != hipSuccess || hipMemsetAsync(w->Qx.p, 0, sizeof(double) * nl, w->stream) != hipSuccess ||
       hipMemsetAsync(w->ctl.p, 0, sizeof(QCtl), w->stream) != hipSuccess || hipHostMalloc((void **)&w->hctl, sizeof(QCtl), hipHostMallocDefault) != hipSuccess)
     return bail("work memory allocation failure");
   // cone layout (abip.c:355-409, same `count` walk) and the start point (update_work, abip.c:912-985)
-  std::vector<int> xkind(n, XK_NONE), c_off, c_len, c_kind;
+  std::vector<int> xkind(nl, XK_NONE), c_off, c_len, c_kind;
   std::vector<double> hu(w->LV, 0.0);
   {
     int count = 0;
     double *x = hu.data() + w->MP;
-    for (int i = 0; K->q && i < K->qsize; ++i) {
-      const int len = K->q[i];
+    for (int i = 0; KK->q && i < KK->qsize; ++i) {
+      const int len = KK->q[i];
       if (len == 0) continue;
       if (len == 1) xkind[count] = XK_ORTHANT;
       else { for (int t = 0; t < len; ++t) xkind[count + t] = XK_CONE; c_off.push_back(count); c_len.push_back(len); c_kind.push_back(0); }
@@ -432,20 +551,20 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       x[count] = 1;
       count += len;
     }
-    for (int i = 0; K->rq && i < K->rqsize; ++i) {
-      const int len = K->rq[i];
+    for (int i = 0; KK->rq && i < KK->rqsize; ++i) {
+      const int len = KK->rq[i];
       if (len < 3) continue; // sic: count is not advanced (abip.c:379-381, 944-946)
       for (int t = 0; t < len; ++t) { xkind[count + t] = XK_CONE; x[count + t] = 0; }
       c_off.push_back(count); c_len.push_back(len); c_kind.push_back(1);
       x[count] = 1; x[count + 1] = 1;
       count += len;
     }
-    for (int t = 0; t < K->f && count + t < n; ++t) { xkind[count + t] = XK_FREE; x[count + t] = 0; }
-    count += K->f;
-    for (int t = 0; t < K->z && count + t < n; ++t) { xkind[count + t] = XK_ZERO; x[count + t] = 0; }
-    count += K->z;
-    for (int t = 0; t < K->l && count + t < n; ++t) { xkind[count + t] = XK_ORTHANT; x[count + t] = 1; }
-    hu[w->MP + n] = 1.0;
+    for (int t = 0; t < KK->f && count + t < nl; ++t) { xkind[count + t] = XK_FREE; x[count + t] = 0; }
+    count += KK->f;
+    for (int t = 0; t < KK->z && count + t < nl; ++t) { xkind[count + t] = XK_ZERO; x[count + t] = 0; }
+    count += KK->z;
+    for (int t = 0; t < KK->l && count + t < nl; ++t) { xkind[count + t] = XK_ORTHANT; x[count + t] = 1; }
+    hu[w->MP + nl] = 1.0;
   }
   w->ncones = (int)c_off.size();
   { // small cones first (one wavefront each), then the large ones (one workgroup each)
@@ -466,7 +585,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   {
     std::vector<double> hr(w->LV, 0.0);
     for (int i = 0; i < m; ++i) hr[i] = w->b[i]; // -(-b)
-    for (int j = 0; j < n; ++j) hr[w->MP + j] = w->c[j];
+    for (int j = 0; j < nl; ++j) hr[w->MP + j] = w->c[j];
     if (hipMemcpyAsync(w->r.p, hr.data(), sizeof(double) * w->LV, hipMemcpyHostToDevice, w->stream) != hipSuccess) return bail("upload failure");
     if (w->pcg) { if (solve_pcg(w, w->r.p, false, -1, 1e-12) < 0) return bail("device failure in pre_calculate"); } // abip.c:899
     else enqueue_solve(w, w->r.p);
@@ -474,17 +593,24 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       return bail("device failure in pre_calculate");
     double acc = 0;
     for (int i = 0; i < m; ++i) acc += (hr[i] * st->rho_y) * hr[i];
-    for (int j = 0; j < n; ++j) acc += (hr[w->MP + j] * st->rho_x) * hr[w->MP + j];
+    acc *= w->wy;
+    for (int j = 0; j < nl; ++j) acc += (hr[w->MP + j] * st->rho_x) * hr[w->MP + j];
+    if (w->dist) { // the x block is sharded: sum the shares (through the exchange area: one double)
+      if (hipMemcpyAsync(w->gsbuf.p, &acc, sizeof(double), hipMemcpyHostToDevice, w->stream) != hipSuccess || ar(w, w->gsbuf.p, 1) ||
+          hipMemcpyAsync(&acc, w->gsbuf.p, sizeof(double), hipMemcpyDeviceToHost, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess)
+        return bail("device failure in pre_calculate");
+    }
     w->a_quad = st->rho_tau + acc;
   }
   info->setup_time = now_ms() - t_init;
   const double t0 = now_ms();
-  const double time_limit_left = 1e3 * st->time_limit - info->setup_time;
+  // (several GPUs: the ranks must take the same decisions, and their clocks differ: the time limit is not enforced there)
+  const double time_limit_left = w->dist ? INFINITY : 1e3 * st->time_limit - info->setup_time;
 
   QResid r;
   info->status_val = 0;
   double tol_inner = 4 * std::pow(w->mu, st->psi);
-  const QDims dm{m, n, w->MP, w->kind == 0 ? 1 : (w->kind == 1 ? 2 : 0)};
+  const QDims dm{m, nl, w->MP, w->kind == 0 ? 1 : (w->kind == 1 ? 2 : 0), w->wy};
   int i = 0, j = 0, k = 0;
   bool finished = false;
   auto get_solution = [&](int ipm_iter, int admm_iter) -> int { // abip.c:559-587
@@ -493,23 +619,37 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
         hipMemcpyAsync(hv2.data(), w->v.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess)
       return -1;
     // the conic (x, y, s) of the formulation; what the caller receives depends on the formulation (below)
-    std::vector<double> X(n), Y(m), S(n);
-    for (int q = 0; q < n; ++q) { X[q] = hu2[w->MP + q]; S[q] = hv2[w->MP + q]; }
+    const int nx = w->dist ? n : nl; // several GPUs: x and s are gathered into the whole problem's order, every rank returns all of them
+    std::vector<double> X(nx), Y(m), S(nx);
+    if (w->dist) {
+      DBuf<double> gx;
+      if (gx.alloc((size_t)2 * n)) return -1;
+      int bad = hipMemsetAsync(gx.p, 0, sizeof(double) * 2 * (size_t)n, w->stream) != hipSuccess;
+      if (!bad) {
+        QLAUNCH(w, kq_dist_place, w->NB, BS, (const double *)(w->u.p + w->MP), nl, w->n0, gx.p);
+        QLAUNCH(w, kq_dist_place, w->NB, BS, (const double *)(w->v.p + w->MP), nl, w->n0, gx.p + n);
+        bad = ar(w, gx.p, (size_t)2 * n) || hipMemcpyAsync(X.data(), gx.p, sizeof(double) * n, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+              hipMemcpyAsync(S.data(), gx.p + n, sizeof(double) * n, hipMemcpyDeviceToHost, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess;
+      }
+      gx.release();
+      if (bad) return -1;
+    } else for (int q = 0; q < nl; ++q) { X[q] = hu2[w->MP + q]; S[q] = hv2[w->MP + q]; }
+    const std::vector<double> &Eu = w->dist ? w->Efull : w->E;
     for (int q = 0; q < m; ++q) Y[q] = hu2[q];
     const int sv = info->status_val;
     if (sv == 0 || sv == 1 || sv == 2) {
       const double sc = safediv_pos(1.0, r.tau);
-      for (int q = 0; q < n; ++q) { X[q] *= sc; S[q] *= sc; }
+      for (int q = 0; q < nx; ++q) { X[q] *= sc; S[q] *= sc; }
       for (int q = 0; q < m; ++q) Y[q] *= sc;
       if (sv == 0 || sv == 2) { strcpy(info->status, "Solved/Inaccurate"); info->status_val = 2; } else { strcpy(info->status, "Solved"); info->status_val = 1; }
     } else if (sv == -2 || sv == -7) {
       const double bty = r.dobj * r.tau;
       for (int q = 0; q < m; ++q) Y[q] *= 1 / bty;
-      for (int q = 0; q < n; ++q) { S[q] *= 1 / bty; X[q] = NAN; }
+      for (int q = 0; q < nx; ++q) { S[q] *= 1 / bty; X[q] = NAN; }
       strcpy(info->status, "Infeasible"); info->status_val = -2;
     } else {
       const double ctx = r.pobj * r.tau;
-      for (int q = 0; q < n; ++q) { X[q] *= -1 / ctx; S[q] = NAN; }
+      for (int q = 0; q < nx; ++q) { X[q] *= -1 / ctx; S[q] = NAN; }
       for (int q = 0; q < m; ++q) Y[q] = NAN;
       strcpy(info->status, "Unbounded"); info->status_val = -1;
     }
@@ -527,7 +667,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       for (int q = 0; q < V.dm; ++q) sol->s[q] = X[3 * V.dn + 4 + q] * (1 / (V.sc_b * V.sc_c));
     } else if (kind == 3) { // un_scaling_svmqp_sol, svm_qp_config.c:595-619: x / (E sc_b), then x: w (dn), y: b (1), s: xi (dm)
       const SvmForm &V = w->sv;
-      for (int q = 0; q < n; ++q) X[q] /= (w->E[q] * w->sc_b);
+      for (int q = 0; q < nl; ++q) X[q] /= (w->E[q] * w->sc_b);
       if (!sol->x) sol->x = (qcp_float *)malloc(sizeof(qcp_float) * V.dn);
       if (!sol->y) sol->y = (qcp_float *)malloc(sizeof(qcp_float));
       if (!sol->s) sol->s = (qcp_float *)malloc(sizeof(qcp_float) * V.dm);
@@ -536,14 +676,14 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       for (int q = 0; q < V.dm; ++q) sol->s[q] = X[V.dn + 1 + q];
     } else {
       if (st->normalize) { // un_scaling_qcp_sol, qcp_config.c:496-513
-        for (int q = 0; q < n; ++q) X[q] /= (w->E[q] * w->sc_b);
+        for (int q = 0; q < nx; ++q) X[q] /= (Eu[q] * w->sc_b);
         for (int q = 0; q < m; ++q) Y[q] /= (w->D[q] * w->sc_c);
-        for (int q = 0; q < n; ++q) S[q] *= w->E[q] / (w->sc_c * st->scale);
+        for (int q = 0; q < nx; ++q) S[q] *= Eu[q] / (w->sc_c * st->scale);
       }
-      if (!sol->x) sol->x = (qcp_float *)malloc(sizeof(qcp_float) * n);
+      if (!sol->x) sol->x = (qcp_float *)malloc(sizeof(qcp_float) * nx);
       if (!sol->y) sol->y = (qcp_float *)malloc(sizeof(qcp_float) * m);
-      if (!sol->s) sol->s = (qcp_float *)malloc(sizeof(qcp_float) * n);
-      for (int q = 0; q < n; ++q) { sol->x[q] = X[q]; sol->s[q] = S[q]; }
+      if (!sol->s) sol->s = (qcp_float *)malloc(sizeof(qcp_float) * nx);
+      for (int q = 0; q < nx; ++q) { sol->x[q] = X[q]; sol->s[q] = S[q]; }
       for (int q = 0; q < m; ++q) sol->y[q] = Y[q];
     }
     info->ipm_iter = ipm_iter + 1; info->admm_iter = admm_iter;
@@ -574,7 +714,13 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     QProxArgs pa;
     pa.u = w->u.p; pa.v = w->v.p; pa.ut = w->ut.p; pa.rel = w->rel.p; pa.p = w->p.p; pa.r = w->r.p; pa.xkind = w->xkind.p;
     pa.alpha = st->alpha; pa.lambda = w->mu / w->beta; pa.rho_x = st->rho_x; pa.rho_tau = st->rho_tau; pa.a_quad = w->a_quad; pa.iter_pos = kk > 0; pa.hasQ = w->hasQ;
-    QLAUNCH(w, kq_ut_prox, w->NB, BS, pa, dm, (const double *)w->part.p, w->NB, w->ctl.p, hc);
+    const double *gsc = nullptr;
+    if (w->dist) { // r'mu, r'(rho o p), p_x'Qp run over the sharded n-space: reduce locally, exchange, hand the totals to kq_ut_prox
+      finalize(w, {Q_T0, Q_T1, Q_PG}, {});
+      if (exchange_sums(w, {Q_T0, Q_T1, Q_PG})) w->dist_failed = true;
+      gsc = reinterpret_cast<const double *>(w->ctl.p);
+    }
+    QLAUNCH(w, kq_ut_prox, w->NB, BS, pa, dm, (const double *)w->part.p, w->NB, w->ctl.p, hc, gsc);
     if (w->ncones) {
       const double lam = (w->mu / w->beta) / st->rho_x;
       if (w->nsmall) { QCones C{w->c_off.p, w->c_len.p, w->c_kind.p, w->nsmall}; QLAUNCH(w, kq_cones<false>, (w->nsmall + WAVES - 1) / WAVES, BS, C, 0, w->u.p, (const double *)w->rel.p, lam, w->MP, hc); }
@@ -582,7 +728,12 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     }
     QLAUNCH(w, kq_dual, w->NB, BS, w->u.p, (const double *)w->rel.p, w->v.p, w->vo.p, st->rho_y, st->rho_x, st->rho_tau, dm, (const QCtl *)w->ctl.p, hc);
     // inner stopping test, qcp_config.c:518-557 (the tau entries and the comparison with tol_inner happen in kq_finalize)
-    if (qmerge) {
+    if (w->dist) { // A'u_y is local; A u_x = sum over the ranks of the block products, then the y-block sums on the replicated result
+      QLAUNCH(w, kq_inner_At, w->NB, BS, w->dAt.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->cd.p, w->ATy.p, w->Qx.p, w->hasQ ? 0 : 1, dm, w->part.p, hc);
+      QLAUNCH(w, kq_prod_A, w->NB, BS, w->dA.view(), (const double *)(w->u.p + w->MP), (const double *)nullptr, w->arbuf.p, 0, hc);
+      if (ar(w, w->arbuf.p, (size_t)m)) w->dist_failed = true;
+      QLAUNCH(w, kq_dist_inner_A_fin, w->NB, BS, (const double *)w->arbuf.p, (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->bd.p, w->Ax.p, dm, w->part.p, hc);
+    } else if (qmerge) {
       QLAUNCH(w, kq_inner_both, 2 * w->NB, BS, w->dA.view(), w->dAt.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->bd.p,
               (const double *)w->cd.p, w->Ax.p, w->ATy.p, w->Qx.p, w->hasQ ? 0 : 1, dm, w->NB, w->part.p, hc);
     } else {
@@ -604,7 +755,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
         nb = std::max(1, std::min(std::min(batch, to_check), (int)st->max_admm_iters - j));
       }
       for (int q = 0; q < nb; ++q) enqueue_iteration(k + q, q == 0);
-      if (read_ctl(w) || pcg_failed) return bail("device error in the inner iteration");
+      if (read_ctl(w) || pcg_failed || w->dist_failed) { if (w->dist) dist_abort_from("conic inner iteration"); return bail("device error in the inner iteration"); }
       { float ms = 0.f; if (hipEventElapsedTime(&ms, w->ev_a, w->ev_b) == hipSuccess) { w->lin_ms += ms; w->lin_n++; } }
       const int ran = w->hctl->it_count - seen;
       seen = w->hctl->it_count;
@@ -639,7 +790,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   }
   info->avg_linsys_time = w->lin_n ? w->lin_ms / (double)w->lin_n : 0; info->avg_cg_iters = w->cg_solves ? (double)w->tot_cg / (double)w->cg_solves : 0; // ms per solve, as lin_sys_time_per_iter (abip.c:1228)
   g_stats[0] = w->ldl.N; g_stats[1] = w->ldl.T; g_stats[2] = (double)w->ldl.lnnz; g_stats[3] = w->ldl.F.nlev; g_stats[4] = w->ldl.B.nlev;
-  g_stats[5] = (double)w->lin_n; g_stats[6] = w->lin_ms; g_stats[7] = (double)(w->ldl.F.idx.n + w->ldl.B.idx.n);
+  g_stats[5] = (double)w->lin_n; g_stats[6] = w->lin_ms; g_stats[7] = w->dist ? (double)w->n_allreduce : (double)(w->ldl.F.idx.n + w->ldl.B.idx.n); // (sharded runs: collectives issued)
   release(w);
   return info->status_val;
 }

@@ -72,6 +72,15 @@ struct QWk {
   DBuf<double> cg_x0, cg_r, cg_z, cg_p, cg_Gp, cg_tm, cg_M, cg_H, cg_part; // m-space: y0, r, z, p, Gp, M; n-space: tn (cg_tm), H^-1
   Ctl *hlp = nullptr;    // pinned mirror of lp_ctl
   int last_cg = 8; long tot_cg = 0, cg_solves = 0;
+  // several GPUs: this rank's column block [n0, n0 + n) of the n_glob columns (qcp_dist.h); m-space is replicated
+  bool dist = false;
+  int rank = 0, world = 1, n_glob = 0, n0 = 0;
+  double wy = 1.0;                 // weight of the sums over the replicated y block: 1 on rank 0, 0 elsewhere
+  std::vector<double> Efull;       // column scale of the whole problem (the gathered solution is un-scaled on every rank)
+  DBuf<double> arbuf, gsbuf;       // exchange areas: m + world doubles (products + the max lanes of the warm start); Q_COUNT + 6 world (packed sums + max lanes)
+  std::vector<double> hstage;      // staging of the callback transport
+  long n_allreduce = 0;            // collectives issued (bench, tests)
+  bool dist_failed = false;       // a collective failed inside an enqueue-only helper
 };
 
 #define QLAUNCH(w, kern, grid, block, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (w)->stream, __VA_ARGS__)
@@ -89,6 +98,7 @@ inline void release(QWk *w) {
   for (auto *b : bufs) b->release();
   w->xkind.release(); w->c_off.release(); w->c_len.release(); w->c_kind.release(); w->ctl.release();
   w->ldl.release();
+  w->arbuf.release(); w->gsbuf.release();
   { DBuf<double> *cb[] = {&w->cg_x0, &w->cg_r, &w->cg_z, &w->cg_p, &w->cg_Gp, &w->cg_tm, &w->cg_M, &w->cg_H, &w->cg_part}; for (auto *b : cb) b->release(); }
   if (w->hlp) (void)hipHostFree(w->hlp);
   if (w->lp_ctl) (void)hipFree(w->lp_ctl);

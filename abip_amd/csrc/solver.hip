@@ -25,6 +25,7 @@
 #include "../../include/abip_hip.h"
 #include "dev_kernels.h"
 #include "dev_ldl.h"
+#include "dist_internal.h"
 #include "host_setup.h"
 #include "dev_host_util.h"
 
@@ -116,6 +117,28 @@ constexpr double EPS_TOL = 1E-18; // glbopts.h:157
 inline double safediv_pos(double x, double y) { return y < EPS_TOL ? x / EPS_TOL : x / y; }
 
 } // namespace
+
+namespace abip { // dist_internal.h: shared with the conic solver
+DistInfo dist_info() { return DistInfo{g_dist.kind, g_dist.rank, g_dist.world}; }
+void dist_abort_from(const char *why) { dist_abort(why); }
+int dist_allreduce(double *buf, size_t count, hipStream_t s, std::vector<double> &hstage) {
+  if (g_dist.kind == 1) {
+    if (!g_dist.comm) return -1; // aborted
+    const int rc = g_dist.api.AllReduce(buf, buf, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, g_dist.comm, s);
+    if (rc != 0) { fprintf(stderr, "abip_hip: ncclAllReduce failed (%d)\n", rc); return -1; }
+    return 0;
+  }
+  if (g_dist.kind != 2) return -1;
+  // host-staged callback (test backend): D2H, reduce on the host through the caller's collective, H2D
+  hstage.resize(count);
+  HIP_OK(hipMemcpyAsync(hstage.data(), buf, sizeof(double) * count, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  g_dist.fn(g_dist.fn_ctx, hstage.data(), (long)count);
+  HIP_OK(hipMemcpyAsync(buf, hstage.data(), sizeof(double) * count, hipMemcpyHostToDevice, s));
+  HIP_OK(hipStreamSynchronize(s));
+  return 0;
+}
+} // namespace abip
 
 struct ABIP_WORK {
   // ---- problem / settings ------------------------------------------------------------------
@@ -284,20 +307,7 @@ inline Dims dims(const W *w) { return Dims{(int)w->m, (int)w->n, w->MP}; }
 // ------------------------------------------------------------------------------------------------
 int allreduce_dev(W *w, double *buf, size_t count) {
   if (!w->dist) return 0;
-  if (g_dist.kind == 1) {
-    if (!g_dist.comm) return -1; // aborted
-    const int rc = g_dist.api.AllReduce(buf, buf, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, g_dist.comm, w->stream);
-    if (rc != 0) { fprintf(stderr, "abip_hip: ncclAllReduce failed (%d)\n", rc); return -1; }
-    return 0;
-  }
-  // host-staged callback (test backend): D2H, reduce on the host through the caller's collective, H2D
-  w->hstage.resize(count);
-  HIP_OK(hipMemcpyAsync(w->hstage.data(), buf, sizeof(double) * count, hipMemcpyDeviceToHost, w->stream));
-  HIP_OK(hipStreamSynchronize(w->stream));
-  g_dist.fn(g_dist.fn_ctx, w->hstage.data(), (long)count);
-  HIP_OK(hipMemcpyAsync(buf, w->hstage.data(), sizeof(double) * count, hipMemcpyHostToDevice, w->stream));
-  HIP_OK(hipStreamSynchronize(w->stream));
-  return 0;
+  return abip::dist_allreduce(buf, count, w->stream, w->hstage);
 }
 void enqueue_fold(W *w, std::initializer_list<int> slots) {
   FoldArgs f; f.nslots = 0;
