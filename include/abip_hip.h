@@ -64,7 +64,11 @@ abip_float abip_hip_get_scalar(ABIPWork *w, const char *name);
  * (x, y, s) on every rank.  The direct back-end does not shard: with it every rank is an independent replica.
  *   RCCL:     rank 0 calls abip_hip_dist_get_unique_id, the host program broadcasts the 128 bytes (MPI,
  *             torch.distributed, ...), every rank calls abip_hip_dist_init_rccl after selecting its device.
- *   callback: host-staged sum through a caller-supplied collective (tests; any number of ranks may share one GPU). */
+ *   callback: host-staged sum through a caller-supplied collective (tests; any number of ranks may share one GPU).
+ * The conic entry point abip_qcp() (include/abip_qcp.h) uses the same context: with the generic formulation (prob_type 2) and the PCG
+ * back-end (linsys_solver 3) it shards the COLUMNS of A over the ranks, cut at cone boundaries (m-space replicated, one all-reduce of m
+ * doubles per PCG iteration); every rank passes the full problem and receives the full (x, y, s), bit-identical across the ranks.
+ * Any other conic configuration runs as independent replicas. */
 typedef void (*abip_hip_allreduce_fn)(void *ctx, double *host_buf, long count); /* in-place sum over all ranks */
 int abip_hip_dist_get_unique_id(void *out128);
 int abip_hip_dist_init_rccl(int rank, int world, const void *unique_id128);
