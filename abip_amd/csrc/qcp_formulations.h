@@ -313,5 +313,32 @@ inline void build_svmqp(QWk *w, const QCPData *d, const QCPCone *k) {
     for (int i = 0; i < dm; ++i) { B.i.push_back(i); B.x.push_back((sign ? -1.0 : 1.0) * (1 / w->D[i])); B.p[n1 + sign * dm + i + 1] = (int)B.i.size(); }
 }
 
+// ---- several GPUs: column blocks of the sharded conic path (qcp_dist.h) --------------------------------------------------------
+// Cut points are allowed behind every cone and anywhere inside the free / zero / orthant blocks; block g ends at the first allowed cut at or
+// beyond the g-th share of the weight (non-zeros + 1 per column), always leaving a cut for every rank still to come.
+// colp: the n + 1 column pointers of A.  Optionally returns the cone extents and the start of the free block.  0 ok; -1 a rotated cone of
+// fewer than 3 entries (the reference's layout walk skips those without advancing, abip.c:379-381: not served sharded); -2 fewer blocks than ranks.
+inline int column_bounds(int n, const int *colp, const QCPCone *K, int world, std::vector<int> &bounds, std::vector<int> *qs, std::vector<int> *qe,
+                         std::vector<int> *rs, std::vector<int> *re, int *f0_out) {
+  std::vector<int> cuts;
+  int pos = 0;
+  for (int i = 0; K->q && i < K->qsize; ++i) { if (K->q[i] <= 0) continue; if (qs) qs->push_back(pos); pos += K->q[i]; if (qe) qe->push_back(pos); cuts.push_back(pos); }
+  for (int i = 0; K->rq && i < K->rqsize; ++i) { if (K->rq[i] < 3) return -1; if (rs) rs->push_back(pos); pos += K->rq[i]; if (re) re->push_back(pos); cuts.push_back(pos); }
+  if (f0_out) *f0_out = pos;
+  for (int t = pos + 1; t <= n; ++t) cuts.push_back(t);
+  std::vector<double> Wt(n + 1, 0.0);
+  for (int j = 0; j < n; ++j) Wt[j + 1] = Wt[j] + (double)(colp[j + 1] - colp[j]) + 1.0;
+  bounds.assign(world + 1, 0);
+  bounds[world] = n;
+  size_t ci = 0;
+  for (int g = 1; g < world; ++g) {
+    const double target = Wt[n] * g / world;
+    while (ci < cuts.size() && (cuts[ci] <= bounds[g - 1] || (Wt[cuts[ci]] < target && cuts.size() - ci > (size_t)(world - g)))) ++ci;
+    if (ci >= cuts.size() || cuts[ci] >= n) return -2;
+    bounds[g] = cuts[ci++];
+  }
+  return bounds[world - 1] < n ? 0 : -2;
+}
+
 } // namespace qcp
 } // namespace abip

@@ -294,6 +294,17 @@ int abip_hip_qcp_cone_prox(int kind, double *x, const double *tmp, double lambda
   return rc;
 }
 
+// Column ranges of the sharded conic path: bounds[g] .. bounds[g+1] are rank g's columns (world + 1 entries out); pure host code.
+// 0 ok, -1 a rotated cone of fewer than 3 entries, -2 fewer blocks than ranks, -3 bad arguments.
+int abip_hip_qcp_dist_partition(const QCPMatrix *A, const QCPCone *K, int world, int *bounds_out) {
+  if (!A || !K || !bounds_out || world < 1 || A->n < 1) return -3;
+  std::vector<int> bounds;
+  const int rc = column_bounds(A->n, A->p, K, world, bounds, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (rc != 0) return rc;
+  for (int g = 0; g <= world; ++g) bounds_out[g] = bounds[g];
+  return 0;
+}
+
 void abip_hip_qcp_last_stats(double *out8) { for (int q = 0; q < 8; ++q) out8[q] = g_stats[q]; }
 
 void abip_qcp_set_default_settings(QCPData *d) { // util.c:203-255
@@ -373,24 +384,15 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   const long nnz_glob = w->A.p[n];
   if (di.kind != 0 && kind == 2 && st->linsys_solver == 3) {
     w->dist = true; w->rank = di.rank; w->world = di.world; w->wy = di.rank == 0 ? 1.0 : 0.0;
-    // allowed cut points: behind every cone, and anywhere inside the free / zero / orthant blocks
-    std::vector<int> cuts, qs, qe, rs, re;
-    int pos = 0;
-    for (int i = 0; K->q && i < K->qsize; ++i) { if (K->q[i] <= 0) continue; qs.push_back(pos); pos += K->q[i]; qe.push_back(pos); cuts.push_back(pos); }
-    for (int i = 0; K->rq && i < K->rqsize; ++i) { if (K->rq[i] < 3) return bail("sharded conic path: rotated cones of fewer than 3 entries are not served"); rs.push_back(pos); pos += K->rq[i]; re.push_back(pos); cuts.push_back(pos); }
-    const int f0 = pos, z0 = f0 + K->f, l0 = z0 + K->z;
-    for (int t = pos + 1; t <= n; ++t) cuts.push_back(t);
-    std::vector<double> Wt(n + 1, 0.0);
-    for (int j = 0; j < n; ++j) Wt[j + 1] = Wt[j] + (double)(w->A.p[j + 1] - w->A.p[j]) + 1.0;
-    std::vector<int> bounds(di.world + 1, 0);
-    bounds[di.world] = n;
-    size_t ci = 0;
-    for (int g = 1; g < di.world; ++g) { // first cut at or beyond the g-th share of the weight, leaving a cut for every rank still to come
-      const double target = Wt[n] * g / di.world;
-      while (ci < cuts.size() && (cuts[ci] <= bounds[g - 1] || (Wt[cuts[ci]] < target && cuts.size() - ci > (size_t)(di.world - g)))) ++ci;
-      if (ci >= cuts.size() || cuts[ci] >= n) return bail("sharded conic path: fewer column blocks (cones, free / zero / orthant entries) than ranks");
-      bounds[g] = cuts[ci++];
+    std::vector<int> bounds, qs, qe, rs, re;
+    int f0 = 0;
+    {
+      std::vector<int> colp(w->A.p.begin(), w->A.p.end());
+      const int rc = column_bounds(n, colp.data(), K, di.world, bounds, &qs, &qe, &rs, &re, &f0);
+      if (rc == -1) return bail("sharded conic path: rotated cones of fewer than 3 entries are not served");
+      if (rc != 0) return bail("sharded conic path: fewer column blocks (cones, free / zero / orthant entries) than ranks");
     }
+    const int z0 = f0 + K->f, l0 = z0 + K->z;
     const int n0 = bounds[di.rank], n1 = bounds[di.rank + 1];
     if (n1 <= n0) return bail("sharded conic path: empty column block");
     w->n0 = n0; nl = n1 - n0;

@@ -180,6 +180,22 @@ def abip_ml(data, settings: dict):
     return dict(x=beta, w=beta, b=float(b0[0]), xi=xi), out
 
 
+def partition_columns(A, cones, world: int) -> np.ndarray:
+    """Column bounds of the sharded conic path (abip_hip_qcp_dist_partition; pure host code, also what abip_qcp() uses): world + 1 entries."""
+    L = _bind()
+    L.abip_hip_qcp_dist_partition.restype = ci
+    L.abip_hip_qcp_dist_partition.argtypes = [C.POINTER(QCPMatrix), C.POINTER(QCPCone), ci, PI]
+    (keep, Am) = _csc(A)
+    q = np.array(_get(cones, "q", []) or [], dtype=np.int32).ravel(); rq = np.array(_get(cones, "rq", []) or [], dtype=np.int32).ravel()
+    K = QCPCone(q.ctypes.data_as(PI) if q.size else None, int(q.size), rq.ctypes.data_as(PI) if rq.size else None, int(rq.size),
+                int(_get(cones, "f", 0) or 0), int(_get(cones, "z", 0) or 0), int(_get(cones, "l", 0) or 0))
+    out = np.zeros(world + 1, dtype=np.int32)
+    rc = L.abip_hip_qcp_dist_partition(C.byref(Am), C.byref(K), int(world), out.ctypes.data_as(PI))
+    if rc != 0:
+        raise ValueError(f"cannot partition the columns over {world} ranks ({rc})")
+    return out
+
+
 def cone_prox(kind: int, tmp, lam: float, x_prev=None):
     """One SOC (kind 0) / rotated-SOC (kind 1) barrier prox on the device (kq_cones); unit-level mirror of cones.c:130-248."""
     L = _bind()

@@ -137,6 +137,10 @@ void abip_qcp_set_default_settings(QCPData *d);
  * out8 = { N, dense-tail size T, nnz(L), forward levels, backward levels, solves timed, total ms of those solves (hipEvents
  * on the solver's stream), nnz of the sparse head (forward + backward copies) }. */
 void abip_hip_qcp_last_stats(double *out8);
+/* Column ranges of the sharded conic path (several GPUs): bounds[g] .. bounds[g+1] are rank g's columns (world + 1 entries out), cut behind
+ * cones or inside the free / zero / orthant blocks, balanced by non-zeros.  Pure host code.  0 ok; -1 a rotated cone of fewer than 3 entries;
+ * -2 fewer blocks than ranks; -3 bad arguments. */
+int abip_hip_qcp_dist_partition(const QCPMatrix *A, const QCPCone *K, int world, int *bounds);
 /* Unit-level access to the cone kernel: x <- barrier prox of one cone at tmp (soc_barrier_subproblem cones.c:130-161 for kind 0,
  * rsoc_barrier_subproblem cones.c:169-248 for kind 1; the latter reads the incoming x[0], cones.c:183).  0 on success. */
 int abip_hip_qcp_cone_prox(int kind, double *x, const double *tmp, double lambda, int len);
