@@ -357,6 +357,9 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   int cnt = 0;
   if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) { printf("ERROR: no usable HIP device: libabip_hip has no CPU fallback\n"); return fail(info, "could not initialize work"); }
   const double t_init = now_ms();
+  const bool tms = getenv("ABIP_HIP_SETUP_TIMES") != nullptr;
+  double t_ph = t_init;
+  auto phase = [&](const char *what) { if (tms) { const double t = now_ms(); printf("[setup] conic: %s %.3f s\n", what, (t - t_ph) / 1e3); t_ph = t; } };
   QWk W; QWk *w = &W;
   w->kind = kind; w->m = m; w->n = n; w->st = st; w->hasQ = kind == 3 || (kind == 2 && d->Q != nullptr);
   w->kkt_rho_x = (kind == 0 || kind == 1) ? 1.0 : st->rho_x; // (lasso_config.c:652-708 and svm_config.c:725-806 hard-code rho_x = 1 in the solve)
@@ -430,6 +433,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     w->n = nl;
   }
   const QCPCone *KK = &Kloc;
+  phase("formulation + scaling (+ column block)");
   w->MP = ((m + 31) / 32) * 32;
   w->LV = ((w->MP + nl + 1 + 31) / 32) * 32;
   if (hipStreamCreate(&w->stream) != hipSuccess) return bail("hipStreamCreate failed");
@@ -445,6 +449,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     const long per = (nrb + MAXNB - 1) / MAXNB;
     w->NB = (int)std::max<long>(1, (nrb + per - 1) / per);
   }
+  phase("row / column forms of the operator, row blocks, upload");
   w->pcg = st->linsys_solver == 3;
   if (w->pcg) { // H = rho_x I + Q must be diagonal; Jacobi preconditioner M_i = 1 / (rho_y + sum_j A_ij^2 / H_jj)  (qcp_pcg.h)
     std::vector<double> Hinv(nl, w->kkt_rho_x), M(m, st->rho_y);
@@ -528,6 +533,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     }
     if (!ok) { printf("\nerror in LDL factorization\n"); return bail("init_lin_sys_work failure"); }
   }
+  phase("KKT back-end (preconditioner, or assembly + LDL')");
   DBuf<double> *lv[] = {&w->u, &w->v, &w->vo, &w->ut, &w->rel, &w->r, &w->p};
   for (auto *b : lv) { if (b->alloc(w->LV)) return bail("work memory allocation failure"); if (hipMemsetAsync(b->p, 0, sizeof(double) * w->LV, w->stream) != hipSuccess) return bail("memset failure"); }
   if (w->bd.upload(w->b, w->stream) || w->cd.upload(w->c, w->stream) || w->Dd.upload(w->D, w->stream) || w->Ed.upload(w->E, w->stream) || w->Ax.alloc(m) ||
@@ -604,6 +610,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     }
     w->a_quad = st->rho_tau + acc;
   }
+  phase("work vectors, cone tables, the set-up solve");
   info->setup_time = now_ms() - t_init;
   const double t0 = now_ms();
   // (several GPUs: the ranks must take the same decisions, and their clocks differ: the time limit is not enforced there)
