@@ -57,3 +57,17 @@ def test_world_size_must_match_gpus():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + QUICK, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert q.returncode != 0 and "contradicts WORLD_SIZE" in q.stderr and not [ln for ln in q.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_conic_workload_sharded_by_bench_itself():
+    """--workload c5 --linsys indirect --gpus 2: the conic PCG path with its columns sharded over two ranks (gloo-callback dry run on one GPU),
+    and the same through one rank over a real RCCL communicator; both reach the single-GPU iteration count."""
+    p, lines = _run(["--gpus", "2", "--workload", "c5", "--linsys", "indirect", "--no-cpu"], {"ABIP_BENCH_TRANSPORT": "gloo-callback"})
+    assert p.returncode == 0 and len(lines) == 1, p.stderr[-3000:]
+    r2 = json.loads(lines[0])
+    assert r2["n_gpus"] == 2 and r2["scaling"] == "strong" and "sharded over 2 ranks" in r2["config"]["parallelism"] and r2["time_to_tol"]["status"] == "Solved"
+    p, lines = _run(["--gpus", "1", "--workload", "c5", "--linsys", "indirect", "--no-cpu"], {"ABIP_BENCH_FORCE_SHARD": "1"})
+    assert p.returncode == 0 and len(lines) == 1, p.stderr[-3000:]
+    r1 = json.loads(lines[0])
+    assert "sharded over 1 ranks" in r1["config"]["parallelism"] and "1 ranks in the communicator" in r1["config"]["parallelism"]
+    assert r1["steps"] == r2["steps"] == 287 and abs(r1["extra"]["pobj"] - r2["extra"]["pobj"]) < 1e-9 * abs(r1["extra"]["pobj"])
