@@ -380,23 +380,29 @@ __global__ __launch_bounds__(BS) void kq_resid(const double *__restrict__ u, con
 // un-scaled X that the reference forms are the stored A u_x (rows 1..dm) and A'u_y (the beta columns) divided by D resp. E:
 //   pr_i = (A u_x)_{1+i} / (D_i tau sc_b) - y_i,   dr_j = (v_j + (A'u_y)_j) / (E_j tau sc_c) - lambda   (both beta blocks),
 //   x = sqrt(sc_cone2) u_z / (tau sc_b),  beta+- = E o u_b / (tau sc_b),  z = D o u_y[1:] / (tau sc_c).
-struct QLasso { int dm, dn; double sqrt_sc2, sc_b, sc_c, lambda; const double *D, *E, *y; };
+// Several GPUs (qcp_dist.h): x-block indices below are GLOBAL columns; the rank owns [n0, n0 + d.n) of them and adds only what it owns, the sums
+// over the replicated y block and over A u_x (replicated after its exchange) carry the weight d.wy.  Single GPU: n0 = 0, every column owned.
+struct QLasso { int dm, dn; double sqrt_sc2, sc_b, sc_c, lambda; const double *D, *E, *y; int n0; };
 __global__ __launch_bounds__(BS) void kq_resid_lasso(const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ Ax,
                                                      const double *__restrict__ ATy, QLasso L, QDims d, double *part) {
   __shared__ double sm[6 * WAVES];
   const double tau = u[d.MP + d.n], ib = 1.0 / (tau * L.sc_b), ic = 1.0 / (tau * L.sc_c);
   double s6[6] = {0, 0, 0, 0, 0, 0};
   const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
-  const double *ux = u + d.MP, *vx = v + d.MP;
+  const double *ux = u + d.MP - L.n0, *vx = v + d.MP - L.n0, *ATg = ATy - L.n0; // indexed by global column
+  const int g0 = L.n0, g1 = L.n0 + d.n;
   for (int i = t0; i < L.dm; i += stride) {
     const double Di = L.D[i], yi = L.y[i];
-    const double pr = Ax[1 + i] / Di * ib - yi, x = ux[2 + i] * (L.sqrt_sc2 * ib), z = u[1 + i] * (Di * ic);
-    s6[0] += pr * pr; s6[2] += x * x; s6[4] += z * z; s6[5] += yi * z;
+    const double pr = Ax[1 + i] / Di * ib - yi, z = u[1 + i] * (Di * ic);
+    s6[0] += pr * pr * d.wy; s6[4] += z * z * d.wy; s6[5] += yi * z * d.wy;
+    const int gq = 2 + i;
+    if (gq >= g0 && gq < g1) { const double x = ux[gq] * (L.sqrt_sc2 * ib); s6[2] += x * x; }
   }
   for (int e = t0; e < 2 * L.dn; e += stride) {
     const int q = L.dm + 2 + e;
+    if (q < g0 || q >= g1) continue;
     const double Ej = L.E[e < L.dn ? e : e - L.dn];
-    const double dr = (vx[q] + ATy[q]) / Ej * ic - L.lambda;
+    const double dr = (vx[q] + ATg[q]) / Ej * ic - L.lambda;
     s6[1] += dr * dr; s6[3] += ux[q] * (Ej * ib);
   }
   const int ws[6] = {Q_L0, Q_L1, Q_L2, Q_L3, Q_L4, Q_L5};
@@ -415,6 +421,8 @@ __global__ __launch_bounds__(BS) void kq_resid_svm(const double *__restrict__ u,
   const double tau = u[d.MP + d.n], ib = 1.0 / (tau * V.sc_b), ic = 1.0 / (tau * V.sc_c);
   double s6[6] = {0, 0, 0, 0, 0, 0};
   const int stride = gridDim.x * BS, t0 = blockIdx.x * BS + threadIdx.x;
+  // (single GPU only: w+ / w- and xi / t pair entries of different columns, which a column cut would separate -- the sharded path serves the
+  //  LASSO and the QP formulation of the SVM, not this one)
   const double *ux = u + d.MP, *vx = v + d.MP;
   const int o_xi = 3 * V.dn + 4, o_t = o_xi + V.dm;
   for (int i = t0; i < V.dm; i += stride) {

@@ -197,9 +197,10 @@ int calc_residuals(QWk *w, QResid &r, int ipm_iter, int admm_iter) { // qcp_conf
   }
   if (w->kind == 0) {
     const LassoForm &L = w->ls;
-    QLasso ql{L.dm, L.dn, std::sqrt(L.sc_cone2), L.sc_b, L.sc_c, L.lambda, L.Dd.p, L.Ed.p, L.yd.p};
+    QLasso ql{L.dm, L.dn, std::sqrt(L.sc_cone2), L.sc_b, L.sc_c, L.lambda, L.Dd.p, L.Ed.p, L.yd.p, w->n0};
     QLAUNCH(w, kq_resid_lasso, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->Ax.p, (const double *)w->ATy.p, ql, d, w->part.p);
     finalize(w, {Q_L0, Q_L1, Q_L2, Q_L3, Q_L4, Q_L5}, {});
+    if (w->dist && exchange_sums(w, {Q_L0, Q_L1, Q_L2, Q_L3, Q_L4, Q_L5})) return -1;
   }
   if (w->kind == 1) {
     const SvmForm &V = w->sv;
@@ -376,8 +377,8 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     scale_data(w, d, K);
   }
   auto bail = [&](const char *msg) { release(w); return fail(info, msg); };
-  // ---- several GPUs (dist_internal.h): this rank's column block, cut at cone boundaries (qcp_dist.h).  Served for the generic formulation with
-  // the PCG back-end; everything else runs as independent replicas (the direct back-end does not shard).
+  // ---- several GPUs (dist_internal.h): this rank's column block, cut at cone boundaries (qcp_dist.h).  Served with the PCG back-end for the generic
+  // formulation, the LASSO front end and the SVM-QP front end; everything else runs as independent replicas (the direct back-end does not shard).
   const DistInfo di = dist_info();
   QCPCone Kloc = *K;
   std::vector<int> kq_loc, krq_loc;
@@ -385,7 +386,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   int nl = n;
   w->n_glob = n;
   const long nnz_glob = w->A.p[n];
-  if (di.kind != 0 && kind == 2 && st->linsys_solver == 3) {
+  if (di.kind != 0 && (kind == 2 || kind == 0 || kind == 3) && st->linsys_solver == 3) { // (not the SVM-SOCP: its residuals pair entries of different columns)
     w->dist = true; w->rank = di.rank; w->world = di.world; w->wy = di.rank == 0 ? 1.0 : 0.0;
     std::vector<int> bounds, qs, qe, rs, re;
     int f0 = 0;
@@ -676,7 +677,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       for (int q = 0; q < V.dm; ++q) sol->s[q] = X[3 * V.dn + 4 + q] * (1 / (V.sc_b * V.sc_c));
     } else if (kind == 3) { // un_scaling_svmqp_sol, svm_qp_config.c:595-619: x / (E sc_b), then x: w (dn), y: b (1), s: xi (dm)
       const SvmForm &V = w->sv;
-      for (int q = 0; q < nl; ++q) X[q] /= (w->E[q] * w->sc_b);
+      for (int q = 0; q < nx; ++q) X[q] /= (Eu[q] * w->sc_b);
       if (!sol->x) sol->x = (qcp_float *)malloc(sizeof(qcp_float) * V.dn);
       if (!sol->y) sol->y = (qcp_float *)malloc(sizeof(qcp_float));
       if (!sol->s) sol->s = (qcp_float *)malloc(sizeof(qcp_float) * V.dm);

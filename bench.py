@@ -186,8 +186,9 @@ def bench_c5(args, rank, world, dist, torch):
         run = lambda: qcp.abip_qcp(data, K, stg)
         nnz_op = int(data["A"].nnz); m_op, n_op = data["A"].shape
     # N > 1 (or ABIP_BENCH_FORCE_SHARD=1): with the PCG back-end ONE problem is solved, its columns sharded over the ranks (qcp_dist.h: one
-    # all-reduce of m doubles per PCG iteration; strong scaling); the direct back-end and the LASSO front end run as N independent replicas
-    sharded = dist is not None and pcg and not ml
+    # all-reduce of m doubles per PCG iteration; strong scaling) -- the generic formulation and the LASSO front end alike; the direct back-end
+    # runs as N independent replicas
+    sharded = dist is not None and pcg
     transport = os.environ.get("ABIP_BENCH_TRANSPORT", "rccl")
     if sharded:
         from abip_amd import dist as adist

@@ -29,7 +29,19 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     from abip_amd import dist as adist
     from abip_amd import qcp
-    data, K = case(name)
+    ml = name.startswith("ml:")          # ml:<prob_type>:<case of tests/_lasso_cases.py or tests/_svm_cases.py>
+    if ml:
+        _, pt, cname = name.split(":")
+        pt = int(pt)
+        if pt == 0:
+            from _lasso_cases import gen
+            X, yv, lam = gen(cname)
+        else:
+            from _svm_cases import gen
+            X, yv = gen(cname)
+            lam = 1e-2
+    else:
+        data, K = case(name)
     if mode == "gloo-callback":
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,7 +50,11 @@ def main():
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl", rank=rank, world_size=world)
         adist.init_torch()
-    sol, info = qcp.abip_qcp(data, K, dict(eps=eps, linsys_solver=3, verbose=0))
+    if ml:
+        sol, info = qcp.abip_ml(dict(X=X, y=yv, **{"lambda": lam}), dict(prob_type=pt, eps=eps, linsys_solver=3, verbose=0))
+        sol = dict(x=sol["x"], y=np.atleast_1d(sol.get("b", 0.0)), s=sol.get("xi", np.zeros(1)))
+    else:
+        sol, info = qcp.abip_qcp(data, K, dict(eps=eps, linsys_solver=3, verbose=0))
     out = dict(rank=rank, world=world, status=info["status"], admm_iter=info["admm_iter"], ipm_iter=info["ipm_iter"], pobj=info["pobj"], dobj=info["dobj"],
                avg_cg_iters=info["avg_cg_iters"], collectives=info["factor"]["head_nnz"], x=sol["x"].tolist(), y=sol["y"].tolist(), s=sol["s"].tolist())
     t = torch.from_numpy(np.concatenate([[float(info["admm_iter"]), info["pobj"], info["dobj"], info["res_pri"], info["res_dual"], info["gap"]], sol["x"], sol["y"], sol["s"]]).astype(np.float64))
