@@ -74,3 +74,16 @@ def test_lasso_surface_errors(gpu):
     assert info["status"] == "Failure" and info["status_val"] == -4
     sol, info = gpu.abip_ml(dict(X=X, y=y, **{"lambda": lam}), dict(prob_type=0, normalize=0, verbose=0))
     assert info["status"] == "Failure"
+
+
+def test_lasso_at_the_reference_protocol_size(gpu, pq):
+    """scripts/bench-qcp/test_lasso.m's smallest size (1000 x 5000, density 0.15, unit noise, eps 1e-3) through the front end on the device against the oracle's
+    restatement: the same iteration counts (a few dozen inner iterations -- the formulation's scaling is tuned to this protocol) and beta."""
+    from abip_amd import problems
+    X, y, lam = problems.lasso_protocol_data(1000, 5000)
+    want, wi = pq.solve_lasso(X, y, lam)
+    sol, info = gpu.abip_ml(dict(X=X, y=y, **{"lambda": lam}), dict(prob_type=0, eps=1e-3, linsys_solver=1, verbose=0))
+    assert info["status"] == wi["status"] == "Solved" and info["ipm_iter"] == wi["ipm_iter"] and info["admm_iter"] == wi["admm_iter"] and info["admm_iter"] < 100
+    assert np.max(np.abs(sol["x"] - want)) <= 1e-8 * max(1.0, np.abs(want).max())
+    solp, infop = gpu.abip_ml(dict(X=X, y=y, **{"lambda": lam}), dict(prob_type=0, eps=1e-3, linsys_solver=3, verbose=0))
+    assert infop["status"] == "Solved" and abs(infop["pobj"] - wi["pobj"]) <= 1e-3 * abs(wi["pobj"])
