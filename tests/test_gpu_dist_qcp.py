@@ -34,7 +34,7 @@ def test_one_rank_sharded_conic_path_equals_plain_path(gpu, name):
     """world = 1 through the sharded code path (split products + exchange + element-wise halves) with an identity collective."""
     from abip_amd import dist as adist
     data, K = make(name)
-    stg = dict(eps=1e-5, linsys_solver=3, verbose=0)
+    stg = dict(eps=1e-3 if name == "lp" else 1e-5, linsys_solver=3, verbose=0)   # (the LP case needs ~50 000 iterations at 1e-5: scripts/gpu_sweep_dist_qcp.sh runs it)
     ref, ri = gpu.abip_qcp(data, K, stg)
     adist.init_callback(0, 1, lambda arr: None)
     try:
@@ -51,7 +51,7 @@ def test_one_rank_sharded_conic_path_equals_plain_path(gpu, name):
 @pytest.mark.parametrize("world,name", [(2, "lasso_small"), (2, "mixed"), (3, "mixed"), (3, "lp")])   # (scripts/gpu_sweep_dist_qcp.sh runs the wider matrix)
 def test_multi_rank_conic_sharding(gpu, world, name):
     data, K = make(name)
-    eps = 1e-5
+    eps = 1e-3 if name == "lp" else 1e-5
     ref, ri = gpu.abip_qcp(data, K, dict(eps=eps, linsys_solver=3, verbose=0))
     port = 29100 + (hash((world, name)) % 300)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
