@@ -19,7 +19,7 @@
 namespace abip {
 
 // out[i] = sum_j A[i, j] x[j] (sc ? sc[j] : 1) over the rank's columns; gated like the kernel it replaces
-__global__ __launch_bounds__(BS) void kq_prod_A(Csr A, const double *__restrict__ x, const double *__restrict__ sc, double *__restrict__ out, int gate_cg, const Ctl *hc) {
+__global__ __launch_bounds__(BS, 8) void kq_prod_A(Csr A, const double *__restrict__ x, const double *__restrict__ sc, double *__restrict__ out, int gate_cg, const Ctl *hc) {
   if (hc->halt || (gate_cg && hc->cg_done)) return;
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];

@@ -52,7 +52,7 @@ struct QPcgVec { double *y0, *r, *z, *p, *Gp, *tn; const double *Minv, *Hinv; };
 
 // b = -g_y - A (H^-1 g_x) into the y block (the PCG's right-hand side); warm start y0 = (u + tau r)_y and the partial of
 // |(u + tau r)[0:n]|_inf (abip.c:208-215: the first n entries of the (m + n)-vector)
-__global__ __launch_bounds__(BS) void kq_pcg_prep(Csr A, double *__restrict__ rhs, const double *__restrict__ u, const double *__restrict__ rv, int warm,
+__global__ __launch_bounds__(BS, 8) void kq_pcg_prep(Csr A, double *__restrict__ rhs, const double *__restrict__ u, const double *__restrict__ rv, int warm,
                                                   QDims d, QPcgVec v, double *ppart, Ctl *hc) {
   if (hc->halt) return;
   __shared__ double lds[CHUNK];
@@ -77,9 +77,11 @@ __global__ __launch_bounds__(BS) void kq_pcg_prep(Csr A, double *__restrict__ rh
   write_partials_max<1>(ppart, ws, wm, sm);
 }
 
+// (launch bounds: 8 waves per SIMD = 64 VGPRs, so that a full grid of 2048 workgroups is resident at once -- at 68 VGPRs only 1792 are, and the
+//  remaining 256 run as a second round: kq_pcg_Aty<false> took 180 us instead of 90 on the LASSO protocol's operator)
 // tn = H^-1 (A' y).  INIT: y = y0.  Loop: the convergence test and beta from the update's partials, then tn = H^-1 (A' z) + beta tn.
 template <bool INIT>
-__global__ __launch_bounds__(BS) void kq_pcg_Aty(Csr At, QPcgVec v, int max_its, double *ppart, int nb, Ctl *hc) {
+__global__ __launch_bounds__(BS, 8) void kq_pcg_Aty(Csr At, QPcgVec v, int max_its, double *ppart, int nb, Ctl *hc) {
   if (hc->halt || hc->cg_done) return;
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(BS) void kq_pcg_Aty(Csr At, QPcgVec v, int max_its,
 // INIT: r = b - (rho_y y0 + A tn); y = y0; z = M r; p = z; partials |r|^2, z'r; the tolerance.
 // Loop: p = z + beta p; Gp = rho_y p + A tn; partial p'Gp.
 template <bool INIT>
-__global__ __launch_bounds__(BS) void kq_pcg_Gp(Csr A, QPcgVec v, double *__restrict__ ysol /* rhs y block: b in, y out */, double rho_y,
+__global__ __launch_bounds__(BS, 8) void kq_pcg_Gp(Csr A, QPcgVec v, double *__restrict__ ysol /* rhs y block: b in, y out */, double rho_y,
                                                 double tol_host, double iter_pow, double *ppart, int nb, Ctl *hc) {
   if (hc->halt || hc->cg_done) return;
   __shared__ double lds[CHUNK];
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(BS) void kq_pcg_update(QPcgVec v, double *__restric
   if (blockIdx.x == 0 && threadIdx.x == 0) hc->cg_it = it + 1;
 }
 // z_x = H^-1 (g_x + A' z_y); runs once the PCG has converged (re-checks: the last update of a chunk has no product behind it)
-__global__ __launch_bounds__(BS) void kq_pcg_post(Csr At, double *__restrict__ rhs, QPcgVec v, int max_its, QDims d, double *ppart, int nb, Ctl *hc) {
+__global__ __launch_bounds__(BS, 8) void kq_pcg_post(Csr At, double *__restrict__ rhs, QPcgVec v, int max_its, QDims d, double *ppart, int nb, Ctl *hc) {
   if (hc->halt) return;
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
