@@ -376,7 +376,8 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     w->nm_inf_b = vnrminf(d->b, m); w->nm_inf_c = vnrminf(d->c, n);
     scale_data(w, d, K);
   }
-  auto bail = [&](const char *msg) { release(w); return fail(info, msg); };
+  // (a rank that gives up inside a sharded solve aborts the communicator first: its peers would otherwise wait in their next collective for ever)
+  auto bail = [&](const char *msg) { if (w->dist) dist_abort_from(msg); release(w); return fail(info, msg); };
   // ---- several GPUs (dist_internal.h): this rank's column block, cut at cone boundaries (qcp_dist.h).  Served with the PCG back-end for the generic
   // formulation, the LASSO front end and the SVM-QP front end; everything else runs as independent replicas (the direct back-end does not shard).
   const DistInfo di = dist_info();
@@ -765,7 +766,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
         nb = std::max(1, std::min(std::min(batch, to_check), (int)st->max_admm_iters - j));
       }
       for (int q = 0; q < nb; ++q) enqueue_iteration(k + q, q == 0);
-      if (read_ctl(w) || pcg_failed || w->dist_failed) { if (w->dist) dist_abort_from("conic inner iteration"); return bail("device error in the inner iteration"); }
+      if (read_ctl(w) || pcg_failed || w->dist_failed) return bail("device error in the inner iteration");
       { float ms = 0.f; if (hipEventElapsedTime(&ms, w->ev_a, w->ev_b) == hipSuccess) { w->lin_ms += ms; w->lin_n++; } }
       const int ran = w->hctl->it_count - seen;
       seen = w->hctl->it_count;
