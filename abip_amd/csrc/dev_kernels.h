@@ -801,6 +801,77 @@ __global__ __launch_bounds__(BS) void k_dist_post(const double *__restrict__ T, 
   const int ws[1] = {S_DH};
   write_partials<1>(part, ws, acc, sm);
 }
+// ---- sharded PCG, COLUMN form of the solve (ABIP_HIP_DIST_CG=cols; solver.hip: enqueue_cg_*).  The iteration around the solve keeps the row
+// blocks; inside the solve the m-space is gathered and REPLICATED and A is used by column blocks: A'p is local, A(A'p) = sum_g A_g (A_g'p) is the
+// one exchange -- m doubles instead of the row form's n -- and p'Gp, |r|^2, z'r are sums over replicated vectors (no exchange).  The kernels
+// that do not touch A are the single-GPU ones (k_cg_spmv_At on the column block, k_cg_update); below: the pieces around the exchanges. ----
+// dst[off + i] = src[i]: a rank's rows into their place of a zeroed whole vector (summed over the ranks = the whole vector); gate: 2 = only once the PCG is done
+__global__ __launch_bounds__(BS) void k_cols_place(const double *__restrict__ src, int len, int off, double *__restrict__ dst, int gate, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (gate == 2 && !ctl->cg_done) return;
+  for (int i = blockIdx.x * BS + threadIdx.x; i < len; i += gridDim.x * BS) dst[off + i] = src[i];
+}
+// dst[i] = src[off + i]: the rank's rows out of a replicated vector, once the PCG is done
+__global__ __launch_bounds__(BS) void k_cols_take(const double *__restrict__ src, int len, int off, double *__restrict__ dst, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (!ctl->cg_done) return;
+  for (int i = blockIdx.x * BS + threadIdx.x; i < len; i += gridDim.x * BS) dst[i] = src[off + i];
+}
+// d = b_x - t over the rank's columns (t = A_g's, the warm start's share; null without one)
+__global__ __launch_bounds__(BS) void k_cols_diff(const double *__restrict__ bx, const double *__restrict__ t, double *__restrict__ dd, int n, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  for (int j = blockIdx.x * BS + threadIdx.x; j < n; j += gridDim.x * BS) dd[j] = t ? bx[j] - t[j] : bx[j];
+}
+// after the exchange of buf = sum_g A_g (b_x - A_g's): r = b_y + buf - rho s, z = M r, x0 = s; |r|^2, z'r; tolerance and counters (k_cg_init_A's second half)
+__global__ __launch_bounds__(BS) void k_cols_init_fin(const double *__restrict__ by, const double *__restrict__ buf, const double *__restrict__ s, const double *__restrict__ Minv,
+                                                      double *__restrict__ x, double *__restrict__ r, double *__restrict__ z, double *__restrict__ p, double rho,
+                                                      double tol_factor, int m, double *part, Ctl *ctl, const double *gs) {
+  ABIP_GATE_HALT(ctl);
+  __shared__ double sm[2 * WAVES];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double tol = sqrt(gs[S_BN]) * tol_factor; // indirect.c:406-409 (|b_y| before the accumulation: summed over the row blocks)
+    tol = fmax(tol, 1e-7);
+    ctl->cg_tol = fmax(tol, 1e-9);
+    ctl->cg_it = 0;
+    ctl->cg_done = 0;
+  }
+  double a2[2] = {0.0, 0.0};
+  for (int i = blockIdx.x * BS + threadIdx.x; i < m; i += gridDim.x * BS) {
+    const double si = s ? s[i] : 0.0;
+    const double ri = s ? (by[i] + buf[i]) - rho * si : by[i] + buf[i];
+    const double zi = ri * Minv[i];
+    x[i] = si; r[i] = ri; z[i] = zi; p[i] = zi;
+    a2[0] += ri * ri; a2[1] += zi * ri;
+  }
+  const int ws[2] = {S_RR0, S_ZR0};
+  write_partials<2>(part, ws, a2, sm);
+}
+// after the exchange of buf = sum_g A_g tmp_g: p = z + beta p, Gp = buf + rho p, p'Gp (k_cg_spmv_A's row epilogue)
+__global__ __launch_bounds__(BS) void k_cols_Gp_fin(const double *__restrict__ buf, const double *__restrict__ z, double *__restrict__ p, double *__restrict__ Gp, double rho, int m,
+                                                    double *part, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (ctl->cg_done) return;
+  __shared__ double sm[WAVES];
+  const double beta = ctl->beta_cur;
+  double acc1[1] = {0.0};
+  for (int i = blockIdx.x * BS + threadIdx.x; i < m; i += gridDim.x * BS) {
+    const double pn = z[i] + beta * p[i];
+    const double gp = buf[i] + rho * pn;
+    p[i] = pn; Gp[i] = gp;
+    acc1[0] += pn * gp;
+  }
+  const int ws[1] = {S_PG};
+  write_partials<1>(part, ws, acc1, sm);
+}
+// the convergence decision at the end of a chunk (the product kernel of the next iteration would take it; there is none)
+__global__ __launch_bounds__(BS) void k_cols_decide(int max_its, double *part, int nb, Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (ctl->cg_done) return;
+  __shared__ double sm[2 * WAVES];
+  int it; double zr;
+  if (cg_converged(ctl, part, nb, max_its, sm, it, zr) && threadIdx.x == 0) ctl->cg_done = 1;
+}
+
 // dual residual sums from T = A'y all-reduced (k_q_At without the SpMV)
 __global__ __launch_bounds__(BS) void k_dist_q(const double *__restrict__ T, const double *__restrict__ uu, const double *__restrict__ vv,
                                                const double *__restrict__ c, const double *__restrict__ wE, Dims d, int slot0, double xw,

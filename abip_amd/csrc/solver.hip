@@ -199,6 +199,12 @@ struct ABIP_WORK {
   size_t n_pad = 0;
   std::vector<double> hstage; // host staging for the callback backend
   bool vy_zero = true;      // v[0:m) == 0 (cold start, no half_update): A'u_y == A'u_t,y, one all-reduce less per iteration
+  // the PCG in its COLUMN form (ABIP_HIP_DIST_CG=cols): inside the solve the m-space is gathered and replicated, A is used by the column block
+  // [col0, col0 + ncol); one exchange of m_glob doubles per PCG iteration instead of n (dev_kernels.h: k_cols_*)
+  bool cg_cols = false;
+  abip_int col0 = 0, ncol = 0;
+  DevCsr dAc, dAct;         // the column block: CSR of A_g (m_glob rows, local column indices), CSR of A_g' (ncol rows)
+  DBuf<double> cc_b, cc_y, cc_r, cc_z, cc_p, cc_Gp, cc_M, cc_tmp, cc_d, cc_buf; // m_glob: b_y, y (x0 in), r, z, p, Gp, M; ncol: A_g'p, b_x - A_g's; exchange area (2 m_glob)
   ABIPMatrix Aloc{};        // this rank's row block in CSC (owned)
   std::vector<double> Aloc_x; std::vector<abip_int> Aloc_i, Aloc_p;
   // ---- profiling -----------------------------------------------------------------------------
@@ -341,6 +347,24 @@ int enqueue_cg_begin(W *w, double *rhs, const double *warm, abip_int iter) {
            w->cg_r.p, w->cg_z.p, w->cg_p.p, w->stgs->rho_y, cg_tol_factor(w, iter), d, w->part.p, w->NB, w->ctl.p, (const double *)nullptr);
     return 0;
   }
+  if (w->cg_cols) { // gather b_y (and the warm start) over the row blocks, then the set-up products by column blocks
+    const int mg = (int)w->m_glob, gm = std::max(1, std::min(w->NB, (mg + BS - 1) / BS)), gn = std::max(1, std::min(w->NB, (int)((w->ncol + BS - 1) / BS)));
+    enqueue_fold(w, {S_BN});
+    if (hipMemsetAsync(w->cc_buf.p, 0, sizeof(double) * 2 * (size_t)mg, w->stream) != hipSuccess) return -1;
+    launch(w, ABIP_HIP_K_VEC, k_cols_place, gm, BS, (const double *)rhs, (int)w->m, (int)w->row0, w->cc_buf.p, 0, ctl);
+    if (warm) launch(w, ABIP_HIP_K_VEC, k_cols_place, gm, BS, warm, (int)w->m, (int)w->row0, w->cc_buf.p + mg, 0, ctl);
+    if (allreduce_dev(w, w->cc_buf.p, (warm ? 2 : 1) * (size_t)mg) || allreduce_scalars(w)) return -1;
+    if (hipMemcpyAsync(w->cc_b.p, w->cc_buf.p, sizeof(double) * mg, hipMemcpyDeviceToDevice, w->stream) != hipSuccess) return -1;
+    if (warm && hipMemcpyAsync(w->cc_y.p, w->cc_buf.p + mg, sizeof(double) * mg, hipMemcpyDeviceToDevice, w->stream) != hipSuccess) return -1;
+    const double *bxl = bx + w->col0; // the rank's columns of the (replicated) x block
+    if (warm) launch(w, ABIP_HIP_K_CG_EDGE, k_spmv_set<false>, w->NB, BS, w->dAct.view(), (const double *)w->cc_y.p, w->cc_tmp.p, 0, ctl);
+    launch(w, ABIP_HIP_K_VEC, k_cols_diff, gn, BS, bxl, warm ? (const double *)w->cc_tmp.p : (const double *)nullptr, w->cc_d.p, (int)w->ncol, ctl);
+    launch(w, ABIP_HIP_K_CG_EDGE, k_spmv_set<false>, w->NB, BS, w->dAc.view(), (const double *)w->cc_d.p, w->cc_buf.p, 0, ctl);
+    if (allreduce_dev(w, w->cc_buf.p, (size_t)mg)) return -1;
+    launch(w, ABIP_HIP_K_CG_VEC, k_cols_init_fin, w->NB, BS, (const double *)w->cc_b.p, (const double *)w->cc_buf.p, warm ? (const double *)w->cc_y.p : (const double *)nullptr,
+           (const double *)w->cc_M.p, w->cc_y.p, w->cc_r.p, w->cc_z.p, w->cc_p.p, w->stgs->rho_y, cg_tol_factor(w, iter), mg, w->part.p, w->ctl.p, (const double *)w->gs);
+    return 0;
+  }
   enqueue_fold(w, {S_BN});
   if (warm) {
     launch(w, ABIP_HIP_K_CG_EDGE, PICK(k_spmv_set, w->dAt), w->NB, BS, w->dAt.view(), warm, w->T.p, 0, ctl);
@@ -354,6 +378,20 @@ int enqueue_cg_begin(W *w, double *rhs, const double *warm, abip_int iter) {
 int enqueue_cg_chunk(W *w, double *rhs, int its) {
   const int max_its = (int)w->m_glob; // indirect.c:418: at most m iterations
   const int gvec = std::max(1, std::min(w->NB, (int)((w->m + 2 * BS - 1) / (2 * BS))));
+  if (w->cg_cols) {
+    const int mg = (int)w->m_glob, gv = std::max(1, std::min(w->NB, (mg + 2 * BS - 1) / (2 * BS)));
+    for (int q = 0; q < its; ++q) {
+      w->ev_tag = w->cg_enq++;
+      launch(w, ABIP_HIP_K_SPMV_AT, k_cg_spmv_At<false>, w->NB, BS, w->dAct.view(), (const double *)w->cc_z.p, w->cc_tmp.p, max_its, w->part.p, w->NB, w->ctl.p, next_stamp(w, ABIP_HIP_K_SPMV_AT));
+      launch(w, ABIP_HIP_K_SPMV_A, k_spmv_set<false>, w->NB, BS, w->dAc.view(), (const double *)w->cc_tmp.p, w->cc_buf.p, 1, (const Ctl *)w->ctl.p);
+      if (allreduce_dev(w, w->cc_buf.p, (size_t)mg)) return -1;
+      launch(w, ABIP_HIP_K_CG_VEC, k_cols_Gp_fin, w->NB, BS, (const double *)w->cc_buf.p, (const double *)w->cc_z.p, w->cc_p.p, w->cc_Gp.p, w->stgs->rho_y, mg, w->part.p, (const Ctl *)w->ctl.p);
+      launch(w, ABIP_HIP_K_CG_VEC, k_cg_update<false>, gv, BS, w->cc_y.p, w->cc_r.p, w->cc_z.p, (const double *)w->cc_p.p, (const double *)w->cc_Gp.p,
+             (const double *)w->cc_M.p, mg, w->stgs->rho_y, w->part.p, w->NB, w->ctl.p, (const double *)nullptr);
+    }
+    w->ev_tag = -1;
+    return 0;
+  }
   for (int q = 0; q < its; ++q) {
     w->ev_tag = w->cg_enq++;
     if (!w->dist) {
@@ -383,6 +421,19 @@ int enqueue_cg_chunk(W *w, double *rhs, int its) {
 int enqueue_cg_post(W *w, double *rhs) {
   if (!w->dist) {
     launch(w, ABIP_HIP_K_CG_EDGE, PICK(k_post_At, w->dAt), w->NB, BS, w->dAt.view(), rhs, (const double *)w->h.p, dims(w), (int)w->m_glob, w->part.p, w->NB, w->ctl.p);
+    return 0;
+  }
+  if (w->cg_cols) { // decision on the replicated |r|^2; then y back to the row block, A_g'y into its place of T, and the row form's tail
+    const int mg = (int)w->m_glob, gm = std::max(1, std::min(w->NB, (mg + BS - 1) / BS)), gn = std::max(1, std::min(w->NB, (int)((w->ncol + BS - 1) / BS)));
+    launch(w, ABIP_HIP_K_CG_VEC, k_cols_decide, 1, BS, mg, w->part.p, w->NB, w->ctl.p);
+    launch(w, ABIP_HIP_K_VEC, k_cols_take, gm, BS, (const double *)w->cc_y.p, (int)w->m, (int)w->row0, rhs, (const Ctl *)w->ctl.p);
+    launch(w, ABIP_HIP_K_CG_EDGE, k_spmv_set<false>, w->NB, BS, w->dAct.view(), (const double *)w->cc_y.p, w->cc_d.p, 2, (const Ctl *)w->ctl.p);
+    if (hipMemsetAsync(w->T.p, 0, sizeof(double) * w->n_pad, w->stream) != hipSuccess) return -1;
+    launch(w, ABIP_HIP_K_VEC, k_cols_place, gn, BS, (const double *)w->cc_d.p, (int)w->ncol, (int)w->col0, w->T.p, 2, (const Ctl *)w->ctl.p);
+    if (allreduce_vec_and_scalars(w)) return -1;
+    launch(w, ABIP_HIP_K_CG_EDGE, k_dist_post, w->NB, BS, (const double *)w->T.p, rhs, (const double *)w->h.p, dims(w), w->xwt, w->part.p, (const Ctl *)w->ctl.p);
+    enqueue_fold(w, {S_DH});
+    if (allreduce_scalars(w)) return -1;
     return 0;
   }
   // late convergence decision on the summed ||r||^2, then (only if converged) the back-substitution A'y
@@ -1023,7 +1074,8 @@ void print_footer(const W *w, const ABIPInfo *info) {
 
 void free_work(W *w) {
   if (!w) return;
-  w->dAt.release(); w->dA.release();
+  w->dAt.release(); w->dA.release(); w->dAc.release(); w->dAct.release();
+  { DBuf<double> *cb[] = {&w->cc_b, &w->cc_y, &w->cc_r, &w->cc_z, &w->cc_p, &w->cc_Gp, &w->cc_M, &w->cc_tmp, &w->cc_d, &w->cc_buf}; for (auto *b : cb) b->release(); }
   DBuf<double> *bufs[] = {&w->u, &w->v, &w->ut, &w->u_avg, &w->v_avg, &w->u_sum, &w->v_sum, &w->u_avgc, &w->v_avgc, &w->h, &w->g, &w->b, &w->c,
                           &w->wD, &w->wE, &w->cg_p, &w->cg_r, &w->cg_Gp, &w->cg_z, &w->cg_M, &w->cg_tmp, &w->cg_pair, &w->a_up, &w->a_vp, &w->a_ut, &w->a_u,
                           &w->a_v, &w->a_utn, &w->a_un, &w->a_vn, &w->part};
@@ -1151,6 +1203,32 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
         if (w->A->i[q] >= r0 && w->A->i[q] < r1) { w->Aloc_i[t] = w->A->i[q] - r0; w->Aloc_x[t] = w->A->x[q]; ++t; }
     w->Aloc.x = w->Aloc_x.data(); w->Aloc.i = w->Aloc_i.data(); w->Aloc.p = w->Aloc_p.data(); w->Aloc.m = w->m; w->Aloc.n = n;
     Ause = &w->Aloc;
+    { const char *e = getenv("ABIP_HIP_DIST_CG"); w->cg_cols = e && !strcmp(e, "cols"); }
+    if (w->cg_cols) { // column block of the scaled matrix, balanced by non-zeros (+1 per column), and the whole Jacobi preconditioner
+      if (n < w->world) return fail("fewer columns than ranks");
+      std::vector<abip_int> cb(w->world + 1, 0);
+      cb[w->world] = n;
+      for (int g = 1; g < w->world; ++g) {
+        const double target = (double)(nnz + n) * g / w->world;
+        abip_int lo = cb[g - 1] + 1, hi = n - (w->world - g);
+        while (lo < hi) { const abip_int mid = (lo + hi) / 2; if ((double)(w->A->p[mid] + mid) < target) lo = mid + 1; else hi = mid; }
+        cb[g] = lo;
+      }
+      w->col0 = cb[w->rank]; w->ncol = cb[w->rank + 1] - cb[w->rank];
+      std::vector<abip_int> cp(w->ncol + 1);
+      const abip_int base = w->A->p[w->col0];
+      for (abip_int j = 0; j <= w->ncol; ++j) cp[j] = w->A->p[w->col0 + j] - base;
+      ABIPMatrix Ac{}; Ac.x = w->A->x + base; Ac.i = w->A->i + base; Ac.p = cp.data(); Ac.m = mg; Ac.n = w->ncol;
+      host::HostCsr hct, hc;
+      host::csc_as_csr(&Ac, hct); host::build_row_blocks(hct, CHUNK);
+      host::transpose_to_csr(&Ac, hc); host::build_row_blocks(hc, CHUNK);
+      std::vector<double> Mfull;
+      host::jacobi_preconditioner(w->A, Mfull);
+      if (w->dAct.upload(hct, w->stream) || w->dAc.upload(hc, w->stream) || w->cc_M.upload(Mfull, w->stream) || w->cc_b.alloc(mg) || w->cc_y.alloc(mg) || w->cc_r.alloc(mg) ||
+          w->cc_z.alloc(mg) || w->cc_p.alloc(mg) || w->cc_Gp.alloc(mg) || w->cc_tmp.alloc(w->ncol) || w->cc_d.alloc(w->ncol) || w->cc_buf.alloc(2 * (size_t)mg))
+        return fail("device allocation failure (column block)");
+      if (hipMemsetAsync(w->cc_tmp.p, 0, sizeof(double) * std::max<abip_int>(w->ncol, 1), w->stream) != hipSuccess) return fail("memset failure");
+    }
     w->n_pad = ((size_t)n + 31) / 32 * 32; // scalars start 256-byte aligned behind the n-vector
     if (w->T.alloc(w->n_pad + S_COUNT)) return fail("work memory allocation failure");
     if (hipMemsetAsync(w->T.p, 0, sizeof(double) * (w->n_pad + S_COUNT), w->stream) != hipSuccess) return fail("memset failure");
@@ -1596,7 +1674,7 @@ abip_float abip_hip_get_scalar(ABIPWork *w, const char *name) {
   RET("mu", w->mu) RET("beta", w->beta) RET("sigma", w->sigma) RET("gamma", w->gamma) RET("g_th", w->g_th)
   RET("sc_b", w->sc_b) RET("sc_c", w->sc_c) RET("nm_b", w->nm_b) RET("nm_c", w->nm_c) RET("tot_cg_its", w->tot_cg_its)
   RET("lnnz", w->ldl.lnnz) RET("levels_fwd", w->ldl.F.nlev) RET("levels_bwd", w->ldl.B.nlev) RET("tail", w->ldl.T) RET("admm_iter", w->k) RET("ipm_iter", w->i)
-  RET("sell_At", w->dAt.nslices) RET("sell_A", w->dA.nslices) RET("nb", w->NB) RET("small_solve", w->ldl.small ? 1 : 0) RET("factor_resid", w->factor_resid)
+  RET("sell_At", w->dAt.nslices) RET("sell_A", w->dA.nslices) RET("nb", w->NB) RET("dist_cols", w->cg_cols ? 1 : 0) RET("small_solve", w->ldl.small ? 1 : 0) RET("factor_resid", w->factor_resid)
 #undef RET
   return NAN;
 }

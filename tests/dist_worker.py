@@ -56,7 +56,7 @@ def main():
     with Solver(A, b, c, linsys="indirect", verbose=0, eps=eps) as S:
         info = S.solve()
         out = dict(rank=rank, world=world, status=info["status"], admm_iter=info["admm_iter"], ipm_iter=info["ipm_iter"], pobj=info["pobj"],
-                   dobj=info["dobj"], cg=S.scalar("tot_cg_its"), x=S.x.tolist(), y=S.y.tolist(), s=S.s.tolist())
+                   dobj=info["dobj"], cg=S.scalar("tot_cg_its"), cols=S.scalar("dist_cols"), x=S.x.tolist(), y=S.y.tolist(), s=S.s.tolist())
         extra = np.array([S.scalar("mu"), S.scalar("beta"), S.scalar("nb"), S.scalar("tot_cg_its"), float(info["admm_iter"]), info["pobj"]])
     # every rank must hold the same full solution, BIT for bit (replicated n-space state and every host decision derive from all-reduced
     # values and from reductions whose grid is the same on every rank), and the same persistent grid NB

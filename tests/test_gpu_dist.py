@@ -99,3 +99,41 @@ def test_multi_rank_skewed_row_blocks_stay_bit_identical(gpu, world):
     assert p.returncode == 0 and lines, p.stdout[-2000:] + p.stderr[-2000:]
     out = json.loads(lines[-1][7:])
     assert out["consistent"] and out["status"] == "Solved" and out["nb"] >= 1
+
+
+def test_one_rank_column_form_of_the_sharded_pcg(gpu, monkeypatch):
+    """ABIP_HIP_DIST_CG=cols: inside the solve the m-space is gathered and replicated and A is used by column blocks (one exchange of m doubles per PCG
+    iteration instead of n).  world = 1 through that code path with an identity collective against the plain path."""
+    from abip_amd import dist as adist
+    z, A, b, c = load("lp_random_sparse_small")
+    ref = _single(gpu, A, b, c, 1e-6)
+    monkeypatch.setenv("ABIP_HIP_DIST_CG", "cols")
+    adist.init_callback(0, 1, lambda arr: None)
+    try:
+        got = _single(gpu, A, b, c, 1e-6)
+    finally:
+        adist.finalize()
+    assert got[0]["status_val"] == ref[0]["status_val"] == 1
+    assert got[0]["ipm_iter"] == ref[0]["ipm_iter"] and abs(got[0]["admm_iter"] - ref[0]["admm_iter"]) <= 0.03 * ref[0]["admm_iter"] + 2
+    for a, r in zip(got[1:4], ref[1:4]):
+        assert rel(a, r) < 1e-5
+
+
+@pytest.mark.parametrize("world,name", [(2, "lp_random_sparse_small"), (3, "lp_afiro_like")])
+def test_multi_rank_column_form_matches_reference(gpu, world, name):
+    eps = 1e-6
+    port = 29800 + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "gloo-callback", name, repr(eps)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ABIP_HIP_DIST_CG="cols")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert p.returncode == 0 and lines, p.stdout[-2000:] + p.stderr[-2000:]
+    out = json.loads(lines[-1][7:])
+    z, A, b, c = load(name)
+    g = info_of(z, f"indirect_{eps:g}")
+    assert out["cols"] == 1.0 and out["consistent"] and out["status"] == "Solved"
+    assert out["ipm_iter"] == g["ipm_iter"] and abs(out["admm_iter"] - g["admm_iter"]) <= 0.03 * g["admm_iter"] + 2
+    for k in "xys":
+        assert rel(np.array(out[k]), z[f"indirect_{eps:g}_{k}"]) < 10 * eps, k
+    assert abs(out["pobj"] - g["pobj"]) <= 10 * eps * (1 + abs(g["pobj"]))
