@@ -1203,7 +1203,9 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
         if (w->A->i[q] >= r0 && w->A->i[q] < r1) { w->Aloc_i[t] = w->A->i[q] - r0; w->Aloc_x[t] = w->A->x[q]; ++t; }
     w->Aloc.x = w->Aloc_x.data(); w->Aloc.i = w->Aloc_i.data(); w->Aloc.p = w->Aloc_p.data(); w->Aloc.m = w->m; w->Aloc.n = n;
     Ause = &w->Aloc;
-    { const char *e = getenv("ABIP_HIP_DIST_CG"); w->cg_cols = e && !strcmp(e, "cols"); }
+    // form of the sharded solve: columns (default: the exchange per PCG iteration is the m-vector -- C4: 1.6 MB against the row form's 4 MB + scalars, and by the
+    // xGMI model of DESIGN.md section 7 that is the difference between parity with one GPU and a slow-down) or rows (ABIP_HIP_DIST_CG=rows)
+    { const char *e = getenv("ABIP_HIP_DIST_CG"); w->cg_cols = !(e && !strcmp(e, "rows")); }
     if (w->cg_cols) { // column block of the scaled matrix, balanced by non-zeros (+1 per column), and the whole Jacobi preconditioner
       if (n < w->world) return fail("fewer columns than ranks");
       std::vector<abip_int> cb(w->world + 1, 0);

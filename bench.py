@@ -470,9 +470,9 @@ def main():
             rec["rank_rows"] = rows
             rec["transport"] = ("rccl" if transport == "rccl" else "gloo-callback (host-staged sums, every rank on cuda:0: a plumbing dry run, NOT a scaling number)") if sharded else "none (replicas)"
             rec["rccl_ranks"] = adist.comm_count() if sharded else 0
-            # form of the sharded solve: "rows" (default: one all-reduce of n doubles + packed scalars per PCG iteration) or "cols" (ABIP_HIP_DIST_CG=cols:
-            # the solve's m-space gathered and replicated, A by column blocks, one all-reduce of m doubles per PCG iteration)
-            rec["dist_cg"] = ("cols" if os.environ.get("ABIP_HIP_DIST_CG") == "cols" else "rows") if sharded else None
+            # form of the sharded solve: "cols" (default: the solve's m-space gathered and replicated, A by column blocks, one all-reduce of m doubles per PCG
+            # iteration) or "rows" (ABIP_HIP_DIST_CG=rows: one all-reduce of n doubles + packed scalars per PCG iteration)
+            rec["dist_cg"] = ("rows" if os.environ.get("ABIP_HIP_DIST_CG") == "rows" else "cols") if sharded else None
         if rank == 0 and world == 1 and args.workload == "c4" and not args.no_extra and not force_shard:
             # the Netlib-class and the pds-class configs, short windows, inside the same driver-run line
             sub = {}

@@ -65,8 +65,9 @@ abip_float abip_hip_get_scalar(ABIPWork *w, const char *name);
  *   RCCL:     rank 0 calls abip_hip_dist_get_unique_id, the host program broadcasts the 128 bytes (MPI,
  *             torch.distributed, ...), every rank calls abip_hip_dist_init_rccl after selecting its device.
  *   callback: host-staged sum through a caller-supplied collective (tests; any number of ranks may share one GPU).
- * ABIP_HIP_DIST_CG=cols (environment, read by abip_init) selects the COLUMN form of the sharded solve: the iteration keeps the row blocks, the PCG gathers
- * its right-hand side into a replicated m-vector and uses A by column blocks -- one all-reduce of m doubles per PCG iteration instead of n + scalars.
+ * The solve inside that iteration runs in its COLUMN form by default: the PCG gathers its right-hand side into a replicated m-vector and uses A by column
+ * blocks -- one all-reduce of m doubles per PCG iteration instead of n + scalars.  ABIP_HIP_DIST_CG=rows (environment, read by abip_init) keeps the solve on
+ * the row blocks too (the all-reduce described above).
  * The conic entry point abip_qcp() (include/abip_qcp.h) uses the same context: with the generic formulation (prob_type 2) and the PCG
  * back-end (linsys_solver 3) it shards the COLUMNS of A over the ranks, cut at cone boundaries (m-space replicated, one all-reduce of m
  * doubles per PCG iteration); every rank passes the full problem and receives the full (x, y, s), bit-identical across the ranks.

@@ -101,13 +101,14 @@ def test_multi_rank_skewed_row_blocks_stay_bit_identical(gpu, world):
     assert out["consistent"] and out["status"] == "Solved" and out["nb"] >= 1
 
 
-def test_one_rank_column_form_of_the_sharded_pcg(gpu, monkeypatch):
-    """ABIP_HIP_DIST_CG=cols: inside the solve the m-space is gathered and replicated and A is used by column blocks (one exchange of m doubles per PCG
-    iteration instead of n).  world = 1 through that code path with an identity collective against the plain path."""
+def test_one_rank_row_form_of_the_sharded_pcg(gpu, monkeypatch):
+    """The sharded solve has two forms: columns (default: inside the solve the m-space is gathered and replicated and A is used by column blocks, one exchange
+    of m doubles per PCG iteration) and rows (ABIP_HIP_DIST_CG=rows: one exchange of n doubles + packed scalars).  Every other test of this file runs the
+    default; this one and the next run the row form.  world = 1 with an identity collective against the plain path."""
     from abip_amd import dist as adist
     z, A, b, c = load("lp_random_sparse_small")
     ref = _single(gpu, A, b, c, 1e-6)
-    monkeypatch.setenv("ABIP_HIP_DIST_CG", "cols")
+    monkeypatch.setenv("ABIP_HIP_DIST_CG", "rows")
     adist.init_callback(0, 1, lambda arr: None)
     try:
         got = _single(gpu, A, b, c, 1e-6)
@@ -120,19 +121,19 @@ def test_one_rank_column_form_of_the_sharded_pcg(gpu, monkeypatch):
 
 
 @pytest.mark.parametrize("world,name", [(2, "lp_random_sparse_small"), (3, "lp_afiro_like")])
-def test_multi_rank_column_form_matches_reference(gpu, world, name):
+def test_multi_rank_row_form_matches_reference(gpu, world, name):
     eps = 1e-6
     port = 29800 + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "gloo-callback", name, repr(eps)]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ABIP_HIP_DIST_CG="cols")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ABIP_HIP_DIST_CG="rows")
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
     assert p.returncode == 0 and lines, p.stdout[-2000:] + p.stderr[-2000:]
     out = json.loads(lines[-1][7:])
     z, A, b, c = load(name)
     g = info_of(z, f"indirect_{eps:g}")
-    assert out["cols"] == 1.0 and out["consistent"] and out["status"] == "Solved"
+    assert out["cols"] == 0.0 and out["consistent"] and out["status"] == "Solved"
     assert out["ipm_iter"] == g["ipm_iter"] and abs(out["admm_iter"] - g["admm_iter"]) <= 0.03 * g["admm_iter"] + 2
     for k in "xys":
         assert rel(np.array(out[k]), z[f"indirect_{eps:g}_{k}"]) < 10 * eps, k
