@@ -615,8 +615,18 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   phase("work vectors, cone tables, the set-up solve");
   info->setup_time = now_ms() - t_init;
   const double t0 = now_ms();
-  // (several GPUs: the ranks must take the same decisions, and their clocks differ: the time limit is not enforced there)
-  const double time_limit_left = w->dist ? INFINITY : 1e3 * st->time_limit - info->setup_time;
+  const double time_limit_left = 1e3 * st->time_limit - info->setup_time;
+  // several GPUs: the ranks must take the same branch and their clocks differ -- with a finite limit the verdicts are summed over the ranks (one more
+  // collective per test; none when time_limit is infinite, the default)
+  bool time_failed = false;
+  auto over_time = [&]() -> bool {
+    const bool mine = (now_ms() - t0) > time_limit_left;
+    if (!w->dist || !std::isfinite(st->time_limit)) return mine;
+    double flag = mine ? 1.0 : 0.0;
+    if (hipMemcpyAsync(w->gsbuf.p, &flag, sizeof(double), hipMemcpyHostToDevice, w->stream) != hipSuccess || ar(w, w->gsbuf.p, 1) ||
+        hipMemcpyAsync(&flag, w->gsbuf.p, sizeof(double), hipMemcpyDeviceToHost, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess) { time_failed = true; return true; }
+    return flag > 0;
+  };
 
   QResid r;
   info->status_val = 0;
@@ -705,7 +715,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     info->solve_time = now_ms() - t0;
     return 0;
   };
-  auto stop_now = [&](int ii) { return (double)k + 1 >= (double)st->max_admm_iters * st->max_ipm_iters || ii + 1 >= st->max_ipm_iters || (now_ms() - t0) > time_limit_left; };
+  auto stop_now = [&](int ii) { const bool ot = over_time(); return (double)k + 1 >= (double)st->max_admm_iters * st->max_ipm_iters || ii + 1 >= st->max_ipm_iters || ot; };
 
   const Ctl *hc = w->lp_ctl;
   const bool batch_ok = !(getenv("ABIP_HIP_BATCH") && atoi(getenv("ABIP_HIP_BATCH")) == 0);
@@ -775,7 +785,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       const int j_last = j + ran - 1;
       const bool halted = w->hctl->halted != 0;
       if (halted && clear_halt(w)) return bail("device error in the inner iteration");
-      if (halted || (now_ms() - t0) > time_limit_left) { j = j_last; break; } // err_inner < tol_inner, abip.c:1147
+      { const bool ot = over_time(); if (time_failed) return bail("collective failure"); if (halted || ot) { j = j_last; break; } } // err_inner < tol_inner, abip.c:1147
       if ((j_last + 1) % st->inner_check_period == 0 || r.error_ratio <= 8) {
         if (calc_residuals(w, r, i, k)) return bail("device error in calc_residuals");
         if ((info->status_val = has_converged(w, r, i, k)) != 0 || stop_now(i)) {

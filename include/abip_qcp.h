@@ -23,7 +23,7 @@
  *   runs the same device path; the caller's X is never modified (the reference folds the SVM labels into it in place).  They need
  *   normalize = 1 (0 and 1 also scale_E = 1): the reference scales unconditionally and un-scales only under `normalize`.
  * Several GPUs (one process per GPU, include/abip_hip.h "multi-GPU"): prob_type 2 with linsys_solver 3 shards the columns of A at cone
- * boundaries; sol->x / y / s come back whole on every rank; settings.time_limit is not enforced there.
+ * boundaries; sol->x / y / s come back whole on every rank (a finite settings.time_limit costs one more small collective per iteration: the ranks vote).
  * Back-ends: the QDLDL-class direct solver (linsys_solver 1) and a
  * device PCG (linsys_solver 3).  The reference's own PCG for this formulation is unreachable through abip() and ill-posed
  * (abip_amd/csrc/qcp_pcg.h), so linsys_solver 3 is defined here: Jacobi-PCG on the y-space Schur

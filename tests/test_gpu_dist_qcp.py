@@ -93,3 +93,16 @@ def test_multi_rank_ml_front_ends(gpu, world, pt, cname):
     assert out["ipm_iter"] == ri["ipm_iter"] and abs(out["admm_iter"] - ri["admm_iter"]) <= 0.03 * ri["admm_iter"] + 3
     assert rel(out["x"], ref["x"]) < 30 * eps
     assert abs(out["pobj"] - ri["pobj"]) <= 30 * eps * (1 + abs(ri["pobj"]))
+
+
+def test_sharded_conic_time_limit(gpu):
+    """A finite time limit in a sharded solve: the ranks sum their verdicts (one small collective per test) and stop together; here one rank, limit already
+    exceeded at the first test -> the solve hands back what it has with an inaccurate status instead of running on."""
+    from abip_amd import dist as adist
+    data, K = make("lasso_small")
+    adist.init_callback(0, 1, lambda arr: None)
+    try:
+        sol, info = gpu.abip_qcp(data, K, dict(eps=1e-9, linsys_solver=3, verbose=0, time_limit=1e-6))
+    finally:
+        adist.finalize()
+    assert info["status"] == "Solved/Inaccurate" and info["admm_iter"] <= 3 and np.all(np.isfinite(sol["x"]))
