@@ -326,7 +326,9 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   const int kind = d->stgs->prob_type; // abip.c:1341-1348: 0 LASSO, 1 SVM, 2 QCP, 3 SVMQP
   if (kind < 0 || kind > 3) return fail(info, "prob_type must be 0 (LASSO), 1 (SVM as an SOCP), 2 (generic QCP) or 3 (SVM as a QP)");
   if (!d->A || !d->b || (kind == 2 && !d->c)) return fail(info, "the device path needs A, b and c");
-  if (d->stgs->linsys_solver != 1 && d->stgs->linsys_solver != 3) return fail(info, "only linsys_solver = 1 (QDLDL-class direct) and 3 (PCG) are served");
+  // linsys_solver: 3 = PCG; 0 (MKL-DSS), 1 (QDLDL), 2 (CSparse Cholesky), 4 (PARDISO), 5 (LAPACK dense Cholesky) are the reference's exact factorisations of the
+  // same KKT system (linsys.c:1129-1170; the default rule of util.c:237-243 picks 5 for dense data): all of them are served by the device LDL'
+  if (d->stgs->linsys_solver < 0 || d->stgs->linsys_solver > 5) { printf("\nlinsys solver type error\n"); return fail(info, "linsys_solver must be 0 .. 5"); }
   const QCPSettings *st = d->stgs;
   if (kind == 0) { // LASSO: data = (X, y, lambda) as abip_ml_mex.c:117-160 hands them over
     if (d->m <= 0 || d->n <= 0 || !(d->lambda > 0)) return fail(info, "LASSO needs a non-empty X and lambda > 0");

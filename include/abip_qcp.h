@@ -24,12 +24,13 @@
  *   normalize = 1 (0 and 1 also scale_E = 1): the reference scales unconditionally and un-scales only under `normalize`.
  * Several GPUs (one process per GPU, include/abip_hip.h "multi-GPU"): prob_type 2 with linsys_solver 3 shards the columns of A at cone
  * boundaries; sol->x / y / s come back whole on every rank (a finite settings.time_limit costs one more small collective per iteration: the ranks vote).
- * Back-ends: the QDLDL-class direct solver (linsys_solver 1) and a
+ * Back-ends: a direct solver (sparse LDL' with a dense tail on the device: linsys_solver 1, the reference's QDLDL; the reference's other exact factorisations
+ * of the same KKT system -- 0 MKL-DSS, 2 CSparse Cholesky, 4 PARDISO, 5 LAPACK dense Cholesky, which its default rule picks for dense data -- select it too) and a
  * device PCG (linsys_solver 3).  The reference's own PCG for this formulation is unreachable through abip() and ill-posed
  * (abip_amd/csrc/qcp_pcg.h), so linsys_solver 3 is defined here: Jacobi-PCG on the y-space Schur
  * complement rho_y I + A (rho_x I + Q)^-1 A' (the reference's `pcg` of linsys.c:629-716 with H^-1 in the middle; Q absent or
  * diagonal), warm start and tolerance as the reference's projection prepares them (abip.c:206-218).  Its MKL / LAPACKE /
- * CSparse-Cholesky back-ends are out of scope; other values are rejected with ABIP_FAILED.
+ * CSparse-Cholesky back-ends are not re-implemented: asking for one runs the device LDL' (same solve, same iterates to rounding); values outside 0..5 are rejected with ABIP_FAILED.
  */
 #ifndef ABIP_HIP_QCP_H
 #define ABIP_HIP_QCP_H
@@ -88,7 +89,7 @@ typedef struct { /* struct ABIP_SETTINGS, abip.h:93-131 */
   qcp_int outer_check_period;
 
   qcp_int verbose;
-  qcp_int linsys_solver; /* 1 = QDLDL-class direct; 3 = PCG on the y-space Schur complement (Q absent or diagonal; abip_amd/csrc/qcp_pcg.h); others: "Failure" */
+  qcp_int linsys_solver; /* 3 = PCG on the y-space Schur complement (Q absent or diagonal; abip_amd/csrc/qcp_pcg.h); 0, 1, 2, 4, 5 = direct (the device LDL') */
   qcp_int prob_type;     /* 0 LASSO, 1 SVM-SOCP, 2 generic QCP (what abip_qcp_mex.c:436 sets), 3 SVM-QP -- see the header comment */
   qcp_float time_limit;  /* seconds */
   qcp_float psi;

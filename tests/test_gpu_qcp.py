@@ -136,7 +136,12 @@ def test_conic_tail_residual_guard(gpu, monkeypatch):
 
 def test_unsupported_back_ends_are_rejected(gpu):
     data, K = toy()
-    sol, info = gpu.abip_qcp(data, K, dict(eps=1e-3, linsys_solver=5, verbose=0))
+    # the reference's other exact factorisations (0 MKL-DSS, 2 Cholesky, 4 PARDISO, 5 LAPACK: what its default rule picks for dense data) run the device LDL'
+    ref, ri = gpu.abip_qcp(data, K, dict(eps=1e-6, linsys_solver=1, verbose=0))
+    for ls in (0, 2, 4, 5):
+        sol, info = gpu.abip_qcp(data, K, dict(eps=1e-6, linsys_solver=ls, verbose=0))
+        assert info["status"] == "Solved" and info["admm_iter"] == ri["admm_iter"] and np.array_equal(sol["x"], ref["x"])
+    sol, info = gpu.abip_qcp(data, K, dict(eps=1e-3, linsys_solver=6, verbose=0))
     assert info["status"] == "Failure" and info["status_val"] == -4
     # the PCG back-end needs H = rho_x I + Q diagonal
     rng = np.random.default_rng(1)
