@@ -372,6 +372,8 @@ void level_sets(int N, TriHost &T, bool backward) {
 } // namespace
 
 void set_tail_request(int t) { g_tail_request = t; }
+namespace { const std::vector<int> *g_order_hint = nullptr; }
+void set_order_hint(const std::vector<int> *P) { g_order_hint = P; }
 
 int host_solve(const LdlHost &F, std::vector<double> &b) {
   const int N = F.N, t0 = F.t0, T = F.T;
@@ -483,7 +485,8 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
   const bool tm = getenv("ABIP_HIP_SETUP_TIMES") != nullptr;
   auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tq = clk();
-  min_degree(N, Gp, Gi, out.P);
+  if (g_order_hint && (int)g_order_hint->size() == N) { out.P = *g_order_hint; if (tm) printf("[setup] ordering: the caller's elimination order\n"); }
+  else min_degree(N, Gp, Gi, out.P);
   if (tm) { printf("[setup] ordering %.3f s\n", clk() - tq); tq = clk(); }
   std::vector<int> Pinv(N);
   for (int i = 0; i < N; ++i) Pinv[out.P[i]] = i;

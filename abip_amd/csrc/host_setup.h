@@ -66,6 +66,10 @@ void complete_schur_on_host(LdlHost &F);
 void set_dev_schur_request(int v);
 // override the tail choice (tests): -2 = environment / automatic, -1 automatic, 0 none, T > 0 forced
 void set_tail_request(int t);
+// An elimination order for the next factor_upper call(s) instead of the minimum-degree pass (P[k] = index of pivot k; nullptr: back to minimum degree).
+// For KKT matrices whose x block is diagonal and whose Schur complement onto the y block is dense anyway (the conic path with n >> m), eliminating
+// the x block first IS the good order -- it is what the reference's reduced systems do -- and the ordering pass (C5: 0.8 s) has nothing to find.
+void set_order_hint(const std::vector<int> *P);
 // Host-only reference solve with a factor as the device would use it (level-ordered head, Schur complement factored densely on
 // the host instead of the device): b <- K^-1 b in pivot order.  For the CPU tests of the ordering / numeric / tail-split code.
 int host_solve(const LdlHost &F, std::vector<double> &b);

@@ -495,9 +495,26 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     Kp[N] = (int)Ki.size();
     host::LdlHost F;
     std::vector<int> pmap(N);
+    // x block diagonal and the Schur complement onto the y block dense anyway (pairs of non-zeros per column >= a quarter of the m (m - 1) / 2 entries):
+    // eliminate the x block first, as the reference's reduced systems do, and skip the minimum-degree pass (ABIP_HIP_ORDER=md forces it)
+    std::vector<int> order;
+    {
+      bool diagH = true;
+      if (w->hasQ) for (int j = 0; j < nl && diagH; ++j) for (int q = w->Q.p[j]; q < w->Q.p[j + 1]; ++q) if (w->Q.i[q] != j && w->Q.x[q] != 0.0) { diagH = false; break; }
+      double pairs = 0;
+      for (int j = 0; j < nl; ++j) { const double kj = w->A.p[j + 1] - w->A.p[j]; pairs += 0.5 * kj * (kj - 1); }
+      const char *e = getenv("ABIP_HIP_ORDER");
+      if (diagH && m >= 256 && pairs >= 0.125 * (double)m * (double)(m - 1) && !(e && !strcmp(e, "md"))) {
+        order.resize(N);
+        for (int j = 0; j < nl; ++j) order[j] = m + j;
+        for (int i = 0; i < m; ++i) order[nl + i] = i;
+      }
+    }
     auto set_up = [&](int tail_request) -> int {
       if (tail_request != -2) host::set_tail_request(tail_request);
+      host::set_order_hint(order.empty() ? nullptr : &order);
       const int rc = host::factor_upper(N, Kp, Ki, Kx, F);
+      host::set_order_hint(nullptr);
       host::set_tail_request(-2);
       if (rc < 0) return -2;
       for (int q = 0; q < N; ++q) pmap[q] = F.P[q] < m ? F.P[q] : w->MP + (F.P[q] - m);
