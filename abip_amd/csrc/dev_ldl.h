@@ -133,6 +133,25 @@ static __global__ __launch_bounds__(256) void k_l21_panel(const long *__restrict
   const double d = Dh[c];
   for (long q = ptr[c] + lane; q < ptr[c + 1]; q += 64) { const long o = (long)row[q] * ldp + col; const double v = val[q]; P[o] = v; PD[o] = v * d; }
 }
+// The same product for a SPARSE L21, row by row: one wavefront owns tail row r, keeps S[r, 0..r] -= ... in an LDS accumulator of T doubles and walks the
+// row's entries (c, l_rc) in order; for each it adds l_rc D_c l_r'c for the entries r' <= r of column c (a prefix of the column's list: rows ascend), one lane
+// per entry -- no two lanes of a step touch the same r', no atomics, a fixed order: deterministic.  cpos[e] = position of row entry e in the column lists.
+static __global__ __launch_bounds__(64) void k_schur_rows(double *__restrict__ S, int T, const long *__restrict__ rptr, const int *__restrict__ rcol, const long *__restrict__ cpos,
+                                                          const long *__restrict__ cptr, const int *__restrict__ crow, const double *__restrict__ cval, const double *__restrict__ Dh) {
+  extern __shared__ double acc[];
+  const int r = blockIdx.x, lane = threadIdx.x;
+  for (int q = lane; q <= r; q += 64) acc[q] = 0.0;
+  __syncthreads();
+  for (long e = rptr[r]; e < rptr[r + 1]; ++e) {
+    const int c = rcol[e];
+    const long last = cpos[e], first = cptr[c];
+    const double f = cval[last] * Dh[c];
+    for (long q = first + lane; q <= last; q += 64) acc[crow[q]] += f * cval[q];
+    __syncthreads(); // (one wavefront: orders this column's LDS updates before the next column's)
+  }
+  double *Srow = S + (long)r * T;
+  for (int q = lane; q <= r; q += 64) Srow[q] -= acc[q];
+}
 // rank-kc update of the lower tile pairs: S[i, j] -= PD[i, :] P[j, :]'
 static __global__ __launch_bounds__(256) void k_schur_sub(double *S, int ld, const double *__restrict__ PD, const double *__restrict__ P, int ldp, int kc) {
   __shared__ double As[DB][DH + 1], Bs[DB * (DH + 1)];
@@ -379,7 +398,25 @@ struct DevLdl {
     if (Wt.upload(H.S, s) || W.alloc((size_t)T * T) || tmp.alloc(T) || Linv.alloc((size_t)nt * DB * DB) || LD.alloc((size_t)T * DB) || flag.upload(zero, s)) return -1;
     if (hipMemsetAsync(W.p, 0, sizeof(double) * (size_t)T * T, s) != hipSuccess) return -1;
     double *S = Wt.p, *Dt = D.p + t0;
-    if (H.dev_schur) { // S arrived as K22: subtract L21 D1 L21' here, a panel of head columns at a time
+    if (H.dev_schur && H.schur_rows) { // sparse L21: the row-wise kernel (LDS accumulator of T doubles per wavefront)
+      std::vector<long> rptr((size_t)T + 1, 0), cposv(H.l21_row.size());
+      std::vector<int> rcol(H.l21_row.size());
+      for (size_t q = 0; q < H.l21_row.size(); ++q) rptr[H.l21_row[q] + 1]++;
+      for (int i = 0; i < T; ++i) rptr[i + 1] += rptr[i];
+      {
+        std::vector<long> pos(rptr.begin(), rptr.end() - 1);
+        for (int c = 0; c < t0; ++c) for (long q = H.l21_ptr[c]; q < H.l21_ptr[c + 1]; ++q) { const long dst = pos[H.l21_row[q]]++; rcol[dst] = c; cposv[dst] = q; }
+      }
+      DBuf<long> drp, dcp, dpos; DBuf<int> drc, dcr; DBuf<double> dcv;
+      auto drop = [&]() { drp.release(); dcp.release(); dpos.release(); drc.release(); dcr.release(); dcv.release(); };
+      if (drp.upload(rptr, s) || drc.upload(rcol, s) || dpos.upload(cposv, s) || dcp.upload(H.l21_ptr, s) || dcr.upload(H.l21_row, s) || dcv.upload(H.l21_val, s)) { drop(); return -1; }
+      const size_t lds = sizeof(double) * (size_t)T;
+      if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(k_schur_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { drop(); return -1; }
+      hipLaunchKernelGGL(k_schur_rows, dim3(T), dim3(64), lds, s, S, T, (const long *)drp.p, (const int *)drc.p, (const long *)dpos.p, (const long *)dcp.p, (const int *)dcr.p,
+                         (const double *)dcv.p, (const double *)D.p);
+      if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { drop(); return -1; }
+      drop();
+    } else if (H.dev_schur) { // S arrived as K22: subtract L21 D1 L21' here, a panel of head columns at a time
       constexpr int KC = 2048;
       DBuf<long> lp; DBuf<int> lr; DBuf<double> lv, P, PD;
       auto drop = [&]() { lp.release(); lr.release(); lv.release(); P.release(); PD.release(); };

@@ -612,10 +612,15 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
     long ncol = 0;
     for (int c = 0; c < t0; ++c) ncol += out.l21_ptr[c + 1] > out.l21_ptr[c];
     const double host_s = cost / 2.4e8, dev_s = 0.02 + (double)T * (double)T * (double)ncol / 3.0e12;
+    // the device's row-wise sparse form: one wavefront step per 64 entries of a column prefix, ~512 wavefronts at a time, ~0.4 us per step
+    double steps = 0;
+    for (int c = 0; c < t0; ++c) { const double kc = (double)(out.l21_ptr[c + 1] - out.l21_ptr[c]); steps += kc * (1.0 + kc / 128.0); }
+    const double rows_s = T <= 20480 ? 0.01 + steps / 512.0 * 0.4e-6 : 1e30;
     const int req = dev_schur_request();
-    out.dev_schur = req == 1 || (req < 0 && host_s > 0.1 && dev_s < host_s);
+    out.dev_schur = req == 1 || req == 2 || (req < 0 && host_s > 0.1 && std::min(dev_s, rows_s) < host_s);
+    out.schur_rows = out.dev_schur && T <= 20480 && (req == 2 || (req != 1 && rows_s < dev_s));
     if (!out.dev_schur) complete_schur_on_host(out);
-    if (tm) { printf("[setup] Schur complement L21 D L21' (%.2e multiply-adds): %s %.3f s\n", cost, out.dev_schur ? "left to the device" : "host", clk() - tq); tq = clk(); }
+    if (tm) { printf("[setup] Schur complement L21 D L21' (%.2e multiply-adds): %s %.3f s\n", cost, out.dev_schur ? (out.schur_rows ? "left to the device (row-wise, sparse)" : "left to the device (dense panels)") : "host", clk() - tq); tq = clk(); }
   }
   // backward form = CSC of the head columns of L (all rows); forward form = CSR of [L11; L21]
   out.bwd.ptr.assign(N + 1, 0);

@@ -56,13 +56,14 @@ struct LdlHost {
   // blocks: 35 000 head columns with 750 tail entries each = 10^10 multiply-adds, 11 s on one host thread, 0.2 s on the device).
   // L21 by head column for that purpose: column c owns [l21_ptr[c], l21_ptr[c+1]) of (l21_row = tail row - t0, l21_val), rows ascending.
   bool dev_schur = false;
+  bool schur_rows = false; // the device multiplies it out row by row from the sparse L21 (k_schur_rows: LDS accumulator, T <= 20480) instead of by dense panels
   std::vector<long> l21_ptr;
   std::vector<int> l21_row;
   std::vector<double> l21_val;
 };
 // S -= L21 D1 L21' on the host (what the device does when dev_schur is set); clears dev_schur.  For host_solve and as the fallback.
 void complete_schur_on_host(LdlHost &F);
-// -1: decide by cost (default); 0: always accumulate on the host; 1: always leave it to the device (tests).  Also env ABIP_HIP_DEV_SCHUR.
+// -1: decide by cost (default); 0: always accumulate on the host; 1: the device's dense panels; 2: the device's row-wise sparse kernel (tests).  Also env ABIP_HIP_DEV_SCHUR.
 void set_dev_schur_request(int v);
 // override the tail choice (tests): -2 = environment / automatic, -1 automatic, 0 none, T > 0 forced
 void set_tail_request(int t);

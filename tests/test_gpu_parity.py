@@ -83,7 +83,7 @@ def test_direct_solve_dense_tail(gpu, oracle_built, tail, monkeypatch):
 @pytest.mark.parametrize("tail", ["128", "512", "auto"])
 def test_schur_complement_formed_on_the_device(gpu, tail, monkeypatch):
     """LdlHost::dev_schur: the host hands over K22 and L21, the device subtracts L21 D1 L21' with dense panels (dev_ldl.h: k_l21_panel,
-    k_schur_sub) before factoring the tail.  Same K^-1 rhs and the same ADMM run as with the host's sparse accumulation."""
+    k_schur_sub; or row by row from the sparse L21, k_schur_rows) before factoring the tail.  Same K^-1 rhs and the same ADMM run as with the host's sparse accumulation."""
     if tail == "auto":
         monkeypatch.delenv("ABIP_HIP_TAIL", raising=False)
     else:
@@ -92,7 +92,7 @@ def test_schur_complement_formed_on_the_device(gpu, tail, monkeypatch):
     rng = np.random.default_rng(11)
     rhs = [rng.standard_normal(A.shape[0] + A.shape[1]) for _ in range(2)]
     out = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):   # host; device, dense panels; device, row-wise sparse kernel
         monkeypatch.setenv("ABIP_HIP_DEV_SCHUR", mode)
         with gpu.Solver(A, b, c, linsys="direct", verbose=0, max_admm_iters=300) as S:
             assert int(S.scalar("tail")) > 0
@@ -102,9 +102,10 @@ def test_schur_complement_formed_on_the_device(gpu, tail, monkeypatch):
             for r, x in zip(rhs, sols):
                 assert rel(K @ x, r) < 1e-11
             out[mode] = (sols, S.solve())
-    for a, b_ in zip(out["0"][0], out["1"][0]):
-        assert rel(a, b_) < 1e-10
-    assert out["0"][1]["admm_iter"] == out["1"][1]["admm_iter"] and abs(out["0"][1]["pobj"] - out["1"][1]["pobj"]) <= 1e-9 * (1 + abs(out["0"][1]["pobj"]))
+    for mode in ("1", "2"):
+        for a, b_ in zip(out["0"][0], out[mode][0]):
+            assert rel(a, b_) < 1e-10
+        assert out["0"][1]["admm_iter"] == out[mode][1]["admm_iter"] and abs(out["0"][1]["pobj"] - out[mode][1]["pobj"]) <= 1e-9 * (1 + abs(out["0"][1]["pobj"]))
 
 
 @pytest.mark.parametrize("name", ["lp_afiro_like", "lp_staircase"])
