@@ -504,7 +504,9 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       double pairs = 0;
       for (int j = 0; j < nl; ++j) { const double kj = w->A.p[j + 1] - w->A.p[j]; pairs += 0.5 * kj * (kj - 1); }
       const char *e = getenv("ABIP_HIP_ORDER");
-      if (diagH && m >= 256 && pairs >= 0.125 * (double)m * (double)(m - 1) && !(e && !strcmp(e, "md"))) {
+      const char *tm_ = getenv("ABIP_HIP_TAIL_MAX"), *tr_ = getenv("ABIP_HIP_TAIL");
+      const bool tail_fits = m + 64 <= (tm_ ? atoi(tm_) : 24576) && !(tr_ && atoi(tr_) >= 0); // the whole y block must fit the dense tail (and the tail be chosen automatically)
+      if (diagH && tail_fits && m >= 256 && pairs >= 0.125 * (double)m * (double)(m - 1) && !(e && !strcmp(e, "md"))) {
         order.resize(N);
         for (int j = 0; j < nl; ++j) order[j] = m + j;
         for (int i = 0; i < m; ++i) order[nl + i] = i;
