@@ -514,7 +514,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     }
     auto set_up = [&](int tail_request) -> int {
       if (tail_request != -2) host::set_tail_request(tail_request);
-      host::set_order_hint(order.empty() ? nullptr : &order);
+      host::set_order_hint(order.empty() || tail_request == 0 ? nullptr : &order); // (the fall-back without a dense tail wants a fill-reducing order)
       const int rc = host::factor_upper(N, Kp, Ki, Kx, F);
       host::set_order_hint(nullptr);
       host::set_tail_request(-2);
