@@ -59,7 +59,7 @@ static __global__ __launch_bounds__(BS) void k_tri_wide(Tri T, const int4 *__res
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
-  const Csr M{T.ptr, T.idx, T.val, rbd, nrb, 0};
+  const Csr M{T.ptr, T.idx, T.val, rbd, nrb, 0, nullptr, nullptr, nullptr, nullptr, 0}; // (no sliced image)
   spmv_stream<1>(M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
                  [&](int pos, double(&acc)[1]) { const int row = T.lev_rows[pos]; x[row] -= acc[0]; });
 }
