@@ -13,8 +13,10 @@
 //   backward:  x2 = W' t                        k_tail_mv on the stored transpose
 //              levels over the head columns     x1 = D1^-1 z1 - L11'.. - L21' x2
 //
-// Set-up kernels are plain LDS-tiled fp64 FMA code (MI355X's fp64 MFMA rate equals its vector rate; set-up is not the hot path).
+// Set-up kernels: the two that carry the flops (the trailing update of the dense LDL' and the Schur complement's rank-k update) run on the matrix cores
+// (v_mfma_f64_16x16x4_f64, 64 x 64 tiles through LDS); the rest is LDS-tiled fp64 FMA code.
 #pragma once
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 
@@ -121,6 +123,83 @@ static __global__ __launch_bounds__(256) void k_dldl_update(double *S, int ld, i
   }
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) S[(i0 + ty * 4 + i) * ld + j0 + tx * 4 + j] -= acc[i][j];
+}
+
+// ---- the same tile products on the matrix cores (v_mfma_f64_16x16x4_f64) -----------------------------------------------------------
+// C (64 x 64) += As (64 x DH) Bs' (64 x DH): wavefront w of the 256-thread workgroup owns the 32 x 32 quadrant (w >> 1, w & 1) as 2 x 2 blocks of 16 x 16.
+// Operand maps (MI355X_MICROARCH.md): lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; it receives D[(l >> 4) + 4 r][l & 15], r = 0..3.
+// LDS rows are padded to DHP = DH + 4 doubles: (l & 15) * 36 + (l >> 4) hits every 8-byte bank pair twice -- the minimum for a 512-byte wavefront read
+// (stride DH + 1, right for the scalar tiles above, would stack four lanes on one bank here).
+constexpr int DHP = DH + 4;
+typedef double v4d __attribute__((ext_vector_type(4)));
+struct MfmaTile { v4d c[2][2]; };
+__device__ __forceinline__ void mfma_zero(MfmaTile &t) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) t.c[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+}
+__device__ __forceinline__ void load_rows_slice_p(double (*dst)[DHP], const double *src, long ld, int q0, int tid) {
+  for (int e = tid; e < DB * DH; e += 256) { const int r = e / DH, q = e % DH; dst[r][q] = src[(long)r * ld + q0 + q]; }
+}
+__device__ __forceinline__ void tile_mac_mfma(MfmaTile &t, const double (*As)[DHP], const double (*Bs)[DHP], int wave, int lane) {
+  const int r0 = (wave >> 1) * 32 + (lane & 15), c0 = (wave & 1) * 32 + (lane & 15), kq = lane >> 4;
+#pragma unroll
+  for (int k4 = 0; k4 < DH; k4 += 4) {
+    const double a0 = As[r0][k4 + kq], a1 = As[r0 + 16][k4 + kq], b0 = Bs[c0][k4 + kq], b1 = Bs[c0 + 16][k4 + kq];
+    t.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, t.c[0][0], 0, 0, 0);
+    t.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, t.c[0][1], 0, 0, 0);
+    t.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, t.c[1][0], 0, 0, 0);
+    t.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, t.c[1][1], 0, 0, 0);
+  }
+}
+// visit the 16 results of this lane: f(row, col, value) with (row, col) inside the 64 x 64 tile
+template <class F>
+__device__ __forceinline__ void mfma_foreach(const MfmaTile &t, int wave, int lane, F f) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) f((wave >> 1) * 32 + 16 * a + (lane >> 4) + 4 * r, (wave & 1) * 32 + 16 * b + (lane & 15), t.c[a][b][r]);
+}
+// (3m) trailing update on the matrix cores: S[i, j] -= LD[i] * L[j, k]'   for tile pairs i >= j > k
+static __global__ __launch_bounds__(256) void k_dldl_update_mfma(double *S, int ld, int k0, const double *LD) {
+  __shared__ double As[DB][DHP], Bs[DB][DHP];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int bi = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((long)(bi + 1) * (bi + 2) / 2 <= (long)blockIdx.x) ++bi;
+  while ((long)bi * (bi + 1) / 2 > (long)blockIdx.x) --bi;
+  const int bj = blockIdx.x - bi * (bi + 1) / 2;
+  const long i0 = k0 + DB + (long)bi * DB, j0 = k0 + DB + (long)bj * DB;
+  MfmaTile t; mfma_zero(t);
+  for (int q0 = 0; q0 < DB; q0 += DH) {
+    __syncthreads();
+    load_rows_slice_p(As, LD + i0 * DB, DB, q0, tid);
+    load_rows_slice_p(Bs, S + j0 * ld + k0, ld, q0, tid);
+    __syncthreads();
+    tile_mac_mfma(t, As, Bs, wave, lane);
+  }
+  mfma_foreach(t, wave, lane, [&](int r, int c, double v) { S[(i0 + r) * ld + j0 + c] -= v; });
+}
+// (0m) rank-kc update of the lower tile pairs on the matrix cores: S[i, j] -= PD[i, :] P[j, :]'
+static __global__ __launch_bounds__(256) void k_schur_sub_mfma(double *S, int ld, const double *__restrict__ PD, const double *__restrict__ P, int ldp, int kc) {
+  __shared__ double As[DB][DHP], Bs[DB][DHP];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int bi = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((long)(bi + 1) * (bi + 2) / 2 <= (long)blockIdx.x) ++bi;
+  while ((long)bi * (bi + 1) / 2 > (long)blockIdx.x) --bi;
+  const int bj = blockIdx.x - bi * (bi + 1) / 2;
+  const long i0 = (long)bi * DB, j0 = (long)bj * DB;
+  MfmaTile t; mfma_zero(t);
+  for (int q0 = 0; q0 < kc; q0 += DH) {
+    __syncthreads();
+    load_rows_slice_p(As, PD + i0 * ldp, ldp, q0, tid);
+    load_rows_slice_p(Bs, P + j0 * ldp, ldp, q0, tid);
+    __syncthreads();
+    tile_mac_mfma(t, As, Bs, wave, lane);
+  }
+  mfma_foreach(t, wave, lane, [&](int r, int c, double v) { S[(i0 + r) * ld + j0 + c] -= v; });
 }
 
 // (0) when the host leaves the product to the device (LdlHost::dev_schur): S -= L21 D1 L21' by dense panels of L21.
@@ -384,12 +463,17 @@ struct DevLdl {
   // pmap[k] = position in the caller's rhs vector of pivot k.  Returns 0, or -1 (allocation / zero pivot).
   int setup(const host::LdlHost &H, const std::vector<int> &pmap, hipStream_t s) {
     N = H.N; t0 = H.t0; T = H.T; lnnz = H.lnnz;
+    const bool tms = getenv("ABIP_HIP_SETUP_TIMES") != nullptr;
+    auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tq = clk();
+    auto lap = [&](const char *what) { if (tms) { (void)hipStreamSynchronize(s); const double t = clk(); printf("[setup]   device: %s %.3f s\n", what, t - tq); tq = t; } };
     // small systems: the whole sparse part in one workgroup (x in LDS), whatever the shape of the levels
     const bool one_wg = N <= XL_MAX && H.fwd.idx.size() <= 32768 && H.bwd.idx.size() <= 32768;
     if (Pmap.upload(pmap, s) || D.upload(H.D, s) || xw.alloc(N) || F.upload(H.fwd, s, one_wg) || B.upload(H.bwd, s, one_wg)) return -1;
     small = F.single_workgroup() && B.single_workgroup() && N <= 65536;
     xl = small && N <= XL_MAX;
     if (xl && !allow_lds<NoFuse>()) xl = false;
+    lap("upload of the sparse head (forward / backward forms)");
     if (T == 0) return 0;
     if (getenv("ABIP_HIP_TAIL_FAIL")) return -1; // test hook: pretend the dense set-up failed (the callers fall back to T = 0)
     const int nt = T / DB;
@@ -398,6 +482,8 @@ struct DevLdl {
     if (Wt.upload(H.S, s) || W.alloc((size_t)T * T) || tmp.alloc(T) || Linv.alloc((size_t)nt * DB * DB) || LD.alloc((size_t)T * DB) || flag.upload(zero, s)) return -1;
     if (hipMemsetAsync(W.p, 0, sizeof(double) * (size_t)T * T, s) != hipSuccess) return -1;
     double *S = Wt.p, *Dt = D.p + t0;
+    lap("upload of S (K22), allocations");
+    const bool use_mfma = !(getenv("ABIP_HIP_MFMA") && atoi(getenv("ABIP_HIP_MFMA")) == 0); // the dense set-up products on the matrix cores (0: the LDS-tiled FMA kernels)
     if (H.dev_schur && H.schur_rows) { // sparse L21: the row-wise kernel (LDS accumulator of T doubles per wavefront)
       std::vector<long> rptr((size_t)T + 1, 0), cposv(H.l21_row.size());
       std::vector<int> rcol(H.l21_row.size());
@@ -426,22 +512,27 @@ struct DevLdl {
         if (H.l21_ptr[c0 + kc] == H.l21_ptr[c0]) continue; // no tail entries in these columns
         if (hipMemsetAsync(P.p, 0, sizeof(double) * (size_t)T * KC, s) != hipSuccess || hipMemsetAsync(PD.p, 0, sizeof(double) * (size_t)T * KC, s) != hipSuccess) { drop(); return -1; }
         hipLaunchKernelGGL(k_l21_panel, dim3((kc + 3) / 4), dim3(256), 0, s, (const long *)lp.p, (const int *)lr.p, (const double *)lv.p, (const double *)D.p, c0, kc, KC, P.p, PD.p);
-        hipLaunchKernelGGL(k_schur_sub, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, S, T, (const double *)PD.p, (const double *)P.p, KC, kcp);
+        if (use_mfma) hipLaunchKernelGGL(k_schur_sub_mfma, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, S, T, (const double *)PD.p, (const double *)P.p, KC, kcp);
+        else hipLaunchKernelGGL(k_schur_sub, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, S, T, (const double *)PD.p, (const double *)P.p, KC, kcp);
       }
       if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { drop(); return -1; }
       drop();
     }
+    lap("Schur complement on the device");
     for (int kb = 0; kb < nt; ++kb) {
       const int k0 = kb * DB, rem = nt - kb - 1;
       hipLaunchKernelGGL(k_dldl_diag, dim3(1), dim3(256), 0, s, S, T, k0, Dt, Linv.p + (size_t)kb * DB * DB, flag.p);
       if (rem > 0) {
         hipLaunchKernelGGL(k_dldl_panel, dim3(rem), dim3(256), 0, s, S, T, k0, (const double *)Dt, (const double *)(Linv.p + (size_t)kb * DB * DB), LD.p);
-        hipLaunchKernelGGL(k_dldl_update, dim3(rem * (rem + 1) / 2), dim3(256), 0, s, S, T, k0, (const double *)LD.p);
+        if (use_mfma) hipLaunchKernelGGL(k_dldl_update_mfma, dim3(rem * (rem + 1) / 2), dim3(256), 0, s, S, T, k0, (const double *)LD.p);
+        else hipLaunchKernelGGL(k_dldl_update, dim3(rem * (rem + 1) / 2), dim3(256), 0, s, S, T, k0, (const double *)LD.p);
       }
     }
+    lap("dense LDL' of the tail");
     for (int kb = 0; kb < nt; ++kb) hipLaunchKernelGGL(k_dtri_inv_row, dim3(kb + 1), dim3(256), 0, s, (const double *)S, T, kb, (const double *)Linv.p, W.p);
     // L22 is no longer needed: its buffer takes the transpose
     hipLaunchKernelGGL(k_dtranspose_lower, dim3(nt, nt), dim3(256), 0, s, (const double *)W.p, Wt.p, T);
+    lap("inverse of L22 and its transpose");
     int bad = 0;
     if (hipMemcpyAsync(&bad, flag.p, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) return -1;
     Linv.release(); LD.release();

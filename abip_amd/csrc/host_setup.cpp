@@ -611,11 +611,13 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
     // KKT matrix), the device's dense panels at ~3 TFLOP/s over T^2 x (head columns that reach the tail) whatever their sparsity
     long ncol = 0;
     for (int c = 0; c < t0; ++c) ncol += out.l21_ptr[c + 1] > out.l21_ptr[c];
-    const double host_s = cost / 2.4e8, dev_s = 0.02 + (double)T * (double)T * (double)ncol / 3.0e12;
-    // the device's row-wise sparse form: one wavefront step per 64 entries of a column prefix, ~512 wavefronts at a time, ~0.4 us per step
+    // measured (profiles/r02x, r02z): host 1.17e8 multiply-adds in 0.49 s; dense panels on the matrix cores 5056^2 x 35002 in 0.058 s (0.077 s with the FMA tiles);
+    // row-wise sparse kernel 1.8e8 wavefront steps in 0.28 s (LASSO protocol), 6e6 in 0.04 s with its uploads (C5)
+    const double host_s = cost / 2.4e8, dev_s = 0.02 + (double)T * (double)T * (double)ncol / 1.5e13;
+    // the device's row-wise sparse form: one wavefront step per 64 entries of a column prefix, ~512 wavefronts at a time, ~0.8 us per step, plus the upload of L21 twice
     double steps = 0;
     for (int c = 0; c < t0; ++c) { const double kc = (double)(out.l21_ptr[c + 1] - out.l21_ptr[c]); steps += kc * (1.0 + kc / 128.0); }
-    const double rows_s = T <= 20480 ? 0.01 + steps / 512.0 * 0.4e-6 : 1e30;
+    const double rows_s = T <= 20480 ? 0.01 + steps / 512.0 * 0.8e-6 + 32.0 * (double)out.l21_ptr[t0] / 5.0e9 : 1e30;
     const int req = dev_schur_request();
     out.dev_schur = req == 1 || req == 2 || (req < 0 && host_s > 0.1 && std::min(dev_s, rows_s) < host_s);
     out.schur_rows = out.dev_schur && T <= 20480 && (req == 2 || (req != 1 && rows_s < dev_s));
