@@ -212,6 +212,10 @@ static __global__ __launch_bounds__(256) void k_l21_panel(const long *__restrict
   const double d = Dh[c];
   for (long q = ptr[c] + lane; q < ptr[c + 1]; q += 64) { const long o = (long)row[q] * ldp + col; const double v = val[q]; P[o] = v; PD[o] = v * d; }
 }
+// K22 from its triplets into the zeroed T x T block (each entry appears once)
+static __global__ __launch_bounds__(256) void k_scatter_k22(const int *__restrict__ row, const int *__restrict__ col, const double *__restrict__ val, int n, double *__restrict__ S, int T) {
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < n; q += gridDim.x * 256) S[(long)row[q] * T + col[q]] = val[q];
+}
 // The same product for a SPARSE L21, row by row: one wavefront owns tail row r, keeps S[r, 0..r] -= ... in an LDS accumulator of T doubles and walks the
 // row's entries (c, l_rc) in order; for each it adds l_rc D_c l_r'c for the entries r' <= r of column c (a prefix of the column's list: rows ascend), one lane
 // per entry -- no two lanes of a step touch the same r', no atomics, a fixed order: deterministic.  cpos[e] = position of row entry e in the column lists.
@@ -479,7 +483,16 @@ struct DevLdl {
     const int nt = T / DB;
     DBuf<double> Linv, LD;
     const std::vector<int> zero(1, 0);
-    if (Wt.upload(H.S, s) || W.alloc((size_t)T * T) || tmp.alloc(T) || Linv.alloc((size_t)nt * DB * DB) || LD.alloc((size_t)T * DB) || flag.upload(zero, s)) return -1;
+    if (H.S.empty()) { // dev_schur: K22 arrives as triplets -- zero the block on the device and scatter them (no 8 T^2-byte host array, no upload of zeros)
+      DBuf<int> kr, kc; DBuf<double> kv;
+      const int nk = (int)H.k22_val.size();
+      int badk = Wt.alloc((size_t)T * T) || hipMemsetAsync(Wt.p, 0, sizeof(double) * (size_t)T * T, s) != hipSuccess || kr.upload(H.k22_row, s) || kc.upload(H.k22_col, s) || kv.upload(H.k22_val, s);
+      if (!badk && nk > 0) hipLaunchKernelGGL(k_scatter_k22, dim3(std::max(1, std::min(2048, (nk + 255) / 256))), dim3(256), 0, s, (const int *)kr.p, (const int *)kc.p, (const double *)kv.p, nk, Wt.p, T);
+      if (!badk) badk = hipStreamSynchronize(s) != hipSuccess;
+      kr.release(); kc.release(); kv.release();
+      if (badk) return -1;
+    } else if (Wt.upload(H.S, s)) return -1;
+    if (W.alloc((size_t)T * T) || tmp.alloc(T) || Linv.alloc((size_t)nt * DB * DB) || LD.alloc((size_t)T * DB) || flag.upload(zero, s)) return -1;
     if (hipMemsetAsync(W.p, 0, sizeof(double) * (size_t)T * T, s) != hipSuccess) return -1;
     double *S = Wt.p, *Dt = D.p + t0;
     lap("upload of S (K22), allocations");

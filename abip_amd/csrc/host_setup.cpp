@@ -391,7 +391,7 @@ int host_solve(const LdlHost &F, std::vector<double> &b) {
   std::vector<double> D(F.D);
   if (T > 0) { // dense LDL' of the Schur complement, then the two triangular solves of the tail (the device applies inv(L22) instead)
     std::vector<double> S(F.S);
-    if (F.dev_schur) { LdlHost G; G.t0 = t0; G.T = T; G.D = F.D; G.S.swap(S); G.l21_ptr = F.l21_ptr; G.l21_row = F.l21_row; G.l21_val = F.l21_val; complete_schur_on_host(G); S.swap(G.S); }
+    if (F.dev_schur) { LdlHost G; G.t0 = t0; G.T = T; G.D = F.D; G.S.swap(S); G.k22_row = F.k22_row; G.k22_col = F.k22_col; G.k22_val = F.k22_val; G.l21_ptr = F.l21_ptr; G.l21_row = F.l21_row; G.l21_val = F.l21_val; complete_schur_on_host(G); S.swap(G.S); }
     for (int c = 0; c < T; ++c) {
       const double d = S[(size_t)c * T + c];
       if (d == 0.0) return -2;
@@ -461,6 +461,10 @@ static int dev_schur_request() {
 }
 void complete_schur_on_host(LdlHost &F) {
   const int t0 = F.t0, T = F.T;
+  if (F.S.empty() && T > 0) { // K22 from its triplets
+    F.S.assign((size_t)T * T, 0.0);
+    for (size_t q = 0; q < F.k22_val.size(); ++q) F.S[(size_t)F.k22_row[q] * T + F.k22_col[q]] += F.k22_val[q];
+  }
   if ((long)F.l21_ptr.size() == (long)t0 + 1)
     for (int c = 0; c < t0; ++c) {
       const double d = F.D[c];
@@ -542,10 +546,7 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
       }
     }
   }
-  if (T > 0) {
-    try { out.S.assign((size_t)T * T, 0.0); }
-    catch (const std::bad_alloc &) { out.S.clear(); T = 0; } // no room for the dense block on the host: plain level-scheduled factor
-  }
+  out.S.clear(); out.k22_row.clear(); out.k22_col.clear(); out.k22_val.clear();
   const int t0 = N - T;
   out.t0 = t0; out.T = T;
 
@@ -565,6 +566,7 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
     for (int q = Cp[k]; q < Cp[k + 1]; ++q) {
       int r = Ci[q];
       if (r == k) { dk += Cx[q]; continue; }
+      if (r >= t0) { out.k22_row.push_back(k - t0); out.k22_col.push_back(r - t0); out.k22_val.push_back(Cx[q]); continue; } // tail-tail: an entry of K22 (its etree path stays in the tail)
       Y[r] += Cx[q];
       int len = 0;
       while (flag[r] != k) { pat[len++] = r; flag[r] = k; r = parent[r]; }
@@ -586,12 +588,7 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
       if (!tail_row) dk -= lkc * yc;
       Li[e] = k; Lx[e] = lkc; fill[c]++;
     }
-    if (k >= t0) {
-      double *Srow = out.S.data() + (size_t)(k - t0) * T;
-      for (int r = t0; r < k; ++r) { Srow[r - t0] = Y[r]; Y[r] = 0.0; }
-      Srow[k - t0] = dk;
-      continue;
-    }
+    if (k >= t0) { out.k22_row.push_back(k - t0); out.k22_col.push_back(k - t0); out.k22_val.push_back(dk); continue; }
     out.D[k] = dk;
     if (dk == 0.0) return -1;
   }
@@ -621,7 +618,10 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
     const int req = dev_schur_request();
     out.dev_schur = req == 1 || req == 2 || (req < 0 && host_s > 0.1 && std::min(dev_s, rows_s) < host_s);
     out.schur_rows = out.dev_schur && T <= 20480 && (req == 2 || (req != 1 && rows_s < dev_s));
-    if (!out.dev_schur) complete_schur_on_host(out);
+    if (!out.dev_schur) {
+      try { complete_schur_on_host(out); }
+      catch (const std::bad_alloc &) { return -3; } // no room for the dense block on the host
+    }
     if (tm) { printf("[setup] Schur complement L21 D L21' (%.2e multiply-adds): %s %.3f s\n", cost, out.dev_schur ? (out.schur_rows ? "left to the device (row-wise, sparse)" : "left to the device (dense panels)") : "host", clk() - tq); tq = clk(); }
   }
   // backward form = CSC of the head columns of L (all rows); forward form = CSR of [L11; L21]

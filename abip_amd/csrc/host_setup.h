@@ -50,7 +50,8 @@ struct LdlHost {
   std::vector<double> D; // pivots of the head [0, t0); the tail's come from the device factorisation
   TriHost fwd, bwd;      // sparse part: columns < t0 of L (rows of the tail included)
   int t0 = 0, T = 0;     // head size, dense-tail size (T % 64 == 0, t0 + T = N)
-  std::vector<double> S; // T x T row-major, lower triangle: Schur complement of the head onto the tail
+  std::vector<double> S; // T x T row-major, lower triangle: Schur complement of the head onto the tail -- EMPTY when dev_schur: then K22 arrives as the triplets below
+  std::vector<int> k22_row, k22_col; std::vector<double> k22_val; // K22 (tail-local indices, row >= col): what S is before L21 D1 L21' is subtracted
   // dev_schur: S holds K22 only and the product L21 D1 L21' is still to be subtracted -- by the device (dev_ldl.h: dense panels of
   // L21 + a tiled rank-k update), which takes over when its dense panels beat the host's sparse accumulation (dense data
   // blocks: 35 000 head columns with 750 tail entries each = 10^10 multiply-adds, 11 s on one host thread, 0.2 s on the device).
