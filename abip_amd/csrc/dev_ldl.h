@@ -16,7 +16,9 @@
 // Set-up kernels: the two that carry the flops (the trailing update of the dense LDL' and the Schur complement's rank-k update) run on the matrix cores
 // (v_mfma_f64_16x16x4_f64, 64 x 64 tiles through LDS); the rest is LDS-tiled fp64 FMA code.
 #pragma once
+#include <algorithm>
 #include <chrono>
+#include <functional>
 #include <cmath>
 #include <cstdlib>
 
@@ -297,6 +299,44 @@ static __global__ __launch_bounds__(256) void k_dtri_inv_row(const double *L, in
   for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) out[(long)(ty * 4 + a) * ld + tx * 4 + b] = -res[a][b];
 }
 
+// (4m) the inverse by halves on the matrix cores: inv [[L11, 0], [L21, L22]] = [[W11, 0], [-W22 L21 W11, W22]] -- the two halves are independent, the corner is two
+// products, and every level of the recursion is a handful of large launches instead of one small launch per block row (C5, T = 10 048: 0.19 s -> see profiles/r02z).
+// C = alpha A B on row-major blocks whose dimensions are multiples of 64: C is M x N (grid N/64 x M/64), A is M x K, B is K x N.  triA: A is lower-triangular
+// (K == M), row block bi stops at k = 64 (bi + 1); triB: B is lower-triangular (K == N), column block bj starts at k = 64 bj.
+static __global__ __launch_bounds__(256) void k_dgemm_mfma(double *__restrict__ C, long ldc, const double *__restrict__ A, long lda, const double *__restrict__ B, long ldb, int K,
+                                                           double alpha, int triA, int triB) {
+  __shared__ double As[DB][DHP], Bs[DH][DB + 8]; // B slice k-major: lane l reads Bs[k4 + (l >> 4)][c0 + (l & 15)]: (l >> 4) * 72 + (l & 15) -> every bank pair twice
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  const int k0 = triB ? bj * DB : 0, k1 = triA ? (K < (bi + 1) * DB ? K : (bi + 1) * DB) : K;
+  const double *Ab = A + (long)bi * DB * lda, *Bb = B + (long)bj * DB;
+  const int r0 = (wave >> 1) * 32 + (lane & 15), c0 = (wave & 1) * 32 + (lane & 15), kq = lane >> 4;
+  MfmaTile t; mfma_zero(t);
+  for (int q0 = k0; q0 < k1; q0 += DH) {
+    __syncthreads();
+    load_rows_slice_p(As, Ab, lda, q0, tid);
+    for (int e = tid; e < DH * DB; e += 256) { const int q = e / DB, c = e % DB; Bs[q][c] = Bb[(long)(q0 + q) * ldb + c]; }
+    __syncthreads();
+#pragma unroll
+    for (int k4 = 0; k4 < DH; k4 += 4) {
+      const double a0 = As[r0][k4 + kq], a1 = As[r0 + 16][k4 + kq], b0 = Bs[k4 + kq][c0], b1 = Bs[k4 + kq][c0 + 16];
+      t.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, t.c[0][0], 0, 0, 0);
+      t.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, t.c[0][1], 0, 0, 0);
+      t.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, t.c[1][0], 0, 0, 0);
+      t.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, t.c[1][1], 0, 0, 0);
+    }
+  }
+  double *Cb = C + (long)bi * DB * ldc + (long)bj * DB;
+  mfma_foreach(t, wave, lane, [&](int r, int c, double v) { Cb[(long)r * ldc + c] = alpha * v; });
+}
+// the diagonal blocks of W: inv(L_kk) as k_dldl_diag left them
+static __global__ __launch_bounds__(256) void k_dtri_inv_diag(const double *__restrict__ Linv_all, double *__restrict__ W, int ld) {
+  const int kb = blockIdx.x;
+  const double *Lk = Linv_all + (long)kb * DB * DB;
+  double *out = W + (long)kb * DB * ld + (long)kb * DB;
+  for (int e = threadIdx.x; e < DB * DB; e += 256) out[(long)(e / DB) * ld + e % DB] = Lk[e];
+}
+
 // (5) Wt = W' (lower triangle of W -> upper triangle of Wt), 64x64 tiles
 static __global__ __launch_bounds__(256) void k_dtranspose_lower(const double *W, double *Wt, int ld) {
   __shared__ double t[DB][DB + 1];
@@ -542,6 +582,34 @@ struct DevLdl {
       }
     }
     lap("dense LDL' of the tail");
+    if (use_mfma && nt >= 4) { // by halves (k_dgemm_mfma): nodes of the recursion in level order; Tm = L21 W11, then W21 = -W22 Tm
+      struct Node { int lo, mid, hi, level; };
+      std::vector<Node> nodes;
+      std::function<int(int, int)> rec = [&](int lo, int hi) -> int {
+        if (hi - lo == 1) return 0;
+        const int mid = (lo + hi) / 2;
+        const int lv = std::max(rec(lo, mid), rec(mid, hi)) + 1;
+        nodes.push_back(Node{lo, mid, hi, lv});
+        return lv;
+      };
+      rec(0, nt);
+      std::stable_sort(nodes.begin(), nodes.end(), [](const Node &a, const Node &b) { return a.level < b.level; });
+      DBuf<double> Tm;
+      const long half = (long)((nt + 1) / 2) * DB;
+      if (Tm.alloc((size_t)half * half)) return -1;
+      hipLaunchKernelGGL(k_dtri_inv_diag, dim3(nt), dim3(256), 0, s, (const double *)Linv.p, W.p, T);
+      for (const Node &nd : nodes) {
+        const int mb = nd.hi - nd.mid, nb = nd.mid - nd.lo; // block rows / block columns of the corner
+        const long Mr = (long)mb * DB, Nc = (long)nb * DB;
+        const double *L21 = S + (long)nd.mid * DB * T + (long)nd.lo * DB;
+        const double *W11 = W.p + (long)nd.lo * DB * T + (long)nd.lo * DB, *W22 = W.p + (long)nd.mid * DB * T + (long)nd.mid * DB;
+        double *W21 = W.p + (long)nd.mid * DB * T + (long)nd.lo * DB;
+        hipLaunchKernelGGL(k_dgemm_mfma, dim3(nb, mb), dim3(256), 0, s, Tm.p, Nc, L21, (long)T, W11, (long)T, (int)Nc, 1.0, 0, 1);
+        hipLaunchKernelGGL(k_dgemm_mfma, dim3(nb, mb), dim3(256), 0, s, W21, (long)T, W22, (long)T, (const double *)Tm.p, Nc, (int)Mr, -1.0, 1, 0);
+      }
+      if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { Tm.release(); return -1; }
+      Tm.release();
+    } else
     for (int kb = 0; kb < nt; ++kb) hipLaunchKernelGGL(k_dtri_inv_row, dim3(kb + 1), dim3(256), 0, s, (const double *)S, T, kb, (const double *)Linv.p, W.p);
     // L22 is no longer needed: its buffer takes the transpose
     hipLaunchKernelGGL(k_dtranspose_lower, dim3(nt, nt), dim3(256), 0, s, (const double *)W.p, Wt.p, T);
