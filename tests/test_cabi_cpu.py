@@ -88,3 +88,79 @@ def test_product_never_touches_the_oracle():
                 if re.search(r"\boracle\b", txt) and not f.endswith("problems.py"):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_linsys_plugin_exports_the_reference_plug_in_interface(lib):
+    """lib/libabip_hip_linsys.so (include/abip_linsys.h): its dynamic symbol table is the reference's linsys.h surface as linsys/direct.c defines it
+    (the nine symbols abip.c calls + free_lin_sys_work_pds) plus the back-end switch and the allocator hook -- and NOT abip_init / abip_solve, which the
+    program it is linked into brings itself.  Without a GPU abip_init_lin_sys_work returns NULL (no CPU fallback)."""
+    import subprocess
+    path = os.path.join(ROOT, "abip_amd", "lib", "libabip_hip_linsys.so")
+    if not os.path.exists(path):
+        import __graft_entry__ as g
+        g.build()
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "abip_linsys.h")).read(), flags=re.S)
+    decl = sorted({mm.group(1) for mm in re.finditer(r"\b(abip_[a-z_A-Z0-9]+)\s*\(", src)})
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln)
+    assert exported == sorted(decl + ["abip_hip_set_linsys", "abip_hip_get_linsys"])
+    L = C.CDLL(path, mode=getattr(os, "RTLD_LOCAL", 0))
+    for s in decl:
+        assert hasattr(L, s)
+    import torch
+    if not torch.cuda.is_available():
+        import numpy as np
+        from abip_amd import default_settings, problems
+        A, b, c = problems.lp_afiro_like()
+        Ax = np.ascontiguousarray(A.data, dtype=np.float64); Ai = np.ascontiguousarray(A.indices, dtype=np.int64); Ap = np.ascontiguousarray(A.indptr, dtype=np.int64)
+        mat = lib.ABIPMatrix(Ax.ctypes.data_as(lib.PF), Ai.ctypes.data_as(lib.PI), Ap.ctypes.data_as(lib.PI), A.shape[0], A.shape[1])
+        st = default_settings()
+        L.abip_init_lin_sys_work.restype = C.c_void_p
+        assert not L.abip_init_lin_sys_work(C.byref(mat), C.byref(st))
+
+
+def test_reference_loop_links_against_the_plugin():
+    """Container only: oracle/_ref/libabip_ref_hiplinsys.so is the reference's abip.c + common.c (from where they lie) linked with -z defs against the plug-in;
+    every abip_* symbol it leaves undefined is one the plug-in exports."""
+    import subprocess
+    ref = os.path.join(ROOT, "oracle", "_ref", "libabip_ref_hiplinsys.so")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref not built (no reference tree)")
+    und = [ln.split()[-1] for ln in subprocess.run(["nm", "-D", ref], check=True, capture_output=True, text=True).stdout.splitlines() if " U abip" in ln]
+    assert sorted(und) == sorted(["abip_accum_by_A", "abip_accum_by_Atrans", "abip_free_lin_sys_work", "abip_get_lin_sys_method", "abip_get_lin_sys_summary",
+                                  "abip_init_lin_sys_work", "abip_normalize_A", "abip_solve_lin_sys", "abip_un_normalize_A"])
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "abip_amd", "lib", "libabip_hip_linsys.so")], check=True, capture_output=True, text=True).stdout
+    have = {ln.split()[-1] for ln in out.splitlines()}
+    assert set(und) <= have
+
+
+def test_plugin_scaling_equals_the_references(lib):
+    """abip_normalize_A of the plug-in against the reference's (linsys/common.c:150-565, through libabip_ref_direct.so): D, E and the scaled values to 1e-14,
+    and un_normalize_A restores A."""
+    import numpy as np
+    from abip_amd import _lib, default_settings
+    from _golden import load, rel
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libabip_ref_direct.so")):
+        pytest.skip("oracle/_ref not built (no reference tree)")
+    z, A, b, c = load("lp_multicommodity_small")
+    L = C.CDLL(os.path.join(ROOT, "abip_amd", "lib", "libabip_hip_linsys.so"), mode=getattr(os, "RTLD_LOCAL", 0))
+    Lr = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libabip_ref_direct.so"), mode=getattr(os, "RTLD_LOCAL", 0))
+
+    class Scal(C.Structure):
+        _fields_ = [("D", _lib.PF), ("E", _lib.PF), ("mean_norm_row_A", C.c_double), ("mean_norm_col_A", C.c_double)]
+
+    outs = []
+    for lib in (L, Lr):
+        Ax = np.ascontiguousarray(A.data, dtype=np.float64).copy(); Ai = np.ascontiguousarray(A.indices, dtype=np.int64); Ap = np.ascontiguousarray(A.indptr, dtype=np.int64)
+        mat = _lib.ABIPMatrix(Ax.ctypes.data_as(_lib.PF), Ai.ctypes.data_as(_lib.PI), Ap.ctypes.data_as(_lib.PI), A.shape[0], A.shape[1])
+        st = default_settings()
+        sc = Scal()
+        lib.abip_normalize_A(C.byref(mat), C.byref(st), C.byref(sc))
+        D = np.ctypeslib.as_array(sc.D, shape=(A.shape[0],)).copy(); E = np.ctypeslib.as_array(sc.E, shape=(A.shape[1],)).copy()
+        scaled = Ax.copy()
+        lib.abip_un_normalize_A(C.byref(mat), C.byref(st), C.byref(sc))
+        outs.append((D, E, scaled, Ax.copy(), sc.mean_norm_row_A, sc.mean_norm_col_A))
+    (D, E, S, back, mr, mc), (Dr, Er, Sr, backr, mrr, mcr) = outs
+    assert rel(D, Dr) < 1e-14 and rel(E, Er) < 1e-14 and rel(S, Sr) < 1e-14
+    assert abs(mr - mrr) <= 1e-13 * mrr and abs(mc - mcr) <= 1e-13 * mcr
+    assert rel(back, A.data) < 1e-14 and rel(backr, A.data) < 1e-14
