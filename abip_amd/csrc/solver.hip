@@ -1597,28 +1597,24 @@ abip_int abip_main(const ABIPData *d, ABIPSolution *sol, ABIPInfo *info) { // ab
 // ---- unit-level device access --------------------------------------------------------------------
 abip_int abip_hip_accum_by_A(ABIPWork *w, const abip_float *x, abip_float *y) { // on a sharded solve: this rank's rows
   if (!w || !x || !y) return -1;
-  DBuf<double> dx, dy;
-  if (dx.alloc(w->n) || dy.alloc(w->m)) return -1;
-  HIP_OK(hipMemcpyAsync(dx.p, x, sizeof(double) * w->n, hipMemcpyHostToDevice, w->stream));
-  HIP_OK(hipMemcpyAsync(dy.p, y, sizeof(double) * w->m, hipMemcpyHostToDevice, w->stream));
-  launch(w, ABIP_HIP_K_SPMV_A, PICK(k_spmv_acc, w->dA), w->NB, BS, w->dA.view(), (const double *)dx.p, dy.p);
-  HIP_OK(hipMemcpyAsync(y, dy.p, sizeof(double) * w->m, hipMemcpyDeviceToHost, w->stream));
+  double *dx = w->a_up.p, *dy = w->a_vp.p; // scratch vectors of the BB search (LV >= m, n each; not live outside it): no allocation per call
+  HIP_OK(hipMemcpyAsync(dx, x, sizeof(double) * w->n, hipMemcpyHostToDevice, w->stream));
+  HIP_OK(hipMemcpyAsync(dy, y, sizeof(double) * w->m, hipMemcpyHostToDevice, w->stream));
+  launch(w, ABIP_HIP_K_SPMV_A, PICK(k_spmv_acc, w->dA), w->NB, BS, w->dA.view(), (const double *)dx, dy);
+  HIP_OK(hipMemcpyAsync(y, dy, sizeof(double) * w->m, hipMemcpyDeviceToHost, w->stream));
   HIP_OK(hipStreamSynchronize(w->stream));
   harvest_events(w);
-  dx.release(); dy.release();
   return 0;
 }
 abip_int abip_hip_accum_by_Atrans(ABIPWork *w, const abip_float *x, abip_float *y) {
   if (!w || !x || !y) return -1;
-  DBuf<double> dx, dy;
-  if (dx.alloc(w->m) || dy.alloc(w->n)) return -1;
-  HIP_OK(hipMemcpyAsync(dx.p, x, sizeof(double) * w->m, hipMemcpyHostToDevice, w->stream));
-  HIP_OK(hipMemcpyAsync(dy.p, y, sizeof(double) * w->n, hipMemcpyHostToDevice, w->stream));
-  launch(w, ABIP_HIP_K_SPMV_AT, PICK(k_spmv_acc, w->dAt), w->NB, BS, w->dAt.view(), (const double *)dx.p, dy.p);
-  HIP_OK(hipMemcpyAsync(y, dy.p, sizeof(double) * w->n, hipMemcpyDeviceToHost, w->stream));
+  double *dx = w->a_up.p, *dy = w->a_vp.p;
+  HIP_OK(hipMemcpyAsync(dx, x, sizeof(double) * w->m, hipMemcpyHostToDevice, w->stream));
+  HIP_OK(hipMemcpyAsync(dy, y, sizeof(double) * w->n, hipMemcpyHostToDevice, w->stream));
+  launch(w, ABIP_HIP_K_SPMV_AT, PICK(k_spmv_acc, w->dAt), w->NB, BS, w->dAt.view(), (const double *)dx, dy);
+  HIP_OK(hipMemcpyAsync(y, dy, sizeof(double) * w->n, hipMemcpyDeviceToHost, w->stream));
   HIP_OK(hipStreamSynchronize(w->stream));
   harvest_events(w);
-  dx.release(); dy.release();
   return 0;
 }
 abip_int abip_hip_kkt_solve(ABIPWork *w, abip_float *rhs, const abip_float *warm, abip_int iter) {
