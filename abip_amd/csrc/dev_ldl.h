@@ -12,6 +12,7 @@
 //              t  = D2^-1 (W w)                 k_tail_mv, one wavefront per row, HBM/Infinity-Cache stream of W
 //   backward:  x2 = W' t                        k_tail_mv on the stored transpose
 //              levels over the head columns     x1 = D1^-1 z1 - L11'.. - L21' x2
+//   large tails (T >= 2048): x2 = M w with M = W' D2^-1 W formed once, lower triangle streamed ONCE per solve (k_tail_sym; half the bytes of the two mat-vecs)
 //
 // Set-up kernels: the two that carry the flops (the trailing update of the dense LDL' and the Schur complement's rank-k update) run on the matrix cores
 // (v_mfma_f64_16x16x4_f64, 64 x 64 tiles through LDS); the rest is LDS-tiled fp64 FMA code.
@@ -303,19 +304,21 @@ static __global__ __launch_bounds__(256) void k_dtri_inv_row(const double *L, in
 // products, and every level of the recursion is a handful of large launches instead of one small launch per block row (C5, T = 10 048: 0.19 s -> see profiles/r02z).
 // C = alpha A B on row-major blocks whose dimensions are multiples of 64: C is M x N (grid N/64 x M/64), A is M x K, B is K x N.  triA: A is lower-triangular
 // (K == M), row block bi stops at k = 64 (bi + 1); triB: B is lower-triangular (K == N), column block bj starts at k = 64 bj.
+// triA == 2: A is UPPER-triangular (row block bi starts at k = 64 bi) and only the blocks bj <= bi of C are formed; bscale: row k of B is divided by bscale[k].
 static __global__ __launch_bounds__(256) void k_dgemm_mfma(double *__restrict__ C, long ldc, const double *__restrict__ A, long lda, const double *__restrict__ B, long ldb, int K,
-                                                           double alpha, int triA, int triB) {
+                                                           double alpha, int triA, int triB, const double *__restrict__ bscale) {
   __shared__ double As[DB][DHP], Bs[DH][DB + 8]; // B slice k-major: lane l reads Bs[k4 + (l >> 4)][c0 + (l & 15)]: (l >> 4) * 72 + (l & 15) -> every bank pair twice
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int bi = blockIdx.y, bj = blockIdx.x;
-  const int k0 = triB ? bj * DB : 0, k1 = triA ? (K < (bi + 1) * DB ? K : (bi + 1) * DB) : K;
+  if (triA == 2 && bj > bi) return;
+  const int k0 = triA == 2 ? bi * DB : (triB ? bj * DB : 0), k1 = triA == 1 ? (K < (bi + 1) * DB ? K : (bi + 1) * DB) : K;
   const double *Ab = A + (long)bi * DB * lda, *Bb = B + (long)bj * DB;
   const int r0 = (wave >> 1) * 32 + (lane & 15), c0 = (wave & 1) * 32 + (lane & 15), kq = lane >> 4;
   MfmaTile t; mfma_zero(t);
   for (int q0 = k0; q0 < k1; q0 += DH) {
     __syncthreads();
     load_rows_slice_p(As, Ab, lda, q0, tid);
-    for (int e = tid; e < DH * DB; e += 256) { const int q = e / DB, c = e % DB; Bs[q][c] = Bb[(long)(q0 + q) * ldb + c]; }
+    for (int e = tid; e < DH * DB; e += 256) { const int q = e / DB, c = e % DB; const double bv = Bb[(long)(q0 + q) * ldb + c]; Bs[q][c] = bscale ? bv / bscale[q0 + q] : bv; }
     __syncthreads();
 #pragma unroll
     for (int k4 = 0; k4 < DH; k4 += 4) {
@@ -376,6 +379,86 @@ static __global__ __launch_bounds__(BS) void k_tail_mv(const double *__restrict_
     double s = (a0 + a1) + (a2 + a3);
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) out[r] = dsc ? s / dsc[r] : s;
+  }
+}
+
+// ---- the tail as ONE symmetric mat-vec --------------------------------------------------------------------------------------------
+// x2 = W' D2^-1 W w = M w with M = inv(S) formed once at set-up (k_dgemm_mfma, lower triangle stored).  Every stored entry serves two outputs
+// (M[r][c] w[c] into row r, M[r][c] w[r] into row c), so a solve streams the triangle ONCE -- T^2 / 2 doubles instead of the T^2 of the two
+// triangular mat-vecs (C5, T = 10 048: 404 MB instead of 808 MB per KKT solve).  Tiles of 64 rows x 512 columns; a tile leaves 64 row sums and
+// 512 column sums in two partial tables which k_tail_sym_fin adds up in a fixed order (no atomics: deterministic).
+constexpr int SYR = 64, SYC = 512;
+static __global__ __launch_bounds__(256) void k_tail_sym(const double *__restrict__ M, int ld, const int2 *__restrict__ tiles, const double *__restrict__ w,
+                                                         double *__restrict__ rowpart, double *__restrict__ colpart, int T, const Ctl *ctl) {
+  if (ctl->halt) return;
+  __shared__ double cs[4][SYC];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int rb = tiles[blockIdx.x].x, cc = tiles[blockIdx.x].y;
+  const int c0 = cc * SYC, r0 = rb * SYR + wave * 16;
+  const bool inside = c0 + SYC <= rb * SYR; // the whole tile lies strictly below the diagonal: no masks
+  double2 wc[4], ca[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + 128 * k + 2 * lane;
+    wc[k] = c + 1 < T ? *reinterpret_cast<const double2 *>(w + c) : make_double2(c < T ? w[c] : 0.0, 0.0);
+    ca[k] = make_double2(0.0, 0.0);
+  }
+#pragma unroll 2
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + i;
+    const double wr = w[r];
+    const double2 *row2 = reinterpret_cast<const double2 *>(M + (long)r * ld + c0);
+    double acc = 0.0;
+    if (inside) {
+      double2 m[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = row2[64 * k + lane];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { acc += m[k].x * wc[k].x; acc += m[k].y * wc[k].y; ca[k].x += m[k].x * wr; ca[k].y += m[k].y * wr; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = c0 + 128 * k + 2 * lane;
+        if (c <= r) { // the pair (c, c + 1) starts inside the row (rows are 512-byte aligned and ld >= T: the load itself is always in bounds)
+          const double2 m = row2[64 * k + lane];
+          acc += m.x * wc[k].x;
+          if (c < r) ca[k].x += m.x * wr;
+          if (c + 1 <= r) { acc += m.y * wc[k].y; if (c + 1 < r) ca[k].y += m.y * wr; }
+        }
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) rowpart[(long)cc * T + r] = acc;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { cs[wave][128 * k + 2 * lane] = ca[k].x; cs[wave][128 * k + 2 * lane + 1] = ca[k].y; }
+  __syncthreads();
+  for (int c = tid; c < SYC; c += 256)
+    if (c0 + c < T) colpart[(long)rb * T + c0 + c] = (cs[0][c] + cs[1][c]) + (cs[2][c] + cs[3][c]);
+}
+// x2[i] = sum over the column chunks of row i's block of rowpart + sum over the row blocks at or below i's of colpart; (xh, Dh, nh) as in k_tail_mv.
+// One 1024-thread workgroup per 64 outputs: 16 groups of lanes share the up to T / 64 column partials of an output and are added in a fixed order.
+static __global__ __launch_bounds__(1024) void k_tail_sym_fin(const double *__restrict__ rowpart, const double *__restrict__ colpart, int T, double *__restrict__ x2, const Ctl *ctl,
+                                                              double *__restrict__ xh, const double *__restrict__ Dh, int nh) {
+  if (ctl->halt) return;
+  __shared__ double ps[16][64];
+  const int tid = threadIdx.x, l = tid & 63, g = tid >> 6;
+  for (int j = blockIdx.x * 1024 + tid; j < nh; j += gridDim.x * 1024) xh[j] /= Dh[j];
+  const int nt = T / SYR;
+  for (int rb = blockIdx.x; rb < nt; rb += gridDim.x) {
+    const int i = rb * SYR + l, ncc = (rb * SYR + SYR + SYC - 1) / SYC;
+    double b = 0.0;
+    for (int cc = g; cc < ncc; cc += 16) b += rowpart[(long)cc * T + i];
+    for (int q = rb + g; q < nt; q += 16) b += colpart[(long)q * T + i];
+    ps[g][l] = b;
+    __syncthreads();
+    if (g == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += ps[k][l];
+      x2[i] = t;
+    }
+    __syncthreads();
   }
 }
 
@@ -491,6 +574,9 @@ struct DevLdl {
   DevTri F, B;
   DBuf<int> Pmap, flag;
   DBuf<double> D, xw, W, Wt, tmp;
+  DBuf<double> Msym, rowpart, colpart; // the tail as one symmetric mat-vec (k_tail_sym): M = W' D2^-1 W, W and W' released
+  DBuf<int2> sym_tiles;
+  int n_sym_tiles = 0;
   bool small = false, xl = false; // one-workgroup sparse part; x in LDS
   int N = 0, t0 = 0, T = 0;
   long lnnz = 0;
@@ -604,8 +690,8 @@ struct DevLdl {
         const double *L21 = S + (long)nd.mid * DB * T + (long)nd.lo * DB;
         const double *W11 = W.p + (long)nd.lo * DB * T + (long)nd.lo * DB, *W22 = W.p + (long)nd.mid * DB * T + (long)nd.mid * DB;
         double *W21 = W.p + (long)nd.mid * DB * T + (long)nd.lo * DB;
-        hipLaunchKernelGGL(k_dgemm_mfma, dim3(nb, mb), dim3(256), 0, s, Tm.p, Nc, L21, (long)T, W11, (long)T, (int)Nc, 1.0, 0, 1);
-        hipLaunchKernelGGL(k_dgemm_mfma, dim3(nb, mb), dim3(256), 0, s, W21, (long)T, W22, (long)T, (const double *)Tm.p, Nc, (int)Mr, -1.0, 1, 0);
+        hipLaunchKernelGGL(k_dgemm_mfma, dim3(nb, mb), dim3(256), 0, s, Tm.p, Nc, L21, (long)T, W11, (long)T, (int)Nc, 1.0, 0, 1, (const double *)nullptr);
+        hipLaunchKernelGGL(k_dgemm_mfma, dim3(nb, mb), dim3(256), 0, s, W21, (long)T, W22, (long)T, (const double *)Tm.p, Nc, (int)Mr, -1.0, 1, 0, (const double *)nullptr);
       }
       if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { Tm.release(); return -1; }
       Tm.release();
@@ -617,7 +703,27 @@ struct DevLdl {
     int bad = 0;
     if (hipMemcpyAsync(&bad, flag.p, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) return -1;
     Linv.release(); LD.release();
-    return bad ? -1 : 0;
+    if (bad) return -1;
+    // large tails: M = W' D2^-1 W once, and every solve streams its lower triangle once (k_tail_sym) instead of W and W'.  Below ~2 000 pivots the two mat-vecs are
+    // latency-bound and spread over more workgroups: kept.  ABIP_HIP_TAIL_SYM=0 / 1 forces either.
+    const char *se = getenv("ABIP_HIP_TAIL_SYM");
+    const bool want_sym = use_mfma && (se ? atoi(se) != 0 : T >= 2048);
+    if (want_sym) {
+      std::vector<int2> tl;
+      for (int rb = nt - 1; rb >= 0; --rb) // long rows first
+        for (int cc = 0; cc * SYC < rb * SYR + SYR; ++cc) tl.push_back(make_int2(rb, cc));
+      const int ncc_max = (T + SYC - 1) / SYC;
+      if (Msym.alloc((size_t)T * T) || rowpart.alloc((size_t)ncc_max * T) || colpart.alloc((size_t)nt * T) || sym_tiles.upload(tl, s)) {
+        Msym.release(); rowpart.release(); colpart.release(); sym_tiles.release(); (void)hipGetLastError(); // no room: the two mat-vecs stay
+      } else {
+        hipLaunchKernelGGL(k_dgemm_mfma, dim3(nt, nt), dim3(256), 0, s, Msym.p, (long)T, (const double *)Wt.p, (long)T, (const double *)W.p, (long)T, T, 1.0, 2, 0, (const double *)Dt);
+        if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) return -1;
+        n_sym_tiles = (int)tl.size();
+        W.release(); Wt.release(); tmp.release();
+      }
+      lap("M = W' D2^-1 W (the tail as one symmetric mat-vec)");
+    }
+    return 0;
   }
 
   // enqueue rhs <- K^-1 rhs; `launch(kernel, grid, block, lds_bytes, args...)` is the caller's launcher (profiling classes differ)
@@ -625,6 +731,12 @@ struct DevLdl {
   void enqueue(LaunchFn &&launch, double *rhs, const Ctl *ctl, int NB, Fuse fz = Fuse{}) const {
     auto tail = [&](bool scale_head) {
       if (T == 0) return;
+      if (n_sym_tiles > 0) {
+        launch(k_tail_sym, n_sym_tiles, 256, (size_t)0, (const double *)Msym.p, T, (const int2 *)sym_tiles.p, (const double *)(xw.p + t0), rowpart.p, colpart.p, T, ctl);
+        launch(k_tail_sym_fin, std::max(T / SYR, std::min(256, scale_head ? (t0 + 1023) / 1024 : 1)), 1024, (size_t)0, (const double *)rowpart.p, (const double *)colpart.p, T, xw.p + t0, ctl,
+               xw.p, (const double *)D.p, scale_head ? t0 : 0);
+        return;
+      }
       const int grid = std::max(1, std::min(MAXNB, (T + BS / 64 - 1) / (BS / 64)));
       launch(k_tail_mv, grid, BS, (size_t)0, (const double *)W.p, T, T, 0, (const double *)(xw.p + t0), tmp.p, (const double *)(D.p + t0), ctl,
              (double *)nullptr, (const double *)nullptr, 0);
@@ -661,7 +773,10 @@ struct DevLdl {
     launch(k_perm_out, gN, BS, (size_t)0, (const int *)Pmap.p, rhs, (const double *)xw.p, N, ctl);
   }
 
-  void release() { F.release(); B.release(); Pmap.release(); flag.release(); D.release(); xw.release(); W.release(); Wt.release(); tmp.release(); }
+  void release() {
+    F.release(); B.release(); Pmap.release(); flag.release(); D.release(); xw.release(); W.release(); Wt.release(); tmp.release();
+    Msym.release(); rowpart.release(); colpart.release(); sym_tiles.release(); n_sym_tiles = 0;
+  }
 };
 
 } // namespace hostutil

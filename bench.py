@@ -217,9 +217,10 @@ def bench_c5(args, rank, world, dist, torch):
     avg_ms = f["solve_ms_total"] / max(f["solves_timed"], 1)
     ach = bytes_solve / (avg_ms * 1e-3) / 1e9
     roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
-                kernel="KKT solve of the conic projection: k_perm_in, k_tri_wide (L21 stream), k_tail_mv x2 (dense inv(L22), inv(L22)'), k_dscale, k_tri_wide, k_perm_out",
+                kernel="KKT solve of the conic projection: k_perm_in, k_tri_wide (L21 stream), the dense tail (T >= 2048: k_tail_sym + k_tail_sym_fin, the lower triangle of "
+                       "inv(S) streamed once; else k_tail_mv x2 on inv(L22), inv(L22)'), k_tri_wide, k_perm_out",
                 avg_launch_us=avg_ms * 1e3, launches=f["solves_timed"], algorithmic_bytes_per_launch=bytes_solve, lnnz=lnnz, dense_tail=T,
-                streamed_bytes_per_solve=8 * T * (T + 1) + 12 * f["head_nnz"], levels=f["levels"])
+                streamed_bytes_per_solve=(4 if tail_sym(T) else 8) * T * (T + 1) + 12 * f["head_nnz"], levels=f["levels"])
     if pcg:   # one solve = prep + (warm set-up pair) + avg_cg_iters x (A'z, A tn, update) + back-substitution: 2 + 2 + 2 cg + 1 products of the matrix
         nnzA, mA, nA = nnz_op, m_op, n_op
         cg = float(info["avg_cg_iters"])
@@ -268,6 +269,11 @@ def bench_c5(args, rank, world, dist, torch):
 
 
 # ---------------------------------------------------------------------------------------------------------
+def tail_sym(T):   # dev_ldl.h: the dense tail applied as one symmetric mat-vec (half the stream of the two triangular ones)
+    e = os.environ.get("ABIP_HIP_TAIL_SYM")
+    return (int(e) != 0) if e else T >= 2048
+
+
 # one LP workload: W untimed steps, K timed steps between barriers, roofline of the dominant kernel from device-side stamps
 # taken INSIDE the timed window, optionally the full solve to eps 1e-6 and the CPU leg
 # ---------------------------------------------------------------------------------------------------------
@@ -358,7 +364,7 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         ach = bytes_solve / max(avg_ms * 1e-3, 1e-12) / 1e9
         T = int(S.scalar("tail"))
         roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
-                    kernel="direct solve P' L^-T D^-1 L^-1 P (k_ldl_small<fwd> / k_tail_mv x2 / k_ldl_small<bwd>, or the segmented level kernels; "
+                    kernel="direct solve P' L^-T D^-1 L^-1 P (k_ldl_small<fwd> / k_tail_mv x2 or k_tail_sym / k_ldl_small<bwd>, or the segmented level kernels; "
                            "k_lp_persist when the whole iteration is one launch)",
                     avg_launch_us=avg_ms * 1e3, launches=nsolve, kernel_launches=nl, algorithmic_bytes_per_launch=bytes_solve, lnnz=lnnz,
                     dense_tail=T, dense_tail_bytes_per_solve=8 * T * (T + 1), levels=[int(S.scalar("levels_fwd")), int(S.scalar("levels_bwd"))],

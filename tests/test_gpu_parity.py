@@ -80,6 +80,36 @@ def test_direct_solve_dense_tail(gpu, oracle_built, tail, monkeypatch):
     assert abs(info["pobj"] - ref.info["pobj"]) <= 1e-8 * (1 + abs(ref.info["pobj"]))
 
 
+@pytest.mark.parametrize("tail", ["64", "128", "512", "auto"])
+def test_tail_as_one_symmetric_matvec(gpu, oracle_built, tail, monkeypatch):
+    """dev_ldl.h: k_tail_sym -- M = W' D2^-1 W formed once, each solve streams its lower triangle once (the default from 2 048 tail pivots on; forced here on
+    small tails, including ones that do not fill a 512-column tile).  Same K^-1 rhs as the two triangular mat-vecs to 1e-10, same ADMM run as the oracle."""
+    if tail == "auto":
+        monkeypatch.delenv("ABIP_HIP_TAIL", raising=False)
+    else:
+        monkeypatch.setenv("ABIP_HIP_TAIL", tail)
+    z, A, b, c = load("lp_staircase")
+    rng = np.random.default_rng(13)
+    rhs = [rng.standard_normal(A.shape[0] + A.shape[1]) for _ in range(3)]
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ABIP_HIP_TAIL_SYM", mode)
+        with gpu.Solver(A, b, c, linsys="direct", verbose=0, max_admm_iters=400) as S:
+            assert int(S.scalar("tail")) > 0
+            Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
+            K = kkt_matrix(Asc, 1e-3)
+            sols = [S.kkt_solve(r, None, -1)[0] for r in rhs]
+            for r, x in zip(rhs, sols):
+                assert rel(K @ x, r) < (1e-11 if mode == "0" else 2e-10)   # the explicit inverse of S costs a digit on this (degenerate) LP; the set-up guard sits at 1e-8
+            out[mode] = (sols, S.solve())
+    for a, b_ in zip(out["0"][0], out["1"][0]):
+        assert rel(a, b_) < 1e-10
+    ref = oracle_built.solve("oracle", A, b, c, linsys="direct", verbose=0, max_admm_iters=400)
+    for mode in ("0", "1"):
+        assert out[mode][1]["admm_iter"] == ref.info["admm_iter"] and out[mode][1]["ipm_iter"] == ref.info["ipm_iter"]
+        assert abs(out[mode][1]["pobj"] - ref.info["pobj"]) <= 1e-8 * (1 + abs(ref.info["pobj"]))
+
+
 @pytest.mark.parametrize("tail", ["128", "512", "auto"])
 def test_schur_complement_formed_on_the_device(gpu, tail, monkeypatch):
     """LdlHost::dev_schur: the host hands over K22 and L21, the device subtracts L21 D1 L21' with dense panels (dev_ldl.h: k_l21_panel,
