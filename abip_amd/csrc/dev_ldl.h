@@ -719,7 +719,35 @@ struct DevLdl {
         hipLaunchKernelGGL(k_dgemm_mfma, dim3(nt, nt), dim3(256), 0, s, Msym.p, (long)T, (const double *)Wt.p, (long)T, (const double *)W.p, (long)T, T, 1.0, 2, 0, (const double *)Dt);
         if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) return -1;
         n_sym_tiles = (int)tl.size();
-        W.release(); Wt.release(); tmp.release();
+        // before W and W' go: M v against W' D2^-1 W v on one pseudo-random v.  The explicit inverse of S must not cost the solve more than the set-up guard
+        // allows (1e-8); if it does, the two mat-vecs stay.
+        bool keep = false;
+        {
+          std::vector<double> hv, ha((size_t)T), hb((size_t)T);
+          host::guard_rhs(T, hv);
+          DBuf<double> dv, da, db;
+          Ctl *zc = nullptr;
+          if (!dv.upload(hv, s) && !da.alloc(T) && !db.alloc(T) && hipMalloc((void **)&zc, sizeof(Ctl)) == hipSuccess && hipMemsetAsync(zc, 0, sizeof(Ctl), s) == hipSuccess) {
+            const int grid = std::max(1, std::min(MAXNB, (T + BS / 64 - 1) / (BS / 64)));
+            hipLaunchKernelGGL(k_tail_mv, dim3(grid), dim3(BS), 0, s, (const double *)W.p, T, T, 0, (const double *)dv.p, tmp.p, (const double *)Dt, (const Ctl *)zc, (double *)nullptr, (const double *)nullptr, 0);
+            hipLaunchKernelGGL(k_tail_mv, dim3(grid), dim3(BS), 0, s, (const double *)Wt.p, T, T, 1, (const double *)tmp.p, da.p, (const double *)nullptr, (const Ctl *)zc, (double *)nullptr, (const double *)nullptr, 0);
+            hipLaunchKernelGGL(k_tail_sym, dim3(n_sym_tiles), dim3(256), 0, s, (const double *)Msym.p, T, (const int2 *)sym_tiles.p, (const double *)dv.p, rowpart.p, colpart.p, T, (const Ctl *)zc);
+            hipLaunchKernelGGL(k_tail_sym_fin, dim3(nt), dim3(1024), 0, s, (const double *)rowpart.p, (const double *)colpart.p, T, db.p, (const Ctl *)zc, (double *)nullptr, (const double *)nullptr, 0);
+            if (hipMemcpyAsync(ha.data(), da.p, sizeof(double) * T, hipMemcpyDeviceToHost, s) == hipSuccess && hipMemcpyAsync(hb.data(), db.p, sizeof(double) * T, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                hipStreamSynchronize(s) == hipSuccess) {
+              double num = 0.0, den = 0.0;
+              for (int i = 0; i < T; ++i) { num += (ha[i] - hb[i]) * (ha[i] - hb[i]); den += ha[i] * ha[i]; }
+              const double dev = std::sqrt(num) / std::max(std::sqrt(den), 1e-300);
+              keep = dev == dev && dev <= 1e-9 && !getenv("ABIP_HIP_TAIL_SYM_FAIL"); // (test hook: pretend the explicit inverse lost the accuracy)
+              if (tms) printf("[setup]   device: M v against W' D2^-1 W v: relative difference %.2e (%s)\n", dev, keep ? "M kept" : "the two mat-vecs stay");
+            }
+          }
+          (void)hipGetLastError();
+          dv.release(); da.release(); db.release();
+          if (zc) (void)hipFree(zc);
+        }
+        if (keep) { W.release(); Wt.release(); tmp.release(); }
+        else { n_sym_tiles = 0; Msym.release(); rowpart.release(); colpart.release(); sym_tiles.release(); }
       }
       lap("M = W' D2^-1 W (the tail as one symmetric mat-vec)");
     }

@@ -110,6 +110,24 @@ def test_tail_as_one_symmetric_matvec(gpu, oracle_built, tail, monkeypatch):
         assert abs(out[mode][1]["pobj"] - ref.info["pobj"]) <= 1e-8 * (1 + abs(ref.info["pobj"]))
 
 
+def test_symmetric_tail_self_check_keeps_the_two_matvecs(gpu, monkeypatch):
+    """Before W and W' are released the set-up compares M v with W' D2^-1 W v (dev_ldl.h); a difference above 1e-9 (forced by the hook) keeps the two triangular
+    mat-vecs.  On this LP their residual is < 1e-11 where the explicit inverse of S gives ~6e-11: the bound below shows which form answered."""
+    monkeypatch.delenv("ABIP_HIP_TAIL", raising=False)
+    monkeypatch.setenv("ABIP_HIP_TAIL_SYM", "1")
+    monkeypatch.setenv("ABIP_HIP_TAIL_SYM_FAIL", "1")
+    z, A, b, c = load("lp_staircase")
+    rng = np.random.default_rng(17)
+    with gpu.Solver(A, b, c, linsys="direct", verbose=0, max_admm_iters=50) as S:
+        assert int(S.scalar("tail")) >= 256
+        Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
+        K = kkt_matrix(Asc, 1e-3)
+        for _ in range(3):
+            rhs = rng.standard_normal(S.m + S.n)
+            sol, _ = S.kkt_solve(rhs, None, -1)
+            assert rel(K @ sol, rhs) < 1e-11
+
+
 @pytest.mark.parametrize("tail", ["128", "512", "auto"])
 def test_schur_complement_formed_on_the_device(gpu, tail, monkeypatch):
     """LdlHost::dev_schur: the host hands over K22 and L21, the device subtracts L21 D1 L21' with dense panels (dev_ldl.h: k_l21_panel,
