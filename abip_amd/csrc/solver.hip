@@ -1724,6 +1724,10 @@ int abip_hip_dist_get_unique_id(void *out128) {
 }
 int abip_hip_dist_init_rccl(int rank, int world, const void *unique_id128) {
   if (world < 1 || rank < 0 || rank >= world || !unique_id128) return -1;
+  // The ranks take their control decisions (PCG exit, inner / outer stopping tests) from their own copies of the all-reduced data: every rank must receive the SAME
+  // bits.  Ring, tree and the all-pairs schedules reduce each chunk in one place and hand the result round; a one-shot "every rank sums all peers itself" kernel
+  // (MSCCL++) adds in a rank-dependent order and may not.  Off unless the user has set it.
+  setenv("RCCL_MSCCLPP_ENABLE", "0", 0);
   if (!load_rccl(g_dist.api)) return -2;
   Uid128 id;
   memcpy(id.b, unique_id128, 128);

@@ -71,7 +71,10 @@ abip_float abip_hip_get_scalar(ABIPWork *w, const char *name);
  * The conic entry point abip_qcp() (include/abip_qcp.h) uses the same context: with the generic formulation (prob_type 2) and the PCG
  * back-end (linsys_solver 3) it shards the COLUMNS of A over the ranks, cut at cone boundaries (m-space replicated, one all-reduce of m
  * doubles per PCG iteration); every rank passes the full problem and receives the full (x, y, s), bit-identical across the ranks.
- * Any other conic configuration runs as independent replicas. */
+ * Any other conic configuration runs as independent replicas.
+ * The transport must deliver the SAME bits of every all-reduced vector to every rank (the ranks take their control decisions from their own copies):
+ * ring, tree and all-pairs schedules do; abip_hip_dist_init_rccl sets RCCL_MSCCLPP_ENABLE=0 unless the caller has set it, because a one-shot
+ * "every rank adds all peers itself" kernel sums in a rank-dependent order.  A callback transport has to honour the same rule. */
 typedef void (*abip_hip_allreduce_fn)(void *ctx, double *host_buf, long count); /* in-place sum over all ranks */
 int abip_hip_dist_get_unique_id(void *out128);
 int abip_hip_dist_init_rccl(int rank, int world, const void *unique_id128);
