@@ -2,7 +2,7 @@
  * abip_linsys.h -- the reference's LINEAR-SYSTEM PLUG-IN interface over the MI355X back-ends.
  *
  * The reference selects its KKT back-end at link time: src/abip-lp/src/abip.c calls the functions of
- * src/abip-lp/include/linsys.h:10-91 and is linked with ONE of linsys/direct.c (LDL') or linsys/indirect.c (PCG).
+ * src/abip-lp/include/linsys.h:10-91 and is linked with ONE of linsys/direct.c (LDL'; compile_direct.m:62-78) or linsys/indirect.c (PCG; compile_indirect.m).
  * lib/libabip_hip_linsys.so is a third such variant: it defines exactly the symbols those two files define, so the
  * reference's own abip.c (+ linalg.c, adaptive.c, normalize.c, util.c, cs.c, ctrlc.c, abip_version.c and
  * linsys/common.c, all unchanged) links against it in place of direct.c + ldl.c + the AMD sources:
