@@ -102,6 +102,66 @@ __global__ __launch_bounds__(BS, 8) void kq_pcg_Aty(Csr At, QPcgVec v, int max_i
       At, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * g[c]; },
       [&](int j, double(&acc)[1]) { const double t = acc[0] * v.Hinv[j]; v.tn[j] = (INIT || beta == 0.0) ? t : t + beta * v.tn[j]; });
 }
+// The same product with the gathered m-vector RESIDENT IN LDS (m <= 16 384: 128 KB): kq_pcg_Aty runs at the rate at which a CU keeps L2 gathers in flight (one
+// request per non-zero); with y / z in LDS the gathers never leave the CU and what remains is the stream of A'.  One 1024-thread workgroup per
+// CU (the vector takes most of its LDS); G lanes per row (16 for short rows, 64 for long ones), four loads in flight per lane, the next row's extent requested
+// before the current row is reduced.  Same entry test and beta as kq_pcg_Aty; a row's products add up lane-strided, then by a G-lane butterfly (deterministic).
+template <bool INIT, int G>
+__global__ __launch_bounds__(1024) void kq_pcg_Aty_lds(Csr At, QPcgVec v, int m, int max_its, const double *__restrict__ ppart, int nb, Ctl *hc) {
+  if (hc->halt || hc->cg_done) return;
+  extern __shared__ double gl[];
+  __shared__ double sm16[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double *g = INIT ? v.y0 : v.z;
+  for (int i = tid; i < m; i += 1024) gl[i] = g[i];
+  double beta = 0.0;
+  if (!INIT) {
+    const int it = hc->cg_it, par = it & 1;
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = tid; i < nb; i += 1024) { a0 += ppart[(PQ_RM0 + par) * MAXNB + i]; a1 += ppart[(PQ_ZR0 + par) * MAXNB + i]; }
+    for (int off = 32; off > 0; off >>= 1) { a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64); }
+    if (lane == 0) { sm16[0][wave] = a0; sm16[1][wave] = a1; }
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { s0 += sm16[0][k]; s1 += sm16[1][k]; }
+    const bool done = (it > 0 && sqrt(s0) < hc->cg_tol) || it >= max_its || s0 == 0.0; // linsys.c:683
+    if (done) { if (blockIdx.x == 0 && tid == 0) hc->cg_done = 1; return; }
+    beta = it == 0 ? 0.0 : s1 / hc->zr_hist[par ^ 1];
+    if (blockIdx.x == 0 && tid == 0) { hc->it_cur = it; hc->beta_cur = beta; hc->zr_cur = s1; hc->zr_hist[par] = s1; }
+  }
+  __syncthreads(); // gl is complete
+  constexpr int GPW = 64 / G;
+  const int gidx = (blockIdx.x * 16 + wave) * GPW + lane / G, gl_ = lane % G, TG = gridDim.x * 16 * GPW, n = At.nrows;
+  // two rows per lane group at a time (eight loads in flight per lane); the next pair's extents are requested before the current pair is reduced
+  auto extent = [&](int row, int &s, int &e) { s = 0; e = 0; if (row < n) { s = At.ptr[row]; e = At.ptr[row + 1]; } };
+  auto finish = [&](int row, double acc) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, G);
+    if (gl_ == 0 && row < n) { const double t = acc * v.Hinv[row]; v.tn[row] = (INIT || beta == 0.0) ? t : t + beta * v.tn[row]; }
+  };
+  int r = gidx, sa, ea, sb, eb;
+  extent(r, sa, ea); extent(r + TG, sb, eb);
+  while (r < n) {
+    int na, ma, nb2, mb;
+    extent(r + 2 * TG, na, ma); extent(r + 3 * TG, nb2, mb);
+    double acca = 0.0, accb = 0.0;
+    for (int qa = sa + gl_, qb = sb + gl_; qa < ea || qb < eb; qa += 4 * G, qb += 4 * G) {
+      double a[4], b[4]; int ca[4], cb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q1 = qa + k * G, q2 = qb + k * G;
+        const bool o1 = q1 < ea, o2 = q2 < eb;
+        a[k] = o1 ? At.val[q1] : 0.0; ca[k] = o1 ? At.idx[q1] : 0;
+        b[k] = o2 ? At.val[q2] : 0.0; cb[k] = o2 ? At.idx[q2] : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { acca += a[k] * gl[ca[k]]; accb += b[k] * gl[cb[k]]; }
+    }
+    finish(r, acca); finish(r + TG, accb);
+    r += 2 * TG; sa = na; ea = ma; sb = nb2; eb = mb;
+  }
+}
 // INIT: r = b - (rho_y y0 + A tn); y = y0; z = M r; p = z; partials |r|^2, z'r; the tolerance.
 // Loop: p = z + beta p; Gp = rho_y p + A tn; partial p'Gp.
 template <bool INIT>

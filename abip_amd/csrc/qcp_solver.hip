@@ -73,6 +73,22 @@ int solve_pcg(QWk *w, double *rhs, bool warm, int iter, double tol_host) {
   const int max_its = w->m;
   double *buf = w->arbuf.p; // several GPUs: the exchange area, [0, m) products, [m, m + world) the max lanes of the warm start
   const double ipow = std::pow((double)iter + 1.0, 1.5);
+  auto aty = [&](bool init) { // tn = H^-1 A' (y0 | z): the m-vector in LDS where it fits (one 1024-thread workgroup per CU), else the streaming kernel
+    if (w->aty_lds) {
+      const size_t lds = sizeof(double) * (size_t)w->m;
+      const double *pp = w->cg_part.p;
+      if (w->aty_lds == 16) {
+        if (init) hipLaunchKernelGGL((kq_pcg_Aty_lds<true, 16>), dim3(w->n_cu), dim3(1024), lds, w->stream, w->dAt.view(), v, w->m, max_its, pp, w->NB, hc);
+        else hipLaunchKernelGGL((kq_pcg_Aty_lds<false, 16>), dim3(w->n_cu), dim3(1024), lds, w->stream, w->dAt.view(), v, w->m, max_its, pp, w->NB, hc);
+      } else {
+        if (init) hipLaunchKernelGGL((kq_pcg_Aty_lds<true, 64>), dim3(w->n_cu), dim3(1024), lds, w->stream, w->dAt.view(), v, w->m, max_its, pp, w->NB, hc);
+        else hipLaunchKernelGGL((kq_pcg_Aty_lds<false, 64>), dim3(w->n_cu), dim3(1024), lds, w->stream, w->dAt.view(), v, w->m, max_its, pp, w->NB, hc);
+      }
+      return;
+    }
+    if (init) QLAUNCH(w, kq_pcg_Aty<true>, w->NB, BS, w->dAt.view(), v, max_its, w->cg_part.p, w->NB, hc);
+    else QLAUNCH(w, kq_pcg_Aty<false>, w->NB, BS, w->dAt.view(), v, max_its, w->cg_part.p, w->NB, hc);
+  };
   if (w->dist) { // qcp_dist.h: products of the rank's column block, all-reduced, then the element-wise halves on the replicated m-space
     QLAUNCH(w, kq_prod_A, w->NB, BS, w->dA.view(), (const double *)(rhs + w->MP), (const double *)w->cg_H.p, buf, 0, (const Ctl *)hc);
     QLAUNCH(w, kq_dist_prep_warm, w->NB, BS, (const double *)w->u.p, (const double *)w->r.p, warm ? 1 : 0, d, w->n0, w->n_glob - w->m, v, w->cg_part.p, hc);
@@ -81,7 +97,7 @@ int solve_pcg(QWk *w, double *rhs, bool warm, int iter, double tol_host) {
     QLAUNCH(w, kq_dist_prep_fin, w->NB, BS, rhs, (const double *)buf, w->m, (const Ctl *)hc);
   } else QLAUNCH(w, kq_pcg_prep, w->NB, BS, w->dA.view(), rhs, (const double *)w->u.p, (const double *)w->r.p, warm ? 1 : 0, d, v, w->cg_part.p, hc);
   if (warm) {
-    QLAUNCH(w, kq_pcg_Aty<true>, w->NB, BS, w->dAt.view(), v, max_its, w->cg_part.p, w->NB, hc);
+    aty(true);
     if (w->dist) {
       QLAUNCH(w, kq_prod_A, w->NB, BS, w->dA.view(), (const double *)w->cg_tm.p, (const double *)nullptr, buf, 1, (const Ctl *)hc);
       if (ar(w, buf, (size_t)w->m)) return -1;
@@ -93,7 +109,7 @@ int solve_pcg(QWk *w, double *rhs, bool warm, int iter, double tol_host) {
   int chunk = std::max(2, w->last_cg + std::max(2, w->last_cg >> 3));
   for (;;) {
     for (int q = 0; q < chunk; ++q) {
-      QLAUNCH(w, kq_pcg_Aty<false>, w->NB, BS, w->dAt.view(), v, max_its, w->cg_part.p, w->NB, hc);
+      aty(false);
       if (w->dist) {
         QLAUNCH(w, kq_prod_A, w->NB, BS, w->dA.view(), (const double *)w->cg_tm.p, (const double *)nullptr, buf, 1, (const Ctl *)hc);
         if (ar(w, buf, (size_t)w->m)) return -1;
@@ -475,6 +491,27 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
         hipMemsetAsync(w->cg_tm.p, 0, sizeof(double) * nl, w->stream) != hipSuccess || hipHostMalloc((void **)&w->hlp, sizeof(Ctl), hipHostMallocDefault) != hipSuccess)
       return bail("init_lin_sys_work failure");
     if (hipMalloc((void **)&w->lp_ctl, sizeof(Ctl)) != hipSuccess || hipMemsetAsync(w->lp_ctl, 0, sizeof(Ctl), w->stream) != hipSuccess) return bail("allocation failure");
+    { // A' y with y resident in LDS (kq_pcg_Aty_lds): where the m-vector fits and the product is large enough to be bound by its gathers.  ABIP_HIP_ATY_LDS=0 / 1 forces.
+      const char *e = getenv("ABIP_HIP_ATY_LDS");
+      const long nnzl = w->A.p[nl];
+      int dev = 0, cus = 0;
+      (void)hipGetDevice(&dev);
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+      w->n_cu = cus;
+      const bool fits = cus > 0 && m <= 16384 && nl >= 1;
+      if (fits && (e ? atoi(e) != 0 : nnzl >= 1000000)) {
+        const int G = (double)nnzl / (double)nl <= 96.0 ? 16 : 64;
+        const int bytes = (int)(sizeof(double) * (size_t)m);
+        bool ok = true;
+        if (bytes > 48 * 1024) {
+          if (G == 16) ok = hipFuncSetAttribute((const void *)kq_pcg_Aty_lds<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+                            hipFuncSetAttribute((const void *)kq_pcg_Aty_lds<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+          else ok = hipFuncSetAttribute((const void *)kq_pcg_Aty_lds<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+                    hipFuncSetAttribute((const void *)kq_pcg_Aty_lds<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+        }
+        if (ok) w->aty_lds = G; else (void)hipGetLastError();
+      }
+    }
   } else { // KKT upper triangle (qcp_config.c:699-748) -> LDL' -> level-scheduled device factors
     const int N = m + nl;
     const double rho_y = st->rho_y, rho_x = w->kkt_rho_x;

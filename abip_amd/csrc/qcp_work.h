@@ -72,6 +72,7 @@ struct QWk {
   DBuf<double> cg_x0, cg_r, cg_z, cg_p, cg_Gp, cg_tm, cg_M, cg_H, cg_part; // m-space: y0, r, z, p, Gp, M; n-space: tn (cg_tm), H^-1
   Ctl *hlp = nullptr;    // pinned mirror of lp_ctl
   int last_cg = 8; long tot_cg = 0, cg_solves = 0;
+  int aty_lds = 0, n_cu = 0; // qcp_pcg.h: kq_pcg_Aty_lds with 16 or 64 lanes per row (0: the streaming kernel), one workgroup per CU
   // several GPUs: this rank's column block [n0, n0 + n) of the n_glob columns (qcp_dist.h); m-space is replicated
   bool dist = false;
   int rank = 0, world = 1, n_glob = 0, n0 = 0;

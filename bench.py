@@ -227,7 +227,7 @@ def bench_c5(args, rank, world, dist, torch):
         bytes_solve = (3 + 2 * cg + 2) * (b_spmv(mA, nA, nnzA) + b_spmv(nA, mA, nnzA)) / 2 + cg * 8 * 8 * mA
         ach = bytes_solve / max(avg_ms * 1e-3, 1e-12) / 1e9
         roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
-                    kernel="KKT solve of the conic projection by y-space PCG: kq_pcg_prep, kq_pcg_Aty/_Gp (set-up), {kq_pcg_Aty, kq_pcg_Gp, kq_pcg_update} x cg, kq_pcg_post; one host round trip per solve",
+                    kernel="KKT solve of the conic projection by y-space PCG: kq_pcg_prep, kq_pcg_Aty/_Gp (set-up), {kq_pcg_Aty (m-vector in LDS where it fits: kq_pcg_Aty_lds), kq_pcg_Gp, kq_pcg_update} x cg, kq_pcg_post; one host round trip per solve",
                     avg_launch_us=avg_ms * 1e3, launches=f["solves_timed"], algorithmic_bytes_per_launch=bytes_solve, avg_cg_iters=cg)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and ml:

@@ -150,6 +150,32 @@ def test_unsupported_back_ends_are_rejected(gpu):
     assert info["status"] == "Failure" and info["status_val"] == -4
 
 
+@pytest.mark.parametrize("case", ["lasso_small", "lasso_mid", "lasso_bigcone", "lasso_long_rows", "lp_afiro"])
+def test_conic_pcg_with_the_gathered_vector_in_lds(gpu, case, monkeypatch):
+    """qcp_pcg.h: kq_pcg_Aty_lds -- A' y with the m-vector resident in LDS (default from 1e6 non-zeros on where m <= 16 384; forced here): short rows (16 lanes per
+    row), long rows (64), rows shorter than a lane group, an m-vector above 64 KB of LDS is covered by the full-size run of bench.py's c5 / lasso workloads.
+    Same ADMM run as with the streaming kernel: status, outer iterations, inner iterations within 1 %, solution to 1e-6 relative of the objective scale."""
+    if case == "lp_afiro":
+        z, A, b, c = load("lp_afiro_like")
+        data, K = dict(A=A, b=b, c=c), dict(l=A.shape[1])
+    elif case == "lasso_long_rows":
+        data, K = lasso_socp(300, 500, 6, density=0.5)      # ~150 non-zeros per column of X: the 64-lane form
+    else:
+        data, K = {"lasso_small": lambda: lasso_socp(30, 60, 2), "lasso_mid": lambda: lasso_socp(400, 1500, 3, density=0.02),
+                   "lasso_bigcone": lambda: lasso_socp(2200, 2600, 4, density=0.004)}[case]()
+    eps = 1e-3 if case == "lasso_bigcone" else 1e-5
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ABIP_HIP_ATY_LDS", mode)
+        out[mode] = gpu.abip_qcp(data, K, dict(eps=eps, linsys_solver=3, verbose=0))
+    (s0, i0), (s1, i1) = out["0"], out["1"]
+    assert i0["status"] == i1["status"] and i0["status_val"] in (1, 2) and i0["ipm_iter"] == i1["ipm_iter"]
+    assert abs(i0["admm_iter"] - i1["admm_iter"]) <= 0.01 * i0["admm_iter"] + 2
+    assert abs(i0["pobj"] - i1["pobj"]) <= 1e-6 * (1 + abs(i0["pobj"]))
+    for k in "xys":
+        assert np.linalg.norm(s0[k] - s1[k]) <= 50 * eps * (1 + np.linalg.norm(s0[k]))
+
+
 @pytest.mark.parametrize("case", ["toy", "lasso_small", "lasso_mid", "lp_afiro", "rsoc_mix", "lasso_bigcone"])
 def test_conic_pcg_back_end(gpu, pq, case):
     """linsys_solver = 3: the device's y-space PCG (abip_amd/csrc/qcp_pcg.h; upstream's own conic PCG is unreachable and ill-posed, so the
