@@ -26,6 +26,8 @@
 #ifndef ABIP_LINSYS_PLUGIN_H
 #define ABIP_LINSYS_PLUGIN_H
 
+#include <stddef.h>
+
 #include "abip.h"
 
 #ifdef __cplusplus

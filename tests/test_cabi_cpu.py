@@ -164,3 +164,12 @@ def test_plugin_scaling_equals_the_references(lib):
     assert rel(D, Dr) < 1e-14 and rel(E, Er) < 1e-14 and rel(S, Sr) < 1e-14
     assert abs(mr - mrr) <= 1e-13 * mrr and abs(mc - mcr) <= 1e-13 * mcr
     assert rel(back, A.data) < 1e-14 and rel(backr, A.data) < 1e-14
+
+
+@pytest.mark.parametrize("header", ["abip.h", "abip_hip.h", "abip_qcp.h", "abip_linsys.h"])
+def test_headers_compile_as_plain_c(header, tmp_path):
+    """The boundary is a C ABI: every header of include/ must stand alone in a C99 translation unit (-Wall -Wextra -Werror)."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text(f'#include "{header}"\nint main(void) {{ return 0; }}\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(src)], check=True)
