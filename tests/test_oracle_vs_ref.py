@@ -66,3 +66,58 @@ def test_sparsity_dependent_inner_caps_against_live_reference(oracle_built, shap
     assert r.info["admm_iter"] == o.info["admm_iter"] and r.info["ipm_iter"] == o.info["ipm_iter"]
     for k in "xys":
         assert rel(getattr(o, k), getattr(r, k)) < (1e-12 if linsys == "indirect" else 1e-7)
+
+
+@pytest.mark.parametrize("linsys", ["indirect", "direct"])
+@pytest.mark.parametrize("variant", ["half", "origin", "qp", "nonorm", "noadapt", "scale5", "tedious"])
+def test_non_default_switches_against_live_reference(oracle_built, variant, linsys):
+    """Every non-default algorithm switch the mex gateway exposes (abip_mex.c:183-341), on a fresh seed: the oracle must walk the reference's path
+    iteration for iteration (the committed fixtures pin the same switches on one tiny LP only)."""
+    from _golden import TINY_VARIANTS
+    po = oracle_built
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    A, b, c = problems.lp_random_sparse(m=60, n=200, per_col=4, seed=21)
+    kw = dict(linsys=linsys, eps=1e-4, **TINY_VARIANTS[variant])
+    r = po.solve("ref", A, b, c, **kw)
+    o = po.solve("oracle", A, b, c, **kw)
+    assert r.info["status_val"] == o.info["status_val"]
+    assert r.info["admm_iter"] == o.info["admm_iter"] and r.info["ipm_iter"] == o.info["ipm_iter"]
+    for k in "xys":
+        # direct: the oracle orders the KKT matrix differently from SuiteSparse AMD, so the solves round differently (1e-16) and the ADMM map carries that forward
+        assert rel(getattr(o, k), getattr(r, k)) < (1e-11 if linsys == "indirect" else 5e-6)
+
+
+@pytest.mark.parametrize("linsys", ["indirect", "direct"])
+@pytest.mark.parametrize("kind", ["infeasible", "unbounded"])
+def test_certificate_statuses_against_live_reference(oracle_built, kind, linsys):
+    """Status logic of get_solution (abip.c:1374-1404) on an infeasible and an unbounded LP: same status code, same iteration counts as the reference."""
+    import scipy.sparse as sp
+    po = oracle_built
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    if kind == "infeasible":
+        A, b, c = sp.csc_matrix(np.array([[1.0, 1.0, 0.0], [0.0, 1.0, 1.0]])), np.array([-1.0, 2.0]), np.array([1.0, 1.0, 1.0])
+    else:
+        A, b, c = sp.csc_matrix(np.array([[1.0, -1.0, 0.0], [0.0, 1.0, -1.0]])), np.array([0.0, 0.0]), np.array([-1.0, 0.0, 0.0])
+    kw = dict(linsys=linsys, eps=1e-5, max_admm_iters=20000)
+    r = po.solve("ref", A, b, c, **kw)
+    o = po.solve("oracle", A, b, c, **kw)
+    assert r.info["status_val"] == o.info["status_val"] and r.info["status_val"] != 1
+    assert r.info["admm_iter"] == o.info["admm_iter"] and r.info["ipm_iter"] == o.info["ipm_iter"]
+
+
+@pytest.mark.parametrize("linsys", ["indirect", "direct"])
+@pytest.mark.parametrize("gen", ["staircase", "multicommodity"])
+def test_structured_lps_against_live_reference(oracle_built, gen, linsys):
+    """The structured generators behind the C2 / C3 surrogates at sizes the reference finishes in seconds, other seeds than the committed fixtures."""
+    po = oracle_built
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    A, b, c = problems.lp_staircase(seed=5, stages=5, rows_per=20, cols_per=44) if gen == "staircase" else problems.lp_multicommodity(seed=3, nodes=24, arcs=80, commodities=3)
+    r = po.solve("ref", A, b, c, linsys=linsys, eps=1e-4)
+    o = po.solve("oracle", A, b, c, linsys=linsys, eps=1e-4)
+    assert r.info["status_val"] == o.info["status_val"]
+    assert r.info["admm_iter"] == o.info["admm_iter"] and r.info["ipm_iter"] == o.info["ipm_iter"]
+    for k in "xys":
+        assert rel(getattr(o, k), getattr(r, k)) < (1e-10 if linsys == "indirect" else 1e-6)
