@@ -313,6 +313,41 @@ int abip_hip_qcp_cone_prox(int kind, double *x, const double *tmp, double lambda
 
 // Column ranges of the sharded conic path: bounds[g] .. bounds[g+1] are rank g's columns (world + 1 entries out); pure host code.
 // 0 ok, -1 a rotated cone of fewer than 3 entries, -2 fewer blocks than ranks, -3 bad arguments.
+// Pure host code (no device needed): the formulation front end and the scaling exactly as abip_qcp applies them (qcp_formulations.h), then two products with the
+// scaled, materialised operator.  For CPU-side parity tests of the host logic against the oracle.  Any output pointer may be NULL.
+int abip_hip_qcp_host_probe(const QCPData *d, const QCPCone *K, const double *x_in, const double *y_in, double *Ax_out, double *Aty_out, double *b_out, double *c_out,
+                            double *scal4, int *dims2) {
+  if (!d || !K || !d->stgs || !d->A || !d->b) return -1;
+  const QCPSettings *st = d->stgs;
+  const int kind = st->prob_type;
+  if (kind < 0 || kind > 3 || (kind == 2 && !d->c) || (kind != 2 && (d->m <= 0 || d->n <= 0 || !(d->lambda > 0)))) return -1;
+  if ((kind == 0 && (!st->normalize || !st->scale_E)) || ((kind == 1 || kind == 3) && !st->normalize) || (kind == 1 && !st->scale_E)) return -1;
+  const int m = kind == 0 ? d->m + 1 : (kind == 1 ? d->m + d->n + 1 : d->m);
+  const int n = kind == 0 ? 2 + 2 * d->n + d->m : (kind == 1 ? 4 + 3 * d->n + 2 * d->m : (kind == 3 ? 1 + d->n + 2 * d->m : d->n));
+  if (dims2) { dims2[0] = m; dims2[1] = n; }
+  QWk W; QWk *w = &W;
+  w->kind = kind; w->m = m; w->n = n; w->st = st; w->hasQ = kind == 3 || (kind == 2 && d->Q != nullptr);
+  w->kkt_rho_x = (kind == 0 || kind == 1) ? 1.0 : st->rho_x;
+  if (kind == 0) build_lasso(w, d);
+  else if (kind == 1) { if (!build_svm(w, d)) return -2; }
+  else if (kind == 3) build_svmqp(w, d, K);
+  else {
+    w->sparsity = (((long long)d->A->p[n] / std::max(1LL, (long long)m * (long long)n)) < 0.05);
+    copy_in(w->A, d->A);
+    if (w->hasQ) copy_in(w->Q, d->Q);
+    w->nm_inf_b = vnrminf(d->b, m); w->nm_inf_c = vnrminf(d->c, n);
+    scale_data(w, d, K);
+  }
+  const HMat &A = w->A;
+  if (A.m != m || A.n != n) return -3;
+  if (Ax_out && x_in) { std::fill(Ax_out, Ax_out + m, 0.0); for (int j = 0; j < n; ++j) for (int q = A.p[j]; q < A.p[j + 1]; ++q) Ax_out[A.i[q]] += A.x[q] * x_in[j]; }
+  if (Aty_out && y_in) for (int j = 0; j < n; ++j) { double t = 0.0; for (int q = A.p[j]; q < A.p[j + 1]; ++q) t += A.x[q] * y_in[A.i[q]]; Aty_out[j] = t; }
+  if (b_out) std::copy(w->b.begin(), w->b.begin() + m, b_out);
+  if (c_out) std::copy(w->c.begin(), w->c.begin() + n, c_out);
+  if (scal4) { scal4[0] = w->sc_b; scal4[1] = w->sc_c; scal4[2] = (double)A.p[n]; scal4[3] = (double)w->sparsity; }
+  return 0;
+}
+
 int abip_hip_qcp_dist_partition(const QCPMatrix *A, const QCPCone *K, int world, int *bounds_out) {
   if (!A || !K || !bounds_out || world < 1 || A->n < 1) return -3;
   std::vector<int> bounds;

@@ -142,6 +142,12 @@ void abip_hip_qcp_last_stats(double *out8);
  * cones or inside the free / zero / orthant blocks, balanced by non-zeros.  Pure host code.  0 ok; -1 a rotated cone of fewer than 3 entries;
  * -2 fewer blocks than ranks; -3 bad arguments. */
 int abip_hip_qcp_dist_partition(const QCPMatrix *A, const QCPCone *K, int world, int *bounds);
+/* Pure host code (runs without a GPU; CPU-side parity tests of the host logic): the formulation front end of d->stgs->prob_type and the scaling exactly as
+ * abip_qcp applies them, then Ax_out (m) = A x_in and Aty_out (n) = A' y_in with the scaled operator as it is handed to the device (for prob_type 0 / 1 / 3
+ * the materialised operator of lasso_config.c:99-128, svm_config.c:177-230, svm_qp_config.c); b_out (m), c_out (n) the scaled right-hand side and cost;
+ * scal4 = {sc_b, sc_c, non-zeros of the operator, sparsity flag}; dims2 = {m, n} of the conic problem.  Any output may be NULL.  Returns 0, < 0 on invalid input. */
+int abip_hip_qcp_host_probe(const QCPData *d, const QCPCone *K, const double *x_in, const double *y_in, double *Ax_out, double *Aty_out, double *b_out, double *c_out,
+                            double *scal4, int *dims2);
 /* Unit-level access to the cone kernel: x <- barrier prox of one cone at tmp (soc_barrier_subproblem cones.c:130-161 for kind 0,
  * rsoc_barrier_subproblem cones.c:169-248 for kind 1; the latter reads the incoming x[0], cones.c:183).  0 on success. */
 int abip_hip_qcp_cone_prox(int kind, double *x, const double *tmp, double lambda, int len);

@@ -1091,6 +1091,11 @@ static F *g_trace = 0; static I g_trace_T = 0, g_trace_n = 0;
 void orc_qcp_set_trace(I T, F *buf) { g_trace = buf; g_trace_T = T; g_trace_n = 0; }
 I orc_qcp_trace_count(void) { return g_trace_n; }
 
+/* test hook: stop after the formulation + scaling and hand out two products with the scaled operator (matrix-free for prob_type 0 / 1 / 3, as the reference
+   applies it), the scaled b and c and {sc_b, sc_c}: the CPU-side check of the product's host front ends (abip_hip_qcp_host_probe) */
+static const F *g_px = 0, *g_py = 0; static F *g_pAx = 0, *g_pAty = 0, *g_pb = 0, *g_pc = 0, *g_ps = 0; static int g_probe = 0;
+void orc_qcp_set_probe(int on, const F *x, const F *y, F *Ax, F *Aty, F *b, F *c, F *scal2) { g_probe = on; g_px = x; g_py = y; g_pAx = Ax; g_pAty = Aty; g_pb = b; g_pc = c; g_ps = scal2; }
+
 qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) { /* abip(), abip.c:1335-1371 */
   const int lasso = d && d->stgs && d->stgs->prob_type == 0; /* abip.c:1341-1348: 0 LASSO, 1 SVM, 2 QCP, 3 SVMQP */
   const int svmqp = d && d->stgs && d->stgs->prob_type == 3, svm = d && d->stgs && d->stgs->prob_type == 1;
@@ -1134,6 +1139,15 @@ qcp_int orc_qcp_solve(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone
   else if (svmqp) { w->nm_inf_b = v_nrminf(sq_b, m); w->nm_inf_c = v_nrminf(sq_c, n); scaling_svmqp_data(w, sq_b, sq_c, K); free(sq_b); free(sq_c); }
   else { w->nm_inf_b = v_nrminf(d->b, m); w->nm_inf_c = v_nrminf(d->c, n); scaling_qcp_data(w, d, K); }
   w->last_Ax_b_norm = INFINITY; w->last_Qx_norm = INFINITY;
+  if (g_probe) {
+    if (g_pAx && g_px) { memset(g_pAx, 0, sizeof(F) * m); op_A(w, g_px, g_pAx); }
+    if (g_pAty && g_py) { memset(g_pAty, 0, sizeof(F) * n); op_At(w, g_py, g_pAty); }
+    if (g_pb) memcpy(g_pb, w->b, sizeof(F) * m);
+    if (g_pc) memcpy(g_pc, w->c, sizeof(F) * n);
+    if (g_ps) { g_ps[0] = w->sc_b; g_ps[1] = w->sc_c; }
+    info->status_val = 0; strcpy(info->status, "Probe");
+    return 0;
+  }
   if (d->stgs->linsys_solver == 3) { if (init_qcp_pcg(w) < 0) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED; } if (getenv("ORC_QCP_PCG_CHECK")) init_kkt(w); }
   else if ((lasso ? init_lasso_linsys(w) : svm ? init_svm_linsys(w) : svmqp ? init_svmqp_linsys(w) : init_kkt(w)) < 0) { info->status_val = ST_FAILED; strcpy(info->status, "Failure"); return ST_FAILED; }
   info->setup_time = now_ms() - t_init;
