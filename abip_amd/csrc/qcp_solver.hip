@@ -314,7 +314,7 @@ int abip_hip_qcp_cone_prox(int kind, double *x, const double *tmp, double lambda
 // Column ranges of the sharded conic path: bounds[g] .. bounds[g+1] are rank g's columns (world + 1 entries out); pure host code.
 // 0 ok, -1 a rotated cone of fewer than 3 entries, -2 fewer blocks than ranks, -3 bad arguments.
 // Pure host code (no device needed): the formulation front end and the scaling exactly as abip_qcp applies them (qcp_formulations.h), then two products with the
-// scaled, materialised operator.  For CPU-side parity tests of the host logic against the oracle.  Any output pointer may be NULL.
+// scaled, materialised operator.  For CPU-side parity tests of the host logic (tests/test_qcp_host_cpu.py).  Any output pointer may be NULL.
 int abip_hip_qcp_host_probe(const QCPData *d, const QCPCone *K, const double *x_in, const double *y_in, double *Ax_out, double *Aty_out, double *b_out, double *c_out,
                             double *scal4, int *dims2) {
   if (!d || !K || !d->stgs || !d->A || !d->b) return -1;
