@@ -109,3 +109,22 @@ def test_host_scaling_is_bit_identical_to_the_oracle(oracle_built, variant):
     po.lib("oracle").orc_normalize_A(C.byref(P.mat), C.byref(P.stgs), po._f(Do), po._f(Eo), po._f(mr), po._f(mc))
     assert np.array_equal(Ax, P.Ax) and np.array_equal(D, Do) and np.array_equal(E, Eo)
     assert means[0] == mr[0] and means[1] == mc[0]
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("name", ["staircase", "network", "wide_lasso2"])
+def test_schur_hand_over_formats(name, mode, monkeypatch):
+    """ABIP_HIP_DEV_SCHUR=1 / 2: the host stops before the Schur complement and hands over K22 as triplets plus L21 by columns (what k_schur_sub / k_schur_rows
+    consume on the device); completed on the host here (host_setup.cpp: complete_schur_on_host), K z = rhs must hold as with the host's own accumulation."""
+    A = sp.csc_matrix(CASES[name]())
+    m, n = A.shape
+    rng = np.random.default_rng(5)
+    rhs = rng.standard_normal(m + n)
+    K = kkt(A, 1e-3)
+    monkeypatch.setenv("ABIP_HIP_DEV_SCHUR", "0")
+    z0, st0 = host_solve(A, 1e-3, 128, rhs)
+    monkeypatch.setenv("ABIP_HIP_DEV_SCHUR", mode)
+    z1, st1 = host_solve(A, 1e-3, 128, rhs)
+    assert st1["T"] == st0["T"] == 128 and st1["lnnz"] == st0["lnnz"]
+    assert np.linalg.norm(K @ z1 - rhs) <= 1e-10 * np.linalg.norm(rhs)
+    assert np.linalg.norm(z1 - z0) <= 1e-9 * np.linalg.norm(z0)
