@@ -534,7 +534,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
       w->n_cu = cus;
       const bool fits = cus > 0 && m <= 16384 && nl >= 1;
-      if (fits && (e ? atoi(e) != 0 : nnzl >= 1000000)) {
+      if (fits && (e ? atoi(e) != 0 : nnzl >= 2000000)) { // (break-even measured at ~1e6 non-zeros, profiles/r02zj_*)
         const int G = (double)nnzl / (double)nl <= 96.0 ? 16 : 64;
         const int bytes = (int)(sizeof(double) * (size_t)m);
         bool ok = true;

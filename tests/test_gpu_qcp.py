@@ -152,7 +152,7 @@ def test_unsupported_back_ends_are_rejected(gpu):
 
 @pytest.mark.parametrize("case", ["lasso_small", "lasso_mid", "lasso_bigcone", "lasso_long_rows", "lp_afiro"])
 def test_conic_pcg_with_the_gathered_vector_in_lds(gpu, case, monkeypatch):
-    """qcp_pcg.h: kq_pcg_Aty_lds -- A' y with the m-vector resident in LDS (default from 1e6 non-zeros on where m <= 16 384; forced here): short rows (16 lanes per
+    """qcp_pcg.h: kq_pcg_Aty_lds -- A' y with the m-vector resident in LDS (default from 2e6 non-zeros on where m <= 16 384; forced here): short rows (16 lanes per
     row), long rows (64), rows shorter than a lane group, an m-vector above 64 KB of LDS is covered by the full-size run of bench.py's c5 / lasso workloads.
     Same ADMM run as with the streaming kernel: status, outer iterations, inner iterations within 1 %, solution to 1e-6 relative of the objective scale."""
     if case == "lp_afiro":
