@@ -76,6 +76,7 @@ struct Ctl {
   int avg_crit;    // 1: the averaged iterate gave the smaller value
   int it_count;    // ADMM iterations completed since abip_init (never reset)
   double pp_cur;   // sharded PCG: ||p||^2 of the current direction, by the recurrence ||z + beta p||^2 = z'z + 2 beta z'p + beta^2 ||p||^2
+  long xcd_cg_total; // one-XCD persistent launch (dev_xcd.h): PCG iterations of all the ADMM iterations it ran
 };
 
 // Device-side launch timing (bench.py's roofline leg, inside the timed region: no hipEvent records, no second pass).  A kernel handed a

@@ -25,6 +25,7 @@
 #include "../../include/abip_hip.h"
 #include "dev_kernels.h"
 #include "dev_ldl.h"
+#include "dev_xcd.h"
 #include "dist_internal.h"
 #include "host_setup.h"
 #include "dev_host_util.h"
@@ -140,6 +141,29 @@ int dist_allreduce(double *buf, size_t count, hipStream_t s, std::vector<double>
 }
 } // namespace abip
 
+// One-XCD persistent launch for cache-resident LPs (dev_xcd.h): what abip_init prepares when the problem fits it.
+struct XcdPlan {
+  bool on = false;
+  int G = abip::XG, NZ = 0, RM = 0, RN = 0;
+  abip::hostutil::DBuf<int> mb, nb, xstat;
+  abip::hostutil::DBuf<unsigned> tickets;
+  abip::hostutil::DBuf<abip::u32x4> xn0, xn1, xm0, xm1, sc;
+  abip::hostutil::DBuf<double> tolf, Minv;
+  double *htolf = nullptr; int *hstat = nullptr; // pinned
+  long ldM = 0;
+  int n_pad = 0, m_pad = 0, max_batch = 2048;
+  unsigned tag = 0, launches = 0;
+  size_t lds = 0;
+  const void *kern = nullptr;
+  long batches = 0, exchanges = 0;
+  void release() {
+    mb.release(); nb.release(); xstat.release(); tickets.release(); xn0.release(); xn1.release(); xm0.release(); xm1.release(); sc.release(); tolf.release(); Minv.release();
+    if (htolf) (void)hipHostFree(htolf);
+    if (hstat) (void)hipHostFree(hstat);
+    htolf = nullptr; hstat = nullptr; on = false;
+  }
+};
+
 struct ABIP_WORK {
   // ---- problem / settings ------------------------------------------------------------------
   abip_int m = 0, n = 0;
@@ -169,6 +193,7 @@ struct ABIP_WORK {
   Ctl *hctl = nullptr; // pinned mirror
   // direct
   DevLdl ldl;
+  XcdPlan xcd;
   // ---- loop state (locals of ABIP(solve)) ------------------------------------------------
   Phase phase = PH_IDLE;
   abip_int i = 0, j = 0, k = 0, inner_stopper = 0;
@@ -744,6 +769,159 @@ int admm_iteration(W *w, double *metric_out) {
   return clear_halt(w);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// One-XCD persistent launch (dev_xcd.h): set-up and one batch of iterations
+// ------------------------------------------------------------------------------------------------
+struct XcdVariant { int nz, rm, rn; const void *pcg, *direct; };
+const XcdVariant kXcdVariants[] = {
+#define XV(a, b, c) {a, b, c, (const void *)k_lp_xcd<a, b, c, true>, (const void *)k_lp_xcd<a, b, c, false>}
+    XV(2, 1, 1), XV(4, 1, 2), XV(6, 1, 2), XV(8, 2, 4),
+#undef XV
+};
+
+// contiguous slices of the rows of M, balanced by (non-zeros + alpha per row); slices may be empty when there are fewer rows than workgroups
+void xcd_slices(const host::HostCsr &M, int G, double alpha, std::vector<int> &bounds, long *max_nnz, int *max_rows, int *max_len) {
+  const int rows = M.nrows;
+  const long nnz = M.ptr[rows];
+  bounds.assign(G + 1, 0);
+  bounds[G] = rows;
+  for (int g = 1; g < G; ++g) {
+    const double target = ((double)nnz + alpha * rows) * g / G;
+    int lo = bounds[g - 1], hi = rows;
+    while (lo < hi) { const int mid = (lo + hi) / 2; if ((double)M.ptr[mid] + alpha * mid < target) lo = mid + 1; else hi = mid; }
+    bounds[g] = lo;
+  }
+  *max_nnz = 0; *max_rows = 0; *max_len = 0;
+  for (int g = 0; g < G; ++g) {
+    *max_nnz = std::max<long>(*max_nnz, M.ptr[bounds[g + 1]] - M.ptr[bounds[g]]);
+    *max_rows = std::max(*max_rows, bounds[g + 1] - bounds[g]);
+  }
+  for (int r = 0; r < rows; ++r) *max_len = std::max(*max_len, M.ptr[r + 1] - M.ptr[r]);
+}
+// the row weight that lets the slices fit the smallest kernel variant: a thread holds NZ non-zeros and R rows, both cost registers
+void xcd_best_slices(const host::HostCsr &M, int G, std::vector<int> &bounds, long *max_nnz, int *max_rows, int *max_len) {
+  double best_cost = 1e300;
+  for (double alpha : {0.0, 0.5, 1.0, 2.0, 3.0, 4.0, 6.0, 8.0, 16.0}) {
+    std::vector<int> b; long nz; int rr, ll;
+    xcd_slices(M, G, alpha, b, &nz, &rr, &ll);
+    const double cost = 3.0 * std::ceil((double)nz / XTB) + 4.0 * std::ceil((double)rr / XTB) + 1e-6 * ((double)nz + rr);
+    if (cost < best_cost) { best_cost = cost; bounds = b; *max_nnz = nz; *max_rows = rr; *max_len = ll; }
+  }
+}
+
+// Decide whether the LP runs its inner loop as the one-XCD persistent launch and prepare it.  Never fails the set-up: when the problem does
+// not fit (or ABIP_HIP_XCD=0) the launch path stays in charge.
+void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
+  XcdPlan &x = w->xcd;
+  x.on = false;
+  { const char *e = getenv("ABIP_HIP_XCD"); if (e && atoi(e) == 0) return; }
+  if (w->dist) return;
+  hipDeviceProp_t prop; int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return;
+  if (prop.multiProcessorCount != 256 || !strstr(prop.gcnArchName, "gfx950")) return; // 8 XCDs x 32 CUs is what the placement argument needs
+  const bool pcg = (w->linsys == ABIP_HIP_LINSYS_INDIRECT);
+  if (!pcg) return; // (direct: below, once the dense inverse is there)
+  std::vector<int> mb, nb;
+  long nzA = 0, nzT = 0; int rA = 0, rT = 0, lA = 0, lT = 0;
+  xcd_best_slices(hA, x.G, mb, &nzA, &rA, &lA);
+  xcd_best_slices(hAt, x.G, nb, &nzT, &rT, &lT);
+  if (std::max(lA, lT) > 512) return; // rows are added up by one thread each
+  const XcdVariant *pick = nullptr;
+  for (const XcdVariant &v : kXcdVariants)
+    if (std::max(nzA, nzT) <= (long)v.nz * XTB && rA <= v.rm * XTB && rT <= v.rn * XTB) { pick = &v; break; }
+  if (!pick) return;
+  x.NZ = pick->nz; x.RM = pick->rm; x.RN = pick->rn;
+  x.kern = pcg ? pick->pcg : pick->direct;
+  x.n_pad = (int)((w->n + 63) / 64 * 64); x.m_pad = (int)((w->m + 63) / 64 * 64);
+  size_t words = (size_t)x.NZ * XTB + XKS + XWAVES * XKS + 96;
+  if (!pcg) words += (size_t)x.m_pad + (size_t)x.RM * XTB;
+  x.lds = std::max<size_t>(words * sizeof(double), (size_t)XCD_LDS_MIN);
+  if (x.lds > 160 * 1024) return;
+  if (hipFuncSetAttribute(x.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x.lds) != hipSuccess) { (void)hipGetLastError(); return; }
+  const std::vector<int> zero2(8 + 2 * XG + 24, 0);
+  const std::vector<unsigned> zero1(1, 0u);
+  bool bad = x.mb.upload(mb, w->stream) || x.nb.upload(nb, w->stream) || x.xstat.upload(zero2, w->stream) || x.tickets.upload(zero1, w->stream) ||
+             x.xn0.alloc(2 * (size_t)x.n_pad) || x.xn1.alloc(2 * (size_t)x.n_pad) || x.xm0.alloc(2 * (size_t)x.m_pad) || x.xm1.alloc(2 * (size_t)x.m_pad) ||
+             x.sc.alloc(2 * (size_t)XG * XKS) || x.tolf.alloc(x.max_batch);
+  if (!bad) bad = hipMemsetAsync(x.xn0.p, 0, sizeof(u32x4) * 2 * x.n_pad, w->stream) != hipSuccess || hipMemsetAsync(x.xn1.p, 0, sizeof(u32x4) * 2 * x.n_pad, w->stream) != hipSuccess ||
+                  hipMemsetAsync(x.xm0.p, 0, sizeof(u32x4) * 2 * x.m_pad, w->stream) != hipSuccess || hipMemsetAsync(x.xm1.p, 0, sizeof(u32x4) * 2 * x.m_pad, w->stream) != hipSuccess ||
+                  hipMemsetAsync(x.sc.p, 0, sizeof(u32x4) * 2 * XG * XKS, w->stream) != hipSuccess;
+  if (!bad) bad = hipHostMalloc((void **)&x.htolf, sizeof(double) * x.max_batch, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&x.hstat, (8 + 2 * XG + 24) * sizeof(int), hipHostMallocDefault) != hipSuccess;
+  if (bad) { (void)hipGetLastError(); x.release(); return; }
+  x.tag = 0; x.launches = 0;
+  x.on = true;
+  if (getenv("ABIP_HIP_XCD_VERBOSE"))
+    printf("[xcd] G %d: slices of A  <= %ld nnz, %d rows (longest row %d); of A' <= %ld nnz, %d rows (longest %d); NZ %d RM %d RN %d, LDS %zu B\n", x.G, nzA, rA, lA, nzT, rT, lT,
+           x.NZ, x.RM, x.RN, x.lds);
+}
+
+// Run up to nb ADMM iterations (k, j), (k+1, j+1), ... as one launch; *ran = iterations that ran (the exit test, or the final check, stops it).
+int xcd_batch(W *w, int nb, int *ran, double *metric_out) {
+  XcdPlan &x = w->xcd;
+  ABIPSettings *st = w->stgs;
+  const bool pcg = (w->linsys == ABIP_HIP_LINSYS_INDIRECT);
+  nb = std::min(nb, x.max_batch);
+  if (x.tag > 0x70000000u) { // tags only ever grow within the life of the buffers: start over long before they wrap
+    HIP_OK(hipMemsetAsync(x.xn0.p, 0, sizeof(u32x4) * 2 * x.n_pad, w->stream)); HIP_OK(hipMemsetAsync(x.xn1.p, 0, sizeof(u32x4) * 2 * x.n_pad, w->stream));
+    HIP_OK(hipMemsetAsync(x.xm0.p, 0, sizeof(u32x4) * 2 * x.m_pad, w->stream)); HIP_OK(hipMemsetAsync(x.xm1.p, 0, sizeof(u32x4) * 2 * x.m_pad, w->stream));
+    HIP_OK(hipMemsetAsync(x.sc.p, 0, sizeof(u32x4) * 2 * XG * XKS, w->stream));
+    x.tag = 0;
+  }
+  XcdArgs a{};
+  a.Ap = w->dA.ptr.p; a.Ai = w->dA.idx.p; a.Ax = w->dA.val.p;
+  a.Tp = w->dAt.ptr.p; a.Ti = w->dAt.idx.p; a.Tx = w->dAt.val.p;
+  a.mb = x.mb.p; a.nb = x.nb.p;
+  a.G = x.G; a.m = (int)w->m; a.n = (int)w->n; a.MP = w->MP;
+  a.upd = upd_args(w, true, false, w->j);
+  a.h = w->h.p; a.wD = st->normalize ? w->wD.p : nullptr; a.wE = st->normalize ? w->wE.p : nullptr;
+  a.Mjac = pcg ? w->cg_M.p : nullptr; a.Minv = x.Minv.p; a.ldM = x.ldM;
+  a.g_th = w->g_th;
+  a.xn0 = x.xn0.p; a.xn1 = x.xn1.p; a.xm0 = x.xm0.p; a.xm1 = x.xm1.p; a.sc = x.sc.p; a.n_pad = x.n_pad; a.m_pad = x.m_pad;
+  a.tag0 = x.tag;
+  a.tickets = x.tickets.p; a.ticket_base = x.launches * 32u;
+  a.ctl = w->ctl.p; a.xstat = x.xstat.p;
+  a.j0 = (long)w->j; a.max_iters = nb;
+  a.thr = w->gamma * w->mu; a.sentinel = (double)st->max_admm_iters;
+  a.tolf = x.tolf.p; a.cg_max_its = (int)w->m_glob;
+  a.fc.on = w->final_check ? 1 : 0; a.fc.pfeasopt = (int)st->pfeasopt; a.fc.ipm_pos = w->i > 0 ? 1 : 0;
+  a.fc.eps = st->eps; a.fc.den = st->normalize ? (st->scale * w->sc_c * w->sc_b) : 1.0; a.fc.nm_b = w->nm_b; a.fc.nm_c = w->nm_c;
+  a.fc.k0 = (long)w->k; a.fc.max_admm = (long)st->max_admm_iters;
+  if (pcg) {
+    for (int q = 0; q < nb; ++q) x.htolf[q] = cg_tol_factor(w, w->k + q);
+    HIP_OK(hipMemcpyAsync(x.tolf.p, x.htolf, sizeof(double) * nb, hipMemcpyHostToDevice, w->stream));
+  }
+  void *params[] = {&a};
+  const double t_launch = now_ms();
+  HIP_OK(hipLaunchKernel(x.kern, dim3(256), dim3(XTB), params, x.lds, w->stream));
+  x.launches++; x.batches++;
+  HIP_OK(hipMemcpyAsync(x.hstat, x.xstat.p, (8 + 2 * XG + 24) * sizeof(int), hipMemcpyDeviceToHost, w->stream));
+  if (sync_ctl(w)) return -1;
+  if (x.hstat[0]) { fprintf(stderr, "abip_hip: after %.1f ms the one-XCD persistent launch gave up waiting for an exchange (tag %d of launch base %u, rank %d, wait site %d, thread %d; found tag %d in a granule of kind %d)\n", now_ms() - t_launch, x.hstat[2], x.tag, x.hstat[3], x.hstat[4], x.hstat[5], x.hstat[7], x.hstat[6] - 2);
+    fprintf(stderr, "  exec %08x%08x ok %08x%08x nt %d na %d wave %d\n", x.hstat[81], x.hstat[80], x.hstat[83], x.hstat[82], x.hstat[84], x.hstat[85], x.hstat[86]);
+    { // the scalar areas of both parities: the tag every granule carries
+      std::vector<unsigned> hsc(2 * XG * XKS * 4);
+      if (hipMemcpy(hsc.data(), x.sc.p, hsc.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
+        for (int par = 0; par < 2; ++par)
+          for (int g = 0; g < x.G; ++g) {
+            fprintf(stderr, "  sc parity %d rank %2d:", par, g);
+            for (int k = 0; k < XKS; ++k) fprintf(stderr, " %u%s", hsc[((size_t)(par * XG + g) * XKS + k) * 4 + 1], hsc[((size_t)(par * XG + g) * XKS + k) * 4 + 1] == hsc[((size_t)(par * XG + g) * XKS + k) * 4 + 3] ? "" : "!");
+            fprintf(stderr, "\n");
+          }
+    }
+    for (int g = 0; g < x.G; ++g) fprintf(stderr, "  rank %2d: last exchange opened %d (after wait site %d)\n", g, x.hstat[8 + 2 * g], x.hstat[9 + 2 * g]);
+    return -1; }
+  x.tag += (unsigned)x.hstat[1]; x.exchanges += x.hstat[1];
+  *ran = w->hctl->it_count - w->it_seen;
+  if (*ran < 1 || *ran > nb) return -1;
+  take_verdict(w, metric_out);
+  w->tot_solves += *ran; w->prof.kkt_solves += *ran; w->prof.admm_iters += *ran;
+  if (pcg) { w->last_cg_its = w->hctl->cg_it; w->tot_cg_its += w->hctl->xcd_cg_total; w->prof.cg_iters += w->hctl->xcd_cg_total; }
+  w->wg_valid = false; // the launch path's partial table does not hold S_WG
+  w->stats_valid = true; w->avg_stats_valid = ((w->j + *ran) % 10 == 0);
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // barrier-parameter strategies (abip.c:753-992) -- host scalars; the LOQO rule needs one device reduction
 // ------------------------------------------------------------------------------------------------
@@ -1080,7 +1258,7 @@ void free_work(W *w) {
                           &w->wD, &w->wE, &w->cg_p, &w->cg_r, &w->cg_Gp, &w->cg_z, &w->cg_M, &w->cg_tmp, &w->cg_pair, &w->a_up, &w->a_vp, &w->a_ut, &w->a_u,
                           &w->a_v, &w->a_utn, &w->a_un, &w->a_vn, &w->part};
   for (auto *b : bufs) b->release();
-  w->ctl.release(); w->ldl.release(); w->T.release();
+  w->ctl.release(); w->ldl.release(); w->T.release(); w->xcd.release();
   if (w->hctl) (void)hipHostFree(w->hctl);
   w->stamps.release();
   if (w->hstamps) (void)hipHostFree(w->hstamps);
@@ -1321,6 +1499,7 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
     const int one = 1; // the post-solve kernels are gated on cg_done: permanently set for the direct back-end
     if (hipMemcpyAsync(&w->ctl.p->cg_done, &one, sizeof(int), hipMemcpyHostToDevice, w->stream) != hipSuccess) return fail("memcpy failure");
   }
+  xcd_setup(w, hA, hAt);
   if (hipStreamSynchronize(w->stream) != hipSuccess) return fail("device set-up failed");
   if (own_copy) { w->A = nullptr; std::vector<double>().swap(w->Aown_x); } // everything lives on the device now
   info->setup_time = now_ms() - t0;
@@ -1446,6 +1625,37 @@ abip_int abip_hip_step(ABIPWork *w, abip_int max_admm_steps, abip_int *steps_don
         if (w->j >= w->inner_stopper) { w->phase = PH_OUTER_END; break; }
         if (steps >= max_admm_steps) return done(0);
         double metric = 0;
+        if (w->xcd.on) { // cache-resident LP: iterations (k, j) ... as ONE persistent launch on one XCD, up to the next decision the host has to take
+          long nb = std::min<long>({(long)w->xcd.max_batch, (long)(max_admm_steps - steps), (long)(w->inner_stopper - w->j)});
+          if (!w->batch_ok) nb = std::min<long>(nb, 1);
+          if (w->final_check && w->i + 1 >= st->max_ipm_iters) nb = std::min<long>(nb, 1);
+          for (long q = 0; q < nb; ++q) if (restart_due(w, w->k + q, w->j + q)) { nb = q; break; }
+          if (nb >= 1) {
+            int ran = 0;
+            if (xcd_batch(w, (int)nb, &ran, &metric)) return hard_fail("error in project_lin_sys");
+            steps += ran; w->k += ran;
+            const int why = w->hctl->halt;
+            if (why && clear_halt(w)) return hard_fail("device memset");
+            if (why == 1) { // the exit test held at the last iteration that ran (abip.c:2173-2188)
+              if (st->half_update) { launch(w, ABIP_HIP_K_VEC, k_clip_v, w->NB, BS, w->v.p, dims(w)); w->stats_valid = false; }
+              w->j += ran - 1;
+              w->phase = PH_OUTER_END;
+              break;
+            }
+            if (w->final_check) { // abip.c:2190-2213 for the last iteration that ran (the device found the earlier ones unconverged)
+              calc_residuals(w, w->i, w->k);
+              if ((info->status_val = has_converged(w, w->i, w->k)) != 0 || w->k + 1 >= st->max_admm_iters || w->i + 1 >= st->max_ipm_iters) {
+                if (st->verbose && w->k > 0) print_summary(w, w->i, w->k);
+                if (finish_solution(w, info, w->i, w->k)) return hard_fail("device error in get_solution");
+                if (st->verbose) print_footer(w, info);
+                w->phase = PH_DONE;
+                return done(1);
+              }
+            }
+            w->j += ran;
+            break;
+          }
+        }
         if (w->linsys == ABIP_HIP_LINSYS_DIRECT && !w->dist && !w->final_check && !st->half_update && w->batch_ok) {
           // no host decision is needed between these iterations: run them as one batch (the device finds the exit, see admm_batch_direct)
           long nb = std::min<long>({(long)w->batch, (long)(max_admm_steps - steps), (long)(w->inner_stopper - w->j)});
@@ -1673,6 +1883,7 @@ abip_float abip_hip_get_scalar(ABIPWork *w, const char *name) {
   RET("sc_b", w->sc_b) RET("sc_c", w->sc_c) RET("nm_b", w->nm_b) RET("nm_c", w->nm_c) RET("tot_cg_its", w->tot_cg_its)
   RET("lnnz", w->ldl.lnnz) RET("levels_fwd", w->ldl.F.nlev) RET("levels_bwd", w->ldl.B.nlev) RET("tail", w->ldl.T) RET("admm_iter", w->k) RET("ipm_iter", w->i)
   RET("sell_At", w->dAt.nslices) RET("sell_A", w->dA.nslices) RET("nb", w->NB) RET("dist_cols", w->cg_cols ? 1 : 0) RET("small_solve", w->ldl.small ? 1 : 0) RET("factor_resid", w->factor_resid)
+  RET("xcd", w->xcd.on ? 1 : 0) RET("xcd_nz", w->xcd.NZ) RET("xcd_batches", w->xcd.batches) RET("xcd_exchanges", w->xcd.exchanges)
 #undef RET
   return NAN;
 }

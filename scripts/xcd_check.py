@@ -1,0 +1,42 @@
+"""Developer check of the one-XCD persistent launch (dev_xcd.h): the same LP with ABIP_HIP_XCD=1 and =0, iteration counts, solutions, rates."""
+import os, sys, time, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from abip_amd import problems
+from abip_amd.solver import Solver
+
+def run(A, b, c, linsys, xcd, eps, verbose=0, max_steps=None):
+    os.environ["ABIP_HIP_XCD"] = "1" if xcd else "0"
+    with Solver(A, b, c, linsys=linsys, eps=eps, verbose=verbose) as s:
+        on = s.scalar("xcd")
+        t0 = time.time()
+        out = s.solve()
+        dt = time.time() - t0
+        return dict(xcd=on, nz=s.scalar("xcd_nz"), batches=s.scalar("xcd_batches"), exch=s.scalar("xcd_exchanges"), dt=dt, x=s.x.copy(), y=s.y.copy(), s=s.s.copy(), **out)
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "small"
+    linsys = sys.argv[2] if len(sys.argv) > 2 else "indirect"
+    eps = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-4
+    if which == "small":
+        A, b, c = problems.lp_multicommodity(nodes=40, arcs=160, commodities=4)
+    elif which == "c3":
+        A, b, c = problems.lp_multicommodity(nodes=1200, arcs=4400, commodities=10)
+    elif which == "c2":
+        A, b, c = problems.lp_staircase()
+    elif which == "afiro":
+        A, b, c = problems.lp_afiro_like()
+    print("problem", which, A.shape, A.nnz, "linsys", linsys, "eps", eps, flush=True)
+    res = {}
+    for xcd in (1, 0):
+        r = run(A, b, c, linsys, xcd, eps)
+        res[xcd] = r
+        print("xcd=%d on=%g nz=%g batches=%g exch=%g status=%s admm=%d ipm=%d pobj=%.10e time=%.3fs  -> %.0f it/s" % (
+            xcd, r["xcd"], r["nz"], r["batches"], r["exch"], r["status"], r["admm_iter"], r["ipm_iter"], r["pobj"], r["dt"], r["admm_iter"] / r["dt"]), flush=True)
+    a, b_ = res[1], res[0]
+    for k in ("x", "y", "s"):
+        d = np.linalg.norm(a[k] - b_[k]) / max(1e-300, np.linalg.norm(b_[k]))
+        print("rel diff", k, "%.3e" % d)
+
+if __name__ == "__main__":
+    main()
