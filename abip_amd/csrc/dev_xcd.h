@@ -2,27 +2,32 @@
 //
 // Why.  On Netlib / pds-class LPs a kernel of the launch path (dev_kernels.h) does 2-5 us of work and the boundary to the next one costs
 // 2-3 us more; a PCG iteration is three such kernels, an ADMM iteration of the direct back-end six.  Here G = 32 workgroups -- the 32 CUs of
-// one XCD, so that one L2 serves every hand-over -- run `max_iters` ADMM iterations (abip.c:2131-2215) inside one launch:
+// one XCD, so that ONE L2 is the point of coherence for every hand-over -- run `max_iters` ADMM iterations (abip.c:2131-2215) in one launch:
 //
-//   * the rows of A and of A' are cut into G contiguous slices (balanced by non-zeros); workgroup g OWNS rows [mb[g], mb[g+1]) of the
-//     m-space and [nb[g], nb[g+1]) of the n-space: it alone reads and writes those entries of u, v, the running sums, the PCG vectors;
-//   * a slice's non-zeros live in REGISTERS for the whole launch (thread t holds entries t, t + 1024, ...: NZ per thread), the PCG's
-//     vectors too; nothing of the matrix is re-read per product;
-//   * a product needs the whole operand vector: the owners PUBLISH their entries as 16-byte granules {lo32, tag, hi32, tag} (one plain
-//     dwordx4 store each) and every consumer GATHERS the entries its non-zeros name with L1-bypassing 8-byte loads, polling the data
-//     itself until both halves carry the tag of this exchange.  No flag, no fence, no grid barrier: tools/xcd_probe.hip measured
-//     1.2 us per such exchange on one XCD against 6.1 us for release-fence + counter + acquire-fence (profiles/r03a_*);
-//   * reductions ride along: every workgroup publishes its partial sums as granules of the same exchange and every workgroup adds the G
-//     partials in rank order -- all workgroups hold bit-identical scalars and take the same decisions (PCG exit, inner-loop exit);
-//   * the tag is the running number of the exchange, the buffers alternate with its parity: a workgroup can be at most one exchange
-//     ahead of the slowest one, so a buffer is never overwritten while somebody may still read it.
+//   * the rows of A and of A' are cut into G contiguous slices (balanced by non-zeros and rows); workgroup g OWNS rows [mb[g], mb[g+1]) of
+//     the m-space and [nb[g], nb[g+1]) of the n-space: it alone reads and writes those entries of u, v, the running sums, the PCG vectors
+//     (the PCG vectors live in registers for the whole solve);
+//   * a product needs the whole operand vector.  One EXCHANGE: the owners store their entries into an exchange area (plain stores: the lines
+//     stay in this XCD's L2), wait until the L2 has acknowledged them (s_waitcnt vmcnt(0)), meet at a workgroup barrier, and then publish
+//     the workgroup's partial sums of the exchange as 16-byte granules {lo32, tag, hi32, tag} -- those granules are the FLAG: a consumer that
+//     sees rank r's granule with the tag of this exchange knows r's entries are in the L2.  Wavefront k of every workgroup polls scalar k of
+//     all G ranks (L1-bypassing loads, 32 lanes, a short sleep between rounds: no flood of the L2's request queues), adds them in rank
+//     order -- every workgroup gets bit-identical sums and takes the same decisions -- and after one more barrier all threads gather the
+//     entries their non-zeros name with L1-bypassing loads.  No atomics, no agent-scope fences (a release / acquire pair costs 6 us here,
+//     tools/xcd_probe.hip, profiles/r03a_*), no grid barrier;
+//   * the tag is the running number of the exchange and the areas alternate with its parity.  Every exchange is a rendez-vous of all ranks
+//     (everybody waits for everybody's granules), so a workgroup is at most one exchange ahead of the slowest one and an area is never
+//     overwritten while somebody may still read it.
+//
+// (First built with the tag on every entry and all threads polling their own entries: 32 k threads re-asking flooded the L2 queues and the
+// rank everybody waited for -- its loads, its spills, its stores -- queued behind them: milliseconds per exchange under load.)
 //
 // Placement.  The launch has 256 workgroups with > 80 KB of LDS each: one per CU, hence exactly 32 on every XCD.  The ones whose
 // HW_REG_XCC_ID is not 0 return at once; the others draw a ticket (= rank).  Every poll is bounded and gives up through xstat[0]
 // (the host then fails loudly), so a placement that breaks the assumption cannot hang the device.
 //
 // Arithmetic = the launch path's (dev_kernels.h) entry for entry; sums are taken in a different order (per row: entry order; per
-// reduction: thread, wavefront, rank order), and p'Gp is formed as rho |p|^2 + |A'p|^2 (the sharded path's identity, saving one
+// reduction: lane, wavefront, rank order), and p'Gp is formed as rho |p|^2 + |A'p|^2 (the sharded path's identity, saving one
 // exchange per PCG iteration).
 #pragma once
 #include "dev_kernels.h"
@@ -32,13 +37,14 @@ namespace abip {
 constexpr int XTB = 1024;          // threads per workgroup
 constexpr int XWAVES = XTB / 64;
 constexpr int XG = 32;             // workgroups taking part = CUs of one XCD
-constexpr int XKS = 16;            // scalar granules per workgroup per exchange
-constexpr int XHB = 15;            // ... the last of them is the heartbeat: "this rank has reached exchange <tag>"
+constexpr int XKS = 16;            // scalar granules per workgroup per exchange (<= XWAVES: wavefront k handles scalar k)
+constexpr int XSTAT_N = 128;       // ints of the status / post-mortem record
 constexpr int XSPIN = 1 << 22;     // polling rounds before a wavefront gives up (a round is ~1 us)
 constexpr int XCD_LDS_MIN = 84 * 1024; // more than half a CU's LDS: one workgroup per CU
+static_assert(XKS <= XWAVES, "one wavefront per scalar of an exchange");
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned long long xu64;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 struct XcdFinal { // the final_check branch of abip.c:2190-2213 evaluated on the device (calc_residuals + has_converged on the finalised sums)
   int on, pfeasopt, ipm_pos;
@@ -56,7 +62,8 @@ struct XcdArgs {
   const double *Mjac;                   // PCG: Jacobi preconditioner (m)
   const double *Minv; long ldM;         // direct: inv(rho I + A A'), dense row-major
   double g_th;
-  u32x4 *xn0, *xn1, *xm0, *xm1, *sc;    // exchange areas: 2 parities x (n_pad | m_pad | XG * XKS) granules
+  double *xn0, *xn1, *xm0, *xm1;        // exchange areas: 2 parities x (n_pad | m_pad) doubles
+  u32x4 *sc;                            // 2 parities x XG x XKS granules: the partial sums = the flags
   int n_pad, m_pad;
   unsigned tag0;
   unsigned *tickets; unsigned ticket_base;
@@ -69,15 +76,23 @@ struct XcdArgs {
 
 __device__ __forceinline__ unsigned x_xcc_id() { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return x & 0xf; }
 
-// Addresses are formed as (uniform base pointer) + (32-bit byte offset) everywhere: the base stays in scalar registers and an
-// element's offset is ONE vector register shared by every array it indexes (signed indices would cost a 64-bit address pair each).
-typedef __amdgpu_buffer_rsrc_t xrsrc; // buffer resource: 4 scalar registers describe an exchange area; an access is (resource, 32-bit byte offset)
+// Addresses are (scalar base) + (32-bit byte offset) everywhere: the exchange areas through buffer resources (4 scalar registers), the
+// owned entries of the l-vectors through x_at -- an element's offset is ONE vector register shared by every array it indexes.
+typedef __amdgpu_buffer_rsrc_t xrsrc;
 __device__ __forceinline__ xrsrc x_rsrc(const void *p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000); }
-__device__ __forceinline__ void x_put(xrsrc r, unsigned off /* bytes */, double v, unsigned tag) { // one plain 16-byte store: the line stays in this XCD's L2
+__device__ __forceinline__ void x_putd(xrsrc r, unsigned off /* bytes */, double v) { // plain store: the line stays in this XCD's L2
+  u32x2 g; g.x = (unsigned)__double2loint(v); g.y = (unsigned)__double2hiint(v);
+  __builtin_amdgcn_raw_buffer_store_b64(g, r, (int)off, 0, 0);
+}
+__device__ __forceinline__ double x_ldd(xrsrc r, unsigned off) { // sc1: past the L1, served by the L2
+  const u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 16);
+  return __hiloint2double((int)g.y, (int)g.x);
+}
+__device__ __forceinline__ void x_putg(xrsrc r, unsigned off, double v, unsigned tag) { // a granule: one 16-byte store
   u32x4 g; g.x = (unsigned)__double2loint(v); g.y = tag; g.z = (unsigned)__double2hiint(v); g.w = tag;
   __builtin_amdgcn_raw_buffer_store_b128(g, r, (int)off, 0, 0);
 }
-__device__ __forceinline__ u32x4 x_ld(xrsrc r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 16 /* sc1: past the L1, served by the L2 */); }
+__device__ __forceinline__ u32x4 x_ldg(xrsrc r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 16); }
 __device__ __forceinline__ bool x_ok(const u32x4 &g, unsigned tag) { return g.y == tag && g.w == tag; } // both 8-byte halves are of this exchange
 __device__ __forceinline__ double x_val(const u32x4 &g) { return __hiloint2double((int)g.z, (int)g.x); }
 // (the byte offset is formed in 32 bits: only then can it ride in the instruction's 32-bit offset register beside a scalar base)
@@ -104,19 +119,15 @@ __device__ __forceinline__ double x_wave_sum63(double v) {
   v += x_dpp<0x143, 0xc>(v); // row_bcast:31 into rows 2, 3
   return v;
 }
-__device__ __forceinline__ double x_wave_total(double v) { // every lane gets the total
-  v = x_wave_sum63(v);
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
-}
 
-struct XWait { // one thread's view of the exchange in flight
+struct XWait { // the exchange in flight
   xrsrc n0, n1, m0, m1, sc;
   unsigned tag;
   int *xstat;
   bool dead;
-  int site, rank; // which wait of the iteration this is / whose: recorded when a wavefront gives up
+  int site, rank; // which exchange of the iteration this is / whose: recorded when a wavefront gives up
 };
-// spin bookkeeping of one WAVEFRONT (its lanes poll together until all of them have their data): true = keep polling
+// spin bookkeeping of one WAVEFRONT (its lanes poll together): true = keep polling
 __device__ __forceinline__ bool x_spin(XWait &w, int &spins, unsigned found, int what) {
   ++spins;
   if ((spins & 255) != 0) return true;
@@ -133,150 +144,88 @@ __device__ __forceinline__ bool x_spin(XWait &w, int &spins, unsigned found, int
   return true;
 }
 
-constexpr int x_rounds(int K) { return (K + XWAVES - 1) / XWAVES; } // scalar granules a thread may have to fetch
-
-// Wait for (and fetch) what this thread needs of the exchange: the entries its A-slice non-zeros name in NVA n-space vectors, the entries
-// its A'-slice non-zeros name in NVT m-space vectors, and the scalar granules of K partial sums: wavefront k (+ XWAVES r) fetches scalar k
-// of rank `lane` -- the wavefront then adds the G partials on its own (x_sum_scalars).  All loads of a round are in flight together; the
-// lanes of a wavefront poll together until all of them have everything (no divergent exits around the polling loads).
-// ai / ti: BYTE offsets of the granules (16 * index), padded to NZ valid entries per thread (padding repeats an entry: always there).
-template <int NZ, int NVA, int NVT, int K>
-__device__ __forceinline__ void x_wait(XWait &w, int G, const unsigned (&ai)[NZ], const unsigned (&ti)[NZ], double (&va)[NVA > 0 ? NVA : 1][NZ],
-                                       double (&vt)[NVT > 0 ? NVT : 1][NZ], double (&sv)[K > 0 ? x_rounds(K) : 1]) {
-  constexpr int NS = K > 0 ? x_rounds(K) : 0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // Every exchange is a full rendez-vous: the last wavefront also waits for the heartbeat granule of EVERY rank.  Without it a workgroup whose
-  // non-zeros name entries of a few ranks only could run two exchanges ahead of a rank it does not depend on and overwrite a buffer (same
-  // parity) that rank is still reading.
-  const bool beat = (wave == XWAVES - 1) && lane < G;
-  int spins = 0;
-  // Only granules that have not arrived are asked for again, and a wavefront that has to ask again first sleeps a little: 32 k threads
-  // re-polling everything flood the L2's request queues (~0.6 M requests a round), and the one rank everybody waits for -- its loads, its
-  // spills, its stores -- queues behind that flood (measured: milliseconds per exchange).
-  u32x4 a0[NVA > 0 ? NZ : 1], a1[NVA > 1 ? NZ : 1], c0[NVT > 0 ? NZ : 1], c1[NVT > 1 ? NZ : 1], sg[NS > 0 ? NS : 1], hb;
-  const unsigned none = w.tag ^ 1u; // "not there yet"
-  hb.y = beat ? none : w.tag; hb.w = w.tag; hb.x = 0; hb.z = 0;
-#pragma unroll
-  for (int u = 0; u < NZ; ++u) {
-    if (NVA > 0) { a0[u].x = 0; a0[u].y = none; a0[u].z = 0; a0[u].w = none; }
-    if (NVA > 1) { a1[u].x = 0; a1[u].y = none; a1[u].z = 0; a1[u].w = none; }
-    if (NVT > 0) { c0[u].x = 0; c0[u].y = none; c0[u].z = 0; c0[u].w = none; }
-    if (NVT > 1) { c1[u].x = 0; c1[u].y = none; c1[u].z = 0; c1[u].w = none; }
-  }
-#pragma unroll
-  for (int r = 0; r < NS; ++r) {
-    const int k = wave + r * XWAVES;
-    sg[r].x = 0; sg[r].z = 0; sg[r].w = w.tag; sg[r].y = (k < K && lane < G) ? none : w.tag;
-  }
-  for (;;) {
-    asm volatile("" ::: "memory"); // (the loads below are issued anew every round)
-    if (hb.y != w.tag || hb.w != w.tag) hb = x_ld(w.sc, (unsigned)(lane * XKS + XHB) * 16u);
-#pragma unroll
-    for (int u = 0; u < NZ; ++u) {
-      if (NVA > 0) { if (!x_ok(a0[u], w.tag)) a0[u] = x_ld(w.n0, ai[u]); }
-      if (NVA > 1) { if (!x_ok(a1[u], w.tag)) a1[u] = x_ld(w.n1, ai[u]); }
-      if (NVT > 0) { if (!x_ok(c0[u], w.tag)) c0[u] = x_ld(w.m0, ti[u]); }
-      if (NVT > 1) { if (!x_ok(c1[u], w.tag)) c1[u] = x_ld(w.m1, ti[u]); }
-    }
-#pragma unroll
-    for (int r = 0; r < NS; ++r) {
-      const int k = wave + r * XWAVES;
-      if (!x_ok(sg[r], w.tag)) sg[r] = x_ld(w.sc, (unsigned)(lane * XKS + k) * 16u);
-    }
-    bool ok = x_ok(hb, w.tag);
-#pragma unroll
-    for (int u = 0; u < NZ; ++u) {
-      if (NVA > 0) ok = ok & x_ok(a0[u], w.tag);
-      if (NVA > 1) ok = ok & x_ok(a1[u], w.tag);
-      if (NVT > 0) ok = ok & x_ok(c0[u], w.tag);
-      if (NVT > 1) ok = ok & x_ok(c1[u], w.tag);
-    }
-#pragma unroll
-    for (int r = 0; r < NS; ++r) ok = ok & x_ok(sg[r], w.tag);
-    if (__all(ok ? 1 : 0)) {
-#pragma unroll
-      for (int u = 0; u < NZ; ++u) {
-        if (NVA > 0) va[0][u] = x_val(a0[u]);
-        if (NVA > 1) va[1][u] = x_val(a1[u]);
-        if (NVT > 0) vt[0][u] = x_val(c0[u]);
-        if (NVT > 1) vt[1][u] = x_val(c1[u]);
-      }
-#pragma unroll
-      for (int r = 0; r < NS; ++r) sv[r] = x_val(sg[r]); // (0.0 where this lane fetched nothing)
-      return;
-    }
-    { // for the post-mortem: the first lane that still misses something speaks for the wavefront
-      unsigned found = 0; int what = ok ? 0 : 7;
-      if (!x_ok(hb, w.tag)) { found = hb.y; what = 1; }
-#pragma unroll
-      for (int r = NS - 1; r >= 0; --r) if (!x_ok(sg[r], w.tag)) { found = sg[r].y; what = 2; }
-#pragma unroll
-      for (int u = NZ - 1; u >= 0; --u) {
-        if (NVA > 0 && !x_ok(a0[u], w.tag)) { found = a0[u].y; what = 300 + u + (int)(ai[u] >> 4) * 1000; }
-        if (NVA > 1 && !x_ok(a1[u], w.tag)) { found = a1[u].y; what = 500 + u + (int)(ai[u] >> 4) * 1000; }
-        if (NVT > 0 && !x_ok(c0[u], w.tag)) { found = c0[u].y; what = 400 + u + (int)(ti[u] >> 4) * 1000; }
-        if (NVT > 1 && !x_ok(c1[u], w.tag)) { found = c1[u].y; what = 600 + u + (int)(ti[u] >> 4) * 1000; }
-      }
-      const unsigned long long miss = __ballot(ok ? 0 : 1);
-      const int src = miss ? (int)__builtin_ctzll(miss) : 0;
-      found = (unsigned)__builtin_amdgcn_readlane((int)found, src); what = __builtin_amdgcn_readlane(what, src);
-      if (!x_spin(w, spins, found, what)) return;
-      __builtin_amdgcn_s_sleep(8); // ~0.25 us
-    }
-  }
-}
-
-// products of one slice -> LDS, then every owned row adds its entries in entry order
-template <int NZ, int R>
-__device__ __forceinline__ void x_rows(double *prod, const double (&mat)[NZ], const double (&vec)[NZ], int cnt, const int (&s)[R], const int (&e)[R], double (&out)[R]) {
-  __syncthreads(); // the readers of the previous use are done
-#pragma unroll
-  for (int u = 0; u < NZ; ++u)
-    if (u < cnt) prod[threadIdx.x + u * XTB] = mat[u] * vec[u];
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < R; ++q) {
-    double acc = 0.0;
-    for (int k = s[q]; k < e[q]; ++k) acc += prod[k];
-    out[q] = acc;
-  }
-}
-
-// workgroup partial sums of K values -> granules 0..K-1 of this rank's scalar area; `red` = K * XWAVES doubles of LDS
+// ---- one exchange, in four steps ----------------------------------------------------------------------------------------------------
+// (1) the owners x_putd their entries;
+// (2) x_publish<K>: this thread's stores are in the L2; workgroup partial sums of K values; their granules go out = the flag of this rank;
+// (3) x_collect<K>: wavefront k polls scalar k of every rank, adds them in rank order; barrier: from here on every rank's entries are there;
+// (4) x_gather: the entries this thread's non-zeros name.
 template <int K>
-__device__ __forceinline__ void x_pub_scalars(double (&v)[K], double *red, xrsrc sc, unsigned sc_off /* byte offset of this rank's granules */, unsigned tag) {
+__device__ __forceinline__ void x_publish(double (&v)[K], double *red, xrsrc sc, unsigned sc_off /* byte offset of this rank's granules */, unsigned tag) {
+  static_assert(K >= 1 && K <= XKS, "1 .. XKS scalars per exchange");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my entries have been acknowledged by the L2
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] = x_wave_sum63(v[k]);
   if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < K; ++k) red[k * XWAVES + wave] = v[k];
   }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < x_rounds(K); ++r) { // wavefront k adds the XWAVES partials of scalar k
-    const int k = wave + r * XWAVES;
-    if (k < K) {
-      const double s = x_wave_sum63(lane < XWAVES ? red[k * XWAVES + lane] : 0.0);
-      if (lane == 63) x_put(sc, sc_off + (unsigned)k * 16u, s, tag);
-    }
+  __syncthreads(); // ... and so have everybody's of this workgroup
+  if (wave < K) { // wavefront k adds the XWAVES partials of scalar k and raises the flag
+    const double s = x_wave_sum63(lane < XWAVES ? red[wave * XWAVES + lane] : 0.0);
+    if (lane == 63) x_putg(sc, sc_off + (unsigned)wave * 16u, s, tag);
   }
 }
-// x_wait left scalar k of rank `lane` in wavefront k (+ XWAVES r): totals in a fixed order, the same bits in every workgroup
 template <int K>
-__device__ __forceinline__ void x_sum_scalars(const double (&sv)[x_rounds(K)], double *tot, double (&out)[K]) {
+__device__ __forceinline__ void x_collect(XWait &w, int G, double *tot, double (&out)[K]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int r = 0; r < x_rounds(K); ++r) {
-    const int k = wave + r * XWAVES;
-    if (k < K) {
-      const double s = x_wave_sum63(sv[r]);
-      if (lane == 63) tot[k] = s;
+  if (wave < K) {
+    u32x4 g; g.x = 0; g.y = w.tag; g.z = 0; g.w = w.tag;
+    int spins = 0;
+    for (;;) {
+      asm volatile("" ::: "memory"); // (the load is issued anew every round)
+      if (lane < G) g = x_ldg(w.sc, (unsigned)(lane * XKS + wave) * 16u);
+      const bool ok = x_ok(g, w.tag);
+      if (__all(ok ? 1 : 0)) break;
+      const unsigned long long miss = __ballot(ok ? 0 : 1);
+      const int src = miss ? (int)__builtin_ctzll(miss) : 0;
+      if (!x_spin(w, spins, (unsigned)__builtin_amdgcn_readlane((int)g.y, src), 1000 + src)) break;
+      __builtin_amdgcn_s_sleep(2);
     }
+    const double s = x_wave_sum63(lane < G ? x_val(g) : 0.0);
+    if (lane == 63) tot[wave] = s;
   }
   __syncthreads();
+  if (__hip_atomic_load(w.xstat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) w.dead = true; // (one wavefront gave up: everybody leaves)
 #pragma unroll
   for (int k = 0; k < K; ++k) out[k] = x_uni(tot[k]);
+}
+template <int NZ>
+__device__ __forceinline__ void x_gather(xrsrc r, const unsigned (&idx)[NZ], double (&v)[NZ]) {
+#pragma unroll
+  for (int u = 0; u < NZ; ++u) v[u] = x_ldd(r, idx[u]);
+}
+
+// products of one slice -> LDS, then every owned row adds its entries in entry order
+template <int NZ, int R>
+__device__ __forceinline__ void x_rows(double *prod2 /* two buffers of NZ * XTB */, int &flip, const double (&mat)[NZ], const double (&vec)[NZ], int cnt, const int (&s)[R], const int (&e)[R], double (&out)[R]) {
+  // the two buffers alternate: whoever writes buffer X again has passed the barrier of the call in between, which every thread reaches only after
+  // it has finished reading X -- one barrier per product instead of two
+  double *prod = prod2 + (flip ? NZ * XTB : 0);
+  flip ^= 1;
+#pragma unroll
+  for (int u = 0; u < NZ; ++u)
+    if (u < cnt) prod[threadIdx.x + u * XTB] = mat[u] * vec[u];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < R; ++q) { // entry order; four LDS reads in flight at a time
+    double acc = 0.0;
+    int k = s[q];
+    const int ke = e[q];
+    for (; k + 4 <= ke; k += 4) {
+      const double p0 = prod[k], p1 = prod[k + 1], p2 = prod[k + 2], p3 = prod[k + 3];
+      acc += p0; acc += p1; acc += p2; acc += p3;
+    }
+    for (; k < ke; ++k) acc += prod[k];
+    out[q] = acc;
+  }
+}
+// the values of a slice's non-zeros (thread t: entries t, t + XTB, ...): read again for every product -- coalesced, cache-resident --
+// instead of living in 2 NZ registers for the whole launch
+template <int NZ>
+__device__ __forceinline__ void x_mat(const double *g, int cnt, double (&v)[NZ]) {
+#pragma unroll
+  for (int u = 0; u < NZ; ++u) v[u] = (u < cnt) ? x_at(g, threadIdx.x + (unsigned)u * XTB) : 0.0;
 }
 
 // calc_residuals (abip.c:458-535) + has_converged (1613-1641) on finalised sums; o = the out[] array, ac = avg_criterion of this iteration
@@ -339,11 +288,23 @@ __device__ __forceinline__ void x_prox(const UpdArgs &a, double uo, double vo, d
   }
 }
 
+#ifdef XCD_PROF // developer build: where the time of the PCG loop goes (ticks of the 100 MHz wall clock, rank 0 thread 0)
+#define XP_DECL unsigned long long xp_t = 0, xp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define XP_START xp_t = wall_clock64();
+#define XP_LAP(k) { const unsigned long long xp_n = wall_clock64(); xp_acc[k] += xp_n - xp_t; xp_t = xp_n; }
+#define XP_DUMP if (rank == 0 && t == 0) for (int q = 0; q < 8; ++q) a.xstat[96 + q] = (int)xp_acc[q];
+#else
+#define XP_DECL
+#define XP_START
+#define XP_LAP(k)
+#define XP_DUMP
+#endif
+
 template <int NZ, int RM, int RN, bool PCG>
 __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   extern __shared__ double xl[];
-  double *prod = xl;                 // NZ * XTB
-  double *tot = prod + NZ * XTB;     // XKS
+  double *prod = xl;                 // 2 x NZ * XTB
+  double *tot = prod + 2 * NZ * XTB; // XKS
   double *red = tot + XKS;           // XWAVES * XKS
   double *outs = red + XWAVES * XKS; // 96: the finalised sums (every workgroup holds the same)
   double *wv = outs + 96;            // direct: the whole right-hand side w (m_pad), then the products of the owned rows (RM * XTB)
@@ -365,22 +326,17 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   const unsigned MP = (unsigned)a.MP;
   const unsigned m0 = (unsigned)a.mb[rank], m1 = (unsigned)a.mb[rank + 1], n0 = (unsigned)a.nb[rank], n1 = (unsigned)a.nb[rank + 1];
   const int ka0 = a.Ap[m0], ka1 = a.Ap[m1], kt0 = a.Tp[n0], kt1 = a.Tp[n1];
-  // ---- the two matrix slices, in registers for the whole launch (indices as byte offsets of the granules they gather) ----
-  double ax[NZ], tx[NZ];
+  // ---- the two slices: the positions their non-zeros gather from (byte offsets), in registers for the whole launch ----
   unsigned ai[NZ], ti[NZ];
   int na = 0, nt = 0;
 #pragma unroll
   for (int u = 0; u < NZ; ++u) {
     const unsigned k = t + u * XTB;
-    ax[u] = 0.0; tx[u] = 0.0; ai[u] = 0; ti[u] = 0;
-    if (ka0 + (int)k < ka1) { ax[u] = x_at(a.Ax, ka0 + k); ai[u] = 16u * (unsigned)x_at(a.Ai, ka0 + k); na = u + 1; }
-    if (kt0 + (int)k < kt1) { tx[u] = x_at(a.Tx, kt0 + k); ti[u] = 16u * (unsigned)x_at(a.Ti, kt0 + k); nt = u + 1; }
+    ai[u] = 0; ti[u] = 0;
+    if (ka0 + (int)k < ka1) { ai[u] = 8u * (unsigned)x_at(a.Ai, ka0 + k); na = u + 1; }
+    if (kt0 + (int)k < kt1) { ti[u] = 8u * (unsigned)x_at(a.Ti, kt0 + k); nt = u + 1; }
   }
-#pragma unroll
-  for (int u = 0; u < NZ; ++u) { // padding: gather an entry that is certainly published whenever the vector is (the product is never used)
-    if (u >= na) ai[u] = na > 0 ? ai[0] : 0u;
-    if (u >= nt) ti[u] = nt > 0 ? ti[0] : 0u;
-  }
+  const double *gA = a.Ax + ka0, *gT = a.Tx + kt0; // the slices' values
   int sa[RM], ea[RM], st[RN], et[RN];
 #pragma unroll
   for (int q = 0; q < RM; ++q) { const unsigned i = m0 + t + q * XTB; sa[q] = 0; ea[q] = 0; if (i < m1) { sa[q] = x_at(a.Ap, i) - ka0; ea[q] = x_at(a.Ap, i + 1) - ka0; } }
@@ -392,23 +348,20 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   const double rho = up.rho;
   const unsigned tail = MP + (unsigned)a.n;
   unsigned tag = a.tag0;
+  int flip = 0;
   XWait w; w.xstat = a.xstat; w.dead = false; w.site = 0; w.rank = rank;
   xrsrc pn0, pn1, pm0, pm1, psc; // the exchange areas of the parity in use
   const unsigned sc_off = (unsigned)rank * XKS * 16u;
-  auto open = [&]() { // next exchange: tag and the buffers of its parity
+  auto open = [&](int site) { // next exchange: tag and the areas of its parity
     tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(tag + 1u)); // (uniform by construction; the loops' give-up exits hide that from the compiler)
     const size_t par = tag & 1u;
-    w.tag = tag;
-    pn0 = x_rsrc(a.xn0 + par * a.n_pad, 16u * (unsigned)a.n_pad); pn1 = x_rsrc(a.xn1 + par * a.n_pad, 16u * (unsigned)a.n_pad);
-    pm0 = x_rsrc(a.xm0 + par * a.m_pad, 16u * (unsigned)a.m_pad); pm1 = x_rsrc(a.xm1 + par * a.m_pad, 16u * (unsigned)a.m_pad);
+    w.tag = tag; w.site = site;
+    pn0 = x_rsrc(a.xn0 + par * a.n_pad, 8u * (unsigned)a.n_pad); pn1 = x_rsrc(a.xn1 + par * a.n_pad, 8u * (unsigned)a.n_pad);
+    pm0 = x_rsrc(a.xm0 + par * a.m_pad, 8u * (unsigned)a.m_pad); pm1 = x_rsrc(a.xm1 + par * a.m_pad, 8u * (unsigned)a.m_pad);
     psc = x_rsrc(a.sc + par * (size_t)(XG * XKS), 16u * XG * XKS);
     w.n0 = pn0; w.n1 = pn1; w.m0 = pm0; w.m1 = pm1; w.sc = psc;
-    if (t == 0) {
-      x_put(psc, sc_off + XHB * 16u, 0.0, tag); // heartbeat: everything this rank read of the exchange before last is in its registers
-      a.xstat[8 + 2 * rank] = (int)tag; a.xstat[9 + 2 * rank] = w.site; // (post-mortem: where every rank was when a wait gave up)
-    }
+    if (t == 0) { a.xstat[8 + 2 * rank] = (int)tag; a.xstat[9 + 2 * rank] = site; } // (post-mortem: where every rank was when a wait gave up)
   };
-  double dumA[1][NZ], dumT[1][NZ], dumS[1];
 
   // ---- prologue: S_WG and the tau entries for the first right-hand side; A'u_y, the warm start's product (PCG) ----
   double aty[RN]; // (A'u_y)_j of the owned columns: left by the stopping test, used by the next solve's set-up
@@ -416,12 +369,12 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
 #pragma unroll
   for (int q = 0; q < RN; ++q) aty[q] = 0.0;
   {
-    open();
+    open(1);
     double p[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < RM; ++q) {
       const unsigned i = m0 + t + q * XTB;
-      if (i < m1) { const double uy = x_at(up.u, i); p[0] += rho * (uy + x_at(up.v, i)) * x_at(up.g, i); if (PCG) x_put(pm0, i * 16u, uy, tag); }
+      if (i < m1) { const double uy = x_at(up.u, i); p[0] += rho * (uy + x_at(up.v, i)) * x_at(up.g, i); if (PCG) x_putd(pm0, i * 8u, uy); }
     }
 #pragma unroll
     for (int q = 0; q < RN; ++q) {
@@ -429,19 +382,21 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       if (j < n1) p[0] += (x_at(up.u, MP + j) + x_at(up.v, MP + j)) * x_at(up.g, MP + j);
     }
     if (rank == 0 && t == 0) { p[1] = x_at(up.u, tail); p[2] = x_at(up.v, tail); }
-    x_pub_scalars<3>(p, red, psc, sc_off, tag);
-    double vt[1][NZ], sv[x_rounds(3)];
-    w.site = 1;
-    if (PCG) x_wait<NZ, 0, 1, 3>(w, G, ai, ti, dumA, vt, sv);
-    else x_wait<NZ, 0, 0, 3>(w, G, ai, ti, dumA, dumT, sv);
-    if (w.dead) return;
-    if (PCG) x_rows<NZ, RN>(prod, tx, vt[0], nt, st, et, aty);
+    x_publish<3>(p, red, psc, sc_off, tag);
     double s3[3];
-    x_sum_scalars<3>(sv, tot, s3);
+    x_collect<3>(w, G, tot, s3);
+    if (w.dead) return;
+    if (PCG) {
+      double tx[NZ], vt[NZ];
+      x_mat<NZ>(gT, nt, tx);
+      x_gather<NZ>(pm0, ti, vt);
+      x_rows<NZ, RN>(prod, flip, tx, vt, nt, st, et, aty);
+    }
     wg = s3[0]; u_tau = s3[1]; v_tau = s3[2];
   }
 
   if (t < 96) outs[t] = a.ctl->out[t]; // slots this launch does not refresh keep what the last finalize left (as on the launch path)
+  XP_DECL
   int ran = 0, halt = 0, last_cg = 0;
   long cg_total = 0;
   double metric = 0.0;
@@ -458,7 +413,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     const double coef = (wg - tsum * a.g_th) / (a.g_th + 1.0);
     double rhs_y[RM], rhs_x[RN];
     double bn[1] = {0.0};
-    open();
+    open(2);
 #pragma unroll
     for (int q = 0; q < RM; ++q) {
       const unsigned i = m0 + tb + q * XTB;
@@ -482,22 +437,26 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         r += -tsum * hj;
         r += -coef * hj;
         rhs_x[q] = -r;
-        x_put(pn0, j2 * 16u, -r, tag);
-        if (PCG) x_put(pn1, j2 * 16u, aty[q], tag);
+        x_putd(pn0, j2 * 8u, -r);
+        if (PCG) x_putd(pn1, j2 * 8u, aty[q]);
       }
     }
+    x_publish<1>(bn, red, psc, sc_off, tag);
+    double bnS[1];
+    x_collect<1>(w, G, tot, bnS);
+    if (w.dead) return;
     double y[RM]; // the y block of the solution
     if (PCG) {
       // ---- PCG set-up (k_cg_init_A, indirect.c:345-365, 415) ----
-      x_pub_scalars<1>(bn, red, psc, sc_off, tag);
-      double va[2][NZ], sv1[1];
-      w.site = 3; x_wait<NZ, 2, 0, 1>(w, G, ai, ti, va, dumT, sv1);
-      if (w.dead) return;
       double sA[RM], sB[RM];
-      x_rows<NZ, RM>(prod, ax, va[0], na, sa, ea, sA);
-      x_rows<NZ, RM>(prod, ax, va[1], na, sa, ea, sB);
-      double bnS[1];
-      x_sum_scalars<1>(sv1, tot, bnS);
+      {
+        double ax[NZ], va[NZ];
+        x_mat<NZ>(gA, na, ax);
+        x_gather<NZ>(pn0, ai, va);
+        x_rows<NZ, RM>(prod, flip, ax, va, na, sa, ea, sA);
+        x_gather<NZ>(pn1, ai, va);
+        x_rows<NZ, RM>(prod, flip, ax, va, na, sa, ea, sB);
+      }
       double tol = sqrt(bnS[0]) * a.tolf[it]; // indirect.c:406-409, 418
       tol = fmax(tol, 1e-7);
       tol = fmax(tol, 1e-9);
@@ -521,27 +480,37 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       for (int q = 0; q < RN; ++q) ctmp[q] = 0.0;
       int cgit = 0;
       double zr_prev = 0.0;
+      XP_START
       for (;;) {
         // ---- z and (|r|^2, z'r) out; convergence test; tmp = A'z + beta tmp (k_cg_spmv_At) ----
-        open();
+        open(3);
 #pragma unroll
-        for (int q = 0; q < RM; ++q) { const unsigned i = m0 + t + q * XTB; if (i < m1) x_put(pm0, i * 16u, cz[q], tag); }
-        x_pub_scalars<2>(rz, red, psc, sc_off, tag);
-        double vt[1][NZ], sv2[1];
-        w.site = 4; x_wait<NZ, 0, 1, 2>(w, G, ai, ti, dumA, vt, sv2);
-        if (w.dead) return;
-        double tq[RN];
-        x_rows<NZ, RN>(prod, tx, vt[0], nt, st, et, tq);
+        for (int q = 0; q < RM; ++q) { const unsigned i = m0 + t + q * XTB; if (i < m1) x_putd(pm0, i * 8u, cz[q]); }
+        XP_LAP(0)
+        x_publish<2>(rz, red, psc, sc_off, tag);
+        XP_LAP(1)
+        double tx[NZ];
+        x_mat<NZ>(gT, nt, tx); // (on their way while the flags are awaited)
         double rzS[2];
-        x_sum_scalars<2>(sv2, tot, rzS);
+        x_collect<2>(w, G, tot, rzS);
+        if (w.dead) return;
+        XP_LAP(2)
         const double nr = sqrt(rzS[0]);
         bool done = (cgit == 0) ? (nr < fmin(tol, 1e-18)) : (nr < tol); // indirect.c:359, 375
         if (cgit >= a.cg_max_its) done = true;                          // indirect.c:368
         if (done) break;
+        double tq[RN];
+        {
+          double vt[NZ];
+          x_gather<NZ>(pm0, ti, vt);
+          XP_LAP(3)
+          x_rows<NZ, RN>(prod, flip, tx, vt, nt, st, et, tq);
+        }
+        XP_LAP(4)
         const double beta = (cgit == 0) ? 0.0 : rzS[1] / zr_prev;
         zr_prev = rzS[1];
         double tp[2] = {0.0, 0.0};
-        open();
+        open(4);
 #pragma unroll
         for (int q = 0; q < RN; ++q) {
           const unsigned j2 = n0 + t + q * XTB;
@@ -549,7 +518,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
             const double v = (cgit == 0) ? tq[q] : tq[q] + beta * ctmp[q];
             ctmp[q] = v;
             tp[0] += v * v;
-            x_put(pn0, j2 * 16u, v, tag);
+            x_putd(pn0, j2 * 8u, v);
           }
         }
 #pragma unroll
@@ -558,14 +527,23 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
           if (i < m1) { const double pn = cz[q] + beta * cp[q]; cp[q] = pn; tp[1] += pn * pn; }
         }
         // ---- tmp and (|A'p|^2, |p|^2) out; Gp = A tmp + rho p; alpha; x, r, z (k_cg_spmv_A + k_cg_update) ----
-        x_pub_scalars<2>(tp, red, psc, sc_off, tag);
-        double va1[1][NZ];
-        w.site = 5; x_wait<NZ, 1, 0, 2>(w, G, ai, ti, va1, dumT, sv2);
-        if (w.dead) return;
-        double gq[RM];
-        x_rows<NZ, RM>(prod, ax, va1[0], na, sa, ea, gq);
+        XP_LAP(0)
+        x_publish<2>(tp, red, psc, sc_off, tag);
+        XP_LAP(1)
+        double ax[NZ];
+        x_mat<NZ>(gA, na, ax);
         double tpS[2];
-        x_sum_scalars<2>(sv2, tot, tpS);
+        x_collect<2>(w, G, tot, tpS);
+        if (w.dead) return;
+        XP_LAP(2)
+        double gq[RM];
+        {
+          double va[NZ];
+          x_gather<NZ>(pn0, ai, va);
+          XP_LAP(3)
+          x_rows<NZ, RM>(prod, flip, ax, va, na, sa, ea, gq);
+        }
+        XP_LAP(4)
         const double pGp = rho * tpS[1] + tpS[0];
         const double alpha = rzS[1] / pGp;
         rz[0] = 0.0; rz[1] = 0.0;
@@ -583,37 +561,27 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         }
         ++cgit;
       }
+      XP_LAP(5)
       last_cg = cgit; cg_total += cgit;
 #pragma unroll
       for (int q = 0; q < RM; ++q) y[q] = cx[q];
     } else {
       // ---- direct: w = rhs_y + A rhs_x; y = inv(rho I + A A') w; (x follows below) ----
-      double va1[1][NZ];
-      w.site = 6; x_wait<NZ, 1, 0, 0>(w, G, ai, ti, va1, dumT, dumS);
-      if (w.dead) return;
       double sA[RM];
-      x_rows<NZ, RM>(prod, ax, va1[0], na, sa, ea, sA);
-      open();
-#pragma unroll
-      for (int q = 0; q < RM; ++q) { const unsigned i = m0 + tb + q * XTB; if (i < m1) x_put(pm0, i * 16u, rhs_y[q] + sA[q], tag); }
-      w.site = 12; x_wait<NZ, 0, 0, 0>(w, G, ai, ti, dumA, dumT, dumS); // (the rendez-vous)
-      if (w.dead) return;
-      { // every workgroup needs the whole w
-        int spins = 0;
-        for (unsigned i0 = wave * 64u; i0 < (unsigned)a.m; i0 += XTB) { // (wave-uniform trip count: the lanes of a wavefront poll together)
-          const unsigned i = i0 + lane;
-          u32x4 g; g.y = tag; g.w = tag; g.x = 0; g.z = 0;
-          for (;;) {
-            asm volatile("" ::: "memory");
-            if (i < (unsigned)a.m) g = x_ld(w.m0, i * 16u);
-            if (__all(x_ok(g, tag) ? 1 : 0)) break;
-            if (!x_spin(w, spins, g.y, 8)) break;
-          }
-          if (w.dead) break;
-          if (i < (unsigned)a.m) wv[i] = x_val(g);
-        }
-        if (w.dead) return;
+      {
+        double ax[NZ], va[NZ];
+        x_mat<NZ>(gA, na, ax);
+        x_gather<NZ>(pn0, ai, va);
+        x_rows<NZ, RM>(prod, flip, ax, va, na, sa, ea, sA);
       }
+      open(5);
+#pragma unroll
+      for (int q = 0; q < RM; ++q) { const unsigned i = m0 + tb + q * XTB; if (i < m1) x_putd(pm0, i * 8u, rhs_y[q] + sA[q]); }
+      double dz[1] = {0.0}, dzS[1];
+      x_publish<1>(dz, red, psc, sc_off, tag);
+      x_collect<1>(w, G, tot, dzS);
+      if (w.dead) return;
+      for (unsigned i = t; i < (unsigned)a.m; i += XTB) wv[i] = x_ldd(pm0, i * 8u); // every workgroup needs the whole w
       __syncthreads();
       double *yv = wv + a.m_pad;
       for (unsigned r = m0 + wave; r < m1; r += XWAVES) { // one wavefront per owned row
@@ -629,19 +597,22 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     }
     // ---- back-substitution x = A'y - rhs_x (indirect.c:419-420) and u_t'h (abip.c:560) ----
     double dh[1] = {0.0};
-    open();
+    open(6);
 #pragma unroll
     for (int q = 0; q < RM; ++q) {
       const unsigned i = m0 + tb + q * XTB;
-      if (i < m1) { x_put(pm0, i * 16u, y[q], tag); x_at(up.ut, i) = y[q]; dh[0] += y[q] * x_at(a.h, i); }
+      if (i < m1) { x_putd(pm0, i * 8u, y[q]); x_at(up.ut, i) = y[q]; dh[0] += y[q] * x_at(a.h, i); }
     }
     double zx[RN];
     {
-      double vt[1][NZ];
-      w.site = 7; x_wait<NZ, 0, 1, 0>(w, G, ai, ti, dumA, vt, dumS);
+      double dz[1] = {0.0}, dzS[1];
+      x_publish<1>(dz, red, psc, sc_off, tag);
+      x_collect<1>(w, G, tot, dzS);
       if (w.dead) return;
-      double tq[RN];
-      x_rows<NZ, RN>(prod, tx, vt[0], nt, st, et, tq);
+      double tx[NZ], vt[NZ], tq[RN];
+      x_mat<NZ>(gT, nt, tx);
+      x_gather<NZ>(pm0, ti, vt);
+      x_rows<NZ, RN>(prod, flip, tx, vt, nt, st, et, tq);
 #pragma unroll
       for (int q = 0; q < RN; ++q) {
         const unsigned j2 = n0 + tb + q * XTB;
@@ -649,17 +620,15 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         if (j2 < n1) { zx[q] = tq[q] - rhs_x[q]; dh[0] += zx[q] * x_at(a.h, MP + j2); }
       }
     }
-    open();
-    x_pub_scalars<1>(dh, red, psc, sc_off, tag);
-    double svd[1];
-    w.site = 8; x_wait<NZ, 0, 0, 1>(w, G, ai, ti, dumA, dumT, svd);
-    if (w.dead) return;
+    open(7);
+    x_publish<1>(dh, red, psc, sc_off, tag);
     double dhS[1];
-    x_sum_scalars<1>(svd, tot, dhS);
+    x_collect<1>(w, G, tot, dhS);
+    if (w.dead) return;
     // ---- element-wise update (k_admm_update): barrier prox, dual update, running sums, averages, statistics ----
     Stat sst = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double tau4[4] = {0.0, 0.0, 0.0, 0.0};
-    open();
+    open(8);
 #pragma unroll
     for (int q = 0; q < RM; ++q) {
       const unsigned i = m0 + tb + q * XTB;
@@ -671,8 +640,8 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         x_at(up.u, i) = un; x_at(up.v, i) = vn;
         x_at(up.u_avg, i) += un; x_at(up.v_avg, i) += vn;
         xs_y(up, i, un, vn, sst);
-        x_put(pm0, i * 16u, un, tag);
-        if (avg_stats) x_put(pm1, i * 16u, x_at(up.u_avgc, i), tag);
+        x_putd(pm0, i * 8u, un);
+        if (avg_stats) x_putd(pm1, i * 8u, x_at(up.u_avgc, i));
       }
     }
 #pragma unroll
@@ -686,8 +655,8 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         x_at(up.u, qq) = un; x_at(up.v, qq) = vn;
         x_at(up.u_avg, qq) += un; x_at(up.v_avg, qq) += vn;
         xs_x(up, qq, j2, false, un, vn, sst);
-        x_put(pn0, j2 * 16u, un, tag);
-        if (avg_stats) x_put(pn1, j2 * 16u, x_at(up.u_avgc, qq), tag);
+        x_putd(pn0, j2 * 8u, un);
+        if (avg_stats) x_putd(pn1, j2 * 8u, x_at(up.u_avgc, qq));
       }
     }
     if (rank == 0 && t == 0) { // the tau / kappa entry
@@ -701,18 +670,26 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       tau4[0] = un; tau4[1] = vn; tau4[2] = x_at(up.u_avgc, tail); tau4[3] = x_at(up.v_avgc, tail);
     }
     double s13[13] = {sst.wg, sst.nu, sst.nv, sst.cx, sst.by, sst.nua, sst.nva, sst.cxa, sst.bya, tau4[0], tau4[1], tau4[2], tau4[3]};
-    x_pub_scalars<13>(s13, red, psc, sc_off, tag);
+    x_publish<13>(s13, red, psc, sc_off, tag);
     // ---- stopping-test products (k_q_both): A u_x and A'u_y, residual sums; A'u_y is also the next solve's warm-start product ----
     double q6[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     double S13[13];
+    x_collect<13>(w, G, tot, S13);
+    if (w.dead) return;
     {
-      double va1[1][NZ], vt[1][NZ], sv13[x_rounds(13)];
-      w.site = 9; x_wait<NZ, 1, 1, 13>(w, G, ai, ti, va1, vt, sv13);
-      if (w.dead) return;
       double pri[RM];
-      x_rows<NZ, RM>(prod, ax, va1[0], na, sa, ea, pri);
-      x_rows<NZ, RN>(prod, tx, vt[0], nt, st, et, aty);
-      x_sum_scalars<13>(sv13, tot, S13);
+      {
+        double ax[NZ], va[NZ];
+        x_mat<NZ>(gA, na, ax);
+        x_gather<NZ>(pn0, ai, va);
+        x_rows<NZ, RM>(prod, flip, ax, va, na, sa, ea, pri);
+      }
+      {
+        double tx[NZ], vt[NZ];
+        x_mat<NZ>(gT, nt, tx);
+        x_gather<NZ>(pm0, ti, vt);
+        x_rows<NZ, RN>(prod, flip, tx, vt, nt, st, et, aty);
+      }
       const double tau = S13[9];
 #pragma unroll
       for (int q = 0; q < RM; ++q) {
@@ -736,13 +713,19 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       }
     }
     if (avg_stats) { // the same on the averaged iterate (its entries went out with the same exchange)
-      double va1[1][NZ], vt[1][NZ];
-      XWait w2 = w; w2.n0 = w.n1; w2.m0 = w.m1; w2.site = 20;
-      w.site = 10; x_wait<NZ, 1, 1, 0>(w2, G, ai, ti, va1, vt, dumS);
-      if (w2.dead) return;
       double pri[RM], atya[RN];
-      x_rows<NZ, RM>(prod, ax, va1[0], na, sa, ea, pri);
-      x_rows<NZ, RN>(prod, tx, vt[0], nt, st, et, atya);
+      {
+        double ax[NZ], va[NZ];
+        x_mat<NZ>(gA, na, ax);
+        x_gather<NZ>(pn1, ai, va);
+        x_rows<NZ, RM>(prod, flip, ax, va, na, sa, ea, pri);
+      }
+      {
+        double tx[NZ], vt[NZ];
+        x_mat<NZ>(gT, nt, tx);
+        x_gather<NZ>(pm1, ti, vt);
+        x_rows<NZ, RN>(prod, flip, tx, vt, nt, st, et, atya);
+      }
       const double tau = S13[11];
 #pragma unroll
       for (int q = 0; q < RM; ++q) {
@@ -765,13 +748,11 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         }
       }
     }
-    open();
-    x_pub_scalars<12>(q6, red, psc, sc_off, tag);
-    double sv12[x_rounds(12)];
-    w.site = 11; x_wait<NZ, 0, 0, 12>(w, G, ai, ti, dumA, dumT, sv12);
-    if (w.dead) return;
+    open(9);
+    x_publish<12>(q6, red, psc, sc_off, tag);
     double Q[12];
-    x_sum_scalars<12>(sv12, tot, Q);
+    x_collect<12>(w, G, tot, Q);
+    if (w.dead) return;
     // ---- finalize (d_finalize): the inner-loop exit test, iterate_Q_norm_resd abip.c:2027-2050 and the comparison of abip.c:2173 ----
     wg = S13[0]; u_tau = S13[9]; v_tau = S13[10];
     if (t == 0) {
@@ -817,6 +798,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     c->xcd_cg_total = cg_total;
     a.xstat[1] = (int)(tag - a.tag0);
   }
+  XP_DUMP
 }
 
 } // namespace abip

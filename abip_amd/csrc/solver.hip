@@ -147,7 +147,8 @@ struct XcdPlan {
   int G = abip::XG, NZ = 0, RM = 0, RN = 0;
   abip::hostutil::DBuf<int> mb, nb, xstat;
   abip::hostutil::DBuf<unsigned> tickets;
-  abip::hostutil::DBuf<abip::u32x4> xn0, xn1, xm0, xm1, sc;
+  abip::hostutil::DBuf<double> xn0, xn1, xm0, xm1;
+  abip::hostutil::DBuf<abip::u32x4> sc;
   abip::hostutil::DBuf<double> tolf, Minv;
   double *htolf = nullptr; int *hstat = nullptr; // pinned
   long ldM = 0;
@@ -834,20 +835,20 @@ void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
   x.NZ = pick->nz; x.RM = pick->rm; x.RN = pick->rn;
   x.kern = pcg ? pick->pcg : pick->direct;
   x.n_pad = (int)((w->n + 63) / 64 * 64); x.m_pad = (int)((w->m + 63) / 64 * 64);
-  size_t words = (size_t)x.NZ * XTB + XKS + XWAVES * XKS + 96;
+  size_t words = 2 * (size_t)x.NZ * XTB + XKS + XWAVES * XKS + 96;
   if (!pcg) words += (size_t)x.m_pad + (size_t)x.RM * XTB;
   x.lds = std::max<size_t>(words * sizeof(double), (size_t)XCD_LDS_MIN);
   if (x.lds > 160 * 1024) return;
   if (hipFuncSetAttribute(x.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x.lds) != hipSuccess) { (void)hipGetLastError(); return; }
-  const std::vector<int> zero2(8 + 2 * XG + 24, 0);
+  const std::vector<int> zero2(XSTAT_N, 0);
   const std::vector<unsigned> zero1(1, 0u);
   bool bad = x.mb.upload(mb, w->stream) || x.nb.upload(nb, w->stream) || x.xstat.upload(zero2, w->stream) || x.tickets.upload(zero1, w->stream) ||
              x.xn0.alloc(2 * (size_t)x.n_pad) || x.xn1.alloc(2 * (size_t)x.n_pad) || x.xm0.alloc(2 * (size_t)x.m_pad) || x.xm1.alloc(2 * (size_t)x.m_pad) ||
              x.sc.alloc(2 * (size_t)XG * XKS) || x.tolf.alloc(x.max_batch);
-  if (!bad) bad = hipMemsetAsync(x.xn0.p, 0, sizeof(u32x4) * 2 * x.n_pad, w->stream) != hipSuccess || hipMemsetAsync(x.xn1.p, 0, sizeof(u32x4) * 2 * x.n_pad, w->stream) != hipSuccess ||
-                  hipMemsetAsync(x.xm0.p, 0, sizeof(u32x4) * 2 * x.m_pad, w->stream) != hipSuccess || hipMemsetAsync(x.xm1.p, 0, sizeof(u32x4) * 2 * x.m_pad, w->stream) != hipSuccess ||
+  if (!bad) bad = hipMemsetAsync(x.xn0.p, 0, sizeof(double) * 2 * x.n_pad, w->stream) != hipSuccess || hipMemsetAsync(x.xn1.p, 0, sizeof(double) * 2 * x.n_pad, w->stream) != hipSuccess ||
+                  hipMemsetAsync(x.xm0.p, 0, sizeof(double) * 2 * x.m_pad, w->stream) != hipSuccess || hipMemsetAsync(x.xm1.p, 0, sizeof(double) * 2 * x.m_pad, w->stream) != hipSuccess ||
                   hipMemsetAsync(x.sc.p, 0, sizeof(u32x4) * 2 * XG * XKS, w->stream) != hipSuccess;
-  if (!bad) bad = hipHostMalloc((void **)&x.htolf, sizeof(double) * x.max_batch, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&x.hstat, (8 + 2 * XG + 24) * sizeof(int), hipHostMallocDefault) != hipSuccess;
+  if (!bad) bad = hipHostMalloc((void **)&x.htolf, sizeof(double) * x.max_batch, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&x.hstat, XSTAT_N * sizeof(int), hipHostMallocDefault) != hipSuccess;
   if (bad) { (void)hipGetLastError(); x.release(); return; }
   x.tag = 0; x.launches = 0;
   x.on = true;
@@ -863,9 +864,7 @@ int xcd_batch(W *w, int nb, int *ran, double *metric_out) {
   const bool pcg = (w->linsys == ABIP_HIP_LINSYS_INDIRECT);
   nb = std::min(nb, x.max_batch);
   if (x.tag > 0x70000000u) { // tags only ever grow within the life of the buffers: start over long before they wrap
-    HIP_OK(hipMemsetAsync(x.xn0.p, 0, sizeof(u32x4) * 2 * x.n_pad, w->stream)); HIP_OK(hipMemsetAsync(x.xn1.p, 0, sizeof(u32x4) * 2 * x.n_pad, w->stream));
-    HIP_OK(hipMemsetAsync(x.xm0.p, 0, sizeof(u32x4) * 2 * x.m_pad, w->stream)); HIP_OK(hipMemsetAsync(x.xm1.p, 0, sizeof(u32x4) * 2 * x.m_pad, w->stream));
-    HIP_OK(hipMemsetAsync(x.sc.p, 0, sizeof(u32x4) * 2 * XG * XKS, w->stream));
+    HIP_OK(hipMemsetAsync(x.sc.p, 0, sizeof(u32x4) * 2 * XG * XKS, w->stream)); // (only the flags carry tags)
     x.tag = 0;
   }
   XcdArgs a{};
@@ -895,7 +894,7 @@ int xcd_batch(W *w, int nb, int *ran, double *metric_out) {
   const double t_launch = now_ms();
   HIP_OK(hipLaunchKernel(x.kern, dim3(256), dim3(XTB), params, x.lds, w->stream));
   x.launches++; x.batches++;
-  HIP_OK(hipMemcpyAsync(x.hstat, x.xstat.p, (8 + 2 * XG + 24) * sizeof(int), hipMemcpyDeviceToHost, w->stream));
+  HIP_OK(hipMemcpyAsync(x.hstat, x.xstat.p, XSTAT_N * sizeof(int), hipMemcpyDeviceToHost, w->stream));
   if (sync_ctl(w)) return -1;
   if (x.hstat[0]) { fprintf(stderr, "abip_hip: after %.1f ms the one-XCD persistent launch gave up waiting for an exchange (tag %d of launch base %u, rank %d, wait site %d, thread %d; found tag %d in a granule of kind %d)\n", now_ms() - t_launch, x.hstat[2], x.tag, x.hstat[3], x.hstat[4], x.hstat[5], x.hstat[7], x.hstat[6] - 2);
     fprintf(stderr, "  exec %08x%08x ok %08x%08x nt %d na %d wave %d\n", x.hstat[81], x.hstat[80], x.hstat[83], x.hstat[82], x.hstat[84], x.hstat[85], x.hstat[86]);
@@ -912,6 +911,10 @@ int xcd_batch(W *w, int nb, int *ran, double *metric_out) {
     for (int g = 0; g < x.G; ++g) fprintf(stderr, "  rank %2d: last exchange opened %d (after wait site %d)\n", g, x.hstat[8 + 2 * g], x.hstat[9 + 2 * g]);
     return -1; }
   x.tag += (unsigned)x.hstat[1]; x.exchanges += x.hstat[1];
+#ifdef XCD_PROF
+  { static long acc[8] = {0}; for (int q = 0; q < 8; ++q) acc[q] += (unsigned)x.hstat[96 + q];
+    fprintf(stderr, "[xcd prof] cumulative us: compute+put %.0f, pub_scalars %.0f, wait %.0f, rows %.0f, sum_scalars %.0f, tail %.0f\n", acc[0] * 0.01, acc[1] * 0.01, acc[2] * 0.01, acc[3] * 0.01, acc[4] * 0.01, acc[5] * 0.01); }
+#endif
   *ran = w->hctl->it_count - w->it_seen;
   if (*ran < 1 || *ran > nb) return -1;
   take_verdict(w, metric_out);
