@@ -568,6 +568,50 @@ static __global__ __launch_bounds__(TBS) void k_ldl_small(Tri F, Tri B, const in
   if (Fuse::active) { __syncthreads(); fz.post(b, tid); }
 }
 
+// lower triangle of a symmetric T x T array -> its upper triangle (64 x 64 tiles)
+static __global__ __launch_bounds__(256) void k_dsym_fill_upper(double *M, int ld) {
+  __shared__ double t[DB][DB + 1];
+  const int bi = blockIdx.y, bj = blockIdx.x, tid = threadIdx.x;
+  if (bj > bi) return;
+  for (int e = tid; e < DB * DB; e += 256) t[e / DB][e % DB] = M[((long)bi * DB + e / DB) * ld + (long)bj * DB + e % DB];
+  __syncthreads();
+  for (int e = tid; e < DB * DB; e += 256) {
+    const int r = e / DB, c = e % DB; // entry (bj*64 + r, bi*64 + c) of the upper part = entry (bi*64 + c, bj*64 + r) of the lower one
+    if (bi != bj || c > r) M[((long)bj * DB + r) * ld + (long)bi * DB + c] = t[c][r];
+  }
+}
+
+namespace hostutil {
+// inv(S) of a symmetric positive definite T x T matrix (T % 64 == 0) given by its LOWER triangle in a device array that is overwritten; the full
+// symmetric inverse is left in `out` (T x T, row-major).  The same kernels as the dense tail of the direct back-end: blocked LDL', inverse of the
+// unit-lower factor, M = W' D^-1 W on the matrix cores.  Returns 0, or -1 (allocation failure / a zero or non-finite pivot).
+inline int dense_spd_inverse(double *S, int T, hipStream_t s, DBuf<double> &out) {
+  const int nt = T / DB;
+  DBuf<double> Linv, LD, W, Dt; DBuf<int> flag;
+  const std::vector<int> zero(1, 0);
+  auto drop = [&]() { Linv.release(); LD.release(); W.release(); Dt.release(); flag.release(); };
+  if (Linv.alloc((size_t)nt * DB * DB) || LD.alloc((size_t)T * DB) || W.alloc((size_t)T * T) || Dt.alloc(T) || flag.upload(zero, s) || out.alloc((size_t)T * T)) { drop(); return -1; }
+  if (hipMemsetAsync(W.p, 0, sizeof(double) * (size_t)T * T, s) != hipSuccess) { drop(); return -1; }
+  for (int kb = 0; kb < nt; ++kb) {
+    const int k0 = kb * DB, rem = nt - kb - 1;
+    hipLaunchKernelGGL(k_dldl_diag, dim3(1), dim3(256), 0, s, S, T, k0, Dt.p, Linv.p + (size_t)kb * DB * DB, flag.p);
+    if (rem > 0) {
+      hipLaunchKernelGGL(k_dldl_panel, dim3(rem), dim3(256), 0, s, S, T, k0, (const double *)Dt.p, (const double *)(Linv.p + (size_t)kb * DB * DB), LD.p);
+      hipLaunchKernelGGL(k_dldl_update_mfma, dim3(rem * (rem + 1) / 2), dim3(256), 0, s, S, T, k0, (const double *)LD.p);
+    }
+  }
+  for (int kb = 0; kb < nt; ++kb) hipLaunchKernelGGL(k_dtri_inv_row, dim3(kb + 1), dim3(256), 0, s, (const double *)S, T, kb, (const double *)Linv.p, W.p);
+  // S (its factor is no longer needed) takes W'
+  hipLaunchKernelGGL(k_dtranspose_lower, dim3(nt, nt), dim3(256), 0, s, (const double *)W.p, S, T);
+  hipLaunchKernelGGL(k_dgemm_mfma, dim3(nt, nt), dim3(256), 0, s, out.p, (long)T, (const double *)S, (long)T, (const double *)W.p, (long)T, T, 1.0, 2, 0, (const double *)Dt.p);
+  hipLaunchKernelGGL(k_dsym_fill_upper, dim3(nt, nt), dim3(256), 0, s, out.p, T);
+  int bad = 0;
+  const bool fail = hipMemcpyAsync(&bad, flag.p, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess;
+  drop();
+  return (fail || bad) ? -1 : 0;
+}
+} // namespace hostutil
+
 namespace hostutil {
 
 struct DevLdl {

@@ -61,6 +61,7 @@ struct XcdArgs {
   const double *h, *wD, *wE;
   const double *Mjac;                   // PCG: Jacobi preconditioner (m)
   const double *Minv; long ldM;         // direct: inv(rho I + A A'), dense row-major
+  int minv_lds_rows;                    // direct: how many of a workgroup's rows of it fit its LDS (the first ones; the others stream from the L2)
   double g_th;
   double *xn0, *xn1, *xm0, *xm1;        // exchange areas: 2 parities x (n_pad | m_pad) doubles
   u32x4 *sc;                            // 2 parities x XG x XKS granules: the partial sums = the flags
@@ -307,7 +308,8 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   double *tot = prod + 2 * NZ * XTB; // XKS
   double *red = tot + XKS;           // XWAVES * XKS
   double *outs = red + XWAVES * XKS; // 96: the finalised sums (every workgroup holds the same)
-  double *wv = outs + 96;            // direct: the whole right-hand side w (m_pad), then the products of the owned rows (RM * XTB)
+  double *wv = outs + 96;            // direct: the whole right-hand side w (m_pad), the products of the owned rows (RM * XTB), then rows of inv(rho I + A A')
+  double *mrow = wv + a.m_pad + RM * XTB;
   __shared__ int s_rank;
   const unsigned t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -395,6 +397,12 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     wg = s3[0]; u_tau = s3[1]; v_tau = s3[2];
   }
 
+  if (!PCG) { // this workgroup's first rows of the dense inverse stay in the LDS for the whole launch
+    for (unsigned rl = wave; (int)rl < a.minv_lds_rows && m0 + rl < m1; rl += XWAVES) {
+      const double *row = a.Minv + (long)(m0 + rl) * a.ldM;
+      for (unsigned c = lane; c < (unsigned)a.m_pad; c += 64) mrow[(size_t)rl * a.m_pad + c] = x_at(row, c);
+    }
+  }
   if (t < 96) outs[t] = a.ctl->out[t]; // slots this launch does not refresh keep what the last finalize left (as on the launch path)
   XP_DECL
   int ran = 0, halt = 0, last_cg = 0;
@@ -411,6 +419,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     // ---- right-hand side (k_rhs, abip.c:552-558) ----
     const double tsum = u_tau + v_tau;
     const double coef = (wg - tsum * a.g_th) / (a.g_th + 1.0);
+    if (!PCG) { XP_START }
     double rhs_y[RM], rhs_x[RN];
     double bn[1] = {0.0};
     open(2);
@@ -574,6 +583,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         x_gather<NZ>(pn0, ai, va);
         x_rows<NZ, RM>(prod, flip, ax, va, na, sa, ea, sA);
       }
+      XP_LAP(0)
       open(5);
 #pragma unroll
       for (int q = 0; q < RM; ++q) { const unsigned i = m0 + tb + q * XTB; if (i < m1) x_putd(pm0, i * 8u, rhs_y[q] + sA[q]); }
@@ -581,19 +591,34 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       x_publish<1>(dz, red, psc, sc_off, tag);
       x_collect<1>(w, G, tot, dzS);
       if (w.dead) return;
+      XP_LAP(1)
       for (unsigned i = t; i < (unsigned)a.m; i += XTB) wv[i] = x_ldd(pm0, i * 8u); // every workgroup needs the whole w
       __syncthreads();
+      XP_LAP(2)
       double *yv = wv + a.m_pad;
-      for (unsigned r = m0 + wave; r < m1; r += XWAVES) { // one wavefront per owned row
-        const double *row = a.Minv + (long)r * a.ldM;
+      for (unsigned r = m0 + wave; r < m1; r += XWAVES) { // one wavefront per owned row: the first rows from the LDS, the others from the L2 (8 loads in flight)
+        const unsigned rl = r - m0;
         double acc = 0.0;
-        for (unsigned c = lane; c < (unsigned)a.m; c += 64) acc += x_at(row, c) * wv[c];
+        if ((int)rl < a.minv_lds_rows) {
+          const double *row = mrow + (size_t)rl * a.m_pad;
+          for (unsigned c = lane; c < (unsigned)a.m; c += 64) acc += row[c] * wv[c];
+        } else {
+          const double *row = a.Minv + (long)r * a.ldM;
+          for (unsigned c0 = 0; c0 < (unsigned)a.m; c0 += 512) {
+            double mv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const unsigned c = c0 + 64u * u + lane; mv[u] = c < (unsigned)a.m ? x_at(row, c) : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const unsigned c = c0 + 64u * u + lane; if (c < (unsigned)a.m) acc += mv[u] * wv[c]; }
+          }
+        }
         acc = x_wave_sum63(acc);
-        if (lane == 63) yv[r - m0] = acc;
+        if (lane == 63) yv[rl] = acc;
       }
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < RM; ++q) { const unsigned i = m0 + tb + q * XTB; y[q] = (i < m1) ? yv[i - m0] : 0.0; }
+      XP_LAP(3)
     }
     // ---- back-substitution x = A'y - rhs_x (indirect.c:419-420) and u_t'h (abip.c:560) ----
     double dh[1] = {0.0};
@@ -625,6 +650,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     double dhS[1];
     x_collect<1>(w, G, tot, dhS);
     if (w.dead) return;
+    if (!PCG) { XP_LAP(4) }
     // ---- element-wise update (k_admm_update): barrier prox, dual update, running sums, averages, statistics ----
     Stat sst = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double tau4[4] = {0.0, 0.0, 0.0, 0.0};
@@ -748,6 +774,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         }
       }
     }
+    if (!PCG) { XP_LAP(5) }
     open(9);
     x_publish<12>(q6, red, psc, sc_off, tag);
     double Q[12];
@@ -782,6 +809,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       metric = avg_crit ? ma : mc;
     }
     ++ran;
+    if (!PCG) { XP_LAP(6) }
     if (metric < a.thr) { halt = 1; break; }
     if (a.fc.on) {
       __syncthreads(); // outs complete

@@ -152,7 +152,7 @@ struct XcdPlan {
   abip::hostutil::DBuf<double> tolf, Minv;
   double *htolf = nullptr; int *hstat = nullptr; // pinned
   long ldM = 0;
-  int n_pad = 0, m_pad = 0, max_batch = 2048;
+  int n_pad = 0, m_pad = 0, max_batch = 2048, minv_lds_rows = 0;
   unsigned tag = 0, launches = 0;
   size_t lds = 0;
   const void *kern = nullptr;
@@ -801,7 +801,8 @@ void xcd_slices(const host::HostCsr &M, int G, double alpha, std::vector<int> &b
   for (int r = 0; r < rows; ++r) *max_len = std::max(*max_len, M.ptr[r + 1] - M.ptr[r]);
 }
 // the row weight that lets the slices fit the smallest kernel variant: a thread holds NZ non-zeros and R rows, both cost registers
-void xcd_best_slices(const host::HostCsr &M, int G, std::vector<int> &bounds, long *max_nnz, int *max_rows, int *max_len) {
+void xcd_best_slices(const host::HostCsr &M, int G, std::vector<int> &bounds, long *max_nnz, int *max_rows, int *max_len, double row_cost = 0.0) {
+  if (row_cost > 0.0) { xcd_slices(M, G, row_cost, bounds, max_nnz, max_rows, max_len); return; } // (direct: a row also costs a row of the dense inverse)
   double best_cost = 1e300;
   for (double alpha : {0.0, 0.5, 1.0, 2.0, 3.0, 4.0, 6.0, 8.0, 16.0}) {
     std::vector<int> b; long nz; int rr, ll;
@@ -822,10 +823,10 @@ void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return;
   if (prop.multiProcessorCount != 256 || !strstr(prop.gcnArchName, "gfx950")) return; // 8 XCDs x 32 CUs is what the placement argument needs
   const bool pcg = (w->linsys == ABIP_HIP_LINSYS_INDIRECT);
-  if (!pcg) return; // (direct: below, once the dense inverse is there)
+  if (!pcg && (w->m > 2048 || !w->A)) return; // direct: inv(rho I + A A') is kept dense
   std::vector<int> mb, nb;
   long nzA = 0, nzT = 0; int rA = 0, rT = 0, lA = 0, lT = 0;
-  xcd_best_slices(hA, x.G, mb, &nzA, &rA, &lA);
+  xcd_best_slices(hA, x.G, mb, &nzA, &rA, &lA, pcg ? 0.0 : (double)w->m);
   xcd_best_slices(hAt, x.G, nb, &nzT, &rT, &lT);
   if (std::max(lA, lT) > 512) return; // rows are added up by one thread each
   const XcdVariant *pick = nullptr;
@@ -837,8 +838,13 @@ void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
   x.n_pad = (int)((w->n + 63) / 64 * 64); x.m_pad = (int)((w->m + 63) / 64 * 64);
   size_t words = 2 * (size_t)x.NZ * XTB + XKS + XWAVES * XKS + 96;
   if (!pcg) words += (size_t)x.m_pad + (size_t)x.RM * XTB;
+  if (words * sizeof(double) > 160 * 1024) return;
+  if (!pcg) { // what is left of the LDS keeps rows of the dense inverse
+    const size_t room = (160 * 1024 - 512) / sizeof(double) - words;
+    x.minv_lds_rows = (int)std::min<size_t>(room / (size_t)x.m_pad, (size_t)rA);
+    words += (size_t)x.minv_lds_rows * x.m_pad;
+  }
   x.lds = std::max<size_t>(words * sizeof(double), (size_t)XCD_LDS_MIN);
-  if (x.lds > 160 * 1024) return;
   if (hipFuncSetAttribute(x.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x.lds) != hipSuccess) { (void)hipGetLastError(); return; }
   const std::vector<int> zero2(XSTAT_N, 0);
   const std::vector<unsigned> zero1(1, 0u);
@@ -850,11 +856,36 @@ void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
                   hipMemsetAsync(x.sc.p, 0, sizeof(u32x4) * 2 * XG * XKS, w->stream) != hipSuccess;
   if (!bad) bad = hipHostMalloc((void **)&x.htolf, sizeof(double) * x.max_batch, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&x.hstat, XSTAT_N * sizeof(int), hipHostMallocDefault) != hipSuccess;
   if (bad) { (void)hipGetLastError(); x.release(); return; }
+  if (!pcg) { // direct: the x block (-I) eliminated first, the y block's Schur complement rho I + A A' inverted densely on the device
+    const int m = (int)w->m, T = x.m_pad;
+    std::vector<double> S((size_t)T * T, 0.0);
+    for (int i = 0; i < T; ++i) S[(size_t)i * T + i] = i < m ? w->stgs->rho_y : 1.0;
+    for (int j = 0; j < hAt.nrows; ++j) // column j of A: all pairs of its entries (rows ascending)
+      for (int p = hAt.ptr[j]; p < hAt.ptr[j + 1]; ++p)
+        for (int q = hAt.ptr[j]; q <= p; ++q) S[(size_t)hAt.idx[p] * T + hAt.idx[q]] += hAt.val[p] * hAt.val[q];
+    DBuf<double> dS;
+    if (dS.upload(S, w->stream) || dense_spd_inverse(dS.p, T, w->stream, x.Minv)) { dS.release(); (void)hipGetLastError(); x.release(); return; }
+    dS.release();
+    x.ldM = T;
+    // guard: (rho I + A A') (Minv v) against v on one pseudo-random vector (host arithmetic on the downloaded inverse)
+    std::vector<double> Mh((size_t)T * T), v, y(m, 0.0), t(hAt.nrows, 0.0), r(m, 0.0);
+    host::guard_rhs(m, v);
+    if (hipMemcpyAsync(Mh.data(), x.Minv.p, sizeof(double) * (size_t)T * T, hipMemcpyDeviceToHost, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess) { (void)hipGetLastError(); x.release(); return; }
+    for (int i = 0; i < m; ++i) { double acc = 0.0; for (int c = 0; c < m; ++c) acc += Mh[(size_t)i * T + c] * v[c]; y[i] = acc; }
+    for (int j = 0; j < hAt.nrows; ++j) { double acc = 0.0; for (int p = hAt.ptr[j]; p < hAt.ptr[j + 1]; ++p) acc += hAt.val[p] * y[hAt.idx[p]]; t[j] = acc; }
+    for (int i = 0; i < m; ++i) r[i] = w->stgs->rho_y * y[i] - v[i];
+    for (int j = 0; j < hAt.nrows; ++j) for (int p = hAt.ptr[j]; p < hAt.ptr[j + 1]; ++p) r[hAt.idx[p]] += hAt.val[p] * t[j];
+    double num = 0.0, den = 0.0;
+    for (int i = 0; i < m; ++i) { num += r[i] * r[i]; den += v[i] * v[i]; }
+    const double res = std::sqrt(num) / std::max(std::sqrt(den), 1e-300);
+    if (getenv("ABIP_HIP_XCD_VERBOSE")) printf("[xcd] dense inverse of rho I + A A' (%d x %d): residual %.2e\n", m, m, res);
+    if (!(res <= 1e-9)) { x.release(); return; }
+  }
   x.tag = 0; x.launches = 0;
   x.on = true;
   if (getenv("ABIP_HIP_XCD_VERBOSE"))
-    printf("[xcd] G %d: slices of A  <= %ld nnz, %d rows (longest row %d); of A' <= %ld nnz, %d rows (longest %d); NZ %d RM %d RN %d, LDS %zu B\n", x.G, nzA, rA, lA, nzT, rT, lT,
-           x.NZ, x.RM, x.RN, x.lds);
+    printf("[xcd] G %d: slices of A  <= %ld nnz, %d rows (longest row %d); of A' <= %ld nnz, %d rows (longest %d); NZ %d RM %d RN %d, LDS %zu B (%d rows of the dense inverse)\n", x.G, nzA, rA, lA, nzT, rT, lT,
+           x.NZ, x.RM, x.RN, x.lds, x.minv_lds_rows);
 }
 
 // Run up to nb ADMM iterations (k, j), (k+1, j+1), ... as one launch; *ran = iterations that ran (the exit test, or the final check, stops it).
@@ -874,7 +905,7 @@ int xcd_batch(W *w, int nb, int *ran, double *metric_out) {
   a.G = x.G; a.m = (int)w->m; a.n = (int)w->n; a.MP = w->MP;
   a.upd = upd_args(w, true, false, w->j);
   a.h = w->h.p; a.wD = st->normalize ? w->wD.p : nullptr; a.wE = st->normalize ? w->wE.p : nullptr;
-  a.Mjac = pcg ? w->cg_M.p : nullptr; a.Minv = x.Minv.p; a.ldM = x.ldM;
+  a.Mjac = pcg ? w->cg_M.p : nullptr; a.Minv = x.Minv.p; a.ldM = x.ldM; a.minv_lds_rows = x.minv_lds_rows;
   a.g_th = w->g_th;
   a.xn0 = x.xn0.p; a.xn1 = x.xn1.p; a.xm0 = x.xm0.p; a.xm1 = x.xm1.p; a.sc = x.sc.p; a.n_pad = x.n_pad; a.m_pad = x.m_pad;
   a.tag0 = x.tag;
@@ -913,7 +944,7 @@ int xcd_batch(W *w, int nb, int *ran, double *metric_out) {
   x.tag += (unsigned)x.hstat[1]; x.exchanges += x.hstat[1];
 #ifdef XCD_PROF
   { static long acc[8] = {0}; for (int q = 0; q < 8; ++q) acc[q] += (unsigned)x.hstat[96 + q];
-    fprintf(stderr, "[xcd prof] cumulative us: compute+put %.0f, pub_scalars %.0f, wait %.0f, rows %.0f, sum_scalars %.0f, tail %.0f\n", acc[0] * 0.01, acc[1] * 0.01, acc[2] * 0.01, acc[3] * 0.01, acc[4] * 0.01, acc[5] * 0.01); }
+    fprintf(stderr, "[xcd prof] cumulative us: %.0f %.0f %.0f %.0f %.0f %.0f %.0f (PCG loop: put, publish, collect, gather, rows, tail | direct: rhs+E1, E_w, all-gather, dense, E_y+E_dh, update+E_u, q+E_fin)\n", acc[0] * 0.01, acc[1] * 0.01, acc[2] * 0.01, acc[3] * 0.01, acc[4] * 0.01, acc[5] * 0.01, acc[6] * 0.01); }
 #endif
   *ran = w->hctl->it_count - w->it_seen;
   if (*ran < 1 || *ran > nb) return -1;
