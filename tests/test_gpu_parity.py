@@ -386,7 +386,8 @@ def _check_against_golden(S, info, z, tag, eps):
     assert info["status_val"] == g["status_val"]
     assert info["ipm_iter"] == g["ipm_iter"]
     assert abs(info["admm_iter"] - g["admm_iter"]) <= 0.03 * g["admm_iter"] + 2
-    tol = 10 * eps
+    # (a flipped inner-loop or PCG decision -- visible as a different iteration count -- moves a run stopped at eps by a few eps more)
+    tol = (10 if info["admm_iter"] == g["admm_iter"] else 30) * eps
     for k in "xys":
         assert rel(getattr(S, k), z[f"{tag}_{k}"]) < tol, (tag, k, info["admm_iter"], g["admm_iter"])
     assert abs(info["pobj"] - g["pobj"]) <= tol * (1 + abs(g["pobj"]))
