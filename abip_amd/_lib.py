@@ -13,7 +13,8 @@ c_flt = C.c_double
 PF = C.POINTER(c_flt)
 PI = C.POINTER(c_int)
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libabip_hip.so")
+# ABIP_HIP_LIBRARY: another variant of the same library (the tests' libabip_hip_hooks.so with the fault-injection hooks compiled in)
+LIB_PATH = os.environ.get("ABIP_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libabip_hip.so")
 
 
 class ABIPMatrix(C.Structure):  # src/abip-lp/linsys/amatrix.h:10-17
@@ -50,13 +51,13 @@ class ABIPInfo(C.Structure):  # src/abip-lp/include/abip.h:88-105
                 ("res_infeas", c_flt), ("res_unbdd", c_flt), ("setup_time", c_flt), ("solve_time", c_flt)]
 
 
-K_CLASSES = ("spmv_At", "spmv_A", "cg_vec", "sptrsv", "vec", "qnorm", "cg_edge")  # include/abip_hip.h ABIP_HIP_K_*
+K_CLASSES = ("spmv_At", "spmv_A", "cg_vec", "sptrsv", "vec", "qnorm", "cg_edge", "xcd")  # include/abip_hip.h ABIP_HIP_K_*
 
 
 class AbipHipProfile(C.Structure):
-    _fields_ = [("ms", C.c_double * 7), ("launches", C.c_long * 7), ("noop_ms", C.c_double), ("noop_launches", C.c_long),
+    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_long * 8), ("noop_ms", C.c_double), ("noop_launches", C.c_long),
                 ("admm_iters", C.c_long), ("cg_iters", C.c_long), ("kkt_solves", C.c_long),
-                ("stamp_ms", C.c_double * 7), ("stamp_launches", C.c_long * 7), ("stamp_noop_launches", C.c_long)]
+                ("stamp_ms", C.c_double * 8), ("stamp_launches", C.c_long * 8), ("stamp_noop_launches", C.c_long)]
 
 
 # every symbol include/abip.h and include/abip_hip.h declare
@@ -68,7 +69,7 @@ EXPORTS = (
     "abip_hip_get_scalar", "abip_hip_profile_enable", "abip_hip_profile_read", "abip_hip_sync",
     "abip_hip_dist_get_unique_id", "abip_hip_dist_init_rccl", "abip_hip_dist_init_callback", "abip_hip_dist_finalize",
     "abip_hip_dist_partition", "abip_hip_dist_rows", "abip_hip_host_factor_solve", "abip_hip_host_normalize_A",
-    "abip_hip_dist_comm_count", "abip_hip_profile_enable_stamps", "abip_hip_set_copy_a_matrix",
+    "abip_hip_dist_comm_count", "abip_hip_profile_enable_stamps", "abip_hip_set_copy_a_matrix", "abip_hip_get_copy_a_matrix",
     "abip_qcp", "abip_qcp_set_default_settings", "abip_hip_qcp_last_stats", "abip_hip_qcp_cone_prox", "abip_hip_qcp_dist_partition", "abip_hip_qcp_host_probe",
 )
 

@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -74,8 +75,10 @@ ABIPLinSysWork *abip_init_lin_sys_work(const ABIPMatrix *A, const ABIPSettings *
   ABIPData d{};
   d.m = A->m; d.n = A->n; d.A = const_cast<ABIPMatrix *>(A); d.b = zb.data(); d.c = zc.data(); d.sp = 0.0; d.stgs = &p->stgs;
   ABIPInfo info{};
+  const int copy_before = abip_hip_get_copy_a_matrix();
   abip_hip_set_copy_a_matrix(1); // the caller's A is const here
   p->w = abip_init(&d, &info);
+  abip_hip_set_copy_a_matrix(copy_before); // (a process-wide switch: leave it as the host program had it)
   if (!p->w) { delete p; return nullptr; }
   return p;
 }
@@ -90,11 +93,19 @@ abip_int abip_solve_lin_sys(const ABIPMatrix *, const ABIPSettings *, ABIPLinSys
   return 0;
 }
 
-void abip_accum_by_Atrans(const ABIPMatrix *, ABIPLinSysWork *p, const abip_float *x, abip_float *y) {
-  if (!p || !p->w || abip_hip_accum_by_Atrans(p->w, x, y) != 0) { fprintf(stderr, "abip_hip linsys plug-in: accum_by_Atrans failed on the device\n"); abort(); } // the interface has no error channel
+// The interface has no error channel.  A device failure fills y with NaN: the reference's own loop then reports "Failure" through its
+// NaN handling (abip.c:219-277) instead of the host process (Matlab) being killed.
+void abip_accum_by_Atrans(const ABIPMatrix *A, ABIPLinSysWork *p, const abip_float *x, abip_float *y) {
+  if (!p || !p->w || abip_hip_accum_by_Atrans(p->w, x, y) != 0) {
+    fprintf(stderr, "abip_hip linsys plug-in: accum_by_Atrans failed on the device\n");
+    if (A && y) for (abip_int j = 0; j < A->n; ++j) y[j] = NAN;
+  }
 }
-void abip_accum_by_A(const ABIPMatrix *, ABIPLinSysWork *p, const abip_float *x, abip_float *y) {
-  if (!p || !p->w || abip_hip_accum_by_A(p->w, x, y) != 0) { fprintf(stderr, "abip_hip linsys plug-in: accum_by_A failed on the device\n"); abort(); }
+void abip_accum_by_A(const ABIPMatrix *A, ABIPLinSysWork *p, const abip_float *x, abip_float *y) {
+  if (!p || !p->w || abip_hip_accum_by_A(p->w, x, y) != 0) {
+    fprintf(stderr, "abip_hip linsys plug-in: accum_by_A failed on the device\n");
+    if (A && y) for (abip_int i = 0; i < A->m; ++i) y[i] = NAN;
+  }
 }
 
 void abip_normalize_A(ABIPMatrix *A, const ABIPSettings *stgs, ABIPScaling *scal) { // ABIP(_normalize_A), linsys/common.c:150-565
@@ -102,8 +113,9 @@ void abip_normalize_A(ABIPMatrix *A, const ABIPSettings *stgs, ABIPScaling *scal
   abip::host::normalize_A(A, stgs, D, E, &scal->mean_norm_row_A, &scal->mean_norm_col_A);
   scal->D = (abip_float *)g_alloc(sizeof(abip_float) * D.size());
   scal->E = (abip_float *)g_alloc(sizeof(abip_float) * E.size());
-  if (scal->D) memcpy(scal->D, D.data(), sizeof(abip_float) * D.size());
-  if (scal->E) memcpy(scal->E, E.data(), sizeof(abip_float) * E.size());
+  if (!scal->D || !scal->E) { fprintf(stderr, "abip_hip linsys plug-in: the allocator returned NULL for the scaling vectors\n"); abort(); } // the caller dereferences them unconditionally (abip.c)
+  memcpy(scal->D, D.data(), sizeof(abip_float) * D.size());
+  memcpy(scal->E, E.data(), sizeof(abip_float) * E.size());
 }
 void abip_un_normalize_A(ABIPMatrix *A, const ABIPSettings *stgs, const ABIPScaling *scal) { // linsys/common.c:569-594
   const std::vector<double> D(scal->D, scal->D + A->m), E(scal->E, scal->E + A->n);

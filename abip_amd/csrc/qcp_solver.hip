@@ -610,7 +610,10 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
         w->ldl.enqueue([&](auto kern, int grid, int block, size_t lds, auto... a) { hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, w->stream, a...); }, tmp.p, (const Ctl *)w->lp_ctl, w->NB);
         if (hipMemcpyAsync(lv.data(), tmp.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream) == hipSuccess && hipStreamSynchronize(w->stream) == hipSuccess) {
           for (int i = 0; i < N; ++i) z[i] = lv[i < m ? i : w->MP + (i - m)];
-          out = (getenv("ABIP_HIP_TAIL_RESID_FAIL") && F.T > 0) ? 1.0 : host::sym_upper_residual(N, Kp, Ki, Kx, z, rhs);
+          out = host::sym_upper_residual(N, Kp, Ki, Kx, z, rhs);
+#ifdef ABIP_HIP_TEST_HOOKS
+          if (getenv("ABIP_HIP_TAIL_RESID_FAIL") && F.T > 0) out = 1.0; // pretend the tail is too ill-conditioned for its explicit inverse
+#endif
         }
       }
       tmp.release();

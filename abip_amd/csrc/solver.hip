@@ -923,7 +923,15 @@ int xcd_batch(W *w, int nb, int *ran, double *metric_out) {
   }
   void *params[] = {&a};
   const double t_launch = now_ms();
+  W::Ev *ev = nullptr;
+  if ((w->prof_mask >> ABIP_HIP_K_XCD) & 1u) {
+    if (w->ev_used == w->ev_pool.size()) { W::Ev e; e.cls = ABIP_HIP_K_XCD; (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); w->ev_pool.push_back(e); }
+    ev = &w->ev_pool[w->ev_used++];
+    ev->cls = ABIP_HIP_K_XCD; ev->tag = -1;
+    (void)hipEventRecord(ev->a, w->stream);
+  }
   HIP_OK(hipLaunchKernel(x.kern, dim3(256), dim3(XTB), params, x.lds, w->stream));
+  if (ev) (void)hipEventRecord(ev->b, w->stream);
   x.launches++; x.batches++;
   HIP_OK(hipMemcpyAsync(x.hstat, x.xstat.p, XSTAT_N * sizeof(int), hipMemcpyDeviceToHost, w->stream));
   if (sync_ctl(w)) return -1;
@@ -1322,7 +1330,8 @@ extern "C" {
 const char *abip_version(void) { return ABIP_VERSION; }
 
 void abip_hip_set_linsys(int which) { g_linsys = which ? ABIP_HIP_LINSYS_INDIRECT : ABIP_HIP_LINSYS_DIRECT; }
-void abip_hip_set_copy_a_matrix(int on) { g_copy_a = on ? 1 : 0; }
+void abip_hip_set_copy_a_matrix(int on) { g_copy_a = on < 0 ? -1 : (on ? 1 : 0); } // < 0: back to the environment / default
+int abip_hip_get_copy_a_matrix(void) { return g_copy_a; } // -1: not set by the program
 int abip_hip_get_linsys(void) { return chosen_linsys(); }
 
 int abip_hip_device_info(char *name, int name_len, long *total_mem_bytes, int *num_cu) {
@@ -1510,7 +1519,9 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
       w->ldl.enqueue([&](auto kern, int grid, int block, size_t lds, auto... a) { launch_lds(w, ABIP_HIP_K_SPTRSV, kern, grid, block, lds, a...); }, w->a_ut.p, (const Ctl *)w->ctl.p, w->NB);
       if (hipMemcpyAsync(lv.data(), w->a_ut.p, sizeof(double) * w->LV, hipMemcpyDeviceToHost, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess) return 1e300;
       for (int i = 0; i < N; ++i) z[i] = lv[i < (int)m ? i : w->MP + (i - (int)m)];
-      if (getenv("ABIP_HIP_TAIL_RESID_FAIL") && F.T > 0) return 1.0; // test hook: pretend the tail is too ill-conditioned for inv(L22)
+#ifdef ABIP_HIP_TEST_HOOKS
+      if (getenv("ABIP_HIP_TAIL_RESID_FAIL") && F.T > 0) return 1.0; // pretend the tail is too ill-conditioned for inv(L22)
+#endif
       return host::sym_upper_residual(N, Kp, Ki, Kx, z, rhs);
     };
     constexpr double kGuardTol = 1e-8; // healthy factors sit at 1e-16 ... 1e-11

@@ -166,10 +166,30 @@ def cpu_baseline(A, b, c, linsys, budget_s=12.0, window=None):
 # ---------------------------------------------------------------------------------------------------------
 # the conic workload
 # ---------------------------------------------------------------------------------------------------------
+def pmc_traffic(case):
+    """Per-kernel HBM traffic of the committed counter passes (scripts/r03_pmc.sh -> profiles/r03_pmc_traffic.json), or {}."""
+    f = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    try:
+        return json.load(open(f)).get(case, {})
+    except Exception:  # noqa: BLE001
+        return {}
+
+
 def bench_c5(args, rank, world, dist, torch):
+    rec = run_conic(args.workload, args.linsys, args.no_cpu, rank, world, dist, torch)
+    if rank == 0:
+        emit(rec)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_conic(workload, linsys, no_cpu, rank, world, dist, torch):
     """BASELINE configs[4]: the conic path on LASSO-as-SOCP.  The direct back-end does not shard: N > 1 = N replicas."""
     import numpy as np
     from abip_amd import problems, qcp
+    class args:  # (the body below was written against the command line)
+        pass
+    args.workload, args.linsys, args.no_cpu = workload, linsys, no_cpu
     ml = args.workload == "lasso"                         # the reference's own LASSO benchmark through the LASSO front end (abip_ml, prob_type 0)
     if ml:
         p, d = 5000, 15000                                # the largest size of scripts/bench-qcp/test_lasso.m:39-40
@@ -213,20 +233,35 @@ def bench_c5(args, rank, world, dist, torch):
     steps = int(info["admm_iter"])
     f = info["factor"]
     N, lnnz, T = f["N"], f["lnnz"], f["dense_tail"]
-    bytes_solve = 2 * (12 * lnnz + 4 * (N + 1) + 16 * N) + 24 * N + 2 * 20 * N      # SURVEY.md 8(d) B_solve_direct
+    bytes_solve = 2 * (12 * lnnz + 4 * (N + 1) + 16 * N) + 24 * N + 2 * 20 * N      # SURVEY.md 8(d) B_solve_direct: what the REFERENCE's algorithm would stream
     avg_ms = f["solve_ms_total"] / max(f["solves_timed"], 1)
-    ach = bytes_solve / (avg_ms * 1e-3) / 1e9
-    roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+    # what THIS back-end streams per solve: the dense tail (one symmetric mat-vec: the lower triangle of inv(S) once + its two partial tables, written and read;
+    # or inv(L22) and its transpose), the head's level streams forward and backward (12 bytes per non-zero each), the permuted vectors
+    ncc, ntile = (T + 511) // 512, T // 64
+    tail_bytes = (4 * T * (T + 1) + 2 * 8 * (ncc + ntile) * T) if tail_sym(T) else 8 * T * (T + 1)
+    streamed = tail_bytes + 2 * 12 * f["head_nnz"] + 2 * 20 * N
+    ach = streamed / (avg_ms * 1e-3) / 1e9
+    tr = pmc_traffic("c5_direct") if not ml else {}
+    traffic = (tr["k_tail_sym"]["traffic_bytes"] + tr.get("k_tail_sym_fin", {}).get("traffic_bytes", 0) + 2 * tr.get("k_tri_wide", {}).get("traffic_bytes", 0)) if "k_tail_sym" in tr else None
+    roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic,
+                traffic_source="profiles/r03_pmc_traffic.json: k_tail_sym + k_tail_sym_fin + 2 k_tri_wide per solve (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
+                effective_frac=bytes_solve / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                explanation="achieved / frac count the bytes this back-end streams per KKT solve; effective_frac prices the same time against SURVEY 8(d)'s B_solve_direct "
+                            "(the two triangular sweeps of the reference's algorithm): the symmetric tail halves the bytes, so the effective figure can exceed the real one",
                 kernel="KKT solve of the conic projection: k_perm_in, k_tri_wide (L21 stream), the dense tail (T >= 2048: k_tail_sym + k_tail_sym_fin, the lower triangle of "
                        "inv(S) streamed once; else k_tail_mv x2 on inv(L22), inv(L22)'), k_tri_wide, k_perm_out",
-                avg_launch_us=avg_ms * 1e3, launches=f["solves_timed"], algorithmic_bytes_per_launch=bytes_solve, lnnz=lnnz, dense_tail=T,
-                streamed_bytes_per_solve=(4 if tail_sym(T) else 8) * T * (T + 1) + 12 * f["head_nnz"], levels=f["levels"])
+                avg_launch_us=avg_ms * 1e3, launches=f["solves_timed"], algorithmic_bytes_per_launch=streamed, reference_algorithm_bytes_per_solve=bytes_solve, lnnz=lnnz, dense_tail=T,
+                streamed_bytes_per_solve=streamed, levels=f["levels"])
     if pcg:   # one solve = prep + (warm set-up pair) + avg_cg_iters x (A'z, A tn, update) + back-substitution: 2 + 2 + 2 cg + 1 products of the matrix
         nnzA, mA, nA = nnz_op, m_op, n_op
         cg = float(info["avg_cg_iters"])
         bytes_solve = (3 + 2 * cg + 2) * (b_spmv(mA, nA, nnzA) + b_spmv(nA, mA, nnzA)) / 2 + cg * 8 * 8 * mA
         ach = bytes_solve / max(avg_ms * 1e-3, 1e-12) / 1e9
-        roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+        tr = pmc_traffic("lasso_pcg" if ml else "c5_pcg")
+        ka = "kq_pcg_Aty_lds" if "kq_pcg_Aty_lds" in tr else "kq_pcg_Aty"
+        traffic = int((cg + 2.5) * (tr[ka]["traffic_bytes"] + tr["kq_pcg_Gp"]["traffic_bytes"]) + cg * tr.get("kq_pcg_update", {}).get("traffic_bytes", 0)) if ka in tr and "kq_pcg_Gp" in tr else None
+        roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic,
+                    traffic_source=f"profiles/r03_pmc_traffic.json: (cg + 2.5) x ({ka} + kq_pcg_Gp) + cg x kq_pcg_update per solve" if traffic else None,
                     kernel="KKT solve of the conic projection by y-space PCG: kq_pcg_prep, kq_pcg_Aty/_Gp (set-up), {kq_pcg_Aty (m-vector in LDS where it fits: kq_pcg_Aty_lds), kq_pcg_Gp, kq_pcg_update} x cg, kq_pcg_post; one host round trip per solve",
                     avg_launch_us=avg_ms * 1e3, launches=f["solves_timed"], algorithmic_bytes_per_launch=bytes_solve, avg_cg_iters=cg)
     cpu = None
@@ -251,7 +286,7 @@ def bench_c5(args, rank, world, dist, torch):
         beta = sol["x"] if ml else sol["x"][p + 2:p + 2 + d] - sol["x"][p + 2 + d:]
         wl = (f"LASSO {p} x {d}, density 0.15 (scripts/bench-qcp/test_lasso.m largest size) through the LASSO front end (prob_type 0): conic n={n_op}, m={m_op}, K.rq=[{p + 2}], K.l={2 * d}; "
               if ml else f"LASSO-as-SOCP p={p} d={d} density 0.005 (BASELINE configs[4]): n={p + 2 + 2 * d}, m={p + 1}, K.q=[{p + 2}], K.l={2 * d}; conic path, ")
-        emit(({
+        return ({
             "metric": "ADMM iterations/s", "value": (steps if sharded else world * steps) / elapsed, "unit": "ADMM iterations/s", "n_gpus": world, "steps": steps, "warmup": int(info0["admm_iter"]),
             "ms_per_step": 1e3 * elapsed / max(steps, 1), "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl + ("y-space PCG" if pcg else "direct LDL'"),
@@ -263,9 +298,8 @@ def bench_c5(args, rank, world, dist, torch):
             "time_to_tol": dict(seconds=info["runtime"], setup_s=info["setup_time"], solve_s=info["solve_time"], status=info["status"], admm_iter=steps,
                                 ipm_iter=info["ipm_iter"], res_pri=info["res_pri"], res_dual=info["res_dual"], rel_gap=info["gap"]),
             "extra": {"nnz": nnz_op, "nonzero_coefficients": int(np.sum(np.abs(beta) > 1e-6)), "pobj": info["pobj"]},
-        }))
-    if dist is not None:
-        dist.destroy_process_group()
+        })
+    return None
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -288,10 +322,13 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
     sharded = sharded and linsys == "indirect"
 
     S = Solver(A, b, c, linsys=linsys, eps=1e-6, verbose=0)
+    xcd = S.scalar("xcd") == 1.0       # cache-resident LP: the inner loop runs as the one-XCD persistent launch (abip_amd/csrc/dev_xcd.h)
     S.begin()
     fin, done_w = S.step(warmup)
     S.sync()
-    if linsys == "indirect":
+    if xcd:
+        S.profile_enable(("xcd",))                        # two event records per launch of up to 2048 iterations: stays on in the timed region
+    elif linsys == "indirect":
         S.profile_enable_stamps(("spmv_At", "spmv_A"))    # device-side begin/end ticks, no event records: stays on in the timed region
     elif args.events_in_timed_region:
         S.profile_enable(("sptrsv",))
@@ -314,7 +351,7 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         elapsed = float(t.item())
     prof = S.profile_read(reset=True)
     events_pass = None
-    if linsys == "direct" and not args.events_in_timed_region and not fin:
+    if linsys == "direct" and not xcd and not args.events_in_timed_region and not fin:
         # direct back-end: a solve is several launches; bracket them with hipEvents in a second pass of the same length
         # (two event records per launch cost ~20 % of wall time on this launch-dense path, so they are kept out of `value`)
         S.profile_enable(("sptrsv",))
@@ -333,7 +370,27 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
     row0, row1 = S.rows()
 
     roof = None
-    if linsys == "indirect":
+    l = m + n + 1
+    cg_step = prof["cg_iters"] / max(prof["admm_iters"], 1)
+    if xcd:
+        # SURVEY.md 8(d), per inner iteration: PCG  cg (2 B_spmv + vectors) + 4 B_spmv + vectors;  direct  B_solve of this back-end = the dense
+        # inverse of rho I + A A' (8 m^2) + the two products around it, + 2 B_spmv of the stopping test + vectors
+        b_cg = b_spmv(n, m, nnz) + b_spmv(m, n, nnz) + 8 * (21 * m + n)
+        b_vec = 8 * (37 * l + 8 * m + 19 * n)
+        b_iter = (cg_step * b_cg + 4 * b_spmv(m, n, nnz) + b_vec) if linsys == "indirect" else (8 * m * m + 4 * b_spmv(m, n, nnz) + b_vec)
+        nl = max(prof["launches"]["xcd"], 1)
+        its = max(prof["admm_iters"], 1)
+        ms = prof["ms"]["xcd"]
+        ach = b_iter * its / max(ms * 1e-3, 1e-12) / 1e9
+        exch = (2 * cg_step + 6) if linsys == "indirect" else 6.0
+        roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+                    kernel="k_lp_xcd: the whole inner ADMM loop as one persistent launch on the 32 CUs of one XCD (slices of A and A' per workgroup, operands handed "
+                           "over through the XCD's L2: stores, acknowledged, partial-sum granules as flags, L1-bypassing gathers); bound by the latency of "
+                           "its exchanges (and, beyond ~1e5 non-zeros, by the L2's request rate: one request per gathered non-zero), not by HBM",
+                    avg_launch_us=1e3 * ms / nl, launches=nl, iterations_per_launch=its / nl, algorithmic_bytes_per_launch=b_iter * its / nl,
+                    algorithmic_bytes_per_iteration=b_iter, us_per_iteration=1e3 * ms / its, exchanges_per_iteration=exch, us_per_exchange=1e3 * ms / its / exch,
+                    timing="hipEvents around every launch inside the timed region")
+    elif linsys == "indirect":
         m_loc = row1 - row0
         nnz_loc = nnz // world if sharded else nnz
         cand = {"spmv_At": (b_spmv(n, m_loc, nnz_loc), "k_cg_spmv_At / k_spmv_set_t (tmp = A'(z + beta p), CSC gather over n rows)"),
@@ -370,10 +427,9 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
                     dense_tail=T, dense_tail_bytes_per_solve=8 * T * (T + 1), levels=[int(S.scalar("levels_fwd")), int(S.scalar("levels_bwd"))],
                     timing="hipEvents around the solve's launches in a second pass of the same length" if events_pass else "hipEvents in the timed region")
 
-    extra = dict(cg_iters_per_step=prof["cg_iters"] / max(prof["admm_iters"], 1), events_pass=events_pass, m=m, n=n, nnz=int(nnz), rows=[int(row0), int(row1)])
+    extra = dict(cg_iters_per_step=cg_step, events_pass=events_pass, m=m, n=n, nnz=int(nnz), rows=[int(row0), int(row1)], one_xcd_launch=bool(xcd))
     if linsys == "indirect":
         cg = extra["cg_iters_per_step"]
-        l = m + n + 1
         b_cg = b_spmv(n, m, nnz) + b_spmv(m, n, nnz) + 8 * (21 * m + n)
         b_vec = 8 * (37 * l + 8 * m + 19 * n)
         b_iter = cg * b_cg + 4 * b_spmv(m, n, nnz) + b_vec            # SURVEY.md 8(d) "Indirect"
@@ -485,6 +541,13 @@ def main():
             for nm, k_, w_ in (("c2", 2000, 200), ("c3", 300, 50)):
                 r = run_lp(nm, k_, w_, args, 0, 1, None, torch, False, to_tol=not args.no_to_tol, cpu=not args.no_cpu, cpu_budget=4.0)
                 sub[nm] = {k: r[k] for k in ("value", "value_whole_solve", "ms_per_step", "steps", "warmup", "config", "roofline", "cpu_baseline", "time_to_tol", "extra") if k in r}
+            # BASELINE configs[4] (both conic back-ends) and the reference's own LASSO protocol: whole solves at eps 1e-3, seconds each
+            for nm, wl_, ls_ in (("c5_direct", "c5", "direct"), ("c5_pcg", "c5", "indirect"), ("lasso", "lasso", None)):
+                try:
+                    r = run_conic(wl_, ls_, args.no_cpu, 0, 1, None, torch)
+                    sub[nm] = {k: r[k] for k in ("value", "ms_per_step", "steps", "config", "roofline", "cpu_baseline", "time_to_tol", "extra")}
+                except Exception as e:  # noqa: BLE001 -- a conic record must not cost the line its LP numbers
+                    sub[nm] = dict(error=repr(e))
             rec["extra"]["configs"] = sub
         if rank == 0:
             emit(rec)

@@ -187,7 +187,8 @@ int abip_hip_get_linsys(void);
  * on = 1 (default, also ABIP_HIP_COPYAMATRIX unset): abip_init scales a private copy of A's values; the caller's matrix is never written
  *          (what the reference's mex build does -- Matlab owns A).
  * on = 0 (or ABIP_HIP_COPYAMATRIX=0): A is scaled in place and un-scaled by abip_finish (abip.c:2310-2317), like the plain C build. */
-void abip_hip_set_copy_a_matrix(int on);
+void abip_hip_set_copy_a_matrix(int on); /* 1 copy (default), 0 scale the caller's A in place, < 0 back to ABIP_HIP_COPYAMATRIX / the default */
+int abip_hip_get_copy_a_matrix(void);    /* what the program set: 1, 0, or -1 if it set nothing */
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

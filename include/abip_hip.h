@@ -108,7 +108,8 @@ void abip_hip_dist_rows(ABIPWork *w, abip_int *row0, abip_int *row1);
 #define ABIP_HIP_K_VEC 4       /* fused rhs / barrier prox / dual / averages passes, finalize */
 #define ABIP_HIP_K_QNORM 5     /* residual SpMV pair + reductions */
 #define ABIP_HIP_K_CG_EDGE 6   /* PCG set-up and back-substitution SpMVs (k_cg_init_At/_A, k_post_At) */
-#define ABIP_HIP_K_CLASSES 7
+#define ABIP_HIP_K_XCD 7       /* k_lp_xcd: the whole inner loop of a cache-resident LP as one persistent launch on one XCD (one "launch" = up to 2048 iterations) */
+#define ABIP_HIP_K_CLASSES 8
 typedef struct {
   double ms[ABIP_HIP_K_CLASSES];     /* summed device time per class, milliseconds (launches that did work) */
   long launches[ABIP_HIP_K_CLASSES]; /* launches per class that did work */

@@ -26,6 +26,28 @@ def gpu():
     return abip_amd
 
 
+def run_with_hooks(body: str, env: dict):
+    """The fault-injection hooks (ABIP_HIP_*_FAIL) exist only in libabip_hip_hooks.so (built -DABIP_HIP_TEST_HOOKS); the shipped library ignores the
+    variables.  A library is bound once per process, so the body runs in a child interpreter that loads the hooks variant (ABIP_HIP_LIBRARY)."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    e["ABIP_HIP_LIBRARY"] = os.path.join(root, "abip_amd", "lib", "libabip_hip_hooks.so")
+    pre = textwrap.dedent(f"""
+        import sys
+        sys.path[:0] = [{root!r}, {os.path.join(root, 'tests')!r}]
+        import numpy as np, scipy.sparse as sp
+        import abip_amd as gpu
+        from _golden import load, rel
+        def kkt_matrix(Asc, rho):
+            m, n = Asc.shape
+            return sp.bmat([[rho * sp.identity(m), Asc], [Asc.T, -sp.identity(n)]], format="csc")
+        """)
+    r = subprocess.run([sys.executable, "-c", pre + textwrap.dedent(body)], env=e, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def kkt_matrix(Asc, rho):
     m, n = Asc.shape
     return sp.bmat([[rho * sp.identity(m), Asc], [Asc.T, -sp.identity(n)]], format="csc")
@@ -114,18 +136,18 @@ def test_symmetric_tail_self_check_keeps_the_two_matvecs(gpu, monkeypatch):
     """Before W and W' are released the set-up compares M v with W' D2^-1 W v (dev_ldl.h); a difference above 1e-9 (forced by the hook) keeps the two triangular
     mat-vecs.  On this LP their residual is < 1e-11 where the explicit inverse of S gives ~6e-11: the bound below shows which form answered."""
     monkeypatch.delenv("ABIP_HIP_TAIL", raising=False)
-    monkeypatch.setenv("ABIP_HIP_TAIL_SYM", "1")
-    monkeypatch.setenv("ABIP_HIP_TAIL_SYM_FAIL", "1")
-    z, A, b, c = load("lp_staircase")
-    rng = np.random.default_rng(17)
-    with gpu.Solver(A, b, c, linsys="direct", verbose=0, max_admm_iters=50) as S:
-        assert int(S.scalar("tail")) >= 256
-        Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
-        K = kkt_matrix(Asc, 1e-3)
-        for _ in range(3):
-            rhs = rng.standard_normal(S.m + S.n)
-            sol, _ = S.kkt_solve(rhs, None, -1)
-            assert rel(K @ sol, rhs) < 1e-11
+    run_with_hooks("""
+        z, A, b, c = load("lp_staircase")
+        rng = np.random.default_rng(17)
+        with gpu.Solver(A, b, c, linsys="direct", verbose=0, max_admm_iters=50) as S:
+            assert int(S.scalar("tail")) >= 256
+            Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
+            K = kkt_matrix(Asc, 1e-3)
+            for _ in range(3):
+                rhs = rng.standard_normal(S.m + S.n)
+                sol, _ = S.kkt_solve(rhs, None, -1)
+                assert rel(K @ sol, rhs) < 1e-11
+        """, {"ABIP_HIP_TAIL_SYM": "1", "ABIP_HIP_TAIL_SYM_FAIL": "1", "ABIP_HIP_XCD": "0"})
 
 
 @pytest.mark.parametrize("tail", ["128", "512", "auto"])
@@ -269,15 +291,16 @@ def test_dense_tail_failure_falls_back_to_the_level_scheduled_factor(gpu, monkey
     """If the dense tail cannot be set up (no room for the two T x T triangles, a pivot the dense LDL' cannot take) abip_init
     re-factors without it instead of failing."""
     monkeypatch.delenv("ABIP_HIP_TAIL", raising=False)
-    monkeypatch.setenv("ABIP_HIP_TAIL_FAIL", "1")
-    z, A, b, c = load("lp_staircase")
-    rng = np.random.default_rng(2)
-    with gpu.Solver(A, b, c, linsys="direct", verbose=0, max_admm_iters=50) as S:
-        assert S.scalar("tail") == 0 and S.scalar("levels_fwd") > 100
-        Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
-        rhs = rng.standard_normal(S.m + S.n)
-        sol, its = S.kkt_solve(rhs, None, -1)
-        assert rel(kkt_matrix(Asc, 1e-3) @ sol, rhs) < 1e-11
+    run_with_hooks("""
+        z, A, b, c = load("lp_staircase")
+        rng = np.random.default_rng(2)
+        with gpu.Solver(A, b, c, linsys="direct", verbose=0, max_admm_iters=50) as S:
+            assert S.scalar("tail") == 0 and S.scalar("levels_fwd") > 100
+            Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
+            rhs = rng.standard_normal(S.m + S.n)
+            sol, its = S.kkt_solve(rhs, None, -1)
+            assert rel(kkt_matrix(Asc, 1e-3) @ sol, rhs) < 1e-11
+        """, {"ABIP_HIP_TAIL_FAIL": "1"})
 
 
 def test_tail_residual_guard_falls_back(gpu, monkeypatch):
@@ -287,14 +310,19 @@ def test_tail_residual_guard_falls_back(gpu, monkeypatch):
     z, A, b, c = load("lp_staircase")
     with gpu.Solver(A, b, c, linsys="direct", verbose=0, max_admm_iters=50) as S:
         assert S.scalar("tail") > 0 and 0 <= S.scalar("factor_resid") < 1e-10
-    monkeypatch.setenv("ABIP_HIP_TAIL_RESID_FAIL", "1")
-    rng = np.random.default_rng(2)
+    monkeypatch.setenv("ABIP_HIP_TAIL_RESID_FAIL", "1")     # the shipped library ignores the hook ...
     with gpu.Solver(A, b, c, linsys="direct", verbose=0, max_admm_iters=50) as S:
-        assert S.scalar("tail") == 0 and S.scalar("levels_fwd") > 100 and 0 <= S.scalar("factor_resid") < 1e-10
-        Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
-        rhs = rng.standard_normal(S.m + S.n)
-        sol, its = S.kkt_solve(rhs, None, -1)
-        assert rel(kkt_matrix(Asc, 1e-3) @ sol, rhs) < 1e-11
+        assert S.scalar("tail") > 0
+    run_with_hooks("""
+        z, A, b, c = load("lp_staircase")
+        rng = np.random.default_rng(2)
+        with gpu.Solver(A, b, c, linsys="direct", verbose=0, max_admm_iters=50) as S:
+            assert S.scalar("tail") == 0 and S.scalar("levels_fwd") > 100 and 0 <= S.scalar("factor_resid") < 1e-10
+            Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
+            rhs = rng.standard_normal(S.m + S.n)
+            sol, its = S.kkt_solve(rhs, None, -1)
+            assert rel(kkt_matrix(Asc, 1e-3) @ sol, rhs) < 1e-11
+        """, {"ABIP_HIP_TAIL_RESID_FAIL": "1"})                # ... the tests' variant takes it
 
 
 def test_direct_solve_wide_head_with_tail(gpu):

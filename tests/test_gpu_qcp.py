@@ -124,14 +124,29 @@ def test_conic_api_dispatch(gpu):
 
 
 def test_conic_tail_residual_guard(gpu, monkeypatch):
-    """The set-up guard of the conic KKT factor: with the check forced to fail the dense tail is dropped and the solve still follows."""
+    """The set-up guard of the conic KKT factor: with the check forced to fail (the fault-injection hook lives only in libabip_hip_hooks.so, so the
+    forced run happens in a child interpreter bound to that variant) the dense tail is dropped and the solve still follows."""
+    import os, subprocess, sys, textwrap, json
     data, K = lasso_socp(400, 1500, 3, density=0.02)
     sol0, i0 = gpu.abip_qcp(data, K, eps_all(1e-5))
     assert i0["factor"]["dense_tail"] > 0
-    monkeypatch.setenv("ABIP_HIP_TAIL_RESID_FAIL", "1")
-    sol1, i1 = gpu.abip_qcp(data, K, eps_all(1e-5))
-    assert i1["factor"]["dense_tail"] == 0 and i1["status"] == i0["status"] == "Solved" and i1["ipm_iter"] == i0["ipm_iter"]
-    assert rel(sol1["x"], sol0["x"]) < 1e-4 and abs(i1["pobj"] - i0["pobj"]) < 1e-5 * (1 + abs(i0["pobj"]))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, ABIP_HIP_TAIL_RESID_FAIL="1", ABIP_HIP_LIBRARY=os.path.join(root, "abip_amd", "lib", "libabip_hip_hooks.so"))
+    code = textwrap.dedent(f"""
+        import sys, json
+        sys.path[:0] = [{root!r}, {os.path.join(root, 'tests')!r}]
+        import numpy as np
+        import abip_amd as gpu
+        from test_gpu_qcp import eps_all, lasso_socp
+        data, K = lasso_socp(400, 1500, 3, density=0.02)
+        sol1, i1 = gpu.abip_qcp(data, K, eps_all(1e-5))
+        print("RESULT " + json.dumps(dict(tail=i1["factor"]["dense_tail"], status=i1["status"], ipm=i1["ipm_iter"], pobj=i1["pobj"], x=sol1["x"].tolist())))
+        """)
+    r = subprocess.run([sys.executable, "-c", code], env=e, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    res = json.loads([l for l in r.stdout.split("\n") if l.startswith("RESULT ")][-1][7:])
+    assert res["tail"] == 0 and res["status"] == i0["status"] == "Solved" and res["ipm"] == i0["ipm_iter"]
+    assert rel(np.array(res["x"]), sol0["x"]) < 1e-4 and abs(res["pobj"] - i0["pobj"]) < 1e-5 * (1 + abs(i0["pobj"]))
 
 
 def test_unsupported_back_ends_are_rejected(gpu):

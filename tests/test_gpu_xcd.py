@@ -1,0 +1,124 @@
+"""GPU (-m gpu): the one-XCD persistent launch (abip_amd/csrc/dev_xcd.h) -- the whole inner ADMM loop of a cache-resident LP in one kernel on
+the 32 CUs of one XCD -- against the launch path (one kernel per step of the iteration, dev_kernels.h), which the rest of the suite holds against
+the reference's fixtures and the oracle.  (With the launch on by default the fixture / oracle tests of test_gpu_parity.py run through it too.)
+
+Bars: the same decisions (status, outer iterations; inner iterations within 1 %), (x, y, s) within 1e-6 relative when both run to eps = 1e-8 (the
+north-star bar: the two paths add in different orders and the direct variant applies inv(rho I + A A') where the launch path solves with LDL');
+bit-identical results whatever the batching of the iterations."""
+import numpy as np
+import pytest
+
+from _golden import load, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    import __graft_entry__ as g
+    g.build()
+    import abip_amd
+    return abip_amd
+
+
+@pytest.mark.parametrize("name", ["lp_afiro_like", "lp_random_sparse_small", "lp_multicommodity_small", "lp_staircase"])
+@pytest.mark.parametrize("linsys", ["indirect", "direct"])
+def test_one_xcd_launch_agrees_with_the_launch_path(gpu, name, linsys, monkeypatch):
+    z, A, b, c = load(name)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ABIP_HIP_XCD", mode)
+        with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-8) as S:
+            assert S.scalar("xcd") == float(mode)
+            info = S.solve()
+            assert (S.scalar("xcd_batches") > 0) == (mode == "1")
+            out[mode] = (info, S.x.copy(), S.y.copy(), S.s.copy())
+    a, l = out["1"], out["0"]
+    assert a[0]["status_val"] == l[0]["status_val"] == 1
+    assert a[0]["ipm_iter"] == l[0]["ipm_iter"]
+    assert abs(a[0]["admm_iter"] - l[0]["admm_iter"]) <= 0.01 * l[0]["admm_iter"] + 1
+    assert abs(a[0]["pobj"] - l[0]["pobj"]) <= 1e-6 * (1 + abs(l[0]["pobj"]))
+    for k in (1, 2, 3):
+        assert rel(a[k], l[k]) < 1e-6
+
+
+@pytest.mark.parametrize("name,linsys", [("lp_multicommodity_small", "indirect"), ("lp_staircase", "direct"), ("lp_afiro_like", "indirect")])
+def test_one_xcd_launch_is_bit_identical_whatever_the_batching(gpu, name, linsys, monkeypatch):
+    """One launch per inner loop, one launch per iteration (ABIP_HIP_BATCH=0), or strides of 7 through the stepping ABI: the same bits.  Every
+    workgroup adds the partial sums of an exchange in rank order, so neither the batching nor the workgroup-to-CU placement can change a sum."""
+    z, A, b, c = load(name)
+    monkeypatch.setenv("ABIP_HIP_XCD", "1")
+    runs = []
+    for mode in ("batched", "stepwise", "strided"):
+        if mode == "stepwise":
+            monkeypatch.setenv("ABIP_HIP_BATCH", "0")
+        else:
+            monkeypatch.delenv("ABIP_HIP_BATCH", raising=False)
+        with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-5) as S:
+            assert S.scalar("xcd") == 1.0
+            if mode == "strided":
+                S.begin()
+                fin = False
+                while not fin:
+                    fin, done = S.step(7)
+                    assert done <= 7
+                info = S.end()
+            else:
+                info = S.solve()
+            runs.append((info["admm_iter"], info["ipm_iter"], info["pobj"], S.scalar("tot_cg_its"), S.x.copy(), S.y.copy(), S.s.copy()))
+    for r in runs[1:]:
+        assert r[:4] == runs[0][:4]
+        for a2, b2 in zip(r[4:], runs[0][4:]):
+            assert np.array_equal(a2, b2)
+
+
+def test_one_xcd_launch_run_to_run_identical(gpu, monkeypatch):
+    """Two solves of the same LP in one process (different tickets, tags continuing): identical bits."""
+    z, A, b, c = load("lp_multicommodity_small")
+    monkeypatch.setenv("ABIP_HIP_XCD", "1")
+    res = []
+    for _ in range(2):
+        with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-6) as S:
+            info = S.solve()
+            res.append((info["admm_iter"], info["pobj"], S.x.copy(), S.y.copy(), S.s.copy()))
+    assert res[0][:2] == res[1][:2]
+    for a2, b2 in zip(res[0][2:], res[1][2:]):
+        assert np.array_equal(a2, b2)
+
+
+def test_problems_that_do_not_fit_stay_on_the_launch_path(gpu, monkeypatch):
+    """The persistent launch takes an LP only when its slices fit the registers / LDS of 32 CUs (and, for the direct back-end, when the dense
+    inverse of the m x m Schur complement is affordable): otherwise abip_init leaves the launch path in charge, silently."""
+    from abip_amd import problems
+    monkeypatch.setenv("ABIP_HIP_XCD", "1")
+    A, b, c = problems.lp_random_sparse(m=20000, n=50000, per_col=16, seed=3)      # 8e5 non-zeros: more than 32 x 8 x 1024
+    with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-3, max_admm_iters=20) as S:
+        assert S.scalar("xcd") == 0.0
+        S.solve()
+    A, b, c = problems.lp_random_sparse(m=2500, n=6000, per_col=4, seed=4)         # direct: m > 2048
+    with gpu.Solver(A, b, c, linsys="direct", verbose=0, eps=1e-3, max_admm_iters=20) as S:
+        assert S.scalar("xcd") == 0.0
+        S.solve()
+    with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-3, max_admm_iters=20) as S:
+        assert S.scalar("xcd") == 1.0
+        info = S.solve()
+        assert info["admm_iter"] >= 20
+
+
+def test_full_size_c2_and_c3_on_the_one_xcd_launch(gpu, monkeypatch):
+    """BASELINE configs[1] / configs[2] surrogates at full size: the persistent launch and the launch path reach the same optimum with the same
+    number of outer iterations (eps 1e-4: seconds)."""
+    from abip_amd import problems
+    for (A, b, c), linsys in ((problems.lp_staircase(), "direct"), (problems.lp_multicommodity(nodes=1200, arcs=4400, commodities=10), "indirect")):
+        out = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("ABIP_HIP_XCD", mode)
+            with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-4) as S:
+                assert S.scalar("xcd") == float(mode)
+                out[mode] = S.solve()
+        assert out["1"]["status_val"] == out["0"]["status_val"] == 1
+        assert out["1"]["ipm_iter"] == out["0"]["ipm_iter"]
+        assert abs(out["1"]["admm_iter"] - out["0"]["admm_iter"]) <= 0.02 * out["0"]["admm_iter"] + 2
+        assert abs(out["1"]["pobj"] - out["0"]["pobj"]) <= 1e-3 * (1 + abs(out["0"]["pobj"]))
