@@ -72,6 +72,9 @@ struct XcdArgs {
   long j0; int max_iters;               // inner index of the first iteration; iterations to run unless the exit test holds earlier
   double thr, sentinel;                 // gamma * mu; Qres_avg when no averaged statistics were taken
   const double *tolf; int cg_max_its;   // PCG: tolerance factor per iteration of this launch (host-computed: indirect.c:406-407)
+  // solve-only mode (the set-up solve, the Barzilai-Borwein look-ahead: solve_lin_sys on a caller's vector, abip.c:552-560 without the prox): K z = srhs in place,
+  // warm start = the y block of swarm (or null), u_t'h left in the partial table as the launch path's kernels expect it
+  int solve_only; double *srhs; const double *swarm; double *part; int npart;
   XcdFinal fc;
 };
 
@@ -349,6 +352,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   up.fuse_avg = 1; up.xw = 1.0; up.gs = nullptr;
   const double rho = up.rho;
   const unsigned tail = MP + (unsigned)a.n;
+  const bool solo = a.solve_only != 0;
   unsigned tag = a.tag0;
   int flip = 0;
   XWait w; w.xstat = a.xstat; w.dead = false; w.site = 0; w.rank = rank;
@@ -376,14 +380,18 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
 #pragma unroll
     for (int q = 0; q < RM; ++q) {
       const unsigned i = m0 + t + q * XTB;
-      if (i < m1) { const double uy = x_at(up.u, i); p[0] += rho * (uy + x_at(up.v, i)) * x_at(up.g, i); if (PCG) x_putd(pm0, i * 8u, uy); }
+      if (i < m1) {
+        const double uy = solo ? (a.swarm ? x_at(a.swarm, i) : 0.0) : x_at(up.u, i);
+        if (!solo) p[0] += rho * (uy + x_at(up.v, i)) * x_at(up.g, i);
+        if (PCG) x_putd(pm0, i * 8u, uy);
+      }
     }
 #pragma unroll
     for (int q = 0; q < RN; ++q) {
       const unsigned j = n0 + t + q * XTB;
-      if (j < n1) p[0] += (x_at(up.u, MP + j) + x_at(up.v, MP + j)) * x_at(up.g, MP + j);
+      if (j < n1 && !solo) p[0] += (x_at(up.u, MP + j) + x_at(up.v, MP + j)) * x_at(up.g, MP + j);
     }
-    if (rank == 0 && t == 0) { p[1] = x_at(up.u, tail); p[2] = x_at(up.v, tail); }
+    if (rank == 0 && t == 0 && !solo) { p[1] = x_at(up.u, tail); p[2] = x_at(up.v, tail); }
     x_publish<3>(p, red, psc, sc_off, tag);
     double s3[3];
     x_collect<3>(w, G, tot, s3);
@@ -428,10 +436,14 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       const unsigned i = m0 + tb + q * XTB;
       rhs_y[q] = 0.0;
       if (i < m1) {
-        const double hi = x_at(a.h, i);
-        double r = (x_at(up.u, i) + x_at(up.v, i)) * rho;
-        r += -tsum * hi;
-        r += -coef * hi;
+        double r;
+        if (solo) r = x_at(a.srhs, i);
+        else {
+          const double hi = x_at(a.h, i);
+          r = (x_at(up.u, i) + x_at(up.v, i)) * rho;
+          r += -tsum * hi;
+          r += -coef * hi;
+        }
         rhs_y[q] = r;
         bn[0] += r * r;
       }
@@ -441,10 +453,14 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       const unsigned j2 = n0 + tb + q * XTB;
       rhs_x[q] = 0.0;
       if (j2 < n1) {
-        const double hj = x_at(a.h, MP + j2);
-        double r = x_at(up.u, MP + j2) + x_at(up.v, MP + j2);
-        r += -tsum * hj;
-        r += -coef * hj;
+        double r;
+        if (solo) r = -x_at(a.srhs, MP + j2);
+        else {
+          const double hj = x_at(a.h, MP + j2);
+          r = x_at(up.u, MP + j2) + x_at(up.v, MP + j2);
+          r += -tsum * hj;
+          r += -coef * hj;
+        }
         rhs_x[q] = -r;
         x_putd(pn0, j2 * 8u, -r);
         if (PCG) x_putd(pn1, j2 * 8u, aty[q]);
@@ -476,7 +492,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         const unsigned i = m0 + tb + q * XTB;
         cr[q] = 0.0; cz[q] = 0.0; cp[q] = 0.0; cx[q] = 0.0; Mj[q] = 0.0;
         if (i < m1) {
-          const double si = x_at(up.u, i);
+          const double si = solo ? (a.swarm ? x_at(a.swarm, i) : 0.0) : x_at(up.u, i);
           const double b = rhs_y[q] + sA[q];
           const double ri = b - (sB[q] + rho * si);
           Mj[q] = x_at(a.Mjac, i);
@@ -626,7 +642,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
 #pragma unroll
     for (int q = 0; q < RM; ++q) {
       const unsigned i = m0 + tb + q * XTB;
-      if (i < m1) { x_putd(pm0, i * 8u, y[q]); x_at(up.ut, i) = y[q]; dh[0] += y[q] * x_at(a.h, i); }
+      if (i < m1) { x_putd(pm0, i * 8u, y[q]); x_at(solo ? a.srhs : up.ut, i) = y[q]; dh[0] += y[q] * x_at(a.h, i); }
     }
     double zx[RN];
     {
@@ -651,6 +667,12 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     x_collect<1>(w, G, tot, dhS);
     if (w.dead) return;
     if (!PCG) { XP_LAP(4) }
+    if (solo) { // the solution goes back in place; u_t'h where the launch path's consumers re-reduce the partial table
+#pragma unroll
+      for (int q = 0; q < RN; ++q) { const unsigned j2 = n0 + tb + q * XTB; if (j2 < n1) x_at(a.srhs, MP + j2) = zx[q]; }
+      if (rank == 0) for (unsigned e = t; e < (unsigned)a.npart; e += XTB) a.part[S_DH * MAXNB + e] = (e == 0) ? dhS[0] : 0.0;
+      break;
+    }
     // ---- element-wise update (k_admm_update): barrier prox, dual update, running sums, averages, statistics ----
     Stat sst = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double tau4[4] = {0.0, 0.0, 0.0, 0.0};
@@ -821,7 +843,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   if (rank == 0 && t < 96 && ran > 0) a.ctl->out[t] = outs[t];
   if (rank == 0 && t == 0) {
     Ctl *c = a.ctl;
-    c->metric = metric; c->avg_crit = avg_crit; c->it_count = c->it_count + ran; c->halt = halt;
+    if (!solo) { c->metric = metric; c->avg_crit = avg_crit; c->it_count = c->it_count + ran; c->halt = halt; }
     c->cg_it = last_cg; c->cg_done = 1;
     c->xcd_cg_total = cg_total;
     a.xstat[1] = (int)(tag - a.tag0);

@@ -195,6 +195,7 @@ struct ABIP_WORK {
   // direct
   DevLdl ldl;
   XcdPlan xcd;
+  bool xcd_solves = true; // ABIP_HIP_XCD_SOLVES=0: the stand-alone solves (set-up, BB look-ahead) stay on the launch path
   // ---- loop state (locals of ABIP(solve)) ------------------------------------------------
   Phase phase = PH_IDLE;
   abip_int i = 0, j = 0, k = 0, inner_stopper = 0;
@@ -538,9 +539,16 @@ int next_chunk(const W *w) {
 
 // Solve K z = rhs in place and leave S_DH = z[0:l-1)'h; synchronises with the host (used outside the hot loop:
 // the set-up solve for g and the BB look-ahead).  Returns CG iterations, <0 on error.
+int xcd_solve(W *w, double *rhs, const double *warm, abip_int iter);
 int kkt_solve_sync(W *w, double *rhs, const double *warm, abip_int iter) {
   w->tot_solves++;
   w->prof.kkt_solves++;
+  if (w->xcd.on && w->xcd_solves) { // cache-resident LP: the solve as one persistent launch too (the BB look-ahead is dozens of solves per outer iteration)
+    const int its = xcd_solve(w, rhs, warm, iter);
+    if (its < 0) return -1;
+    if (w->linsys == ABIP_HIP_LINSYS_INDIRECT) { w->last_cg_its = its; if (iter >= 0) { w->tot_cg_its += its; w->prof.cg_iters += its; } }
+    return its;
+  }
   if (w->linsys == ABIP_HIP_LINSYS_DIRECT) {
     enqueue_direct(w, rhs);
     if (sync_ctl(w)) return -1;
@@ -883,13 +891,26 @@ void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
   }
   x.tag = 0; x.launches = 0;
   x.on = true;
+  // stand-alone solves (set-up, BB look-ahead) through the persistent kernel: worth it for the PCG back-end (a launch-path solve is 3 launches per PCG
+  // iteration); the direct back-end's launch-path solve is 4 launches in all and wins (ABIP_HIP_XCD_SOLVES=0 / 1 forces either)
+  { const char *e = getenv("ABIP_HIP_XCD_SOLVES"); w->xcd_solves = e ? atoi(e) != 0 : pcg; }
   if (getenv("ABIP_HIP_XCD_VERBOSE"))
     printf("[xcd] G %d: slices of A  <= %ld nnz, %d rows (longest row %d); of A' <= %ld nnz, %d rows (longest %d); NZ %d RM %d RN %d, LDS %zu B (%d rows of the dense inverse)\n", x.G, nzA, rA, lA, nzT, rT, lT,
            x.NZ, x.RM, x.RN, x.lds, x.minv_lds_rows);
 }
 
+int xcd_batch(W *w, int nb, int *ran, double *metric_out, double *srhs = nullptr, const double *swarm = nullptr, abip_int siter = 0);
+// K z = rhs in place by ONE launch of the persistent kernel in its solve-only mode (warm: l-vector whose y block starts the PCG, or null);
+// leaves u_t'h in the partial table like the launch path's post-solve kernels.  Returns the PCG iterations (0 for the direct back-end), < 0 on error.
+int xcd_solve(W *w, double *rhs, const double *warm, abip_int iter) {
+  int ran = 0; double metric = 0;
+  if (xcd_batch(w, 1, &ran, &metric, rhs, warm, iter)) return -1;
+  return w->linsys == ABIP_HIP_LINSYS_INDIRECT ? w->hctl->cg_it : 0;
+}
+
 // Run up to nb ADMM iterations (k, j), (k+1, j+1), ... as one launch; *ran = iterations that ran (the exit test, or the final check, stops it).
-int xcd_batch(W *w, int nb, int *ran, double *metric_out) {
+// srhs != null: the solve-only mode (one KKT solve on srhs, nothing else).
+int xcd_batch(W *w, int nb, int *ran, double *metric_out, double *srhs, const double *swarm, abip_int siter) {
   XcdPlan &x = w->xcd;
   ABIPSettings *st = w->stgs;
   const bool pcg = (w->linsys == ABIP_HIP_LINSYS_INDIRECT);
@@ -914,17 +935,18 @@ int xcd_batch(W *w, int nb, int *ran, double *metric_out) {
   a.j0 = (long)w->j; a.max_iters = nb;
   a.thr = w->gamma * w->mu; a.sentinel = (double)st->max_admm_iters;
   a.tolf = x.tolf.p; a.cg_max_its = (int)w->m_glob;
+  a.solve_only = srhs ? 1 : 0; a.srhs = srhs; a.swarm = swarm; a.part = w->part.p; a.npart = w->NB;
   a.fc.on = w->final_check ? 1 : 0; a.fc.pfeasopt = (int)st->pfeasopt; a.fc.ipm_pos = w->i > 0 ? 1 : 0;
   a.fc.eps = st->eps; a.fc.den = st->normalize ? (st->scale * w->sc_c * w->sc_b) : 1.0; a.fc.nm_b = w->nm_b; a.fc.nm_c = w->nm_c;
   a.fc.k0 = (long)w->k; a.fc.max_admm = (long)st->max_admm_iters;
   if (pcg) {
-    for (int q = 0; q < nb; ++q) x.htolf[q] = cg_tol_factor(w, w->k + q);
+    for (int q = 0; q < nb; ++q) x.htolf[q] = srhs ? cg_tol_factor(w, siter) : cg_tol_factor(w, w->k + q);
     HIP_OK(hipMemcpyAsync(x.tolf.p, x.htolf, sizeof(double) * nb, hipMemcpyHostToDevice, w->stream));
   }
   void *params[] = {&a};
   const double t_launch = now_ms();
   W::Ev *ev = nullptr;
-  if ((w->prof_mask >> ABIP_HIP_K_XCD) & 1u) {
+  if (((w->prof_mask >> ABIP_HIP_K_XCD) & 1u) && !srhs) { // (iteration batches only: the stand-alone solves are not iterations)
     if (w->ev_used == w->ev_pool.size()) { W::Ev e; e.cls = ABIP_HIP_K_XCD; (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); w->ev_pool.push_back(e); }
     ev = &w->ev_pool[w->ev_used++];
     ev->cls = ABIP_HIP_K_XCD; ev->tag = -1;
@@ -950,6 +972,7 @@ int xcd_batch(W *w, int nb, int *ran, double *metric_out) {
     for (int g = 0; g < x.G; ++g) fprintf(stderr, "  rank %2d: last exchange opened %d (after wait site %d)\n", g, x.hstat[8 + 2 * g], x.hstat[9 + 2 * g]);
     return -1; }
   x.tag += (unsigned)x.hstat[1]; x.exchanges += x.hstat[1];
+  if (srhs) return 0; // solve-only: no iteration ran
 #ifdef XCD_PROF
   { static long acc[8] = {0}; for (int q = 0; q < 8; ++q) acc[q] += (unsigned)x.hstat[96 + q];
     fprintf(stderr, "[xcd prof] cumulative us: %.0f %.0f %.0f %.0f %.0f %.0f %.0f (PCG loop: put, publish, collect, gather, rows, tail | direct: rhs+E1, E_w, all-gather, dense, E_y+E_dh, update+E_u, q+E_fin)\n", acc[0] * 0.01, acc[1] * 0.01, acc[2] * 0.01, acc[3] * 0.01, acc[4] * 0.01, acc[5] * 0.01, acc[6] * 0.01); }
@@ -1948,6 +1971,46 @@ int abip_hip_host_factor_solve(const ABIPMatrix *A, double rho_y, int tail, doub
   stats8[0] = F.N; stats8[1] = (double)F.lnnz; stats8[2] = F.T; stats8[3] = (double)F.fwd.lev_ptr.size() - 1; stats8[4] = (double)F.bwd.lev_ptr.size() - 1;
   stats8[5] = (double)F.fwd.idx.size(); stats8[6] = 0; stats8[7] = 0;
   return 0;
+}
+
+// Unit-level access to the direct back-end's factorisation as both paths use it (LP: K = [[rho I, A],[A', -I]]; conic: qcp_config.c:699-748): any
+// symmetric quasi-definite K given by its UPPER triangle in CSC form (32-bit indices).  on_device = 0: ordering + head factor + Schur complement + dense tail
+// all on the host (host::host_solve; runs without a GPU); 1: the head on the host, the dense tail factored and every solve applied on the device
+// (DevLdl::setup / enqueue).  tail: -1 automatic, 0 none, T > 0 forced.  rhs (N) is overwritten with K^-1 rhs.  stats4 = {T, nnz(L), forward levels, backward levels}.
+int abip_hip_ldl_solve(int N, const int *Kp, const int *Ki, const double *Kx, int tail, int on_device, double *rhs, double *stats4) {
+  if (N <= 0 || !Kp || !Ki || !Kx || !rhs) return -1;
+  std::vector<int> kp(Kp, Kp + N + 1), ki(Ki, Ki + Kp[N]);
+  std::vector<double> kx(Kx, Kx + Kp[N]);
+  host::LdlHost F;
+  host::set_tail_request(tail);
+  const int rc = host::factor_upper(N, kp, ki, kx, F);
+  host::set_tail_request(-2);
+  if (rc < 0) return -2;
+  if (stats4) { stats4[0] = F.T; stats4[1] = (double)F.lnnz; stats4[2] = (double)F.fwd.lev_ptr.size() - 1; stats4[3] = (double)F.bwd.lev_ptr.size() - 1; }
+  if (!on_device) {
+    if (F.dev_schur) host::complete_schur_on_host(F);
+    std::vector<double> b(rhs, rhs + N);
+    if (host::host_solve(F, b)) return -3; // (takes and returns the caller's order)
+    std::copy(b.begin(), b.end(), rhs);
+    return 0;
+  }
+  char devname[128];
+  if (abip_hip_device_info(devname, sizeof(devname), nullptr, nullptr) != 0) return -4;
+  hipStream_t st = nullptr;
+  if (hipStreamCreate(&st) != hipSuccess) return -4;
+  DevLdl L;
+  DBuf<double> dv; DBuf<Ctl> ctl;
+  std::vector<int> pmap(F.P.begin(), F.P.end());
+  int ret = 0;
+  if (L.setup(F, pmap, st) || dv.alloc(N) || ctl.alloc(1) || hipMemsetAsync(ctl.p, 0, sizeof(Ctl), st) != hipSuccess ||
+      hipMemcpyAsync(dv.p, rhs, sizeof(double) * N, hipMemcpyHostToDevice, st) != hipSuccess) ret = -5;
+  if (!ret) {
+    L.enqueue([&](auto kern, int grid, int block, size_t lds, auto... a) { hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, a...); }, dv.p, (const Ctl *)ctl.p, 256);
+    if (hipMemcpyAsync(rhs, dv.p, sizeof(double) * N, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) ret = -6;
+  }
+  L.release(); dv.release(); ctl.release();
+  (void)hipStreamDestroy(st);
+  return ret;
 }
 
 // pure host code: ABIP(_normalize_A) as abip_init applies it (A scaled in place; D has m entries, E has n, means = {row, col})

@@ -99,6 +99,12 @@ int abip_hip_host_normalize_A(ABIPMatrix *A, const ABIPSettings *stgs, double *D
 /* this rank's row range [row0, row1) of the last abip_init (0, m on a single GPU) */
 void abip_hip_dist_rows(ABIPWork *w, abip_int *row0, abip_int *row1);
 
+/* Unit-level access to the direct back-end's LDL' as the LP and the conic path use it: K symmetric quasi-definite, given by its UPPER triangle in CSC
+ * form (32-bit indices); rhs (N) <- K^-1 rhs.  on_device 0: everything on the host (no GPU needed); 1: sparse head on the host, dense tail factored and
+ * the solve applied on the device.  tail: -1 automatic, 0 none, T forced.  stats4 (may be NULL) = {T, nnz(L), forward levels, backward levels}.
+ * Held against the reference's QDLDL (src/external/qdldl/src/qdldl.c: QDLDL_factor / QDLDL_solve, the conic solve of linsys.c:310-316) by tests/test_qdldl_pin*.py. */
+int abip_hip_ldl_solve(int N, const int *Kp, const int *Ki, const double *Kx, int tail, int on_device, double *rhs, double *stats4);
+
 /* --- measurement ------------------------------------------------------------ */
 /* Kernel classes timed with hipEvents on the solver's own stream. */
 #define ABIP_HIP_K_SPMV_AT 0   /* k_cg_spmv_At: tmp = A'(z + beta p)  (CSC gather, n rows) -- PCG SpMV 1 */

@@ -1088,6 +1088,22 @@ static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &
 
 /* optional trace of (u, v, u_t) after each of the first T inner iterations */
 static F *g_trace = 0; static I g_trace_T = 0, g_trace_n = 0;
+/* test hook: the oracle's own LDL' (orc_ldl.h) on any symmetric quasi-definite K (upper triangle, CSC): b <- K^-1 b.  Held against the reference's
+ * QDLDL by tests/test_qdldl_pin_cpu.py -- the one piece of the conic path that can be pinned against reference code in this image. */
+int orc_ldl_solve_upper(int N, const int *Kp, const int *Ki, const double *Kx, double *b) {
+  orc_I *P = NULL, *Lp = NULL, *Li = NULL; orc_F *Lx = NULL, *Dg = NULL;
+  orc_I *kp = (orc_I *)malloc(sizeof(orc_I) * ((size_t)N + 1)), *ki = (orc_I *)malloc(sizeof(orc_I) * (size_t)(Kp[N] > 0 ? Kp[N] : 1));
+  for (int j = 0; j <= N; ++j) kp[j] = Kp[j];
+  for (int q = 0; q < Kp[N]; ++q) ki[q] = Ki[q];
+  const int rc = orc_ldl_factor(N, kp, ki, Kx, &P, &Lp, &Li, &Lx, &Dg);
+  if (rc == 0) {
+    orc_F *bp = (orc_F *)malloc(sizeof(orc_F) * N);
+    orc_ldl_solve(N, P, Lp, Li, Lx, Dg, b, bp);
+    free(bp);
+  }
+  free(kp); free(ki); free(P); free(Lp); free(Li); free(Lx); free(Dg);
+  return rc;
+}
 void orc_qcp_set_trace(I T, F *buf) { g_trace = buf; g_trace_T = T; g_trace_n = 0; }
 I orc_qcp_trace_count(void) { return g_trace_n; }
 

@@ -39,3 +39,37 @@ def test_int32_library_exports_the_same_abi():
             g.build()
         exp.append({ln.split()[-1] for ln in subprocess.run(["nm", "-D", "--defined-only", p], capture_output=True, text=True, check=True).stdout.splitlines()})
     assert exp[0] == exp[1] and "abip_main" in exp[0]
+
+
+def test_conic_struct_layouts_equal_the_reference_header(tmp_path):
+    """include/abip_qcp.h against the reference's OWN conic header (src/abip-qcp/include/abip.h:63-241, which needs no MKL): sizes and offsets of
+    ABIPData / ABIPSettings / ABIPCone / ABIPSolution / ABIPInfo, as the compiler lays them out (the reference builds its conic code with abip_int = int:
+    glbopts.h:10 leaves DLONG commented out).  Container only (the reference tree is not on the GPU box)."""
+    import os, subprocess
+    ref = "/root/reference/src/abip-qcp/include"
+    if not os.path.isdir(ref):
+        pytest.skip("the reference tree is not here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    body = """
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "%s"
+    #define P(T, f) printf(#f " %%zu\\n", offsetof(T, f))
+    int main(void) {
+      printf("%%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(%sData), sizeof(%sSettings), sizeof(%sCone), sizeof(%sSolution), sizeof(%sInfo), sizeof(%sMatrix));
+      P(%sData, A); P(%sData, Q); P(%sData, b); P(%sData, c); P(%sData, lambda); P(%sData, stgs);
+      P(%sSettings, rho_y); P(%sSettings, eps_unb); P(%sSettings, alpha); P(%sSettings, verbose); P(%sSettings, linsys_solver); P(%sSettings, prob_type);
+      P(%sSettings, time_limit); P(%sSettings, psi); P(%sSettings, pc_scaling);
+      P(%sCone, q); P(%sCone, qsize); P(%sCone, rq); P(%sCone, rqsize); P(%sCone, f); P(%sCone, z); P(%sCone, l);
+      P(%sInfo, status_val); P(%sInfo, admm_iter); P(%sInfo, pobj); P(%sInfo, rel_gap); P(%sInfo, solve_time); P(%sInfo, avg_cg_iters);
+      return 0;
+    }
+    """
+    outs = []
+    for hdr, pre, inc in (("abip.h", "ABIP", ref), ("abip_qcp.h", "QCP", os.path.join(root, "include"))):
+        src = tmp_path / f"lay_{pre}.c"
+        src.write_text(body % ((hdr,) + (pre,) * 34))
+        exe = tmp_path / f"lay_{pre}"
+        subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe)], check=True)
+        outs.append(subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout)
+    assert outs[0] == outs[1] and len(outs[0].split("\n")) > 25

@@ -136,7 +136,7 @@ def test_conic_tail_residual_guard(gpu, monkeypatch):
         import sys, json
         sys.path[:0] = [{root!r}, {os.path.join(root, 'tests')!r}]
         import numpy as np
-        import abip_amd as gpu
+        from abip_amd import qcp as gpu
         from test_gpu_qcp import eps_all, lasso_socp
         data, K = lasso_socp(400, 1500, 3, density=0.02)
         sol1, i1 = gpu.abip_qcp(data, K, eps_all(1e-5))
