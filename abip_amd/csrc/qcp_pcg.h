@@ -108,10 +108,15 @@ __global__ __launch_bounds__(BS, 8) void kq_pcg_Aty(Csr At, QPcgVec v, int max_i
 // before the current row is reduced.  Same entry test and beta as kq_pcg_Aty; a row's products add up lane-strided, then by a G-lane butterfly (deterministic).
 template <bool INIT, int G>
 __global__ __launch_bounds__(1024) void kq_pcg_Aty_lds(Csr At, QPcgVec v, int m, int max_its, const double *__restrict__ ppart, int nb, Ctl *hc) {
-  if (hc->halt || hc->cg_done) return;
   extern __shared__ double gl[];
   __shared__ double sm16[2][16];
+  __shared__ int s_gate;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the gate is read ONCE per workgroup: workgroup 0 of this very launch may raise cg_done below, and a late wavefront that saw 1 where its
+  // siblings saw 0 would leave them alone at the barriers
+  if (tid == 0) s_gate = (hc->halt || hc->cg_done) ? 1 : 0;
+  __syncthreads();
+  if (s_gate) return;
   const double *g = INIT ? v.y0 : v.z;
   for (int i = tid; i < m; i += 1024) gl[i] = g[i];
   double beta = 0.0;

@@ -534,8 +534,14 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
       w->n_cu = cus;
       const bool fits = cus > 0 && m <= 16384 && nl >= 1;
-      if (fits && (e ? atoi(e) != 0 : nnzl >= 2000000)) { // (break-even measured at ~1e6 non-zeros, profiles/r02zj_*)
-        const int G = (double)nnzl / (double)nl <= 96.0 ? 16 : 64;
+      // Sharded: every rank must run the SAME kernel -- the two A'y kernels add |r|^2 and z'r in different orders, so ranks on different kernels would
+      // differ in the last bit of beta and of the exit test, leave the PCG loop in different chunks and mismatch their collectives.  The choice therefore
+      // reads global quantities only (non-zeros and columns of the whole matrix per rank), never this rank's block.
+      const long nnz_dec = w->dist ? nnz_glob / w->world : nnzl;
+      const long col_dec = w->dist ? std::max<long>(1, (long)w->n_glob / w->world) : (long)nl;
+      (void)nnzl;
+      if (fits && (e ? atoi(e) != 0 : nnz_dec >= 2000000)) { // (break-even measured at ~1e6 non-zeros, profiles/r02zj_*)
+        const int G = (double)nnz_dec / (double)col_dec <= 96.0 ? 16 : 64;
         const int bytes = (int)(sizeof(double) * (size_t)m);
         bool ok = true;
         if (bytes > 48 * 1024) {

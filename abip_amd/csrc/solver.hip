@@ -283,6 +283,7 @@ void harvest_events(W *w) { // call only after the stream has been synchronised
     if (hipEventElapsedTime(&ms, w->ev_pool[q].a, w->ev_pool[q].b) != hipSuccess) continue;
     const W::Ev &e = w->ev_pool[q];
     // a PCG launch tagged with iteration index t did work iff t < (iterations the device actually ran)
+    if (e.cls == ABIP_HIP_K_CLASSES) { w->prof.allreduce_ms += ms; continue; }
     if (e.tag >= 0 && e.tag >= w->hctl->cg_it) { w->prof.noop_ms += ms; w->prof.noop_launches++; }
     else { w->prof.ms[e.cls] += ms; w->prof.launches[e.cls]++; }
   }
@@ -340,7 +341,17 @@ inline Dims dims(const W *w) { return Dims{(int)w->m, (int)w->n, w->MP}; }
 // ------------------------------------------------------------------------------------------------
 int allreduce_dev(W *w, double *buf, size_t count) {
   if (!w->dist) return 0;
-  return abip::dist_allreduce(buf, count, w->stream, w->hstage);
+  w->prof.allreduce_calls++; w->prof.allreduce_bytes += (double)(sizeof(double) * count);
+  W::Ev *ev = nullptr;
+  if (((w->prof_mask >> ABIP_HIP_K_CLASSES) & 1u) && g_dist.kind == 1) { // RCCL: bracket the collective on the solver's stream (the host-staged test transport synchronises by itself)
+    if (w->ev_used == w->ev_pool.size()) { W::Ev e; e.cls = ABIP_HIP_K_CLASSES; (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); w->ev_pool.push_back(e); }
+    ev = &w->ev_pool[w->ev_used++];
+    ev->cls = ABIP_HIP_K_CLASSES; ev->tag = -1; // (class "one past the kernels": the collective)
+    (void)hipEventRecord(ev->a, w->stream);
+  }
+  const int rc = abip::dist_allreduce(buf, count, w->stream, w->hstage);
+  if (ev) (void)hipEventRecord(ev->b, w->stream);
+  return rc;
 }
 void enqueue_fold(W *w, std::initializer_list<int> slots) {
   FoldArgs f; f.nslots = 0;
@@ -1447,9 +1458,10 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
         if (w->A->i[q] >= r0 && w->A->i[q] < r1) { w->Aloc_i[t] = w->A->i[q] - r0; w->Aloc_x[t] = w->A->x[q]; ++t; }
     w->Aloc.x = w->Aloc_x.data(); w->Aloc.i = w->Aloc_i.data(); w->Aloc.p = w->Aloc_p.data(); w->Aloc.m = w->m; w->Aloc.n = n;
     Ause = &w->Aloc;
-    // form of the sharded solve: columns (default: the exchange per PCG iteration is the m-vector -- C4: 1.6 MB against the row form's 4 MB + scalars, and by the
-    // xGMI model of DESIGN.md section 7 that is the difference between parity with one GPU and a slow-down) or rows (ABIP_HIP_DIST_CG=rows)
-    { const char *e = getenv("ABIP_HIP_DIST_CG"); w->cg_cols = !(e && !strcmp(e, "rows")); }
+    // form of the sharded solve: rows (default: north_star's contract -- row blocks, one all-reduce of the A'-partials + packed scalars per PCG iteration) or
+    // columns (ABIP_HIP_DIST_CG=cols: inside the solve the m-space is gathered and replicated, the exchange per PCG iteration is the m-vector -- C4: 1.6 MB
+    // against 4 MB).  Neither has run on two GPUs yet; bench.py --gpus N measures both in one invocation, and the default follows a measurement, not a model.
+    { const char *e = getenv("ABIP_HIP_DIST_CG"); w->cg_cols = (e && !strcmp(e, "cols")); }
     if (w->cg_cols) { // column block of the scaled matrix, balanced by non-zeros (+1 per column), and the whole Jacobi preconditioner
       if (n < w->world) return fail("fewer columns than ranks");
       std::vector<abip_int> cb(w->world + 1, 0);

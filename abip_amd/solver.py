@@ -152,7 +152,7 @@ class Solver:
     def profile_enable(self, classes=K_CLASSES) -> None:
         mask = 0
         for cname in classes:
-            mask |= 1 << K_CLASSES.index(cname)
+            mask |= 1 << (len(K_CLASSES) if cname == "allreduce" else K_CLASSES.index(cname))   # "allreduce": the collectives of a sharded solve
         self.L.abip_hip_profile_enable(self.w, mask)
 
     def profile_enable_stamps(self, classes=("spmv_At", "spmv_A")) -> None:
@@ -172,7 +172,8 @@ class Solver:
                     admm_iters=p.admm_iters, cg_iters=p.cg_iters, kkt_solves=p.kkt_solves,
                     stamp_ms={k: p.stamp_ms[i] for i, k in enumerate(K_CLASSES)},
                     stamp_launches={k: p.stamp_launches[i] for i, k in enumerate(K_CLASSES)},
-                    stamp_noop_launches=p.stamp_noop_launches)
+                    stamp_noop_launches=p.stamp_noop_launches,
+                    allreduce_ms=p.allreduce_ms, allreduce_calls=p.allreduce_calls, allreduce_bytes=p.allreduce_bytes)
 
     def close(self) -> None:
         if getattr(self, "w", None):

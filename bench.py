@@ -326,6 +326,8 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
     S.begin()
     fin, done_w = S.step(warmup)
     S.sync()
+    if sharded:
+        S.profile_enable(("allreduce",))                  # two event records per collective
     if xcd:
         S.profile_enable(("xcd",))                        # two event records per launch of up to 2048 iterations: stays on in the timed region
     elif linsys == "indirect":
@@ -427,7 +429,13 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
                     dense_tail=T, dense_tail_bytes_per_solve=8 * T * (T + 1), levels=[int(S.scalar("levels_fwd")), int(S.scalar("levels_bwd"))],
                     timing="hipEvents around the solve's launches in a second pass of the same length" if events_pass else "hipEvents in the timed region")
 
-    extra = dict(cg_iters_per_step=cg_step, events_pass=events_pass, m=m, n=n, nnz=int(nnz), rows=[int(row0), int(row1)], one_xcd_launch=bool(xcd))
+    coll = None
+    if sharded:
+        its_ = max(prof["admm_iters"], 1)
+        coll = dict(collectives_per_step=prof["allreduce_calls"] / its_, bytes_per_step=prof["allreduce_bytes"] / its_,
+                    ms_in_allreduce_per_step=prof["allreduce_ms"] / its_, share_of_step=prof["allreduce_ms"] / its_ / max(1e3 * elapsed / max(steps_eff, 1), 1e-12),
+                    timing="hipEvents around every ncclAllReduce on the solver's stream (rank 0's view)")
+    extra = dict(collectives=coll, cg_iters_per_step=cg_step, events_pass=events_pass, m=m, n=n, nnz=int(nnz), rows=[int(row0), int(row1)], one_xcd_launch=bool(xcd))
     if linsys == "indirect":
         cg = extra["cg_iters_per_step"]
         b_cg = b_spmv(n, m, nnz) + b_spmv(m, n, nnz) + 8 * (21 * m + n)
@@ -524,8 +532,18 @@ def main():
                 adist.init_torch()
             else:
                 adist.init_callback(rank, world, lambda arr: dist.all_reduce(torch.from_numpy(arr)))
+        if sharded and "ABIP_HIP_DIST_CG" not in os.environ:
+            os.environ["ABIP_HIP_DIST_CG"] = "rows"       # the headline of an N-GPU line is north_star's form: row blocks, all-reduce of the A'-partials
         rec = run_lp(args.workload, steps, warmup, args, rank, world, dist, torch, sharded, linsys_override=args.linsys,
                      to_tol=(args.to_tol or world == 1) and not args.no_to_tol, cpu=not args.no_cpu)
+        if sharded and os.environ.get("ABIP_BENCH_ONE_FORM") != "1":
+            # ... and the column form of the sharded solve, same window, same invocation (the one multi-GPU run the driver may do should show both)
+            form0 = os.environ["ABIP_HIP_DIST_CG"]
+            os.environ["ABIP_HIP_DIST_CG"] = "cols" if form0 == "rows" else "rows"
+            r2 = run_lp(args.workload, steps, warmup, args, rank, world, dist, torch, sharded, linsys_override=args.linsys, to_tol=False, cpu=False)
+            rec["extra"]["dist_" + os.environ["ABIP_HIP_DIST_CG"]] = {k: r2[k] for k in ("value", "ms_per_step", "roofline") if k in r2} | dict(collectives=r2["extra"]["collectives"],
+                                                                                                                      cg_iters_per_step=r2["extra"]["cg_iters_per_step"])
+            os.environ["ABIP_HIP_DIST_CG"] = form0
         if dist is not None:
             rows = [None] * world
             dist.all_gather_object(rows, rec["extra"]["rows"])
@@ -534,7 +552,7 @@ def main():
             rec["rccl_ranks"] = adist.comm_count() if sharded else 0
             # form of the sharded solve: "cols" (default: the solve's m-space gathered and replicated, A by column blocks, one all-reduce of m doubles per PCG
             # iteration) or "rows" (ABIP_HIP_DIST_CG=rows: one all-reduce of n doubles + packed scalars per PCG iteration)
-            rec["dist_cg"] = ("rows" if os.environ.get("ABIP_HIP_DIST_CG") == "rows" else "cols") if sharded else None
+            rec["dist_cg"] = ("cols" if os.environ.get("ABIP_HIP_DIST_CG") == "cols" else "rows") if sharded else None
         if rank == 0 and world == 1 and args.workload == "c4" and not args.no_extra and not force_shard:
             # the Netlib-class and the pds-class configs, short windows, inside the same driver-run line
             sub = {}

@@ -128,6 +128,10 @@ typedef struct {
   double stamp_ms[ABIP_HIP_K_CLASSES];
   long stamp_launches[ABIP_HIP_K_CLASSES];
   long stamp_noop_launches;          /* stamped launches that returned at a gate (enqueued past PCG convergence) */
+  /* sharded solves: the collectives issued by this rank (all of them counted; timed with hipEvents on the solver's stream when bit ABIP_HIP_K_CLASSES of the mask is set, RCCL only) */
+  double allreduce_ms;
+  long allreduce_calls;
+  double allreduce_bytes;
 } AbipHipProfile;
 /* mask = bitmask of classes to bracket with events (0 disables).  Timing a class adds two event
  * records per launch of that class only. */

@@ -15,6 +15,14 @@ import pytest
 from _golden import info_of, load, rel
 
 pytestmark = pytest.mark.gpu
+def _free_port():
+    """A port nobody holds (hash() of a tuple with a str is salted per interpreter: neither reproducible nor collision-free)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -68,7 +76,7 @@ def test_one_rank_rccl_transport(gpu):
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("name,eps", [("lp_random_sparse_small", 1e-6), ("lp_afiro_like", 1e-6)])
 def test_multi_rank_sharding_matches_reference(gpu, world, name, eps):
-    port = 29500 + (hash((world, name)) % 400)
+    port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "gloo-callback", name, repr(eps)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -90,7 +98,7 @@ def test_multi_rank_skewed_row_blocks_stay_bit_identical(gpu, world):
     """Row blocks balanced by non-zeros can hold very different numbers of rows (a few nearly dense rows on one rank).  The replicated
     n-space reductions must still add in the same order on every rank: the persistent grid is derived from global quantities only, so
     x, y, s, mu, beta, the CG count -- everything -- is bit-identical across the ranks ('consistent'), and NB is the same number."""
-    port = 29950 + world
+    port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "gloo-callback", "gen:skew:11", "1e-05"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -101,14 +109,16 @@ def test_multi_rank_skewed_row_blocks_stay_bit_identical(gpu, world):
     assert out["consistent"] and out["status"] == "Solved" and out["nb"] >= 1
 
 
-def test_one_rank_row_form_of_the_sharded_pcg(gpu, monkeypatch):
-    """The sharded solve has two forms: columns (default: inside the solve the m-space is gathered and replicated and A is used by column blocks, one exchange
-    of m doubles per PCG iteration) and rows (ABIP_HIP_DIST_CG=rows: one exchange of n doubles + packed scalars).  Every other test of this file runs the
-    default; this one and the next run the row form.  world = 1 with an identity collective against the plain path."""
+@pytest.mark.parametrize("form", ["rows", "cols"])
+def test_one_rank_both_forms_of_the_sharded_pcg(gpu, monkeypatch, form):
+    """The sharded solve has two forms: rows (default, north_star's: A by row blocks, one exchange of n doubles + packed scalars per PCG iteration) and
+    columns (ABIP_HIP_DIST_CG=cols: inside the solve the m-space is gathered and replicated and A is used by column blocks, one exchange of m doubles per
+    PCG iteration).  Every other test of this file runs the default; this one and the next name the form.  world = 1 with an identity collective against
+    the plain path."""
     from abip_amd import dist as adist
     z, A, b, c = load("lp_random_sparse_small")
     ref = _single(gpu, A, b, c, 1e-6)
-    monkeypatch.setenv("ABIP_HIP_DIST_CG", "rows")
+    monkeypatch.setenv("ABIP_HIP_DIST_CG", form)
     adist.init_callback(0, 1, lambda arr: None)
     try:
         got = _single(gpu, A, b, c, 1e-6)
@@ -120,20 +130,21 @@ def test_one_rank_row_form_of_the_sharded_pcg(gpu, monkeypatch):
         assert rel(a, r) < 1e-5
 
 
+@pytest.mark.parametrize("form", ["rows", "cols"])
 @pytest.mark.parametrize("world,name", [(2, "lp_random_sparse_small"), (3, "lp_afiro_like")])
-def test_multi_rank_row_form_matches_reference(gpu, world, name):
+def test_multi_rank_both_forms_match_reference(gpu, world, name, form):
     eps = 1e-6
-    port = 29800 + world
+    port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "gloo-callback", name, repr(eps)]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ABIP_HIP_DIST_CG="rows")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ABIP_HIP_DIST_CG=form)
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
     assert p.returncode == 0 and lines, p.stdout[-2000:] + p.stderr[-2000:]
     out = json.loads(lines[-1][7:])
     z, A, b, c = load(name)
     g = info_of(z, f"indirect_{eps:g}")
-    assert out["cols"] == 0.0 and out["consistent"] and out["status"] == "Solved"
+    assert out["cols"] == (1.0 if form == "cols" else 0.0) and out["consistent"] and out["status"] == "Solved"
     assert out["ipm_iter"] == g["ipm_iter"] and abs(out["admm_iter"] - g["admm_iter"]) <= 0.03 * g["admm_iter"] + 2
     for k in "xys":
         assert rel(np.array(out[k]), z[f"indirect_{eps:g}_{k}"]) < 10 * eps, k

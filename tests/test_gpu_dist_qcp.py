@@ -11,6 +11,14 @@ import pytest
 from qcp_cases import make
 
 pytestmark = pytest.mark.gpu
+def _free_port():
+    """A port nobody holds (hash() of a tuple with a str is salted per interpreter: neither reproducible nor collision-free)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -53,7 +61,7 @@ def test_multi_rank_conic_sharding(gpu, world, name):
     data, K = make(name)
     eps = 1e-3 if name == "lp" else 1e-5
     ref, ri = gpu.abip_qcp(data, K, dict(eps=eps, linsys_solver=3, verbose=0))
-    port = 29100 + (hash((world, name)) % 300)
+    port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_qcp.py"), "gloo-callback", name, repr(eps)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -94,3 +94,23 @@ def test_objsense_max_is_refused_and_free_bound_with_value(tmp_path):
     p.write_text("NAME T\nROWS\n N COST\n E R1\nCOLUMNS\n X COST 1.0 R1 1.0\n Y COST 2.0 R1 1.0\nRHS\n RHS R1 1.0\nBOUNDS\n FR BND X 0\n MI BND Y\nENDATA\n")
     prob = mps.mpsread(str(p))
     assert prob["lb"][0] == -np.inf and prob["ub"][0] == np.inf and prob["lb"][1] == -np.inf
+
+
+def test_netlib_afiro_known_optimum():
+    """Netlib AFIRO itself (public domain; 27 rows x 32 structurals, 83 non-zeros + 5 costs; tests/data/afiro.mps) -- BASELINE configs[0] is no longer a
+    surrogate.  Published optimum -4.6475314286e+02: HiGHS on the bounded form, the LP oracle and (in the container) the real reference on the standard
+    form of scripts/bench-lp/preprocess.m (27 x 51, 102 non-zeros)."""
+    prob = mps.mpsread(os.path.join(DATA, "afiro.mps"))
+    assert prob["f"].shape == (32,) and prob["Aeq"].shape == (8, 32) and prob["Aineq"].shape == (19, 32)
+    assert prob["Aeq"].nnz + prob["Aineq"].nnz == 83 and np.count_nonzero(prob["f"]) == 5
+    r = highs(prob)
+    assert abs(r.fun - (-464.7531428571)) < 1e-8
+    A, b, c, extra = mps.load_standard_form(os.path.join(DATA, "afiro.mps"))
+    assert A.shape == (27, 51) and A.nnz == 102
+    from oracle import pyoracle as po
+    po.build(ref=False)
+    for which in ("oracle",) + (("ref",) if po.have_ref() else ()):
+        for linsys in ("direct", "indirect"):
+            o = po.solve(which, A, b, c, linsys=linsys, eps=1e-8)
+            assert o.info["status"] == "Solved"
+            assert abs(o.info["pobj"] - (-464.7531428571)) <= 1e-6 * 465, (which, linsys, o.info["pobj"])
