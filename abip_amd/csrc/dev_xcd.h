@@ -157,13 +157,13 @@ template <int K>
 __device__ __forceinline__ void x_publish(double (&v)[K], double *red, xrsrc sc, unsigned sc_off /* byte offset of this rank's granules */, unsigned tag) {
   static_assert(K >= 1 && K <= XKS, "1 .. XKS scalars per exchange");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my entries have been acknowledged by the L2
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] = x_wave_sum63(v[k]);
+  for (int k = 0; k < K; ++k) v[k] = x_wave_sum63(v[k]); // (while the stores travel)
   if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < K; ++k) red[k * XWAVES + wave] = v[k];
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my entries have been acknowledged by the L2
   __syncthreads(); // ... and so have everybody's of this workgroup
   if (wave < K) { // wavefront k adds the XWAVES partials of scalar k and raises the flag
     const double s = x_wave_sum63(lane < XWAVES ? red[wave * XWAVES + lane] : 0.0);

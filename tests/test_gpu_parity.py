@@ -487,6 +487,29 @@ def test_final_solution_matches_reference_fixture(gpu, name, eps_list, linsys):
             _check_against_golden(S, info, z, f"{linsys}_{eps:g}", eps)
 
 
+@pytest.mark.parametrize("xcd", ["1", "0"])
+@pytest.mark.parametrize("name,eps_list", [("lp_afiro_like", (1e-3, 1e-6, 1e-8)), ("lp_random_sparse_small", (1e-3, 1e-6, 1e-8)),
+                                           ("lp_multicommodity_small", (1e-4, 1e-8)), ("lp_staircase", (1e-3, 1e-6))])
+def test_direct_back_end_exact_iteration_counts(gpu, monkeypatch, name, eps_list, xcd):
+    """The direct back-end has no inner stopping test to flip (the KKT solve is exact to rounding), so its runs are held to the reference's
+    fixtures at the EXACT inner and outer iteration counts, and (x, y, s) at 10 eps -- through the one-XCD launch (the dense inverse of
+    rho I + A A') and through the launch-per-operation path (the sparse LDL' solve) alike."""
+    monkeypatch.setenv("ABIP_HIP_XCD", xcd)
+    z, A, b, c = load(name)
+    for eps in eps_list:
+        tag = f"direct_{eps:g}"
+        g = info_of(z, tag)
+        with gpu.Solver(A, b, c, linsys="direct", verbose=0, eps=eps, max_admm_iters=400000) as S:
+            assert S.scalar("xcd") == float(xcd)
+            info = S.solve()
+            assert info["status_val"] == g["status_val"] and info["ipm_iter"] == g["ipm_iter"]
+            assert info["admm_iter"] == g["admm_iter"], (name, eps, info["admm_iter"], g["admm_iter"])
+            if name != "lp_staircase":
+                for k in "xys":
+                    assert rel(getattr(S, k), z[f"{tag}_{k}"]) < 10 * eps, (name, eps, k)
+            assert abs(info["pobj"] - g["pobj"]) <= 10 * eps * (1 + abs(g["pobj"]))
+
+
 @pytest.mark.parametrize("variant", sorted(TINY_VARIANTS))
 @pytest.mark.parametrize("linsys", ["indirect", "direct"])
 def test_non_default_switches_match_reference_fixture(gpu, variant, linsys):
