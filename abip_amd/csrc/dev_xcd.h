@@ -36,9 +36,10 @@ namespace abip {
 
 constexpr int XTB = 1024;          // threads per workgroup
 constexpr int XWAVES = XTB / 64;
-constexpr int XG = 32;             // workgroups taking part = CUs of one XCD
+constexpr int XG = 256;            // most workgroups taking part: the CUs of one XCD (32), or of 2, 4, 8 XCDs
+constexpr int XQ = XG / 64;        // flags a polling lane looks after
 constexpr int XKS = 16;            // scalar granules per workgroup per exchange (<= XWAVES: wavefront k handles scalar k)
-constexpr int XSTAT_N = 128;       // ints of the status / post-mortem record
+constexpr int XSTAT_N = 1024;       // ints of the status / post-mortem record
 constexpr int XSPIN = 1 << 22;     // polling rounds before a wavefront gives up (a round is ~1 us)
 constexpr int XCD_LDS_MIN = 84 * 1024; // more than half a CU's LDS: one workgroup per CU
 static_assert(XKS <= XWAVES, "one wavefront per scalar of an exchange");
@@ -75,6 +76,7 @@ struct XcdArgs {
   // solve-only mode (the set-up solve, the Barzilai-Borwein look-ahead: solve_lin_sys on a caller's vector, abip.c:552-560 without the prox): K z = srhs in place,
   // warm start = the y block of swarm (or null), u_t'h left in the partial table as the launch path's kernels expect it
   int solve_only; double *srhs; const double *swarm; double *part; int npart;
+  int nxcd;                             // XCDs whose workgroups take a ticket: 1 (G = 32), or 2, 4, 8 (G = 32 nxcd, the CROSS variants)
   XcdFinal fc;
 };
 
@@ -84,17 +86,22 @@ __device__ __forceinline__ unsigned x_xcc_id() { unsigned x; asm volatile("s_get
 // owned entries of the l-vectors through x_at -- an element's offset is ONE vector register shared by every array it indexes.
 typedef __amdgpu_buffer_rsrc_t xrsrc;
 __device__ __forceinline__ xrsrc x_rsrc(const void *p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000); }
-__device__ __forceinline__ void x_putd(xrsrc r, unsigned off /* bytes */, double v) { // plain store: the line stays in this XCD's L2
+// SA: cache policy of the exchange's stores.  0 = plain: the line stays in this XCD's L2, where the other 31 CUs find it.  16 (sc1) = written through,
+// for the launch spread over several XCDs: their L2s are not coherent with each other (tools/xcd_probe.hip: st sc1 / ld sc1 is exact across XCDs,
+// 1.7 us per exchange against 1.2).
+template <int SA>
+__device__ __forceinline__ void x_putd(xrsrc r, unsigned off /* bytes */, double v) {
   u32x2 g; g.x = (unsigned)__double2loint(v); g.y = (unsigned)__double2hiint(v);
-  __builtin_amdgcn_raw_buffer_store_b64(g, r, (int)off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(g, r, (int)off, 0, SA);
 }
 __device__ __forceinline__ double x_ldd(xrsrc r, unsigned off) { // sc1: past the L1, served by the L2
   const u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 16);
   return __hiloint2double((int)g.y, (int)g.x);
 }
+template <int SA>
 __device__ __forceinline__ void x_putg(xrsrc r, unsigned off, double v, unsigned tag) { // a granule: one 16-byte store
   u32x4 g; g.x = (unsigned)__double2loint(v); g.y = tag; g.z = (unsigned)__double2hiint(v); g.w = tag;
-  __builtin_amdgcn_raw_buffer_store_b128(g, r, (int)off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(g, r, (int)off, 0, SA);
 }
 __device__ __forceinline__ u32x4 x_ldg(xrsrc r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 16); }
 __device__ __forceinline__ bool x_ok(const u32x4 &g, unsigned tag) { return g.y == tag && g.w == tag; } // both 8-byte halves are of this exchange
@@ -153,7 +160,7 @@ __device__ __forceinline__ bool x_spin(XWait &w, int &spins, unsigned found, int
 // (2) x_publish<K>: this thread's stores are in the L2; workgroup partial sums of K values; their granules go out = the flag of this rank;
 // (3) x_collect<K>: wavefront k polls scalar k of every rank, adds them in rank order; barrier: from here on every rank's entries are there;
 // (4) x_gather: the entries this thread's non-zeros name.
-template <int K>
+template <int K, int SA>
 __device__ __forceinline__ void x_publish(double (&v)[K], double *red, xrsrc sc, unsigned sc_off /* byte offset of this rank's granules */, unsigned tag) {
   static_assert(K >= 1 && K <= XKS, "1 .. XKS scalars per exchange");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -167,26 +174,38 @@ __device__ __forceinline__ void x_publish(double (&v)[K], double *red, xrsrc sc,
   __syncthreads(); // ... and so have everybody's of this workgroup
   if (wave < K) { // wavefront k adds the XWAVES partials of scalar k and raises the flag
     const double s = x_wave_sum63(lane < XWAVES ? red[wave * XWAVES + lane] : 0.0);
-    if (lane == 63) x_putg(sc, sc_off + (unsigned)wave * 16u, s, tag);
+    if (lane == 63) x_putg<SA>(sc, sc_off + (unsigned)wave * 16u, s, tag);
   }
 }
 template <int K>
 __device__ __forceinline__ void x_collect(XWait &w, int G, double *tot, double (&out)[K]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (wave < K) {
-    u32x4 g; g.x = 0; g.y = w.tag; g.z = 0; g.w = w.tag;
+    u32x4 g[XQ];
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) { g[q].x = 0; g[q].y = w.tag; g[q].z = 0; g[q].w = w.tag; }
     int spins = 0;
     for (;;) {
-      asm volatile("" ::: "memory"); // (the load is issued anew every round)
-      if (lane < G) g = x_ldg(w.sc, (unsigned)(lane * XKS + wave) * 16u);
-      const bool ok = x_ok(g, w.tag);
+      asm volatile("" ::: "memory"); // (the loads are issued anew every round)
+      bool ok = true;
+#pragma unroll
+      for (int q = 0; q < XQ; ++q) {
+        if (q * 64 >= G) break; // (uniform)
+        if (q * 64 + lane < G) g[q] = x_ldg(w.sc, (unsigned)((q * 64 + lane) * XKS + wave) * 16u);
+        ok = ok && x_ok(g[q], w.tag);
+      }
       if (__all(ok ? 1 : 0)) break;
       const unsigned long long miss = __ballot(ok ? 0 : 1);
       const int src = miss ? (int)__builtin_ctzll(miss) : 0;
-      if (!x_spin(w, spins, (unsigned)__builtin_amdgcn_readlane((int)g.y, src), 1000 + src)) break;
+      if (!x_spin(w, spins, (unsigned)__builtin_amdgcn_readlane((int)g[0].y, src), 1000 + src)) break;
       __builtin_amdgcn_s_sleep(2);
     }
-    const double s = x_wave_sum63(lane < G ? x_val(g) : 0.0);
+    double s = 0.0; // rank order: 64 ranks at a time, lane order inside
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+      if (q * 64 >= G) break;
+      s += x_wave_sum63(q * 64 + lane < G ? x_val(g[q]) : 0.0);
+    }
     if (lane == 63) tot[wave] = s;
   }
   __syncthreads();
@@ -296,7 +315,7 @@ __device__ __forceinline__ void x_prox(const UpdArgs &a, double uo, double vo, d
 #define XP_DECL unsigned long long xp_t = 0, xp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define XP_START xp_t = wall_clock64();
 #define XP_LAP(k) { const unsigned long long xp_n = wall_clock64(); xp_acc[k] += xp_n - xp_t; xp_t = xp_n; }
-#define XP_DUMP if (rank == 0 && t == 0) for (int q = 0; q < 8; ++q) a.xstat[96 + q] = (int)xp_acc[q];
+#define XP_DUMP if (rank == 0 && t == 0) for (int q = 0; q < 8; ++q) a.xstat[600 + q] = (int)xp_acc[q];
 #else
 #define XP_DECL
 #define XP_START
@@ -304,8 +323,9 @@ __device__ __forceinline__ void x_prox(const UpdArgs &a, double uo, double vo, d
 #define XP_DUMP
 #endif
 
-template <int NZ, int RM, int RN, bool PCG>
+template <int NZ, int RM, int RN, bool PCG, bool CROSS = false> // CROSS: the ranks sit on several XCDs (stores of the exchanges written through)
 __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
+  constexpr int SA = CROSS ? 16 : 0;
   extern __shared__ double xl[];
   double *prod = xl;                 // 2 x NZ * XTB
   double *tot = prod + 2 * NZ * XTB; // XKS
@@ -318,7 +338,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   const int lane = t & 63, wave = t >> 6;
   if (t == 0) {
     int r = -1;
-    if (x_xcc_id() == 0) {
+    if (x_xcc_id() < (unsigned)a.nxcd) {
       r = (int)(atomicAdd(a.tickets, 1u) - a.ticket_base);
       if (r < 0 || r >= a.G) r = -1;
     }
@@ -383,7 +403,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       if (i < m1) {
         const double uy = solo ? (a.swarm ? x_at(a.swarm, i) : 0.0) : x_at(up.u, i);
         if (!solo) p[0] += rho * (uy + x_at(up.v, i)) * x_at(up.g, i);
-        if (PCG) x_putd(pm0, i * 8u, uy);
+        if (PCG) x_putd<SA>(pm0, i * 8u, uy);
       }
     }
 #pragma unroll
@@ -392,7 +412,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       if (j < n1 && !solo) p[0] += (x_at(up.u, MP + j) + x_at(up.v, MP + j)) * x_at(up.g, MP + j);
     }
     if (rank == 0 && t == 0 && !solo) { p[1] = x_at(up.u, tail); p[2] = x_at(up.v, tail); }
-    x_publish<3>(p, red, psc, sc_off, tag);
+    x_publish<3, SA>(p, red, psc, sc_off, tag);
     double s3[3];
     x_collect<3>(w, G, tot, s3);
     if (w.dead) return;
@@ -462,11 +482,11 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
           r += -coef * hj;
         }
         rhs_x[q] = -r;
-        x_putd(pn0, j2 * 8u, -r);
-        if (PCG) x_putd(pn1, j2 * 8u, aty[q]);
+        x_putd<SA>(pn0, j2 * 8u, -r);
+        if (PCG) x_putd<SA>(pn1, j2 * 8u, aty[q]);
       }
     }
-    x_publish<1>(bn, red, psc, sc_off, tag);
+    x_publish<1, SA>(bn, red, psc, sc_off, tag);
     double bnS[1];
     x_collect<1>(w, G, tot, bnS);
     if (w.dead) return;
@@ -510,9 +530,9 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         // ---- z and (|r|^2, z'r) out; convergence test; tmp = A'z + beta tmp (k_cg_spmv_At) ----
         open(3);
 #pragma unroll
-        for (int q = 0; q < RM; ++q) { const unsigned i = m0 + t + q * XTB; if (i < m1) x_putd(pm0, i * 8u, cz[q]); }
+        for (int q = 0; q < RM; ++q) { const unsigned i = m0 + t + q * XTB; if (i < m1) x_putd<SA>(pm0, i * 8u, cz[q]); }
         XP_LAP(0)
-        x_publish<2>(rz, red, psc, sc_off, tag);
+        x_publish<2, SA>(rz, red, psc, sc_off, tag);
         XP_LAP(1)
         double tx[NZ];
         x_mat<NZ>(gT, nt, tx); // (on their way while the flags are awaited)
@@ -543,7 +563,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
             const double v = (cgit == 0) ? tq[q] : tq[q] + beta * ctmp[q];
             ctmp[q] = v;
             tp[0] += v * v;
-            x_putd(pn0, j2 * 8u, v);
+            x_putd<SA>(pn0, j2 * 8u, v);
           }
         }
 #pragma unroll
@@ -553,7 +573,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         }
         // ---- tmp and (|A'p|^2, |p|^2) out; Gp = A tmp + rho p; alpha; x, r, z (k_cg_spmv_A + k_cg_update) ----
         XP_LAP(0)
-        x_publish<2>(tp, red, psc, sc_off, tag);
+        x_publish<2, SA>(tp, red, psc, sc_off, tag);
         XP_LAP(1)
         double ax[NZ];
         x_mat<NZ>(gA, na, ax);
@@ -602,9 +622,9 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       XP_LAP(0)
       open(5);
 #pragma unroll
-      for (int q = 0; q < RM; ++q) { const unsigned i = m0 + tb + q * XTB; if (i < m1) x_putd(pm0, i * 8u, rhs_y[q] + sA[q]); }
+      for (int q = 0; q < RM; ++q) { const unsigned i = m0 + tb + q * XTB; if (i < m1) x_putd<SA>(pm0, i * 8u, rhs_y[q] + sA[q]); }
       double dz[1] = {0.0}, dzS[1];
-      x_publish<1>(dz, red, psc, sc_off, tag);
+      x_publish<1, SA>(dz, red, psc, sc_off, tag);
       x_collect<1>(w, G, tot, dzS);
       if (w.dead) return;
       XP_LAP(1)
@@ -642,12 +662,12 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
 #pragma unroll
     for (int q = 0; q < RM; ++q) {
       const unsigned i = m0 + tb + q * XTB;
-      if (i < m1) { x_putd(pm0, i * 8u, y[q]); x_at(solo ? a.srhs : up.ut, i) = y[q]; dh[0] += y[q] * x_at(a.h, i); }
+      if (i < m1) { x_putd<SA>(pm0, i * 8u, y[q]); x_at(solo ? a.srhs : up.ut, i) = y[q]; dh[0] += y[q] * x_at(a.h, i); }
     }
     double zx[RN];
     {
       double dz[1] = {0.0}, dzS[1];
-      x_publish<1>(dz, red, psc, sc_off, tag);
+      x_publish<1, SA>(dz, red, psc, sc_off, tag);
       x_collect<1>(w, G, tot, dzS);
       if (w.dead) return;
       double tx[NZ], vt[NZ], tq[RN];
@@ -662,7 +682,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       }
     }
     open(7);
-    x_publish<1>(dh, red, psc, sc_off, tag);
+    x_publish<1, SA>(dh, red, psc, sc_off, tag);
     double dhS[1];
     x_collect<1>(w, G, tot, dhS);
     if (w.dead) return;
@@ -688,8 +708,8 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         x_at(up.u, i) = un; x_at(up.v, i) = vn;
         x_at(up.u_avg, i) += un; x_at(up.v_avg, i) += vn;
         xs_y(up, i, un, vn, sst);
-        x_putd(pm0, i * 8u, un);
-        if (avg_stats) x_putd(pm1, i * 8u, x_at(up.u_avgc, i));
+        x_putd<SA>(pm0, i * 8u, un);
+        if (avg_stats) x_putd<SA>(pm1, i * 8u, x_at(up.u_avgc, i));
       }
     }
 #pragma unroll
@@ -703,8 +723,8 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         x_at(up.u, qq) = un; x_at(up.v, qq) = vn;
         x_at(up.u_avg, qq) += un; x_at(up.v_avg, qq) += vn;
         xs_x(up, qq, j2, false, un, vn, sst);
-        x_putd(pn0, j2 * 8u, un);
-        if (avg_stats) x_putd(pn1, j2 * 8u, x_at(up.u_avgc, qq));
+        x_putd<SA>(pn0, j2 * 8u, un);
+        if (avg_stats) x_putd<SA>(pn1, j2 * 8u, x_at(up.u_avgc, qq));
       }
     }
     if (rank == 0 && t == 0) { // the tau / kappa entry
@@ -718,7 +738,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       tau4[0] = un; tau4[1] = vn; tau4[2] = x_at(up.u_avgc, tail); tau4[3] = x_at(up.v_avgc, tail);
     }
     double s13[13] = {sst.wg, sst.nu, sst.nv, sst.cx, sst.by, sst.nua, sst.nva, sst.cxa, sst.bya, tau4[0], tau4[1], tau4[2], tau4[3]};
-    x_publish<13>(s13, red, psc, sc_off, tag);
+    x_publish<13, SA>(s13, red, psc, sc_off, tag);
     // ---- stopping-test products (k_q_both): A u_x and A'u_y, residual sums; A'u_y is also the next solve's warm-start product ----
     double q6[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     double S13[13];
@@ -798,7 +818,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     }
     if (!PCG) { XP_LAP(5) }
     open(9);
-    x_publish<12>(q6, red, psc, sc_off, tag);
+    x_publish<12, SA>(q6, red, psc, sc_off, tag);
     double Q[12];
     x_collect<12>(w, G, tot, Q);
     if (w.dead) return;

@@ -144,7 +144,8 @@ int dist_allreduce(double *buf, size_t count, hipStream_t s, std::vector<double>
 // One-XCD persistent launch for cache-resident LPs (dev_xcd.h): what abip_init prepares when the problem fits it.
 struct XcdPlan {
   bool on = false;
-  int G = abip::XG, NZ = 0, RM = 0, RN = 0;
+  int G = 32, nxcd = 1, NZ = 0, RM = 0, RN = 0;
+  unsigned tickets_used = 0; // tickets drawn by the launches so far (G per launch)
   abip::hostutil::DBuf<int> mb, nb, xstat;
   abip::hostutil::DBuf<unsigned> tickets;
   abip::hostutil::DBuf<double> xn0, xn1, xm0, xm1;
@@ -793,9 +794,9 @@ int admm_iteration(W *w, double *metric_out) {
 // ------------------------------------------------------------------------------------------------
 // One-XCD persistent launch (dev_xcd.h): set-up and one batch of iterations
 // ------------------------------------------------------------------------------------------------
-struct XcdVariant { int nz, rm, rn; const void *pcg, *direct; };
+struct XcdVariant { int nz, rm, rn; const void *pcg, *direct, *pcg2 /* spread over several XCDs */; };
 const XcdVariant kXcdVariants[] = {
-#define XV(a, b, c) {a, b, c, (const void *)k_lp_xcd<a, b, c, true>, (const void *)k_lp_xcd<a, b, c, false>}
+#define XV(a, b, c) {a, b, c, (const void *)k_lp_xcd<a, b, c, true>, (const void *)k_lp_xcd<a, b, c, false>, (const void *)k_lp_xcd<a, b, c, true, true>}
     XV(2, 1, 1), XV(4, 1, 2), XV(6, 1, 2), XV(8, 2, 4),
 #undef XV
 };
@@ -845,6 +846,20 @@ void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
   if (!pcg && (w->m > 2048 || !w->A)) return; // direct: inv(rho I + A A') is kept dense
   std::vector<int> mb, nb;
   long nzA = 0, nzT = 0; int rA = 0, rT = 0, lA = 0, lT = 0;
+  // How many XCDs.  A second (fourth) XCD halves (quarters) a slice -- the gathers and row sums of an exchange -- and costs ~0.5 us per exchange for
+  // stores written through to where the other XCDs' loads find them.  PCG back-end, c3 (136 k non-zeros), 32 / 64 / 128 / 256 workgroups:
+  // 3.24 / 2.89 / 2.58 / 3.04 us per exchange -> aim at ~1000 non-zeros per slice, at most 4 XCDs (ABIP_HIP_XCD_G forces 32 .. 256).
+  x.G = 32;
+  if (pcg) {
+    const char *e = getenv("ABIP_HIP_XCD_G");
+    const int ge = e ? atoi(e) : 0;
+    if (ge == 32 || ge == 64 || ge == 128 || ge == 256) x.G = ge;
+    else {
+      const long nnz = hA.ptr[hA.nrows];
+      while (x.G < 128 && nnz > 1536L * x.G) x.G *= 2;
+    }
+  }
+  x.nxcd = x.G / 32;
   xcd_best_slices(hA, x.G, mb, &nzA, &rA, &lA, pcg ? 0.0 : (double)w->m);
   xcd_best_slices(hAt, x.G, nb, &nzT, &rT, &lT);
   if (std::max(lA, lT) > 512) return; // rows are added up by one thread each
@@ -852,8 +867,9 @@ void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
   for (const XcdVariant &v : kXcdVariants)
     if (std::max(nzA, nzT) <= (long)v.nz * XTB && rA <= v.rm * XTB && rT <= v.rn * XTB) { pick = &v; break; }
   if (!pick) return;
+  if (pcg && x.G >= 128 && pick->nz > 4 && !getenv("ABIP_HIP_XCD_G")) return; // ~5e5 non-zeros: the launch path has caught up (rand 20000 x 50000 x 16: 1513 against 1549 it/s)
   x.NZ = pick->nz; x.RM = pick->rm; x.RN = pick->rn;
-  x.kern = pcg ? pick->pcg : pick->direct;
+  x.kern = pcg ? (x.G > 32 ? pick->pcg2 : pick->pcg) : pick->direct;
   x.n_pad = (int)((w->n + 63) / 64 * 64); x.m_pad = (int)((w->m + 63) / 64 * 64);
   size_t words = 2 * (size_t)x.NZ * XTB + XKS + XWAVES * XKS + 96;
   if (!pcg) words += (size_t)x.m_pad + (size_t)x.RM * XTB;
@@ -900,13 +916,13 @@ void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
     if (getenv("ABIP_HIP_XCD_VERBOSE")) printf("[xcd] dense inverse of rho I + A A' (%d x %d): residual %.2e\n", m, m, res);
     if (!(res <= 1e-9)) { x.release(); return; }
   }
-  x.tag = 0; x.launches = 0;
+  x.tag = 0; x.launches = 0; x.tickets_used = 0;
   x.on = true;
   // stand-alone solves (set-up, BB look-ahead) through the persistent kernel: worth it for the PCG back-end (a launch-path solve is 3 launches per PCG
   // iteration); the direct back-end's launch-path solve is 4 launches in all and wins (ABIP_HIP_XCD_SOLVES=0 / 1 forces either)
   { const char *e = getenv("ABIP_HIP_XCD_SOLVES"); w->xcd_solves = e ? atoi(e) != 0 : pcg; }
   if (getenv("ABIP_HIP_XCD_VERBOSE"))
-    printf("[xcd] G %d: slices of A  <= %ld nnz, %d rows (longest row %d); of A' <= %ld nnz, %d rows (longest %d); NZ %d RM %d RN %d, LDS %zu B (%d rows of the dense inverse)\n", x.G, nzA, rA, lA, nzT, rT, lT,
+    printf("[xcd] %d workgroups on %d XCD(s): slices of A  <= %ld nnz, %d rows (longest row %d); of A' <= %ld nnz, %d rows (longest %d); NZ %d RM %d RN %d, LDS %zu B (%d rows of the dense inverse)\n", x.G, x.nxcd, nzA, rA, lA, nzT, rT, lT,
            x.NZ, x.RM, x.RN, x.lds, x.minv_lds_rows);
 }
 
@@ -941,7 +957,8 @@ int xcd_batch(W *w, int nb, int *ran, double *metric_out, double *srhs, const do
   a.g_th = w->g_th;
   a.xn0 = x.xn0.p; a.xn1 = x.xn1.p; a.xm0 = x.xm0.p; a.xm1 = x.xm1.p; a.sc = x.sc.p; a.n_pad = x.n_pad; a.m_pad = x.m_pad;
   a.tag0 = x.tag;
-  a.tickets = x.tickets.p; a.ticket_base = x.launches * 32u;
+  a.tickets = x.tickets.p; a.ticket_base = x.tickets_used; a.nxcd = x.nxcd;
+  x.tickets_used += (unsigned)x.G;
   a.ctl = w->ctl.p; a.xstat = x.xstat.p;
   a.j0 = (long)w->j; a.max_iters = nb;
   a.thr = w->gamma * w->mu; a.sentinel = (double)st->max_admm_iters;
@@ -985,7 +1002,7 @@ int xcd_batch(W *w, int nb, int *ran, double *metric_out, double *srhs, const do
   x.tag += (unsigned)x.hstat[1]; x.exchanges += x.hstat[1];
   if (srhs) return 0; // solve-only: no iteration ran
 #ifdef XCD_PROF
-  { static long acc[8] = {0}; for (int q = 0; q < 8; ++q) acc[q] += (unsigned)x.hstat[96 + q];
+  { static long acc[8] = {0}; for (int q = 0; q < 8; ++q) acc[q] += (unsigned)x.hstat[600 + q];
     fprintf(stderr, "[xcd prof] cumulative us: %.0f %.0f %.0f %.0f %.0f %.0f %.0f (PCG loop: put, publish, collect, gather, rows, tail | direct: rhs+E1, E_w, all-gather, dense, E_y+E_dh, update+E_u, q+E_fin)\n", acc[0] * 0.01, acc[1] * 0.01, acc[2] * 0.01, acc[3] * 0.01, acc[4] * 0.01, acc[5] * 0.01, acc[6] * 0.01); }
 #endif
   *ran = w->hctl->it_count - w->it_seen;
@@ -1963,7 +1980,7 @@ abip_float abip_hip_get_scalar(ABIPWork *w, const char *name) {
   RET("sc_b", w->sc_b) RET("sc_c", w->sc_c) RET("nm_b", w->nm_b) RET("nm_c", w->nm_c) RET("tot_cg_its", w->tot_cg_its)
   RET("lnnz", w->ldl.lnnz) RET("levels_fwd", w->ldl.F.nlev) RET("levels_bwd", w->ldl.B.nlev) RET("tail", w->ldl.T) RET("admm_iter", w->k) RET("ipm_iter", w->i)
   RET("sell_At", w->dAt.nslices) RET("sell_A", w->dA.nslices) RET("nb", w->NB) RET("dist_cols", w->cg_cols ? 1 : 0) RET("small_solve", w->ldl.small ? 1 : 0) RET("factor_resid", w->factor_resid)
-  RET("xcd", w->xcd.on ? 1 : 0) RET("xcd_nz", w->xcd.NZ) RET("xcd_batches", w->xcd.batches) RET("xcd_exchanges", w->xcd.exchanges)
+  RET("xcd", w->xcd.on ? 1 : 0) RET("xcd_nz", w->xcd.NZ) RET("xcd_g", w->xcd.on ? w->xcd.G : 0) RET("xcd_batches", w->xcd.batches) RET("xcd_exchanges", w->xcd.exchanges)
 #undef RET
   return NAN;
 }

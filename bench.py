@@ -322,7 +322,8 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
     sharded = sharded and linsys == "indirect"
 
     S = Solver(A, b, c, linsys=linsys, eps=1e-6, verbose=0)
-    xcd = S.scalar("xcd") == 1.0       # cache-resident LP: the inner loop runs as the one-XCD persistent launch (abip_amd/csrc/dev_xcd.h)
+    xcd = S.scalar("xcd") == 1.0       # cache-resident LP: the inner loop runs as the persistent launch on 1, 2 or 4 XCDs (abip_amd/csrc/dev_xcd.h)
+    xg = int(S.scalar("xcd_g")) if xcd else 0
     S.begin()
     fin, done_w = S.step(warmup)
     S.sync()
@@ -386,9 +387,10 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         ach = b_iter * its / max(ms * 1e-3, 1e-12) / 1e9
         exch = (2 * cg_step + 6) if linsys == "indirect" else 6.0
         roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
-                    kernel="k_lp_xcd: the whole inner ADMM loop as one persistent launch on the 32 CUs of one XCD (slices of A and A' per workgroup, operands handed "
-                           "over through the XCD's L2: stores, acknowledged, partial-sum granules as flags, L1-bypassing gathers); bound by the latency of "
-                           "its exchanges (and, beyond ~1e5 non-zeros, by the L2's request rate: one request per gathered non-zero), not by HBM",
+                    kernel="k_lp_xcd: the whole inner ADMM loop as one persistent launch, one workgroup per CU on %d XCD(s) (slices of A and A' per workgroup; operands "
+                           "handed over through the L2%s: stores, acknowledged, partial-sum granules as flags, L1-bypassing gathers); bound by the latency "
+                           "of its exchanges -- a chain of L2 round trips and two workgroup barriers -- not by HBM" % (xg // 32, " (written through between XCDs)" if xg > 32 else ""),
+                    workgroups=xg,
                     avg_launch_us=1e3 * ms / nl, launches=nl, iterations_per_launch=its / nl, algorithmic_bytes_per_launch=b_iter * its / nl,
                     algorithmic_bytes_per_iteration=b_iter, us_per_iteration=1e3 * ms / its, exchanges_per_iteration=exch, us_per_exchange=1e3 * ms / its / exch,
                     timing="hipEvents around every launch inside the timed region")
@@ -435,7 +437,7 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         coll = dict(collectives_per_step=prof["allreduce_calls"] / its_, bytes_per_step=prof["allreduce_bytes"] / its_,
                     ms_in_allreduce_per_step=prof["allreduce_ms"] / its_, share_of_step=prof["allreduce_ms"] / its_ / max(1e3 * elapsed / max(steps_eff, 1), 1e-12),
                     timing="hipEvents around every ncclAllReduce on the solver's stream (rank 0's view)")
-    extra = dict(collectives=coll, cg_iters_per_step=cg_step, events_pass=events_pass, m=m, n=n, nnz=int(nnz), rows=[int(row0), int(row1)], one_xcd_launch=bool(xcd))
+    extra = dict(collectives=coll, cg_iters_per_step=cg_step, events_pass=events_pass, m=m, n=n, nnz=int(nnz), rows=[int(row0), int(row1)], persistent_launch=bool(xcd), persistent_launch_workgroups=xg)
     if linsys == "indirect":
         cg = extra["cg_iters_per_step"]
         b_cg = b_spmv(n, m, nnz) + b_spmv(m, n, nnz) + 8 * (21 * m + n)

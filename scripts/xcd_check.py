@@ -12,7 +12,7 @@ def run(A, b, c, linsys, xcd, eps, verbose=0, max_steps=None):
         t0 = time.time()
         out = s.solve()
         dt = time.time() - t0
-        return dict(xcd=on, nz=s.scalar("xcd_nz"), batches=s.scalar("xcd_batches"), exch=s.scalar("xcd_exchanges"), dt=dt, x=s.x.copy(), y=s.y.copy(), s=s.s.copy(), **out)
+        return dict(xcd=on, g=s.scalar("xcd_g"), nz=s.scalar("xcd_nz"), batches=s.scalar("xcd_batches"), exch=s.scalar("xcd_exchanges"), dt=dt, x=s.x.copy(), y=s.y.copy(), s=s.s.copy(), **out)
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "small"
@@ -26,13 +26,19 @@ def main():
         A, b, c = problems.lp_staircase()
     elif which == "afiro":
         A, b, c = problems.lp_afiro_like()
+    elif which.startswith("rand:"):      # rand:m:n:per_col
+        _, m_, n_, pc = which.split(":")
+        A, b, c = problems.lp_random_sparse(m=int(m_), n=int(n_), per_col=int(pc), seed=3)
+    elif which.startswith("mc:"):        # mc:nodes:arcs:commodities
+        _, nd, ar, cm = which.split(":")
+        A, b, c = problems.lp_multicommodity(nodes=int(nd), arcs=int(ar), commodities=int(cm))
     print("problem", which, A.shape, A.nnz, "linsys", linsys, "eps", eps, flush=True)
     res = {}
     for xcd in (1, 0):
         r = run(A, b, c, linsys, xcd, eps)
         res[xcd] = r
-        print("xcd=%d on=%g nz=%g batches=%g exch=%g status=%s admm=%d ipm=%d pobj=%.10e time=%.3fs  -> %.0f it/s" % (
-            xcd, r["xcd"], r["nz"], r["batches"], r["exch"], r["status"], r["admm_iter"], r["ipm_iter"], r["pobj"], r["dt"], r["admm_iter"] / r["dt"]), flush=True)
+        print("xcd=%d on=%g G=%g nz=%g batches=%g exch=%g status=%s admm=%d ipm=%d pobj=%.10e time=%.3fs  -> %.0f it/s" % (
+            xcd, r["xcd"], r["g"], r["nz"], r["batches"], r["exch"], r["status"], r["admm_iter"], r["ipm_iter"], r["pobj"], r["dt"], r["admm_iter"] / r["dt"]), flush=True)
     a, b_ = res[1], res[0]
     for k in ("x", "y", "s"):
         d = np.linalg.norm(a[k] - b_[k]) / max(1e-300, np.linalg.norm(b_[k]))

@@ -122,3 +122,33 @@ def test_full_size_c2_and_c3_on_the_one_xcd_launch(gpu, monkeypatch):
         assert out["1"]["ipm_iter"] == out["0"]["ipm_iter"]
         assert abs(out["1"]["admm_iter"] - out["0"]["admm_iter"]) <= 0.02 * out["0"]["admm_iter"] + 2
         assert abs(out["1"]["pobj"] - out["0"]["pobj"]) <= 1e-3 * (1 + abs(out["0"]["pobj"]))
+
+
+@pytest.mark.parametrize("G", [64, 128, 256])
+@pytest.mark.parametrize("name", ["lp_multicommodity_small", "lp_random_sparse_small"])
+def test_launch_spread_over_several_xcds_agrees_with_the_launch_path(gpu, name, G, monkeypatch):
+    """PCG variants may place their workgroups on 2, 4 or 8 XCDs (G = 64, 128, 256; chosen from the non-zero count, here forced): the stores of an
+    exchange are then written through (the L2s of two XCDs are not coherent with each other).  Same bars as on one XCD, and the same bits
+    whatever the batching -- the partial sums are added in rank order, 64 ranks at a time."""
+    z, A, b, c = load(name)
+    monkeypatch.setenv("ABIP_HIP_XCD_G", str(G))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ABIP_HIP_XCD", mode)
+        with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-8) as S:
+            assert S.scalar("xcd") == float(mode) and S.scalar("xcd_g") == (float(G) if mode == "1" else 0.0)
+            info = S.solve()
+            out[mode] = (info, S.x.copy(), S.y.copy(), S.s.copy())
+    a, l = out["1"], out["0"]
+    assert a[0]["status_val"] == l[0]["status_val"] == 1 and a[0]["ipm_iter"] == l[0]["ipm_iter"]
+    assert abs(a[0]["admm_iter"] - l[0]["admm_iter"]) <= 0.01 * l[0]["admm_iter"] + 1
+    for k in (1, 2, 3):
+        assert rel(a[k], l[k]) < 1e-6
+    monkeypatch.setenv("ABIP_HIP_XCD", "1")
+    runs = []
+    for batch in ("1", "0"):
+        monkeypatch.setenv("ABIP_HIP_BATCH", batch)
+        with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-5) as S:
+            info = S.solve()
+            runs.append((info["admm_iter"], S.x.copy(), S.y.copy()))
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
