@@ -736,14 +736,32 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       x_at(up.u_avg, tail) += un; x_at(up.v_avg, tail) += vn;
       xs_x(up, tail, (unsigned)a.n, true, un, vn, sst);
       tau4[0] = un; tau4[1] = vn; tau4[2] = x_at(up.u_avgc, tail); tau4[3] = x_at(up.v_avgc, tail);
+      // the tau / kappa entries are nobody's sum: they travel as granules of rank 0 behind the sums' (slots 12..15), acknowledged before its flags go out
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x_putg<SA>(psc, sc_off + (unsigned)(12 + q) * 16u, tau4[q], tag);
     }
-    double s13[13] = {sst.wg, sst.nu, sst.nv, sst.cx, sst.by, sst.nua, sst.nva, sst.cxa, sst.bya, tau4[0], tau4[1], tau4[2], tau4[3]};
-    x_publish<13, SA>(s13, red, psc, sc_off, tag);
-    // ---- stopping-test products (k_q_both): A u_x and A'u_y, residual sums; A'u_y is also the next solve's warm-start product ----
+    // (an exchange costs per scalar it carries -- a wavefront sum in every wavefront, a polling wavefront: the averaged iterate's four sums go
+    //  out only on the iterations that test it, one in ten)
     double q6[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     double S13[13];
-    x_collect<13>(w, G, tot, S13);
+    if (avg_stats) {
+      double s9[9] = {sst.wg, sst.nu, sst.nv, sst.cx, sst.by, sst.nua, sst.nva, sst.cxa, sst.bya}, S9[9];
+      x_publish<9, SA>(s9, red, psc, sc_off, tag);
+      x_collect<9>(w, G, tot, S9);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) S13[q] = S9[q];
+    } else {
+      double s5[5] = {sst.wg, sst.nu, sst.nv, sst.cx, sst.by}, S5[5];
+      x_publish<5, SA>(s5, red, psc, sc_off, tag);
+      x_collect<5>(w, G, tot, S5);
+#pragma unroll
+      for (int q = 0; q < 5; ++q) S13[q] = S5[q];
+      S13[5] = 0.0; S13[6] = 0.0; S13[7] = 0.0; S13[8] = 0.0;
+    }
     if (w.dead) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) S13[9 + q] = x_uni(x_val(x_ldg(psc, (unsigned)(12 + q) * 16u))); // (rank 0's granules: there since its flags are)
+    // ---- stopping-test products (k_q_both): A u_x and A'u_y, residual sums; A'u_y is also the next solve's warm-start product ----
     {
       double pri[RM];
       {
@@ -818,9 +836,17 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     }
     if (!PCG) { XP_LAP(5) }
     open(9);
-    x_publish<12, SA>(q6, red, psc, sc_off, tag);
     double Q[12];
-    x_collect<12>(w, G, tot, Q);
+    if (avg_stats) {
+      x_publish<12, SA>(q6, red, psc, sc_off, tag);
+      x_collect<12>(w, G, tot, Q);
+    } else {
+      double q[6] = {q6[0], q6[1], q6[2], q6[3], q6[4], q6[5]}, Q6[6];
+      x_publish<6, SA>(q, red, psc, sc_off, tag);
+      x_collect<6>(w, G, tot, Q6);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { Q[k] = Q6[k]; Q[6 + k] = 0.0; }
+    }
     if (w.dead) return;
     // ---- finalize (d_finalize): the inner-loop exit test, iterate_Q_norm_resd abip.c:2027-2050 and the comparison of abip.c:2173 ----
     wg = S13[0]; u_tau = S13[9]; v_tau = S13[10];
