@@ -9,7 +9,9 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 for wl in c4 c2 c3; do
-  timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/$wl" --output-format csv -- python3 "$ROOT/bench.py" --workload $wl --steps 20 --warmup 5 --no-cpu --no-extra --no-to-tol \
+  win="--steps 20 --warmup 5"                       # c4: the driver's window; c2 / c3: the windows their records on the default line are quoted on
+  [ "$wl" != c4 ] && win=""
+  timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/$wl" --output-format csv -- python3 "$ROOT/bench.py" --workload $wl $win --no-cpu --no-extra --no-to-tol \
       > "$OUT/${wl}_bench_under_rocprof.json" 2> "$OUT/${wl}.err"
   echo "$wl rc $?" >> "$OUT/summary.txt"
   f=$(find "$OUT/$wl" -name '*kernel_stats.csv' | head -1)
