@@ -408,7 +408,17 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         if pmc and name == "c4" and world == 1 and os.path.exists(pmcf):
             rec = json.load(open(pmcf)).get("k_cg_" + kname, {})
             traffic, tsrc = rec.get("traffic_bytes"), "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=tsrc,
+        trace = None
+        trf = os.path.join(ROOT, "profiles", "r03_trace_durations.json")   # rocprofv3 kernel-trace durations of the same kernels, committed (scripts/r03_trace.sh)
+        if name == "c4" and world == 1 and os.path.exists(trf):
+            tr = json.load(open(trf)).get("k_cg_" + kname)
+            if tr:
+                # the stamps leave out dispatch and drain; scale this run's stamp figure by the ratio trace / stamp measured in ONE profiled run
+                ratio = tr["mean_working_us"] / tr["stamp_avg_us_same_run"]
+                trace = dict(profiled_run_trace_us=tr["mean_working_us"], profiled_run_stamp_us=tr["stamp_avg_us_same_run"], trace_over_stamp=ratio,
+                             avg_launch_us_trace_equivalent=avg_ms * 1e3 * ratio, frac_trace_equivalent=ach / HBM_PEAK_GBS / ratio,
+                             source="profiles/r03_trace_durations.json <- profiles/r03i_c4_kernel_medians.txt")
+        roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=tsrc, trace=trace,
                     kernel=cand[kname][1], avg_launch_us=avg_ms * 1e3, launches=nl, algorithmic_bytes_per_launch=cand[kname][0],
                     timing="device wall-clock ticks (first sampled workgroup begin .. last sampled workgroup end) of every launch that did work, "
                            "inside the timed region",
