@@ -358,6 +358,7 @@ int abip_hip_qcp_dist_partition(const QCPMatrix *A, const QCPCone *K, int world,
 }
 
 void abip_hip_qcp_last_stats(double *out8) { for (int q = 0; q < 8; ++q) out8[q] = g_stats[q]; }
+void abip_hip_qcp_phase_times(double *out5) { for (int q = 0; q < 5; ++q) out5[q] = g_phase[q]; }
 
 void abip_qcp_set_default_settings(QCPData *d) { // util.c:203-255
   QCPSettings *s = d->stgs;
@@ -493,6 +494,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   w->LV = ((w->MP + nl + 1 + 31) / 32) * 32;
   if (hipStreamCreate(&w->stream) != hipSuccess) return bail("hipStreamCreate failed");
   if (hipEventCreate(&w->ev_a) != hipSuccess || hipEventCreate(&w->ev_b) != hipSuccess) return bail("hipEventCreate failed");
+  for (hipEvent_t &e : w->ev_ph) if (hipEventCreate(&e) != hipSuccess) return bail("hipEventCreate failed");
   { // matrices
     host::HostCsr hAt, hA, hQ;
     hcsr_from(w->A, hAt, false); hcsr_from(w->A, hA, true);
@@ -827,6 +829,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   // one inner iteration (abip.c:1120-1160), everything on the stream; `timed` brackets the KKT solve with events
   auto enqueue_iteration = [&](int kk, bool timed) {
     // projection, abip.c:186-255
+    if (timed) (void)hipEventRecord(w->ev_ph[0], w->stream);
     QLAUNCH(w, kq_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->r.p, w->p.p, st->rho_y, st->rho_x, dm, w->part.p, hc);
     if (timed) (void)hipEventRecord(w->ev_a, w->stream);
     if (w->pcg) { if (solve_pcg(w, w->p.p, true, kk, std::min(r.Ax_b_norm, r.Qx_ATy_c_s_norm)) < 0) pcg_failed = true; } // abip.c:206-224
@@ -834,6 +837,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     if (timed) (void)hipEventRecord(w->ev_b, w->stream);
     QLAUNCH(w, kq_dots, w->NB, BS, (const double *)w->r.p, (const double *)w->p.p, st->rho_y, st->rho_x, dm, w->part.p, hc);
     if (w->hasQ) QLAUNCH(w, kq_Qp, w->NB, BS, w->dQ.view(), (const double *)w->p.p, dm, w->part.p, hc);
+    if (timed) (void)hipEventRecord(w->ev_ph[1], w->stream); // end of project_lin_sys
     QProxArgs pa;
     pa.u = w->u.p; pa.v = w->v.p; pa.ut = w->ut.p; pa.rel = w->rel.p; pa.p = w->p.p; pa.r = w->r.p; pa.xkind = w->xkind.p;
     pa.alpha = st->alpha; pa.lambda = w->mu / w->beta; pa.rho_x = st->rho_x; pa.rho_tau = st->rho_tau; pa.a_quad = w->a_quad; pa.iter_pos = kk > 0; pa.hasQ = w->hasQ;
@@ -849,7 +853,9 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       if (w->nsmall) { QCones C{w->c_off.p, w->c_len.p, w->c_kind.p, w->nsmall}; QLAUNCH(w, kq_cones<false>, (w->nsmall + WAVES - 1) / WAVES, BS, C, 0, w->u.p, (const double *)w->rel.p, lam, w->MP, hc); }
       if (w->ncones > w->nsmall) { QCones C{w->c_off.p, w->c_len.p, w->c_kind.p, w->ncones}; QLAUNCH(w, kq_cones<true>, w->ncones - w->nsmall, QC_TB, C, w->nsmall, w->u.p, (const double *)w->rel.p, lam, w->MP, hc); }
     }
+    if (timed) (void)hipEventRecord(w->ev_ph[2], w->stream); // end of solve_barrier_subproblem
     QLAUNCH(w, kq_dual, w->NB, BS, w->u.p, (const double *)w->rel.p, w->v.p, w->vo.p, st->rho_y, st->rho_x, st->rho_tau, dm, (const QCtl *)w->ctl.p, hc);
+    if (timed) (void)hipEventRecord(w->ev_ph[3], w->stream); // end of the dual update ("updating work")
     // inner stopping test, qcp_config.c:518-557 (the tau entries and the comparison with tol_inner happen in kq_finalize)
     if (w->dist) { // A'u_y is local; A u_x = sum over the ranks of the block products, then the y-block sums on the replicated result
       QLAUNCH(w, kq_inner_At, w->NB, BS, w->dAt.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->cd.p, w->ATy.p, w->Qx.p, w->hasQ ? 0 : 1, dm, w->part.p, hc);
@@ -865,6 +871,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     }
     if (w->hasQ) QLAUNCH(w, kq_inner_Q, w->NB, BS, w->dQ.view(), (const double *)w->u.p, (const double *)w->vo.p, (const double *)w->cd.p, (const double *)w->ATy.p, w->Qx.p, dm, w->part.p, hc);
     finalize(w, {Q_D1, Q_D2, Q_D3, Q_E1, Q_E2, Q_E3}, {Q_D1, Q_D3, Q_E1, Q_E2, Q_E3}, tol_inner);
+    if (timed) (void)hipEventRecord(w->ev_ph[4], w->stream); // end of err_inner
   };
 
   for (i = 0; i < st->max_ipm_iters && !finished; ++i) {
@@ -880,6 +887,9 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       for (int q = 0; q < nb; ++q) enqueue_iteration(k + q, q == 0);
       if (read_ctl(w) || pcg_failed || w->dist_failed) return bail("device error in the inner iteration");
       { float ms = 0.f; if (hipEventElapsedTime(&ms, w->ev_a, w->ev_b) == hipSuccess) { w->lin_ms += ms; w->lin_n++; } }
+      { float ph[4]; bool ok = true;
+        for (int q = 0; q < 4; ++q) ok = ok && hipEventElapsedTime(&ph[q], w->ev_ph[q], w->ev_ph[q + 1]) == hipSuccess;
+        if (ok) { for (int q = 0; q < 4; ++q) w->ph_ms[q] += ph[q]; w->ph_n++; } else (void)hipGetLastError(); }
       const int ran = w->hctl->it_count - seen;
       seen = w->hctl->it_count;
       if (ran < 1 || ran > nb) return bail("device error in the inner iteration");
@@ -889,7 +899,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       if (halted && clear_halt(w)) return bail("device error in the inner iteration");
       { const bool ot = over_time(); if (time_failed) return bail("collective failure"); if (halted || ot) { j = j_last; break; } } // err_inner < tol_inner, abip.c:1147
       if ((j_last + 1) % st->inner_check_period == 0 || r.error_ratio <= 8) {
-        if (calc_residuals(w, r, i, k)) return bail("device error in calc_residuals");
+        { const double tr0 = now_ms(); const int rc = calc_residuals(w, r, i, k); w->res_ms += now_ms() - tr0; if (rc) return bail("device error in calc_residuals"); }
         if ((info->status_val = has_converged(w, r, i, k)) != 0 || stop_now(i)) {
           if (get_solution(i, k)) return bail("device error in get_solution");
           finished = true;
@@ -902,7 +912,7 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     }
     if (finished) break;
     if (w->sparsity || (i + 1) % st->outer_check_period == 0) {
-      if (calc_residuals(w, r, i, k)) return bail("device error in calc_residuals");
+      { const double tr0 = now_ms(); const int rc = calc_residuals(w, r, i, k); w->res_ms += now_ms() - tr0; if (rc) return bail("device error in calc_residuals"); }
       if ((info->status_val = has_converged(w, r, i, k)) != 0 || stop_now(i)) {
         if (get_solution(i, k)) return bail("device error in get_solution");
         finished = true;
@@ -910,6 +920,14 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
       }
     }
     tol_inner = adjust_barrier(w, r);
+  }
+  { // per-phase totals in the reference's order and units (seconds; abip.c:1196-1201)
+    const double sc = w->ph_n ? (double)k / (double)w->ph_n * 1e-3 : 0.0;
+    g_phase[0] = w->ph_ms[0] * sc; g_phase[1] = w->ph_ms[1] * sc; g_phase[2] = w->res_ms * 1e-3; g_phase[3] = w->ph_ms[3] * sc; g_phase[4] = w->ph_ms[2] * sc;
+    if (st->verbose)
+      printf("\ntotal time of project_lin_sys: %.2es\ntotal time of solve_barrier_subproblem: %.2es\ntotal time of calculate res: %.2es\ntotal time of calculate err_inner: %.2es\n"
+             "total time of updating work: %.2es\n(device phases: hipEvents around one iteration per control read, %ld of %d iterations, scaled)\n",
+             g_phase[0], g_phase[1], g_phase[2], g_phase[3], g_phase[4], w->ph_n, (int)k);
   }
   info->avg_linsys_time = w->lin_n ? w->lin_ms / (double)w->lin_n : 0; info->avg_cg_iters = w->cg_solves ? (double)w->tot_cg / (double)w->cg_solves : 0; // ms per solve, as lin_sys_time_per_iter (abip.c:1228)
   g_stats[0] = w->ldl.N; g_stats[1] = w->ldl.T; g_stats[2] = (double)w->ldl.lnnz; g_stats[3] = w->ldl.F.nlev; g_stats[4] = w->ldl.B.nlev;

@@ -65,6 +65,11 @@ struct QWk {
   DevLdl ldl;
   hipEvent_t ev_a = nullptr, ev_b = nullptr; // bracket of the KKT solve of the current iteration (avg_linsys_time)
   double lin_ms = 0; long lin_n = 0;
+  // the reference's per-phase timers (abip.c:1084-1093, printed at 1196-1201): project_lin_sys, solve_barrier_subproblem, updating work, err_inner --
+  // hipEvents at the phase boundaries of the ONE iteration per control read that is bracketed anyway (sampled; totals = mean x iterations);
+  // calc_residuals by the host clock around its calls (it ends in a synchronisation)
+  hipEvent_t ev_ph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  double ph_ms[4] = {0, 0, 0, 0}; long ph_n = 0; double res_ms = 0;
   int ncones = 0, nsmall = 0; // cone table: the nsmall cones of <= QC_BIG entries first
   Ctl *lp_ctl = nullptr; // dev_sptrsv kernels are gated on an LP-style control block (halt flag): a zeroed one
   // indirect back-end (linsys_solver = 3, qcp_pcg.h)
@@ -87,11 +92,13 @@ struct QWk {
 #define QLAUNCH(w, kern, grid, block, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (w)->stream, __VA_ARGS__)
 
 inline double g_stats[8] = {0};
+inline double g_phase[5] = {0}; // seconds: project_lin_sys, solve_barrier_subproblem, calc_residuals, err_inner, updating work (the order the reference prints them in)
 
 inline void release(QWk *w) {
   if (w->ev_a) (void)hipEventDestroy(w->ev_a);
   if (w->ev_b) (void)hipEventDestroy(w->ev_b);
   w->ev_a = w->ev_b = nullptr;
+  for (hipEvent_t &e : w->ev_ph) { if (e) (void)hipEventDestroy(e); e = nullptr; }
   w->dA.release(); w->dAt.release(); w->dQ.release();
   w->ls.Dd.release(); w->ls.Ed.release(); w->ls.yd.release();
   w->sv.Dd.release(); w->sv.Ed.release(); w->sv.wEd.release();

@@ -113,6 +113,9 @@ def abip_qcp(data, cones, settings: dict):
     L.abip_hip_qcp_last_stats(st)
     out["factor"] = dict(N=int(st[0]), dense_tail=int(st[1]), lnnz=int(st[2]), levels=[int(st[3]), int(st[4])], solves_timed=int(st[5]),
                          solve_ms_total=float(st[6]), head_nnz=int(st[7]))
+    ph = (C.c_double * 5)()
+    L.abip_hip_qcp_phase_times(ph)   # the reference's per-phase timers (abip.c:1084-1093), seconds
+    out["phase_times"] = dict(project_lin_sys=ph[0], solve_barrier_subproblem=ph[1], calc_residuals=ph[2], err_inner=ph[3], updating_work=ph[4])
     return dict(x=x, y=y, s=s), out
 
 

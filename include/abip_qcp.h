@@ -138,6 +138,10 @@ void abip_qcp_set_default_settings(QCPData *d);
  * out8 = { N, dense-tail size T, nnz(L), forward levels, backward levels, solves timed, total ms of those solves (hipEvents
  * on the solver's stream), nnz of the sparse head (forward + backward copies) }. */
 void abip_hip_qcp_last_stats(double *out8);
+/* the reference's per-phase timers of the last solve (src/abip-qcp/source/abip.c:1084-1093, printed at 1196-1201), seconds, in its order:
+   project_lin_sys, solve_barrier_subproblem, calculate res, calculate err_inner, updating work.  The four device phases are sampled
+   (hipEvents around one iteration per control read) and scaled to the iteration count; calculate res is the host clock around its calls. */
+void abip_hip_qcp_phase_times(double *out5);
 /* Column ranges of the sharded conic path (several GPUs): bounds[g] .. bounds[g+1] are rank g's columns (world + 1 entries out), cut behind
  * cones or inside the free / zero / orthant blocks, balanced by non-zeros.  Pure host code.  0 ok; -1 a rotated cone of fewer than 3 entries;
  * -2 fewer blocks than ranks; -3 bad arguments. */

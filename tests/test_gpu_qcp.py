@@ -55,6 +55,11 @@ def test_toy_qcp_matches_recorded_reference_output(gpu):
     assert abs(info["pobj"] - (-0.984063813)) < 5e-9 and abs(info["dobj"] - (-0.984063938)) < 5e-9
     want = np.array([0.046341, 0.044938, 0.011319, 0.342543, 0.061490, 0.205246, -2.161307, 2.006235])
     assert np.max(np.abs(sol["x"] - want)) < 6e-7
+    # the reference's per-phase timers (abip.c:1084-1093, 1196-1201): five non-negative totals that fit inside the solve time
+    ph = info["phase_times"]
+    assert set(ph) == {"project_lin_sys", "solve_barrier_subproblem", "calc_residuals", "err_inner", "updating_work"}
+    assert all(v >= 0.0 for v in ph.values()) and ph["project_lin_sys"] > 0.0 and ph["solve_barrier_subproblem"] > 0.0
+    assert sum(ph.values()) <= 1.5 * info["solve_time"] + 1e-3
 
 
 @pytest.mark.parametrize("case", ["toy", "lasso_small", "lasso_mid", "lp_afiro", "lp_rand", "qp", "rsoc_mix", "lasso_bigcone"])
