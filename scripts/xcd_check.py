@@ -29,6 +29,9 @@ def main():
     elif which.startswith("rand:"):      # rand:m:n:per_col
         _, m_, n_, pc = which.split(":")
         A, b, c = problems.lp_random_sparse(m=int(m_), n=int(n_), per_col=int(pc), seed=3)
+    elif which.startswith("stair:"):     # stair:stages:rows_per:cols_per
+        _, st_, rp, cp = which.split(":")
+        A, b, c = problems.lp_staircase(stages=int(st_), rows_per=int(rp), cols_per=int(cp))[:3]
     elif which.startswith("mc:"):        # mc:nodes:arcs:commodities
         _, nd, ar, cm = which.split(":")
         A, b, c = problems.lp_multicommodity(nodes=int(nd), arcs=int(ar), commodities=int(cm))
