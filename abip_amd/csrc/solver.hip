@@ -832,20 +832,12 @@ void xcd_best_slices(const host::HostCsr &M, int G, std::vector<int> &bounds, lo
   }
 }
 
-// Decide whether the LP runs its inner loop as the one-XCD persistent launch and prepare it.  Never fails the set-up: when the problem does
-// not fit (or ABIP_HIP_XCD=0) the launch path stays in charge.
-void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
-  XcdPlan &x = w->xcd;
-  x.on = false;
-  { const char *e = getenv("ABIP_HIP_XCD"); if (e && atoi(e) == 0) return; }
-  if (w->dist) return;
-  hipDeviceProp_t prop; int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return;
-  if (prop.multiProcessorCount != 256 || !strstr(prop.gcnArchName, "gfx950")) return; // 8 XCDs x 32 CUs is what the placement argument needs
-  const bool pcg = (w->linsys == ABIP_HIP_LINSYS_INDIRECT);
-  if (!pcg && (w->m > 2048 || !w->A)) return; // direct: inv(rho I + A A') is kept dense
-  std::vector<int> mb, nb;
-  long nzA = 0, nzT = 0; int rA = 0, rT = 0, lA = 0, lT = 0;
+// The host half of the decision (no device needed: abip_hip_xcd_plan exports it for the CPU tests): how many workgroups, which slices of A and A'
+// they own, which kernel variant holds them, how the LDS is divided.  false = the problem stays on the launch path.
+bool xcd_plan(XcdPlan &x, const host::HostCsr &hA, const host::HostCsr &hAt, bool pcg, std::vector<int> &mb, std::vector<int> &nb, long *nzA, long *nzT, int *rA, int *rT,
+              int *lA, int *lT) {
+  const long m = hA.nrows, n = hAt.nrows;
+  if (!pcg && m > 2048) return false; // direct: inv(rho I + A A') is kept dense
   // How many XCDs.  A second (fourth) XCD halves (quarters) a slice -- the gathers and row sums of an exchange -- and costs ~0.5 us per exchange for
   // stores written through to where the other XCDs' loads find them.  PCG back-end, c3 (136 k non-zeros), 32 / 64 / 128 / 256 workgroups:
   // 3.24 / 2.89 / 2.58 / 3.04 us per exchange -> aim at ~1000 non-zeros per slice, at most 4 XCDs (ABIP_HIP_XCD_G forces 32 .. 256).
@@ -860,26 +852,45 @@ void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
     }
   }
   x.nxcd = x.G / 32;
-  xcd_best_slices(hA, x.G, mb, &nzA, &rA, &lA, pcg ? 0.0 : (double)w->m);
-  xcd_best_slices(hAt, x.G, nb, &nzT, &rT, &lT);
-  if (std::max(lA, lT) > 512) return; // rows are added up by one thread each
+  xcd_best_slices(hA, x.G, mb, nzA, rA, lA, pcg ? 0.0 : (double)m);
+  xcd_best_slices(hAt, x.G, nb, nzT, rT, lT);
+  if (std::max(*lA, *lT) > 512) return false; // rows are added up by one thread each
   const XcdVariant *pick = nullptr;
   for (const XcdVariant &v : kXcdVariants)
-    if (std::max(nzA, nzT) <= (long)v.nz * XTB && rA <= v.rm * XTB && rT <= v.rn * XTB) { pick = &v; break; }
-  if (!pick) return;
-  if (pcg && x.G >= 128 && pick->nz > 4 && !getenv("ABIP_HIP_XCD_G")) return; // ~5e5 non-zeros: the launch path has caught up (rand 20000 x 50000 x 16: 1513 against 1549 it/s)
+    if (std::max(*nzA, *nzT) <= (long)v.nz * XTB && *rA <= v.rm * XTB && *rT <= v.rn * XTB) { pick = &v; break; }
+  if (!pick) return false;
+  if (pcg && x.G >= 128 && pick->nz > 4 && !getenv("ABIP_HIP_XCD_G")) return false; // ~5e5 non-zeros: the launch path has caught up (rand 20000 x 50000 x 16: 1513 against 1549 it/s)
   x.NZ = pick->nz; x.RM = pick->rm; x.RN = pick->rn;
   x.kern = pcg ? (x.G > 32 ? pick->pcg2 : pick->pcg) : pick->direct;
-  x.n_pad = (int)((w->n + 63) / 64 * 64); x.m_pad = (int)((w->m + 63) / 64 * 64);
+  x.n_pad = (int)((n + 63) / 64 * 64); x.m_pad = (int)((m + 63) / 64 * 64);
   size_t words = 2 * (size_t)x.NZ * XTB + XKS + XWAVES * XKS + 96;
   if (!pcg) words += (size_t)x.m_pad + (size_t)x.RM * XTB;
-  if (words * sizeof(double) > 160 * 1024) return;
+  if (words * sizeof(double) > 160 * 1024) return false;
+  x.minv_lds_rows = 0;
   if (!pcg) { // what is left of the LDS keeps rows of the dense inverse
     const size_t room = (160 * 1024 - 512) / sizeof(double) - words;
-    x.minv_lds_rows = (int)std::min<size_t>(room / (size_t)x.m_pad, (size_t)rA);
+    x.minv_lds_rows = (int)std::min<size_t>(room / (size_t)x.m_pad, (size_t)*rA);
     words += (size_t)x.minv_lds_rows * x.m_pad;
   }
   x.lds = std::max<size_t>(words * sizeof(double), (size_t)XCD_LDS_MIN);
+  return true;
+}
+
+// Decide whether the LP runs its inner loop as the one-XCD persistent launch and prepare it.  Never fails the set-up: when the problem does
+// not fit (or ABIP_HIP_XCD=0) the launch path stays in charge.
+void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
+  XcdPlan &x = w->xcd;
+  x.on = false;
+  { const char *e = getenv("ABIP_HIP_XCD"); if (e && atoi(e) == 0) return; }
+  if (w->dist) return;
+  hipDeviceProp_t prop; int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return;
+  if (prop.multiProcessorCount != 256 || !strstr(prop.gcnArchName, "gfx950")) return; // 8 XCDs x 32 CUs is what the placement argument needs
+  const bool pcg = (w->linsys == ABIP_HIP_LINSYS_INDIRECT);
+  std::vector<int> mb, nb;
+  long nzA = 0, nzT = 0; int rA = 0, rT = 0, lA = 0, lT = 0;
+  if (!pcg && !w->A) return;
+  if (!xcd_plan(x, hA, hAt, pcg, mb, nb, &nzA, &nzT, &rA, &rT, &lA, &lT)) return;
   if (hipFuncSetAttribute(x.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x.lds) != hipSuccess) { (void)hipGetLastError(); return; }
   const std::vector<int> zero2(XSTAT_N, 0);
   const std::vector<unsigned> zero1(1, 0u);
@@ -2006,6 +2017,25 @@ int abip_hip_host_factor_solve(const ABIPMatrix *A, double rho_y, int tail, doub
 // symmetric quasi-definite K given by its UPPER triangle in CSC form (32-bit indices).  on_device = 0: ordering + head factor + Schur complement + dense tail
 // all on the host (host::host_solve; runs without a GPU); 1: the head on the host, the dense tail factored and every solve applied on the device
 // (DevLdl::setup / enqueue).  tail: -1 automatic, 0 none, T > 0 forced.  rhs (N) is overwritten with K^-1 rhs.  stats4 = {T, nnz(L), forward levels, backward levels}.
+// Pure host code (runs without a GPU): the plan of the persistent launch for an LP with the sparsity pattern (m, n, Ap, Ai) of A (CSC, as in ABIPMatrix)
+// and back-end linsys -- out8 = {admitted 0/1, workgroups, XCDs, NZ, RM, RN, LDS bytes, rows of the dense inverse kept in LDS}; mb (workgroups + 1) /
+// nb (workgroups + 1) receive the row boundaries of the slices of A / A' when not NULL (room for 257 each).  For tests/test_xcd_plan_cpu.py.
+int abip_hip_xcd_plan(abip_int m, abip_int n, const abip_int *Ap, const abip_int *Ai, int linsys, double *out8, int *mb_out, int *nb_out) {
+  if (m <= 0 || n <= 0 || !Ap || !Ai || !out8) return -1;
+  std::vector<abip_float> ones((size_t)std::max<abip_int>(Ap[n], 1), 1.0);
+  ABIPMatrix A; A.m = m; A.n = n; A.p = const_cast<abip_int *>(Ap); A.i = const_cast<abip_int *>(Ai); A.x = ones.data();
+  host::HostCsr hA, hAt;
+  host::transpose_to_csr(&A, hA);
+  host::csc_as_csr(&A, hAt);
+  XcdPlan x;
+  std::vector<int> mb, nb;
+  long nzA = 0, nzT = 0; int rA = 0, rT = 0, lA = 0, lT = 0;
+  const bool ok = xcd_plan(x, hA, hAt, linsys == ABIP_HIP_LINSYS_INDIRECT, mb, nb, &nzA, &nzT, &rA, &rT, &lA, &lT);
+  out8[0] = ok ? 1 : 0; out8[1] = x.G; out8[2] = x.nxcd; out8[3] = ok ? x.NZ : 0; out8[4] = ok ? x.RM : 0; out8[5] = ok ? x.RN : 0; out8[6] = ok ? (double)x.lds : 0; out8[7] = ok ? x.minv_lds_rows : 0;
+  if (ok && mb_out) std::copy(mb.begin(), mb.end(), mb_out);
+  if (ok && nb_out) std::copy(nb.begin(), nb.end(), nb_out);
+  return 0;
+}
 int abip_hip_ldl_solve(int N, const int *Kp, const int *Ki, const double *Kx, int tail, int on_device, double *rhs, double *stats4) {
   if (N <= 0 || !Kp || !Ki || !Kx || !rhs) return -1;
   std::vector<int> kp(Kp, Kp + N + 1), ki(Ki, Ki + Kp[N]);

@@ -99,6 +99,12 @@ int abip_hip_host_normalize_A(ABIPMatrix *A, const ABIPSettings *stgs, double *D
 /* this rank's row range [row0, row1) of the last abip_init (0, m on a single GPU) */
 void abip_hip_dist_rows(ABIPWork *w, abip_int *row0, abip_int *row1);
 
+/* Pure host code (runs without a GPU; CPU-side tests of the host logic): the plan of the persistent launch (abip_amd/csrc/dev_xcd.h) for an LP with the
+ * sparsity pattern (m, n, Ap, Ai) of A in CSC form and KKT back-end linsys.  out8 = {admitted 0 / 1, workgroups, XCDs, non-zeros per thread, rows of A per
+ * thread, rows of A' per thread, LDS bytes per workgroup, rows of the dense inverse kept in LDS}; mb / nb (each workgroups + 1 ints, room for 257; may be
+ * NULL) receive the row boundaries of the workgroups' slices of A / A'.  ABIP_HIP_XCD_G in the environment forces the workgroup count as it does in
+ * abip_init.  Returns 0, < 0 on invalid arguments. */
+int abip_hip_xcd_plan(abip_int m, abip_int n, const abip_int *Ap, const abip_int *Ai, int linsys, double *out8, int *mb, int *nb);
 /* Unit-level access to the direct back-end's LDL' as the LP and the conic path use it: K symmetric quasi-definite, given by its UPPER triangle in CSC
  * form (32-bit indices); rhs (N) <- K^-1 rhs.  on_device 0: everything on the host (no GPU needed); 1: sparse head on the host, dense tail factored and
  * the solve applied on the device.  tail: -1 automatic, 0 none, T forced.  stats4 (may be NULL) = {T, nnz(L), forward levels, backward levels}.
