@@ -386,7 +386,10 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         ms = prof["ms"]["xcd"]
         ach = b_iter * its / max(ms * 1e-3, 1e-12) / 1e9
         exch = (2 * cg_step + 6) if linsys == "indirect" else 6.0
-        roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+        # HBM bytes per launch from the committed counter passes (per inner iteration there, FETCH_SIZE / WRITE_SIZE summed over the kernel's dispatches)
+        tpi = pmc_traffic(name).get("k_lp_xcd", {}).get("traffic_bytes_per_iteration") if pmc and world == 1 else None
+        roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=(tpi * its / nl) if tpi else None,
+                    traffic_source="profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; per inner iteration x iterations per launch)" if tpi else None,
                     kernel="k_lp_xcd: the whole inner ADMM loop as one persistent launch, one workgroup per CU on %d XCD(s) (slices of A and A' per workgroup; operands "
                            "handed over through the L2%s: stores, acknowledged, partial-sum granules as flags, L1-bypassing gathers); bound by the latency "
                            "of its exchanges -- a chain of L2 round trips and two workgroup barriers -- not by HBM" % (xg // 32, " (written through between XCDs)" if xg > 32 else ""),

@@ -18,6 +18,8 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   run c5_direct $ctr "$ROOT/scripts/pmc_conic.py" c5 direct 12
   run c5_pcg $ctr "$ROOT/scripts/pmc_conic.py" c5 pcg 12
   run lasso_pcg $ctr "$ROOT/scripts/pmc_conic.py" lasso pcg 8
+  run c2 $ctr "$ROOT/scripts/pmc_lp.py" c2 600
+  run c3 $ctr "$ROOT/scripts/pmc_lp.py" c3 60
 done
 python3 "$ROOT/scripts/pmc_summarize.py" "$OUT" > "$OUT/r03_pmc_traffic.json" 2>> "$OUT/summary.txt"
 cat "$OUT/summary.txt"
