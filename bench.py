@@ -407,10 +407,9 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         avg_ms = prof["stamp_ms"][kname] / nl
         ach = cand[kname][0] / max(avg_ms * 1e-3, 1e-12) / 1e9
         traffic, tsrc = None, None
-        pmcf = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # PMC counters need rocprofv3: measured in separate passes, committed
-        if pmc and name == "c4" and world == 1 and os.path.exists(pmcf):
-            rec = json.load(open(pmcf)).get("k_cg_" + kname, {})
-            traffic, tsrc = rec.get("traffic_bytes"), "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        if pmc and name == "c4" and world == 1:   # PMC counters need rocprofv3: measured in separate passes (scripts/r03_pmc.sh), committed
+            rec = pmc_traffic("c4").get("k_cg_" + kname, {})
+            traffic, tsrc = rec.get("traffic_bytes"), "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         trace = None
         trf = os.path.join(ROOT, "profiles", "r03_trace_durations.json")   # rocprofv3 kernel-trace durations of the same kernels, committed (scripts/r03_trace.sh)
         if name == "c4" and world == 1 and os.path.exists(trf):
