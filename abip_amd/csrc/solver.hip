@@ -794,9 +794,9 @@ int admm_iteration(W *w, double *metric_out) {
 // ------------------------------------------------------------------------------------------------
 // One-XCD persistent launch (dev_xcd.h): set-up and one batch of iterations
 // ------------------------------------------------------------------------------------------------
-struct XcdVariant { int nz, rm, rn; const void *pcg, *direct, *pcg2 /* spread over several XCDs */; };
+struct XcdVariant { int nz, rm, rn; const void *pcg, *direct, *pcg2 /* spread over several XCDs */, *direct2; };
 const XcdVariant kXcdVariants[] = {
-#define XV(a, b, c) {a, b, c, (const void *)k_lp_xcd<a, b, c, true>, (const void *)k_lp_xcd<a, b, c, false>, (const void *)k_lp_xcd<a, b, c, true, true>}
+#define XV(a, b, c) {a, b, c, (const void *)k_lp_xcd<a, b, c, true>, (const void *)k_lp_xcd<a, b, c, false>, (const void *)k_lp_xcd<a, b, c, true, true>, (const void *)k_lp_xcd<a, b, c, false, true>}
     XV(2, 1, 1), XV(4, 1, 2), XV(6, 1, 2), XV(8, 2, 4),
 #undef XV
 };
@@ -840,16 +840,17 @@ bool xcd_plan(XcdPlan &x, const host::HostCsr &hA, const host::HostCsr &hAt, boo
   if (!pcg && m > 2048) return false; // direct: inv(rho I + A A') is kept dense
   // How many XCDs.  A second (fourth) XCD halves (quarters) a slice -- the gathers and row sums of an exchange -- and costs ~0.5 us per exchange for
   // stores written through to where the other XCDs' loads find them.  PCG back-end, c3 (136 k non-zeros), 32 / 64 / 128 / 256 workgroups:
-  // 3.24 / 2.89 / 2.58 / 3.04 us per exchange -> aim at ~1000 non-zeros per slice, at most 4 XCDs (ABIP_HIP_XCD_G forces 32 .. 256).
+  // 3.24 / 2.89 / 2.58 / 3.04 us per exchange -> aim at ~1000 non-zeros per slice, at most 4 XCDs (ABIP_HIP_XCD_G forces 32 .. 256, either back-end).
   x.G = 32;
-  if (pcg) {
+  {
     const char *e = getenv("ABIP_HIP_XCD_G");
     const int ge = e ? atoi(e) : 0;
     if (ge == 32 || ge == 64 || ge == 128 || ge == 256) x.G = ge;
-    else {
+    else if (pcg) {
       const long nnz = hA.ptr[hA.nrows];
       while (x.G < 128 && nnz > 1536L * x.G) x.G *= 2;
-    }
+    } else if (m >= 1280) x.G = 128; // direct: the rows of the dense inverse dominate from there (staircase LPs, 32 / 64 / 128 workgroups: m = 816: 48.3 / 37.2 / 33.1 k it/s,
+                                     // m = 1400: 29.1 / 28.8 / 30.9 k, m = 2000: 21.0 / 23.5 / 25.3 k)
   }
   x.nxcd = x.G / 32;
   xcd_best_slices(hA, x.G, mb, nzA, rA, lA, pcg ? 0.0 : (double)m);
@@ -861,7 +862,7 @@ bool xcd_plan(XcdPlan &x, const host::HostCsr &hA, const host::HostCsr &hAt, boo
   if (!pick) return false;
   if (pcg && x.G >= 128 && pick->nz > 4 && !getenv("ABIP_HIP_XCD_G")) return false; // ~5e5 non-zeros: the launch path has caught up (rand 20000 x 50000 x 16: 1513 against 1549 it/s)
   x.NZ = pick->nz; x.RM = pick->rm; x.RN = pick->rn;
-  x.kern = pcg ? (x.G > 32 ? pick->pcg2 : pick->pcg) : pick->direct;
+  x.kern = pcg ? (x.G > 32 ? pick->pcg2 : pick->pcg) : (x.G > 32 ? pick->direct2 : pick->direct);
   x.n_pad = (int)((n + 63) / 64 * 64); x.m_pad = (int)((m + 63) / 64 * 64);
   size_t words = 2 * (size_t)x.NZ * XTB + XKS + XWAVES * XKS + 96;
   if (!pcg) words += (size_t)x.m_pad + (size_t)x.RM * XTB;

@@ -126,17 +126,18 @@ def test_full_size_c2_and_c3_on_the_one_xcd_launch(gpu, monkeypatch):
 
 
 @pytest.mark.parametrize("G", [64, 128, 256])
-@pytest.mark.parametrize("name", ["lp_multicommodity_small", "lp_random_sparse_small"])
-def test_launch_spread_over_several_xcds_agrees_with_the_launch_path(gpu, name, G, monkeypatch):
-    """PCG variants may place their workgroups on 2, 4 or 8 XCDs (G = 64, 128, 256; chosen from the non-zero count, here forced): the stores of an
-    exchange are then written through (the L2s of two XCDs are not coherent with each other).  Same bars as on one XCD, and the same bits
-    whatever the batching -- the partial sums are added in rank order, 64 ranks at a time."""
+@pytest.mark.parametrize("name,linsys", [("lp_multicommodity_small", "indirect"), ("lp_random_sparse_small", "indirect"), ("lp_staircase", "direct"),
+                                         ("lp_random_sparse_small", "direct")])
+def test_launch_spread_over_several_xcds_agrees_with_the_launch_path(gpu, name, linsys, G, monkeypatch):
+    """The workgroups may sit on 2, 4 or 8 XCDs (G = 64, 128, 256; chosen from the non-zero count -- PCG -- or from m -- direct --, here forced): the
+    stores of an exchange are then written through (the L2s of two XCDs are not coherent with each other).  Same bars as on one XCD, and the same
+    bits whatever the batching -- the partial sums are added in rank order, 64 ranks at a time."""
     z, A, b, c = load(name)
     monkeypatch.setenv("ABIP_HIP_XCD_G", str(G))
     out = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("ABIP_HIP_XCD", mode)
-        with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-8) as S:
+        with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-8) as S:
             assert S.scalar("xcd") == float(mode) and S.scalar("xcd_g") == (float(G) if mode == "1" else 0.0)
             info = S.solve()
             out[mode] = (info, S.x.copy(), S.y.copy(), S.s.copy())
@@ -149,7 +150,7 @@ def test_launch_spread_over_several_xcds_agrees_with_the_launch_path(gpu, name, 
     runs = []
     for batch in ("1", "0"):
         monkeypatch.setenv("ABIP_HIP_BATCH", batch)
-        with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-5) as S:
+        with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-5) as S:
             info = S.solve()
             runs.append((info["admm_iter"], S.x.copy(), S.y.copy()))
     assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])

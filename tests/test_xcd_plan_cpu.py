@@ -77,6 +77,16 @@ def test_forced_workgroup_counts(G, monkeypatch):
     check_slices(tiny, q)
 
 
+def test_direct_back_end_spreads_out_when_the_dense_inverse_dominates(monkeypatch):
+    monkeypatch.delenv("ABIP_HIP_XCD_G", raising=False)
+    small = problems.lp_staircase()[0]                                            # m = 816
+    big = problems.lp_staircase(stages=20, rows_per=100, cols_per=230)[0]         # m = 2000
+    p, q = plan(small, "direct"), plan(big, "direct")
+    assert p["ok"] and p["G"] == 32 and q["ok"] and q["G"] == 128 and q["xcds"] == 4
+    check_slices(big, q)
+    assert q["minv_rows"] >= 1
+
+
 def test_what_does_not_fit_is_left_to_the_launch_path(monkeypatch):
     monkeypatch.delenv("ABIP_HIP_XCD_G", raising=False)
     A = problems.lp_random_sparse(m=20000, n=50000, per_col=16, seed=3)[0]       # 5e5 non-zeros: the launch path has caught up
