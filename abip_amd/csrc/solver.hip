@@ -837,7 +837,9 @@ void xcd_best_slices(const host::HostCsr &M, int G, std::vector<int> &bounds, lo
 bool xcd_plan(XcdPlan &x, const host::HostCsr &hA, const host::HostCsr &hAt, bool pcg, std::vector<int> &mb, std::vector<int> &nb, long *nzA, long *nzT, int *rA, int *rT,
               int *lA, int *lT) {
   const long m = hA.nrows, n = hAt.nrows;
-  if (!pcg && m > 2048) return false; // direct: inv(rho I + A A') is kept dense
+  // direct: inv(rho I + A A') is kept dense -- 8 m^2 bytes read per iteration.  Staircase LPs, persistent launch against launch path: m = 2000: 25.3 k / 12.2 k it/s,
+  // 3000: 19.7 k / 11.5 k, 4000: 15.3 k / 10.8 k; the curves meet somewhere beyond (ABIP_HIP_XCD_MMAX moves the limit)
+  { const char *e = getenv("ABIP_HIP_XCD_MMAX"); if (!pcg && m > (e ? atol(e) : 4096L)) return false; }
   // How many XCDs.  A second (fourth) XCD halves (quarters) a slice -- the gathers and row sums of an exchange -- and costs ~0.5 us per exchange for
   // stores written through to where the other XCDs' loads find them.  PCG back-end, c3 (136 k non-zeros), 32 / 64 / 128 / 256 workgroups:
   // 3.24 / 2.89 / 2.58 / 3.04 us per exchange -> aim at ~1000 non-zeros per slice, at most 4 XCDs (ABIP_HIP_XCD_G forces 32 .. 256, either back-end).

@@ -91,14 +91,14 @@ def test_one_xcd_launch_run_to_run_identical(gpu, monkeypatch):
 def test_problems_that_do_not_fit_stay_on_the_launch_path(gpu, monkeypatch):
     """The persistent launch takes an LP only when its slices fit the registers / LDS of the workgroups of at most 4 XCDs with at most 4 non-zeros per
     thread (beyond ~5e5 non-zeros the launch path has caught up) and, for the direct back-end, when the dense inverse of the m x m Schur complement
-    is affordable (m <= 2048): otherwise abip_init leaves the launch path in charge, silently.  (The plan itself: tests/test_xcd_plan_cpu.py.)"""
+    is affordable (m <= 4096): otherwise abip_init leaves the launch path in charge, silently.  (The plan itself: tests/test_xcd_plan_cpu.py.)"""
     from abip_amd import problems
     monkeypatch.setenv("ABIP_HIP_XCD", "1")
     A, b, c = problems.lp_random_sparse(m=20000, n=50000, per_col=16, seed=3)      # 5e5 non-zeros: 6 per thread on 128 workgroups
     with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-3, max_admm_iters=20) as S:
         assert S.scalar("xcd") == 0.0
         S.solve()
-    A, b, c = problems.lp_random_sparse(m=2500, n=6000, per_col=4, seed=4)         # direct: m > 2048
+    A, b, c = problems.lp_random_sparse(m=4500, n=9000, per_col=4, seed=4)         # direct: m > 4096
     with gpu.Solver(A, b, c, linsys="direct", verbose=0, eps=1e-3, max_admm_iters=20) as S:
         assert S.scalar("xcd") == 0.0
         S.solve()

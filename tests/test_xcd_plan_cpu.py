@@ -91,8 +91,8 @@ def test_what_does_not_fit_is_left_to_the_launch_path(monkeypatch):
     monkeypatch.delenv("ABIP_HIP_XCD_G", raising=False)
     A = problems.lp_random_sparse(m=20000, n=50000, per_col=16, seed=3)[0]       # 5e5 non-zeros: the launch path has caught up
     assert not plan(A, "indirect")["ok"]
-    A = problems.lp_random_sparse(m=2500, n=6000, per_col=4, seed=4)[0]
-    assert not plan(A, "direct")["ok"] and plan(A, "indirect")["ok"]             # direct: m > 2048
+    A = problems.lp_random_sparse(m=4500, n=9000, per_col=4, seed=4)[0]
+    assert not plan(A, "direct")["ok"] and plan(A, "indirect")["ok"]             # direct: m > 4096
     rng = np.random.default_rng(0)
     D = sp.hstack([sp.csc_matrix(np.ones((1, 700))), sp.csc_matrix((1, 300))])  # one row of 700 entries: longer than a thread adds up
     A = sp.vstack([D, sp.random(60, 1000, density=0.01, random_state=rng, format="csc")]).tocsc()
