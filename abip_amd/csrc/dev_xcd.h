@@ -34,15 +34,16 @@
 
 namespace abip {
 
-constexpr int XTB = 1024;          // threads per workgroup
+constexpr int XTB = 768;           // threads per workgroup: 12 wavefronts, 3 per SIMD -> 168 VGPRs each: the NZ = 2 variants need no scratch (at 1024 threads /
+                                   // 128 VGPRs they spilled 100-190 bytes per lane); measured +3 % on c2 / c3 (profiles/r03f_xcd_gather_experiments.txt (g))
 constexpr int XWAVES = XTB / 64;
 constexpr int XG = 256;            // most workgroups taking part: the CUs of one XCD (32), or of 2, 4, 8 XCDs
 constexpr int XQ = XG / 64;        // flags a polling lane looks after
-constexpr int XKS = 16;            // scalar granules per workgroup per exchange (<= XWAVES: wavefront k handles scalar k)
+constexpr int XKS = 16;            // granule slots per workgroup per exchange: sums 0..11 (wavefront k handles sum k), slots 12..15 the tau entries
 constexpr int XSTAT_N = 1024;       // ints of the status / post-mortem record
 constexpr int XSPIN = 1 << 22;     // polling rounds before a wavefront gives up (a round is ~1 us)
 constexpr int XCD_LDS_MIN = 84 * 1024; // more than half a CU's LDS: one workgroup per CU
-static_assert(XKS <= XWAVES, "one wavefront per scalar of an exchange");
+static_assert(12 <= XWAVES, "one wavefront per sum of an exchange (at most 12; the granule slots 12..15 carry the tau entries)");
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -162,7 +163,7 @@ __device__ __forceinline__ bool x_spin(XWait &w, int &spins, unsigned found, int
 // (4) x_gather: the entries this thread's non-zeros name.
 template <int K, int SA>
 __device__ __forceinline__ void x_publish(double (&v)[K], double *red, xrsrc sc, unsigned sc_off /* byte offset of this rank's granules */, unsigned tag) {
-  static_assert(K >= 1 && K <= XKS, "1 .. XKS scalars per exchange");
+  static_assert(K >= 1 && K <= 12 && K <= XWAVES, "wavefront k handles sum k: at most 12 sums per exchange");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] = x_wave_sum63(v[k]); // (while the stores travel)

@@ -1,6 +1,6 @@
 """CPU: the host half of the persistent launch for cache-resident LPs (abip_amd/csrc/solver.hip xcd_plan, dev_xcd.h) without a GPU, through the
 pure-host entry point abip_hip_xcd_plan: which problems are admitted, on how many workgroups / XCDs, that the slices of A and A' partition
-the rows, fit the kernel variant's registers (NZ non-zeros and RM / RN rows per thread, 1024 threads) and the 160 KB of LDS."""
+the rows, fit the kernel variant's registers (NZ non-zeros and RM / RN rows per thread, 768 threads) and the 160 KB of LDS."""
 import ctypes as C
 
 import numpy as np
@@ -9,7 +9,7 @@ import scipy.sparse as sp
 
 from abip_amd import _lib, problems
 
-XTB = 1024
+XTB = 768     # threads per workgroup (dev_xcd.h)
 
 
 def plan(A, linsys, G=None, monkeypatch=None):
