@@ -60,6 +60,23 @@ enum Slot : int {
   S_COUNT
 };
 
+// What a persistent launch that spans outer iterations (dev_xcd.h, XcdOuter) hands back: the loop state of abip.c:2102-2294 at the point it stopped
+struct XcdOut {
+  int phase;        // where the host goes on: 0 = inner loop (iteration (k, j) is next), 1 = outer end pending (abip.c:2217), 2 = outer begin pending with i already advanced (abip.c:2102)
+  int reason;       // XR_* (dev_xcd.h): why the launch ended
+  int final_check, avg_crit;
+  int stats_valid;  // Ctl::out describes the current iterate (the last thing the launch did was an ADMM iteration)
+  int avg_stats;    // ... and holds the averaged iterate's sums too
+  int outer_done;   // outer iterations closed inside the launch (mu update, reinitialisation, Barzilai-Borwein search)
+  int log_n;        // rows written to the outer-iteration log
+  int last_cg, bb_lookaheads;
+  long i, j, k;     // the loop variables of abip.c:2102, 2131 and the running iteration count
+  long ran;         // ADMM iterations of this launch
+  long solves;      // KKT solves of this launch (iterations + look-ahead solves of the search)
+  long cg_total;    // PCG iterations of all of them
+  double mu, beta, dyn_sigma;
+};
+
 // device-resident control block (also copied to the host once per ADMM iteration)
 struct Ctl {
   int halt;      // 1: every gated kernel returns immediately
@@ -77,6 +94,7 @@ struct Ctl {
   int it_count;    // ADMM iterations completed since abip_init (never reset)
   double pp_cur;   // sharded PCG: ||p||^2 of the current direction, by the recurrence ||z + beta p||^2 = z'z + 2 beta z'p + beta^2 ||p||^2
   long xcd_cg_total; // one-XCD persistent launch (dev_xcd.h): PCG iterations of all the ADMM iterations it ran
+  XcdOut xo;         // ... and, when the launch spans outer iterations, the loop state it stopped in
 };
 
 // Device-side launch timing (bench.py's roofline leg, inside the timed region: no hipEvent records, no second pass).  A kernel handed a

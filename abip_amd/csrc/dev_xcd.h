@@ -31,6 +31,7 @@
 // exchange per PCG iteration).
 #pragma once
 #include "dev_kernels.h"
+#include "lp_scalars.h"
 
 namespace abip {
 
@@ -41,7 +42,7 @@ constexpr int XG = 256;            // most workgroups taking part: the CUs of on
 constexpr int XQ = XG / 64;        // flags a polling lane looks after
 constexpr int XKS = 16;            // granule slots per workgroup per exchange: sums 0..11 (wavefront k handles sum k), slots 12..15 the tau entries
 constexpr int XSTAT_N = 1024;       // ints of the status / post-mortem record
-constexpr int XSPIN = 1 << 22;     // polling rounds before a wavefront gives up (a round is ~1 us)
+constexpr int XSPIN = 1 << 17;     // polling rounds before a wavefront gives up (a round is ~1 us: about a tenth of a second, then the launch path takes over)
 constexpr int XCD_LDS_MIN = 84 * 1024; // more than half a CU's LDS: one workgroup per CU
 static_assert(12 <= XWAVES, "one wavefront per sum of an exchange (at most 12; the granule slots 12..15 carry the tau entries)");
 
@@ -53,6 +54,35 @@ struct XcdFinal { // the final_check branch of abip.c:2190-2213 evaluated on the
   double eps, den, nm_b, nm_c;
   long k0, max_admm;
 };
+
+// A launch that SPANS OUTER ITERATIONS (round 4; abip.c:2217-2293 and src/adaptive.c:87-251 on the device).  With `on` the kernel does not return when
+// the inner loop's exit test holds: every workgroup takes the reference's scalar decisions itself, from sums that are bit-identical in all of them
+// (lp_scalars.h: calc_residuals, has_converged, the mu rule), rescales its own entries (reinitialize_vars), runs the Barzilai-Borwein search -- up to
+// adaptive_lookback pairs of look-ahead steps through the same projection code, on the scratch vectors a_* -- zeroes its running sums and starts the next
+// inner loop.  It hands the loop back to the host (XcdOut, XR_*) only when the host has something to do: the solve has converged or hit a limit
+// (the host extracts the solution), the iteration budget of the call or the wall-clock slice is used up, a restart is due (abip.c:608-627: the launch
+// path runs that one iteration), or the outer end needs a rule that is not on the device (the "tedious" table, an averaged iterate that won the stopping test).
+struct XcdOuter {
+  int on;
+  int phase;            // entry point: 0 = iteration (k, j) of the inner loop, 1 = the outer end of abip.c:2217 (Ctl::out holds the iterate's sums)
+  int avg_crit;         // stgs->avg_criterion at entry
+  int adaptive, lookback, hybrid_mu;
+  long i, fre_old;
+  double mu, beta, sigma, gamma, dyn_sigma;
+  long max_ipm, inner_stopper, restart_thresh, restart_fre;
+  long max_steps;       // ADMM iterations this launch may run (abip_hip_step's budget)
+  double eps_cor, eps_pen, hybrid_thresh, dyn_sigma_second;
+  unsigned long long slice_ticks; // wall-clock budget of the launch in ticks of wall_clock64 (100 MHz): looked at once per outer iteration
+  const double *mu_tab; int mu_tab_n; // mu after 1, 2, ... applications of update_barrier_dynamic_2 to the entry mu (pow() stays on the host)
+  int log_cap; double *log;           // one row of XLOG_W doubles per outer iteration closed here (print_summary's columns)
+  double *a_up, *a_vp, *a_u, *a_v, *a_un, *a_vn; // adaptive.c:13-32 (u_prev, v_prev, u, v, u_next, v_next; ut / ut_next and the three differences never leave registers)
+};
+constexpr int XLOG_W = 12; // i, k, mu, res_pri, res_dual, rel_gap, c'x / tau-free, b'y, tau, kap, ticks since launch, spare
+enum { XM_MAIN = 0, XM_BB1 = 1, XM_BB2 = 2 };                  // whose projection is running: the ADMM iteration's, the first / second look-ahead step's
+enum { XS_PROJECT = 0, XS_OUTER_END = 1, XS_OUTER_BEGIN = 2 }; // what the launch does next
+enum { CS_MU = 0, CS_BETA, CS_DYNS, CS_OI, CS_FRE, CS_BBPREV, CS_BUPT, CS_BVPT, CS_BUT, CS_BVT, CS_RUT, CS_RVT, CS_ODONE, CS_DYN2, CS_LOGN, CS_BBTOT, CS_BBIT, CS_AV, CS_PHASE, CS_REASON, CS_T0 }; // cs[]: see the kernel
+enum { XR_BATCH = 0 /* one batch of iterations, the exit test or the batch's end */, XR_STEPS = 1, XR_RESTART = 2, XR_FINAL = 3 /* the final check holds */,
+       XR_HOST_OUTER = 4 /* this outer end is the host's */, XR_SLICE = 5, XR_MAXIPM = 6 };
 
 struct XcdArgs {
   const int *Ap, *Ai; const double *Ax; // CSR of A  (m rows, gathers the n-space)
@@ -73,12 +103,14 @@ struct XcdArgs {
   Ctl *ctl; int *xstat;                 // xstat[0]: a poll gave up; xstat[1]: exchanges used by this launch
   long j0; int max_iters;               // inner index of the first iteration; iterations to run unless the exit test holds earlier
   double thr, sentinel;                 // gamma * mu; Qres_avg when no averaged statistics were taken
-  const double *tolf; int cg_max_its;   // PCG: tolerance factor per iteration of this launch (host-computed: indirect.c:406-407)
+  const double *tolf; int cg_max_its;   // PCG: tolerance factor per iteration of this launch (host-computed: indirect.c:406-407; a launch that spans outer iterations forms 0.1 / (k + 1)^2 itself)
   // solve-only mode (the set-up solve, the Barzilai-Borwein look-ahead: solve_lin_sys on a caller's vector, abip.c:552-560 without the prox): K z = srhs in place,
   // warm start = the y block of swarm (or null), u_t'h left in the partial table as the launch path's kernels expect it
   int solve_only; double *srhs; const double *swarm; double *part; int npart;
   int nxcd;                             // XCDs whose workgroups take a ticket: 1 (G = 32), or 2, 4, 8 (G = 32 nxcd, the CROSS variants)
+  int desert;                           // fault injection (libabip_hip_hooks.so only): the rank that leaves at once, so that every wait gives up; -1 otherwise
   XcdFinal fc;
+  XcdOuter outer;
 };
 
 __device__ __forceinline__ unsigned x_xcc_id() { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return x & 0xf; }
@@ -252,26 +284,6 @@ __device__ __forceinline__ void x_mat(const double *g, int cnt, double (&v)[NZ])
   for (int u = 0; u < NZ; ++u) v[u] = (u < cnt) ? x_at(g, threadIdx.x + (unsigned)u * XTB) : 0.0;
 }
 
-// calc_residuals (abip.c:458-535) + has_converged (1613-1641) on finalised sums; o = the out[] array, ac = avg_criterion of this iteration
-__device__ __forceinline__ int x_converged(const double *o, int ac, const XcdFinal &f, long k) {
-  const double ut = ac ? o[82] : o[80], vt = ac ? o[83] : o[81];
-  const double tau = fabs(ut);
-  (void)vt;
-  const double nmpr = sqrt(ac ? o[S_RPA] : o[S_RP]), nmax = sqrt(ac ? o[S_NAXA] : o[S_NAX]);
-  const double nmdr = sqrt(ac ? o[S_RDA] : o[S_RD]), nmaty = sqrt(ac ? o[S_NATYA] : o[S_NATY]);
-  const double by_t = (ac ? o[S_BYA] : o[S_BY]) / f.den, cx_t = (ac ? o[S_CXA] : o[S_CX]) / f.den;
-  const double nan_ = __longlong_as_double(0x7ff8000000000000LL);
-  const double res_infeas = by_t > 0 ? f.nm_b * nmaty / by_t : nan_;
-  const double res_unbdd = cx_t < 0 ? f.nm_c * nmax / -cx_t : nan_;
-  auto sdiv = [](double x, double y) { return y < 1E-18 ? x / 1E-18 : x / y; };
-  const double by = sdiv(by_t, tau), cx = sdiv(cx_t, tau);
-  const double res_pri = sdiv(nmpr / (1 + f.nm_b), tau), res_dual = sdiv(nmdr / (1 + f.nm_c), tau);
-  const double rel_gap = fabs(cx - by) / (1 + fabs(cx) + fabs(by));
-  if (res_pri < f.eps && (res_dual < f.eps || f.pfeasopt) && rel_gap < f.eps) return 1;
-  if (res_unbdd < f.eps && f.ipm_pos && k > 0) return 1;
-  if (res_infeas < f.eps && f.ipm_pos && k > 0) return 1;
-  return 0;
-}
 
 // compute_avg + statistics of one element (dev_kernels.h: avg_and_stats_y / _x, prox_x) with 32-bit unsigned indices
 __device__ __forceinline__ void xs_y(const UpdArgs &a, unsigned i, double un, double vn, Stat &st) {
@@ -324,6 +336,56 @@ __device__ __forceinline__ void x_prox(const UpdArgs &a, double uo, double vo, d
 #define XP_DUMP
 #endif
 
+
+// the finalised sums of one iterate as lp_scalars.h reads them (o = the out[] array; ac: the averaged iterate's)
+__host__ __device__ inline LpSums x_sums(const double *o, int ac) {
+  LpSums s;
+  s.ut = ac ? o[82] : o[80]; s.vt = ac ? o[83] : o[81];
+  s.rp = ac ? o[S_RPA] : o[S_RP]; s.nax = ac ? o[S_NAXA] : o[S_NAX];
+  s.rd = ac ? o[S_RDA] : o[S_RD]; s.naty = ac ? o[S_NATYA] : o[S_NATY];
+  s.by = ac ? o[S_BYA] : o[S_BY]; s.cx = ac ? o[S_CXA] : o[S_CX];
+  return s;
+}
+// calc_residuals (abip.c:458-535) + has_converged (1613-1641) on finalised sums; ac = avg_criterion of this iteration
+__device__ __forceinline__ int x_converged(const double *o, int ac, const XcdFinal &f, long ipm_iter, long k) {
+  LpResid r;
+  lp_residuals(x_sums(o, ac), f.den, f.nm_b, f.nm_c, r);
+  return lp_converged(r, f.eps, f.pfeasopt, ipm_iter, k) != 0;
+}
+
+// the smallest of one value per thread, in every thread (outer iterations only: a handful of calls per solve)
+__device__ __forceinline__ double x_block_min(double v, double *mnb /* XWAVES doubles of their own */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+  __syncthreads(); // (the previous call's readers are through)
+  if ((threadIdx.x & 63) == 0) mnb[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double m = mnb[0];
+#pragma unroll
+  for (int w = 1; w < XWAVES; ++w) m = fmin(m, mnb[w]);
+  return x_uni(m);
+}
+
+// one look-ahead step of the Barzilai-Borwein search on one (x, tau) entry (adaptive.c:106-121; dev_kernels.h k_adapt_step)
+__device__ __forceinline__ void x_bbstep(double alpha, double mu_over_beta, double utq, double uo, double vo, double &un, double &vn) {
+  const double t = alpha * utq + (1 - alpha) * uo - vo;
+  const double hlf = t / 2;
+  un = hlf + sqrt(hlf * hlf + mu_over_beta);
+  vn = vo + (un - alpha * utq - (1 - alpha) * uo);
+}
+// the five inner products of the difference vectors, one entry's terms (adaptive.c:154-174; dev_kernels.h k_adapt_dots)
+__device__ __forceinline__ void x_bbdots(double alpha, double u, double v, double un, double vn, double vp, double (&a)[5]) {
+  const double dut = 2.0 * v + un - u - vn - vp;
+  const double du = u - un;
+  const double dv = (un - u) * (alpha - 1.0) + vn - v;
+  a[0] += dut * dut; a[1] += dut * dv; a[2] += du * du; a[3] += dv * dv; a[4] += du * dv;
+}
+// reinitialize_vars, abip.c:996-1075, one (x, tau) entry: indx 0, then 1 when the search follows (two passes of the reference over the same entry)
+__device__ __forceinline__ void x_reinit01(double sigma, bool also1, double &u, double &v) {
+  if (u > v) v = sigma * v; else u = sigma * u;
+  if (also1) { const double sq = sqrt(sigma); u = sq * u; v = sq * v; }
+}
+
 template <int NZ, int RM, int RN, bool PCG, bool CROSS = false> // CROSS: the ranks sit on several XCDs (stores of the exchanges written through)
 __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   constexpr int SA = CROSS ? 16 : 0;
@@ -332,7 +394,9 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   double *tot = prod + 2 * NZ * XTB; // XKS
   double *red = tot + XKS;           // XWAVES * XKS
   double *outs = red + XWAVES * XKS; // 96: the finalised sums (every workgroup holds the same)
-  double *wv = outs + 96;            // direct: the whole right-hand side w (m_pad), the products of the owned rows (RM * XTB), then rows of inv(rho I + A A')
+  double *mnb = outs + 96;           // 16: x_block_min
+  double *cs = mnb + 16;             // 32: the loop state only the outer iterations touch (CS_*; the same in every workgroup): out of the registers the inner loop needs
+  double *wv = cs + 32;              // direct: the whole right-hand side w (m_pad), the products of the owned rows (RM * XTB), then rows of inv(rho I + A A')
   double *mrow = wv + a.m_pad + RM * XTB;
   __shared__ int s_rank;
   const unsigned t = threadIdx.x;
@@ -344,10 +408,14 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       if (r < 0 || r >= a.G) r = -1;
     }
     s_rank = r;
+    cs[CS_MU] = a.outer.mu; cs[CS_BETA] = a.outer.beta; cs[CS_DYNS] = a.outer.dyn_sigma; cs[CS_OI] = (double)a.outer.i; cs[CS_FRE] = (double)a.outer.fre_old;
+    cs[CS_BBPREV] = 1.0; cs[CS_BUPT] = 0.0; cs[CS_BVPT] = 0.0; cs[CS_BUT] = 0.0; cs[CS_BVT] = 0.0; cs[CS_RUT] = 0.0; cs[CS_RVT] = 0.0;
+    cs[CS_ODONE] = 0.0; cs[CS_DYN2] = 0.0; cs[CS_LOGN] = 0.0; cs[CS_BBTOT] = 0.0; cs[CS_BBIT] = 0.0; cs[CS_AV] = 0.0; cs[CS_PHASE] = 0.0; cs[CS_REASON] = (double)XR_BATCH;
+    cs[CS_T0] = __longlong_as_double(wall_clock64());
   }
   __syncthreads();
   const int rank = __builtin_amdgcn_readfirstlane(s_rank); // (uniform, and the compiler may know it: everything derived from it lives in scalar registers)
-  if (rank < 0) return;
+  if (rank < 0 || rank == a.desert) return;
   const int G = a.G;
   const unsigned MP = (unsigned)a.MP;
   const unsigned m0 = (unsigned)a.mb[rank], m1 = (unsigned)a.mb[rank + 1], n0 = (unsigned)a.nb[rank], n1 = (unsigned)a.nb[rank + 1];
@@ -374,6 +442,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   const double rho = up.rho;
   const unsigned tail = MP + (unsigned)a.n;
   const bool solo = a.solve_only != 0;
+  const bool whole = a.outer.on != 0 && !solo;
   unsigned tag = a.tag0;
   int flip = 0;
   XWait w; w.xstat = a.xstat; w.dead = false; w.site = 0; w.rank = rank;
@@ -390,42 +459,6 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     if (t == 0) { a.xstat[8 + 2 * rank] = (int)tag; a.xstat[9 + 2 * rank] = site; } // (post-mortem: where every rank was when a wait gave up)
   };
 
-  // ---- prologue: S_WG and the tau entries for the first right-hand side; A'u_y, the warm start's product (PCG) ----
-  double aty[RN]; // (A'u_y)_j of the owned columns: left by the stopping test, used by the next solve's set-up
-  double wg, u_tau, v_tau;
-#pragma unroll
-  for (int q = 0; q < RN; ++q) aty[q] = 0.0;
-  {
-    open(1);
-    double p[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int q = 0; q < RM; ++q) {
-      const unsigned i = m0 + t + q * XTB;
-      if (i < m1) {
-        const double uy = solo ? (a.swarm ? x_at(a.swarm, i) : 0.0) : x_at(up.u, i);
-        if (!solo) p[0] += rho * (uy + x_at(up.v, i)) * x_at(up.g, i);
-        if (PCG) x_putd<SA>(pm0, i * 8u, uy);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < RN; ++q) {
-      const unsigned j = n0 + t + q * XTB;
-      if (j < n1 && !solo) p[0] += (x_at(up.u, MP + j) + x_at(up.v, MP + j)) * x_at(up.g, MP + j);
-    }
-    if (rank == 0 && t == 0 && !solo) { p[1] = x_at(up.u, tail); p[2] = x_at(up.v, tail); }
-    x_publish<3, SA>(p, red, psc, sc_off, tag);
-    double s3[3];
-    x_collect<3>(w, G, tot, s3);
-    if (w.dead) return;
-    if (PCG) {
-      double tx[NZ], vt[NZ];
-      x_mat<NZ>(gT, nt, tx);
-      x_gather<NZ>(pm0, ti, vt);
-      x_rows<NZ, RN>(prod, flip, tx, vt, nt, st, et, aty);
-    }
-    wg = s3[0]; u_tau = s3[1]; v_tau = s3[2];
-  }
-
   if (!PCG) { // this workgroup's first rows of the dense inverse stay in the LDS for the whole launch
     for (unsigned rl = wave; (int)rl < a.minv_lds_rows && m0 + rl < m1; rl += XWAVES) {
       const double *row = a.Minv + (long)(m0 + rl) * a.ldM;
@@ -434,19 +467,235 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   }
   if (t < 96) outs[t] = a.ctl->out[t]; // slots this launch does not refresh keep what the last finalize left (as on the launch path)
   XP_DECL
-  int ran = 0, halt = 0, last_cg = 0;
+
+  // ---- the loop state of abip.c:2102-2294 (uniform: every workgroup carries the same values and takes the same branches).  What only the outer
+  //      iterations touch lives in the LDS (cs[]: written by thread 0, read by everybody after a barrier); the inner loop's share in registers ----
+  const XcdOuter &xo = a.outer;
+  auto csr = [&](int k) { return x_uni(cs[k]); };
+  auto csw = [&](int k, double v) { if (t == 0) cs[k] = v; };
+  int mode = XM_MAIN, stage = (whole && xo.phase == 1) ? XS_OUTER_END : XS_PROJECT;
+  long jj = a.j0;
+  double thr = a.thr;
+  int final_check = a.fc.on;
+  int ran = 0, halt = 0, last_cg = 0, avg_stats_last = 0;
+  bool stats_valid = false;
   long cg_total = 0;
   double metric = 0.0;
-  int avg_crit = 0;
-  for (int it = 0; it < a.max_iters; ++it) {
+  int avg_crit = whole ? xo.avg_crit : 0;
+  bool need_pre = true;
+  double aty[RN]; // (A'u_y)_j of the owned columns: left by the stopping test (or by the exchange below), used by the next solve's set-up
+  double wg = 0.0, u_tau = 0.0, v_tau = 0.0;
+#pragma unroll
+  for (int q = 0; q < RN; ++q) aty[q] = 0.0;
+
+  for (;;) {
     // (an index the optimiser cannot see through: otherwise it hoists the element addresses of an iteration out of this loop and spills them)
     unsigned tb = t; asm volatile("" : "+v"(tb));
-    const long j = a.j0 + it;
-    const bool avg_stats = ((j + 1) % 10 == 0); // abip.c:2000
-    up.dom = (double)(j + 1);
-    up.avg_stats = avg_stats ? 1 : 0;
+    // ================================================================================================================================
+    // outer end (abip.c:2217-2293): time, final_check, residuals, convergence, mu, reinitialize_vars; then the search or the next outer iteration
+    // ================================================================================================================================
+    if (__builtin_expect(stage == XS_OUTER_END, 0)) {
+      csw(CS_PHASE, 1.0);
+      if (ran > 0 && ran >= xo.max_steps) { csw(CS_REASON, (double)XR_STEPS); break; } // abip_hip_step hands back right after the last iteration it was asked for: the outer end waits for the next call
+      // avg_criterion (abip.c:2042, 2048): the averaged iterate won the last stopping test -- residuals, the LOQO products and reinitialize_vars then work on
+      // (u_avgcon, v_avgcon) (abip.c:473-484, 940-946, 1007-1039), the search still starts from (u, v) (adaptive.c:87-88), and the next inner loop from the average (abip.c:2125-2129)
+      const bool av = avg_crit != 0;
+      double *RU = av ? up.u_avgc : up.u, *RV = av ? up.v_avgc : up.v;
+      double mu = csr(CS_MU);
+      const long oi = (long)csr(CS_OI);
+      int log_n = (int)csr(CS_LOGN), dyn2_used = (int)csr(CS_DYN2);
+      const unsigned long long t_launch = (unsigned long long)__double_as_longlong(csr(CS_T0));
+      // one exchange: has rank 0 seen the slice's end; sum and minimum of u_i v_i over i >= m (abip.c:962-965)
+      open(11);
+      double p2[2] = {0.0, 0.0};
+      double mn = 1e+10;
+#pragma unroll
+      for (int q = 0; q < RN; ++q) {
+        const unsigned j2 = n0 + tb + q * XTB;
+        if (j2 < n1) { const double x = x_at(RU, MP + j2) * x_at(RV, MP + j2); p2[1] += x; mn = fmin(mn, x); }
+      }
+      if (rank == 0 && t == 0) {
+        const double x = x_at(RU, tail) * x_at(RV, tail);
+        p2[1] += x; mn = fmin(mn, x);
+        p2[0] = ((unsigned long long)wall_clock64() - t_launch > xo.slice_ticks) ? 1.0 : 0.0;
+      }
+      mn = x_block_min(mn, mnb);
+      if (t == 0) x_putg<SA>(psc, sc_off + 12u * 16u, mn, tag); // (acknowledged before this rank's flags go out)
+      x_publish<2, SA>(p2, red, psc, sc_off, tag);
+      double P2[2];
+      x_collect<2>(w, G, tot, P2);
+      if (__builtin_expect(w.dead, 0)) return;
+      double gmin = 1e+10;
+      if ((int)t < G) gmin = x_val(x_ldg(psc, (t * XKS + 12u) * 16u));
+      gmin = x_block_min(gmin, mnb);
+      if (P2[0] > 0.0) { csw(CS_REASON, (double)XR_SLICE); break; } // (nothing of this outer end has been applied: the next launch enters here again)
+      if (mu < a.fc.eps) final_check = 1;                          // abip.c:2224-2227
+      __syncthreads();                                             // outs complete
+      LpResid r;
+      lp_residuals(x_sums(outs, av ? 1 : 0), a.fc.den, a.fc.nm_b, a.fc.nm_c, r);
+      const long kk = a.fc.k0 + ran;
+      if (rank == 0 && t == 0 && xo.log && log_n < xo.log_cap) {
+        double *row = xo.log + (size_t)log_n * XLOG_W;
+        row[0] = (double)oi; row[1] = (double)kk; row[2] = mu; row[3] = r.res_pri; row[4] = r.res_dual; row[5] = r.rel_gap;
+        row[6] = r.ct_x_by_tau; row[7] = r.bt_y_by_tau; row[8] = r.tau; row[9] = r.kap;
+        row[10] = (double)((unsigned long long)wall_clock64() - t_launch); row[11] = 0.0;
+      }
+      if (lp_converged(r, a.fc.eps, a.fc.pfeasopt, oi, kk) != 0 || kk + 1 >= a.fc.max_admm) { csw(CS_REASON, (double)XR_HOST_OUTER); break; } // the host extracts the solution
+      double ds = csr(CS_DYNS);
+      const int rule = __builtin_amdgcn_readfirstlane(lp_mu_rule(xo.hybrid_mu, xo.dyn_sigma_second, xo.hybrid_thresh, a.fc.eps, mu, ds));
+      if (rule == LP_MU_TABLE) { csw(CS_REASON, (double)XR_HOST_OUTER); break; }
+      if (rule == LP_MU_LOQO) {
+        if (gmin <= 0.0) { csw(CS_REASON, (double)XR_HOST_OUTER); break; } // the reference asserts here: the host reports it
+        mu = mu * lp_loqo_sigma(P2[1], gmin, (long)a.n + 1, ds);
+      } else if (rule == LP_MU_DYN2) {
+        if (dyn2_used >= xo.mu_tab_n) { csw(CS_REASON, (double)XR_SLICE); break; }
+        mu = xo.mu_tab[dyn2_used];
+        ++dyn2_used;
+      }
+      if (log_n < xo.log_cap) ++log_n;
+      mu = x_uni(mu);
+      // reinitialize_vars(0), and (1) when the search follows (abip.c:2279-2283)
+      const bool search = xo.adaptive != 0;
+      u_tau = outs[80]; v_tau = outs[81];
+      double r_ut = av ? outs[82] : outs[80], r_vt = av ? outs[83] : outs[81];
+#pragma unroll
+      for (int q = 0; q < RN; ++q) {
+        const unsigned j2 = n0 + tb + q * XTB;
+        if (j2 < n1) {
+          double uu = x_at(RU, MP + j2), vv = x_at(RV, MP + j2);
+          x_reinit01(xo.sigma, search, uu, vv);
+          x_at(RU, MP + j2) = uu; x_at(RV, MP + j2) = vv;
+          if (search) { x_at(xo.a_up, MP + j2) = av ? x_at(up.u, MP + j2) : uu; x_at(xo.a_vp, MP + j2) = av ? x_at(up.v, MP + j2) : vv; } // u_prev, v_prev <- u, v (adaptive.c:87-88)
+        }
+      }
+      x_reinit01(xo.sigma, search, r_ut, r_vt);
+      r_ut = x_uni(r_ut); r_vt = x_uni(r_vt);
+      if (rank == 0 && t == 0) { x_at(RU, tail) = r_ut; x_at(RV, tail) = r_vt; }
+      if (!av) { u_tau = r_ut; v_tau = r_vt; }
+      stats_valid = false;
+      csw(CS_MU, mu); csw(CS_DYNS, ds); csw(CS_LOGN, (double)log_n); csw(CS_DYN2, (double)dyn2_used); csw(CS_ODONE, csr(CS_ODONE) + 1.0);
+      csw(CS_RUT, r_ut); csw(CS_RVT, r_vt); csw(CS_AV, av ? 1.0 : 0.0);
+      if (search && xo.lookback > 0) {
+        csw(CS_BETA, 1.0); // abip.c:2284
+#pragma unroll
+        for (int q = 0; q < RM; ++q) {
+          const unsigned i = m0 + tb + q * XTB;
+          if (i < m1) { x_at(xo.a_up, i) = x_at(up.u, i); x_at(xo.a_vp, i) = x_at(up.v, i); }
+        }
+        csw(CS_BUPT, u_tau); csw(CS_BVPT, v_tau); csw(CS_BBPREV, 1.0); csw(CS_BBIT, 0.0);
+        mode = XM_BB1; need_pre = true; stage = XS_PROJECT;
+      } else {
+        if (search) { // (adaptive.c:90: the loop does not run, beta stays 0; reinitialize_vars(2))
+          csw(CS_BETA, 0.0);
+          const double sq = sqrt(1.0 / xo.sigma);
+#pragma unroll
+          for (int q = 0; q < RN; ++q) { const unsigned j2 = n0 + tb + q * XTB; if (j2 < n1) { x_at(RU, MP + j2) = sq * x_at(RU, MP + j2); x_at(RV, MP + j2) = sq * x_at(RV, MP + j2); } }
+          r_ut = x_uni(sq * r_ut); r_vt = x_uni(sq * r_vt);
+          if (rank == 0 && t == 0) { x_at(RU, tail) = r_ut; x_at(RV, tail) = r_vt; }
+          csw(CS_RUT, r_ut); csw(CS_RVT, r_vt);
+        }
+        stage = XS_OUTER_BEGIN;
+      }
+    }
+    // ================================================================================================================================
+    // outer begin (abip.c:2102-2129)
+    // ================================================================================================================================
+    if (__builtin_expect(stage == XS_OUTER_BEGIN, 0)) {
+      __syncthreads(); // (cs[] as the block above, or the search's last look-ahead, left it)
+      const long oi = (long)csr(CS_OI) + 1;
+      const double mu = csr(CS_MU), beta = csr(CS_BETA);
+      const bool av = csr(CS_AV) != 0.0;
+      const double r_ut = csr(CS_RUT), r_vt = csr(CS_RVT);
+      __syncthreads(); // (everybody has read what thread 0 overwrites next)
+      csw(CS_OI, (double)oi); csw(CS_PHASE, 2.0);
+      if (oi >= xo.max_ipm) { csw(CS_REASON, (double)XR_MAXIPM); break; } // abip.c:2296: the host closes the solve
+      csw(CS_FRE, 0.0);
+#pragma unroll
+      for (int q = 0; q < RM; ++q) {
+        const unsigned i = m0 + tb + q * XTB;
+        if (i < m1) {
+          x_at(up.u_avg, i) = 0.0; x_at(up.v_avg, i) = 0.0; x_at(up.u_sum, i) = 0.0; x_at(up.v_sum, i) = 0.0;
+          if (av) { x_at(up.u, i) = x_at(up.u_avgc, i); x_at(up.v, i) = x_at(up.v_avgc, i); } // abip.c:2125-2129
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < RN; ++q) {
+        const unsigned j2 = n0 + tb + q * XTB;
+        if (j2 < n1) {
+          x_at(up.u_avg, MP + j2) = 0.0; x_at(up.v_avg, MP + j2) = 0.0; x_at(up.u_sum, MP + j2) = 0.0; x_at(up.v_sum, MP + j2) = 0.0;
+          if (av) { x_at(up.u, MP + j2) = x_at(up.u_avgc, MP + j2); x_at(up.v, MP + j2) = x_at(up.v_avgc, MP + j2); }
+        }
+      }
+      if (rank == 0 && t == 0) {
+        x_at(up.u_avg, tail) = 0.0; x_at(up.v_avg, tail) = 0.0; x_at(up.u_sum, tail) = 0.0; x_at(up.v_sum, tail) = 0.0;
+        if (av) { x_at(up.u, tail) = r_ut; x_at(up.v, tail) = r_vt; }
+      }
+      jj = 0;
+      up.mu_over_beta = x_uni(mu / beta);
+      thr = x_uni(xo.gamma * mu);
+      mode = XM_MAIN; need_pre = true; stage = XS_PROJECT;
+      __syncthreads(); // (cs[] complete before anybody reads it again)
+    }
+    // ---- may this launch start another ADMM iteration? (abip_hip_step's budget; abip.c:608-609: a restart is the launch path's) ----
+    if (mode == XM_MAIN && !solo) {
+      if (whole) {
+        csw(CS_PHASE, 0.0);
+        if (ran >= xo.max_steps) { csw(CS_REASON, (double)XR_STEPS); break; }
+        const long kk = a.fc.k0 + ran;
+        if (kk >= xo.restart_thresh && (jj + 1 - (long)csr(CS_FRE)) % xo.restart_fre == 0) { csw(CS_REASON, (double)XR_RESTART); break; }
+      } else if (ran >= a.max_iters) break;
+    }
+    const double *srcU = (mode == XM_MAIN) ? up.u : (mode == XM_BB1 ? xo.a_up : xo.a_u); // the iterate the projection starts from
+    const double *srcV = (mode == XM_MAIN) ? up.v : (mode == XM_BB1 ? xo.a_vp : xo.a_v);
+
+    // ================================================================================================================================
+    // S_WG and the tau entries for the right-hand side; A'u_y, the warm start's product (PCG): the first projection of a launch, of an inner loop, of a look-ahead step
+    // ================================================================================================================================
+    if (__builtin_expect(need_pre, 0)) {
+      open(1);
+      double p[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < RM; ++q) {
+        const unsigned i = m0 + tb + q * XTB;
+        if (i < m1) {
+          const double uy = solo ? (a.swarm ? x_at(a.swarm, i) : 0.0) : x_at(srcU, i);
+          if (!solo) p[0] += rho * (uy + x_at(srcV, i)) * x_at(up.g, i);
+          if (PCG) x_putd<SA>(pm0, i * 8u, uy);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < RN; ++q) {
+        const unsigned j = n0 + tb + q * XTB;
+        if (j < n1 && !solo) p[0] += (x_at(srcU, MP + j) + x_at(srcV, MP + j)) * x_at(up.g, MP + j);
+      }
+      if (rank == 0 && t == 0 && !solo && mode == XM_MAIN) { p[1] = x_at(up.u, tail); p[2] = x_at(up.v, tail); }
+      x_publish<3, SA>(p, red, psc, sc_off, tag);
+      double s3[3];
+      x_collect<3>(w, G, tot, s3);
+      if (__builtin_expect(w.dead, 0)) return;
+      if (PCG) {
+        double tx[NZ], vt[NZ];
+        x_mat<NZ>(gT, nt, tx);
+        x_gather<NZ>(pm0, ti, vt);
+        x_rows<NZ, RN>(prod, flip, tx, vt, nt, st, et, aty);
+      }
+      wg = s3[0];
+      if (mode == XM_MAIN) { u_tau = s3[1]; v_tau = s3[2]; }
+      need_pre = false;
+    }
+
+    // ================================================================================================================================
+    // The inner loop proper (abip.c:2131-2215): one projection per trip and, for an ADMM iteration, everything up to its exit test.  A look-ahead
+    // step of the search (and the solve-only mode) leaves after the projection; what they do with it follows the loop.
+    // ================================================================================================================================
+    double y[RM], zx[RN], dhS[1], tsum; // what a projection leaves behind: the solution's y and x blocks, u_t'h, the tau entry of the right-hand side
+    int leave = 0;
+    for (;;) {
+    unsigned tb = t; asm volatile("" : "+v"(tb)); // (see the outer loop)
+    const bool avg_stats = ((jj + 1) % 10 == 0); // abip.c:2000
+    if (mode == XM_MAIN) { up.dom = (double)(jj + 1); up.avg_stats = avg_stats ? 1 : 0; }
     // ---- right-hand side (k_rhs, abip.c:552-558) ----
-    const double tsum = u_tau + v_tau;
+    tsum = (mode == XM_MAIN) ? (u_tau + v_tau) : (mode == XM_BB1 ? (csr(CS_BUPT) + csr(CS_BVPT)) : (csr(CS_BUT) + csr(CS_BVT)));
     const double coef = (wg - tsum * a.g_th) / (a.g_th + 1.0);
     if (!PCG) { XP_START }
     double rhs_y[RM], rhs_x[RN];
@@ -461,7 +710,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         if (solo) r = x_at(a.srhs, i);
         else {
           const double hi = x_at(a.h, i);
-          r = (x_at(up.u, i) + x_at(up.v, i)) * rho;
+          r = (x_at(srcU, i) + x_at(srcV, i)) * rho;
           r += -tsum * hi;
           r += -coef * hi;
         }
@@ -478,7 +727,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         if (solo) r = -x_at(a.srhs, MP + j2);
         else {
           const double hj = x_at(a.h, MP + j2);
-          r = x_at(up.u, MP + j2) + x_at(up.v, MP + j2);
+          r = x_at(srcU, MP + j2) + x_at(srcV, MP + j2);
           r += -tsum * hj;
           r += -coef * hj;
         }
@@ -490,8 +739,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     x_publish<1, SA>(bn, red, psc, sc_off, tag);
     double bnS[1];
     x_collect<1>(w, G, tot, bnS);
-    if (w.dead) return;
-    double y[RM]; // the y block of the solution
+    if (__builtin_expect(w.dead, 0)) return;
     if (PCG) {
       // ---- PCG set-up (k_cg_init_A, indirect.c:345-365, 415) ----
       double sA[RM], sB[RM];
@@ -503,7 +751,10 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         x_gather<NZ>(pn1, ai, va);
         x_rows<NZ, RM>(prod, flip, ax, va, na, sa, ea, sB);
       }
-      double tol = sqrt(bnS[0]) * a.tolf[it]; // indirect.c:406-409, 418
+      double tolf;
+      if (whole) { const double kp = (double)(a.fc.k0 + ran + 1); tolf = 1e-1 / (kp * kp); } // indirect.c:406-407 with cg_rate = 2 (the host admits nothing else here); the search solves with iter = k (adaptive.c:98)
+      else tolf = a.tolf[ran];
+      double tol = sqrt(bnS[0]) * tolf; // indirect.c:406-409, 418
       tol = fmax(tol, 1e-7);
       tol = fmax(tol, 1e-9);
       double cr[RM], cz[RM], cp[RM], cx[RM], Mj[RM], ctmp[RN];
@@ -513,7 +764,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         const unsigned i = m0 + tb + q * XTB;
         cr[q] = 0.0; cz[q] = 0.0; cp[q] = 0.0; cx[q] = 0.0; Mj[q] = 0.0;
         if (i < m1) {
-          const double si = solo ? (a.swarm ? x_at(a.swarm, i) : 0.0) : x_at(up.u, i);
+          const double si = solo ? (a.swarm ? x_at(a.swarm, i) : 0.0) : x_at(srcU, i);
           const double b = rhs_y[q] + sA[q];
           const double ri = b - (sB[q] + rho * si);
           Mj[q] = x_at(a.Mjac, i);
@@ -539,7 +790,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         x_mat<NZ>(gT, nt, tx); // (on their way while the flags are awaited)
         double rzS[2];
         x_collect<2>(w, G, tot, rzS);
-        if (w.dead) return;
+        if (__builtin_expect(w.dead, 0)) return;
         XP_LAP(2)
         const double nr = sqrt(rzS[0]);
         bool done = (cgit == 0) ? (nr < fmin(tol, 1e-18)) : (nr < tol); // indirect.c:359, 375
@@ -553,7 +804,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
           x_rows<NZ, RN>(prod, flip, tx, vt, nt, st, et, tq);
         }
         XP_LAP(4)
-        const double beta = (cgit == 0) ? 0.0 : rzS[1] / zr_prev;
+        const double cbeta = (cgit == 0) ? 0.0 : rzS[1] / zr_prev;
         zr_prev = rzS[1];
         double tp[2] = {0.0, 0.0};
         open(4);
@@ -561,7 +812,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         for (int q = 0; q < RN; ++q) {
           const unsigned j2 = n0 + t + q * XTB;
           if (j2 < n1) {
-            const double v = (cgit == 0) ? tq[q] : tq[q] + beta * ctmp[q];
+            const double v = (cgit == 0) ? tq[q] : tq[q] + cbeta * ctmp[q];
             ctmp[q] = v;
             tp[0] += v * v;
             x_putd<SA>(pn0, j2 * 8u, v);
@@ -570,7 +821,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
 #pragma unroll
         for (int q = 0; q < RM; ++q) {
           const unsigned i = m0 + t + q * XTB;
-          if (i < m1) { const double pn = cz[q] + beta * cp[q]; cp[q] = pn; tp[1] += pn * pn; }
+          if (i < m1) { const double pn = cz[q] + cbeta * cp[q]; cp[q] = pn; tp[1] += pn * pn; }
         }
         // ---- tmp and (|A'p|^2, |p|^2) out; Gp = A tmp + rho p; alpha; x, r, z (k_cg_spmv_A + k_cg_update) ----
         XP_LAP(0)
@@ -580,7 +831,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         x_mat<NZ>(gA, na, ax);
         double tpS[2];
         x_collect<2>(w, G, tot, tpS);
-        if (w.dead) return;
+        if (__builtin_expect(w.dead, 0)) return;
         XP_LAP(2)
         double gq[RM];
         {
@@ -627,7 +878,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       double dz[1] = {0.0}, dzS[1];
       x_publish<1, SA>(dz, red, psc, sc_off, tag);
       x_collect<1>(w, G, tot, dzS);
-      if (w.dead) return;
+      if (__builtin_expect(w.dead, 0)) return;
       XP_LAP(1)
       for (unsigned i = t; i < (unsigned)a.m; i += XTB) wv[i] = x_ldd(pm0, i * 8u); // every workgroup needs the whole w
       __syncthreads();
@@ -663,14 +914,18 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
 #pragma unroll
     for (int q = 0; q < RM; ++q) {
       const unsigned i = m0 + tb + q * XTB;
-      if (i < m1) { x_putd<SA>(pm0, i * 8u, y[q]); x_at(solo ? a.srhs : up.ut, i) = y[q]; dh[0] += y[q] * x_at(a.h, i); }
+      if (i < m1) {
+        x_putd<SA>(pm0, i * 8u, y[q]);
+        if (solo) x_at(a.srhs, i) = y[q];
+        else if (mode == XM_MAIN) x_at(up.ut, i) = y[q];
+        dh[0] += y[q] * x_at(a.h, i);
+      }
     }
-    double zx[RN];
     {
       double dz[1] = {0.0}, dzS[1];
       x_publish<1, SA>(dz, red, psc, sc_off, tag);
       x_collect<1>(w, G, tot, dzS);
-      if (w.dead) return;
+      if (__builtin_expect(w.dead, 0)) return;
       double tx[NZ], vt[NZ], tq[RN];
       x_mat<NZ>(gT, nt, tx);
       x_gather<NZ>(pm0, ti, vt);
@@ -684,16 +939,10 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     }
     open(7);
     x_publish<1, SA>(dh, red, psc, sc_off, tag);
-    double dhS[1];
     x_collect<1>(w, G, tot, dhS);
-    if (w.dead) return;
+    if (__builtin_expect(w.dead, 0)) return;
     if (!PCG) { XP_LAP(4) }
-    if (solo) { // the solution goes back in place; u_t'h where the launch path's consumers re-reduce the partial table
-#pragma unroll
-      for (int q = 0; q < RN; ++q) { const unsigned j2 = n0 + tb + q * XTB; if (j2 < n1) x_at(a.srhs, MP + j2) = zx[q]; }
-      if (rank == 0) for (unsigned e = t; e < (unsigned)a.npart; e += XTB) a.part[S_DH * MAXNB + e] = (e == 0) ? dhS[0] : 0.0;
-      break;
-    }
+    if (__builtin_expect(solo || mode != XM_MAIN, 0)) break; // (not an ADMM iteration: see below the loop)
     // ---- element-wise update (k_admm_update): barrier prox, dual update, running sums, averages, statistics ----
     Stat sst = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double tau4[4] = {0.0, 0.0, 0.0, 0.0};
@@ -759,7 +1008,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       for (int q = 0; q < 5; ++q) S13[q] = S5[q];
       S13[5] = 0.0; S13[6] = 0.0; S13[7] = 0.0; S13[8] = 0.0;
     }
-    if (w.dead) return;
+    if (__builtin_expect(w.dead, 0)) return;
 #pragma unroll
     for (int q = 0; q < 4; ++q) S13[9 + q] = x_uni(x_val(x_ldg(psc, (unsigned)(12 + q) * 16u))); // (rank 0's granules: there since its flags are)
     // ---- stopping-test products (k_q_both): A u_x and A'u_y, residual sums; A'u_y is also the next solve's warm-start product ----
@@ -848,7 +1097,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) { Q[k] = Q6[k]; Q[6 + k] = 0.0; }
     }
-    if (w.dead) return;
+    if (__builtin_expect(w.dead, 0)) return;
     // ---- finalize (d_finalize): the inner-loop exit test, iterate_Q_norm_resd abip.c:2027-2050 and the comparison of abip.c:2173 ----
     wg = S13[0]; u_tau = S13[9]; v_tau = S13[10];
     if (t == 0) {
@@ -878,13 +1127,143 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       metric = avg_crit ? ma : mc;
     }
     ++ran;
+    stats_valid = true; avg_stats_last = avg_stats ? 1 : 0;
     if (!PCG) { XP_LAP(6) }
-    if (metric < a.thr) { halt = 1; break; }
-    if (a.fc.on) {
+    if (__builtin_expect(metric < thr, 0)) { // abip.c:2173-2188: the inner loop is left (j is not advanced)
+      if (!whole) { halt = 1; leave = 1; break; }
+      stage = XS_OUTER_END;
+      break;
+    }
+    if (__builtin_expect(final_check != 0, 0)) { // abip.c:2190-2213
       __syncthreads(); // outs complete
       const long k = a.fc.k0 + ran;
-      if (x_converged(outs, avg_crit, a.fc, k) || k + 1 >= a.fc.max_admm) { halt = 2; break; }
+      const long oi = (long)csr(CS_OI);
+      if (x_converged(outs, avg_crit, a.fc, oi, k) || k + 1 >= a.fc.max_admm || (whole && oi + 1 >= xo.max_ipm)) { halt = 2; csw(CS_REASON, (double)XR_FINAL); if (whole) ++jj; leave = 1; break; }
     }
+    ++jj;
+    if (whole) { // abip.c:2131; abip_hip_step's budget; abip.c:608-609: a restart is the launch path's
+      if (__builtin_expect(jj >= xo.inner_stopper, 0)) { stage = XS_OUTER_END; break; }
+      if (__builtin_expect(ran >= xo.max_steps, 0)) { csw(CS_REASON, (double)XR_STEPS); leave = 1; break; }
+      const long kk = a.fc.k0 + ran;
+      if (__builtin_expect(kk >= xo.restart_thresh, 0)) {
+        if ((jj + 1 - (long)csr(CS_FRE)) % xo.restart_fre == 0) { csw(CS_REASON, (double)XR_RESTART); leave = 1; break; }
+      }
+    } else if (ran >= a.max_iters) { leave = 1; break; }
+    } // (the inner loop)
+    if (leave) break;
+    if (__builtin_expect(solo, 0)) { // the solution goes back in place; u_t'h where the launch path's consumers re-reduce the partial table
+#pragma unroll
+      for (int q = 0; q < RN; ++q) { const unsigned j2 = n0 + tb + q * XTB; if (j2 < n1) x_at(a.srhs, MP + j2) = zx[q]; }
+      if (rank == 0) for (unsigned e = t; e < (unsigned)a.npart; e += XTB) a.part[S_DH * MAXNB + e] = (e == 0) ? dhS[0] : 0.0;
+      break;
+    }
+
+    // ================================================================================================================================
+    // look-ahead steps of the Barzilai-Borwein search (adaptive.c:101-251): the prox on scratch vectors, the five inner products, the next penalty
+    // ================================================================================================================================
+    if (__builtin_expect(mode != XM_MAIN, 0)) {
+      const double mu = csr(CS_MU);
+      double bb_prev = csr(CS_BBPREV);
+      const double bup_t = csr(CS_BUPT), bvp_t = csr(CS_BVPT);
+      const double mob = mu / bb_prev, al = up.alpha;
+      const double utq_t = tsum + dhS[0]; // adaptive.c:99, 131
+      if (mode == XM_BB1) { // (u_prev, v_prev) -> (u, v)
+#pragma unroll
+        for (int q = 0; q < RM; ++q) { const unsigned i = m0 + tb + q * XTB; if (i < m1) x_at(xo.a_u, i) = y[q] - x_at(xo.a_vp, i); }
+#pragma unroll
+        for (int q = 0; q < RN; ++q) {
+          const unsigned j2 = n0 + tb + q * XTB;
+          if (j2 < n1) {
+            double un, vn;
+            x_bbstep(al, mob, zx[q], x_at(xo.a_up, MP + j2), x_at(xo.a_vp, MP + j2), un, vn);
+            x_at(xo.a_u, MP + j2) = un; x_at(xo.a_v, MP + j2) = vn;
+          }
+        }
+        double un, vn;
+        x_bbstep(al, mob, utq_t, bup_t, bvp_t, un, vn);
+        csw(CS_BUT, un); csw(CS_BVT, vn);
+        mode = XM_BB2; need_pre = true;
+        continue;
+      }
+      // (u, v) -> (u_next, v_next), and the inner products of the three difference vectors
+      const double bu_t = csr(CS_BUT), bv_t = csr(CS_BVT);
+      double d5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < RM; ++q) {
+        const unsigned i = m0 + tb + q * XTB;
+        if (i < m1) {
+          const double vv = x_at(xo.a_v, i), vnn = x_at(xo.a_vn, i); // (the y blocks of v and v_next are never written: adaptive.c:118-121, 147-150)
+          const double un = y[q] - vv;
+          x_at(xo.a_un, i) = un;
+          x_bbdots(al, x_at(xo.a_u, i), vv, un, vnn, x_at(xo.a_vp, i), d5);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < RN; ++q) {
+        const unsigned j2 = n0 + tb + q * XTB;
+        if (j2 < n1) {
+          const double uo = x_at(xo.a_u, MP + j2), vo = x_at(xo.a_v, MP + j2);
+          double un, vn;
+          x_bbstep(al, mob, zx[q], uo, vo, un, vn);
+          x_at(xo.a_un, MP + j2) = un; x_at(xo.a_vn, MP + j2) = vn;
+          x_bbdots(al, uo, vo, un, vn, x_at(xo.a_vp, MP + j2), d5);
+        }
+      }
+      {
+        double un, vn;
+        x_bbstep(al, mob, utq_t, bu_t, bv_t, un, vn);
+        if (rank == 0 && t == 0) x_bbdots(al, bu_t, bv_t, un, vn, bvp_t, d5);
+      }
+      open(12);
+      x_publish<5, SA>(d5, red, psc, sc_off, tag);
+      double D5[5];
+      x_collect<5>(w, G, tot, D5);
+      if (__builtin_expect(w.dead, 0)) return;
+      const int bb_it = (int)csr(CS_BBIT);
+      const double bb_tot = csr(CS_BBTOT);
+      __syncthreads(); // (everybody has read the state thread 0 overwrites below)
+      csw(CS_BBTOT, bb_tot + 1.0);
+      double bnew = 0.0;
+      const int act = __builtin_amdgcn_readfirstlane(lp_bb_beta(D5[0], D5[1], D5[2], D5[3], D5[4], xo.eps_cor, xo.eps_pen, bb_prev, bnew));
+      bnew = x_uni(bnew);
+      if (act != 0 && bb_it + 1 < xo.lookback) { // go on from (u, v) (adaptive.c:230-247)
+        if (act == 1) bb_prev = bnew;
+        const double mob2 = mu / bb_prev;
+#pragma unroll
+        for (int q = 0; q < RM; ++q) {
+          const unsigned i = m0 + tb + q * XTB;
+          if (i < m1) { x_at(xo.a_up, i) = x_at(xo.a_u, i); x_at(xo.a_vp, i) = x_at(xo.a_v, i); }
+        }
+#pragma unroll
+        for (int q = 0; q < RN; ++q) {
+          const unsigned j2 = n0 + tb + q * XTB;
+          if (j2 < n1) {
+            const double uo = x_at(xo.a_u, MP + j2);
+            x_at(xo.a_up, MP + j2) = uo;
+            x_at(xo.a_vp, MP + j2) = (act == 1) ? mob2 / uo : x_at(xo.a_v, MP + j2);
+          }
+        }
+        csw(CS_BBPREV, bb_prev); csw(CS_BUPT, bu_t); csw(CS_BVPT, (act == 1) ? mob2 / bu_t : bv_t); csw(CS_BBIT, (double)(bb_it + 1));
+        mode = XM_BB1; need_pre = true;
+        continue;
+      }
+      // the search is over (adaptive.c:253): w->beta; reinitialize_vars(2) (abip.c:2291) on the vectors the outer end rescaled
+      csw(CS_BETA, bnew);
+      {
+        const bool av = csr(CS_AV) != 0.0;
+        double *RU = av ? up.u_avgc : up.u, *RV = av ? up.v_avgc : up.v;
+        const double sq = sqrt(1.0 / xo.sigma);
+#pragma unroll
+        for (int q = 0; q < RN; ++q) { const unsigned j2 = n0 + tb + q * XTB; if (j2 < n1) { x_at(RU, MP + j2) = sq * x_at(RU, MP + j2); x_at(RV, MP + j2) = sq * x_at(RV, MP + j2); } }
+        const double r_ut = x_uni(sq * csr(CS_RUT)), r_vt = x_uni(sq * csr(CS_RVT));
+        if (rank == 0 && t == 0) { x_at(RU, tail) = r_ut; x_at(RV, tail) = r_vt; }
+        csw(CS_RUT, r_ut); csw(CS_RVT, r_vt);
+        if (!av) { u_tau = r_ut; v_tau = r_vt; }
+      }
+      stage = XS_OUTER_BEGIN;
+      continue;
+    }
+
   }
   __syncthreads();
   if (rank == 0 && t < 96 && ran > 0) a.ctl->out[t] = outs[t];
@@ -893,6 +1272,13 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     if (!solo) { c->metric = metric; c->avg_crit = avg_crit; c->it_count = c->it_count + ran; c->halt = halt; }
     c->cg_it = last_cg; c->cg_done = 1;
     c->xcd_cg_total = cg_total;
+    if (whole) {
+      XcdOut &o = c->xo;
+      o.phase = (int)cs[CS_PHASE]; o.reason = (int)cs[CS_REASON]; o.final_check = final_check; o.avg_crit = avg_crit; o.stats_valid = stats_valid ? 1 : 0; o.avg_stats = avg_stats_last;
+      o.outer_done = (int)cs[CS_ODONE]; o.log_n = (int)cs[CS_LOGN]; o.last_cg = last_cg; o.bb_lookaheads = (int)cs[CS_BBTOT];
+      o.i = (long)cs[CS_OI]; o.j = jj; o.k = a.fc.k0 + ran; o.ran = ran; o.solves = (long)ran + 2 * (long)cs[CS_BBTOT]; o.cg_total = cg_total;
+      o.mu = cs[CS_MU]; o.beta = cs[CS_BETA]; o.dyn_sigma = cs[CS_DYNS];
+    }
     a.xstat[1] = (int)(tag - a.tag0);
   }
   XP_DUMP

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <ctime>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -103,9 +104,9 @@ int chosen_linsys() {
   return ABIP_HIP_LINSYS_DIRECT;
 }
 
-struct Resid { // ABIPResiduals, include/abip.h:178-195
+struct Resid : abip::LpResid { // ABIPResiduals, include/abip.h:178-195 (the numbers: lp_scalars.h)
   abip_int last_ipm_iter = -1, last_admm_iter = -1;
-  double res_pri = 0, res_dual = 0, rel_gap = 0, res_infeas = 0, res_unbdd = 0, ct_x_by_tau = 0, bt_y_by_tau = 0, tau = 0, kap = 0;
+  Resid() : abip::LpResid{0, 0, 0, 0, 0, 0, 0, 0, 0} {}
 };
 
 enum Phase { PH_IDLE, PH_OUTER_BEGIN, PH_INNER, PH_OUTER_END, PH_DONE };
@@ -158,11 +159,26 @@ struct XcdPlan {
   size_t lds = 0;
   const void *kern = nullptr;
   long batches = 0, exchanges = 0;
+  // launches that span outer iterations (dev_xcd.h XcdOuter; ABIP_HIP_XCD_OUTER=0: one batch of inner iterations per launch, as in round 3)
+  bool outer = true;
+  static constexpr int MU_TAB = 64, LOG_CAP = 64;
+  abip::hostutil::DBuf<double> mu_tab, xlog;
+  double *hmu_tab = nullptr, *hlog = nullptr; // pinned
+  long outer_done = 0, lookaheads = 0, whole_launches = 0;
+  double its_per_ms = 0.0;   // measured rate of the launches so far: sizes the next launch's iteration budget (a launch is kept to about a second)
+  double ticks_per_ms = 1e5; // wall_clock64
+  // what a launch needs to be abandoned: the iterate and its running sums as they were when it started (restored when a wait gives up; the launch path goes on from there)
+  abip::hostutil::DBuf<double> snap; size_t snap_len = 0;
+  long giveups = 0;
+  int desert_at = -1; // fault injection (libabip_hip_hooks.so): the launch number whose last rank leaves at once
   void release() {
     mb.release(); nb.release(); xstat.release(); tickets.release(); xn0.release(); xn1.release(); xm0.release(); xm1.release(); sc.release(); tolf.release(); Minv.release();
+    mu_tab.release(); xlog.release(); snap.release();
     if (htolf) (void)hipHostFree(htolf);
     if (hstat) (void)hipHostFree(hstat);
-    htolf = nullptr; hstat = nullptr; on = false;
+    if (hmu_tab) (void)hipHostFree(hmu_tab);
+    if (hlog) (void)hipHostFree(hlog);
+    htolf = nullptr; hstat = nullptr; hmu_tab = nullptr; hlog = nullptr; on = false;
   }
 };
 
@@ -197,6 +213,7 @@ struct ABIP_WORK {
   DevLdl ldl;
   XcdPlan xcd;
   bool xcd_solves = true; // ABIP_HIP_XCD_SOLVES=0: the stand-alone solves (set-up, BB look-ahead) stay on the launch path
+  bool host_outer_once = false; // the persistent launch handed this outer end (abip.c:2217-2293) to the host
   // ---- loop state (locals of ABIP(solve)) ------------------------------------------------
   Phase phase = PH_IDLE;
   abip_int i = 0, j = 0, k = 0, inner_stopper = 0;
@@ -557,9 +574,11 @@ int kkt_solve_sync(W *w, double *rhs, const double *warm, abip_int iter) {
   w->prof.kkt_solves++;
   if (w->xcd.on && w->xcd_solves) { // cache-resident LP: the solve as one persistent launch too (the BB look-ahead is dozens of solves per outer iteration)
     const int its = xcd_solve(w, rhs, warm, iter);
-    if (its < 0) return -1;
-    if (w->linsys == ABIP_HIP_LINSYS_INDIRECT) { w->last_cg_its = its; if (iter >= 0) { w->tot_cg_its += its; w->prof.cg_iters += its; } }
-    return its;
+    if (its == -1) return -1;
+    if (its >= 0) {
+      if (w->linsys == ABIP_HIP_LINSYS_INDIRECT) { w->last_cg_its = its; if (iter >= 0) { w->tot_cg_its += its; w->prof.cg_iters += its; } }
+      return its;
+    } // (-2: the launch was abandoned and rhs restored -- solve it below)
   }
   if (w->linsys == ABIP_HIP_LINSYS_DIRECT) {
     enqueue_direct(w, rhs);
@@ -588,31 +607,12 @@ void calc_residuals(W *w, abip_int ipm_iter, abip_int admm_iter) {
   Resid &r = w->r;
   if (admm_iter && r.last_admm_iter == admm_iter) return;
   r.last_ipm_iter = ipm_iter; r.last_admm_iter = admm_iter;
-  const bool avg = w->stgs->avg_criterion != 0;
-  const double *o = w->hctl->out;
   const double den = w->stgs->normalize ? (w->stgs->scale * w->sc_c * w->sc_b) : 1.0;
-  const double ut = avg ? o[82] : o[80], vt = avg ? o[83] : o[81];
-  r.tau = std::fabs(ut);
-  r.kap = std::fabs(vt) / den;
-  const double nmpr_tau = std::sqrt(avg ? o[S_RPA] : o[S_RP]), nm_A_x_tau = std::sqrt(avg ? o[S_NAXA] : o[S_NAX]);
-  const double nmdr_tau = std::sqrt(avg ? o[S_RDA] : o[S_RD]), nm_At_ys_tau = std::sqrt(avg ? o[S_NATYA] : o[S_NATY]);
-  r.bt_y_by_tau = (avg ? o[S_BYA] : o[S_BY]) / den;
-  r.ct_x_by_tau = (avg ? o[S_CXA] : o[S_CX]) / den;
-  r.res_infeas = r.bt_y_by_tau > 0 ? w->nm_b * nm_At_ys_tau / r.bt_y_by_tau : NAN;
-  r.res_unbdd = r.ct_x_by_tau < 0 ? w->nm_c * nm_A_x_tau / -r.ct_x_by_tau : NAN;
-  const double bt_y = safediv_pos(r.bt_y_by_tau, r.tau), ct_x = safediv_pos(r.ct_x_by_tau, r.tau);
-  r.res_pri = safediv_pos(nmpr_tau / (1 + w->nm_b), r.tau);
-  r.res_dual = safediv_pos(nmdr_tau / (1 + w->nm_c), r.tau);
-  r.rel_gap = std::fabs(ct_x - bt_y) / (1 + std::fabs(ct_x) + std::fabs(bt_y));
+  lp_residuals(x_sums(w->hctl->out, w->stgs->avg_criterion != 0), den, w->nm_b, w->nm_c, r); // (one source with the persistent launch: lp_scalars.h)
 }
 
 abip_int has_converged(const W *w, abip_int ipm_iter, abip_int admm_iter) { // abip.c:1613-1641
-  const Resid &r = w->r;
-  const double eps = w->stgs->eps;
-  if (r.res_pri < eps && (r.res_dual < eps || w->stgs->pfeasopt) && r.rel_gap < eps) return ABIP_SOLVED;
-  if (r.res_unbdd < eps && ipm_iter > 0 && admm_iter > 0) return ABIP_UNBOUNDED;
-  if (r.res_infeas < eps && ipm_iter > 0 && admm_iter > 0) return ABIP_INFEASIBLE;
-  return 0;
+  return (abip_int)lp_converged(w->r, w->stgs->eps, (int)w->stgs->pfeasopt, (long)ipm_iter, (long)admm_iter); // ABIP_SOLVED 1, ABIP_UNBOUNDED -1, ABIP_INFEASIBLE -2
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -866,17 +866,18 @@ bool xcd_plan(XcdPlan &x, const host::HostCsr &hA, const host::HostCsr &hAt, boo
   x.NZ = pick->nz; x.RM = pick->rm; x.RN = pick->rn;
   x.kern = pcg ? (x.G > 32 ? pick->pcg2 : pick->pcg) : (x.G > 32 ? pick->direct2 : pick->direct);
   x.n_pad = (int)((n + 63) / 64 * 64); x.m_pad = (int)((m + 63) / 64 * 64);
-  size_t words = 2 * (size_t)x.NZ * XTB + XKS + XWAVES * XKS + 96;
+  size_t words = 2 * (size_t)x.NZ * XTB + XKS + XWAVES * XKS + 96 + 16 + 32;
   if (!pcg) words += (size_t)x.m_pad + (size_t)x.RM * XTB;
-  if (words * sizeof(double) > 160 * 1024) return false;
+  constexpr size_t kLdsWords = (160 * 1024 - 512) / sizeof(double); // (the kernel's one static word lives in the remaining 512 bytes)
+  if (words > kLdsWords) return false;
   x.minv_lds_rows = 0;
   if (!pcg) { // what is left of the LDS keeps rows of the dense inverse
-    const size_t room = (160 * 1024 - 512) / sizeof(double) - words;
+    const size_t room = kLdsWords - words;
     x.minv_lds_rows = (int)std::min<size_t>(room / (size_t)x.m_pad, (size_t)*rA);
     words += (size_t)x.minv_lds_rows * x.m_pad;
   }
   x.lds = std::max<size_t>(words * sizeof(double), (size_t)XCD_LDS_MIN);
-  return true;
+  return x.lds <= 160 * 1024;
 }
 
 // Decide whether the LP runs its inner loop as the one-XCD persistent launch and prepare it.  Never fails the set-up: when the problem does
@@ -894,16 +895,26 @@ void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
   long nzA = 0, nzT = 0; int rA = 0, rT = 0, lA = 0, lT = 0;
   if (!pcg && !w->A) return;
   if (!xcd_plan(x, hA, hAt, pcg, mb, nb, &nzA, &nzT, &rA, &rT, &lA, &lT)) return;
-  if (hipFuncSetAttribute(x.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)x.lds) != hipSuccess) { (void)hipGetLastError(); return; }
+  // (the cap is per kernel function, not per work: two works of one variant with different LDS sizes must not lower it under each other)
+  const bool chatty = getenv("ABIP_HIP_XCD_VERBOSE") != nullptr;
+  if (hipFuncSetAttribute(x.kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) { (void)hipGetLastError(); if (chatty) printf("[xcd] off: the LDS cap could not be raised\n"); return; }
+  { // one workgroup per CU must be able to be resident at all: 256 workgroups on 256 CUs, every one of them waited for by the others
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, x.kern, XTB, x.lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); if (chatty) printf("[xcd] off: occupancy query says %d workgroups per CU\n", per_cu); return; }
+  }
   const std::vector<int> zero2(XSTAT_N, 0);
   const std::vector<unsigned> zero1(1, 0u);
   bool bad = x.mb.upload(mb, w->stream) || x.nb.upload(nb, w->stream) || x.xstat.upload(zero2, w->stream) || x.tickets.upload(zero1, w->stream) ||
              x.xn0.alloc(2 * (size_t)x.n_pad) || x.xn1.alloc(2 * (size_t)x.n_pad) || x.xm0.alloc(2 * (size_t)x.m_pad) || x.xm1.alloc(2 * (size_t)x.m_pad) ||
-             x.sc.alloc(2 * (size_t)XG * XKS) || x.tolf.alloc(x.max_batch);
+             x.sc.alloc(2 * (size_t)XG * XKS) || x.tolf.alloc(x.max_batch) || x.mu_tab.alloc(XcdPlan::MU_TAB) || x.xlog.alloc((size_t)XcdPlan::LOG_CAP * XLOG_W) ||
+             x.snap.alloc(9 * (size_t)w->LV);
+  x.snap_len = (size_t)w->LV;
   if (!bad) bad = hipMemsetAsync(x.xn0.p, 0, sizeof(double) * 2 * x.n_pad, w->stream) != hipSuccess || hipMemsetAsync(x.xn1.p, 0, sizeof(double) * 2 * x.n_pad, w->stream) != hipSuccess ||
                   hipMemsetAsync(x.xm0.p, 0, sizeof(double) * 2 * x.m_pad, w->stream) != hipSuccess || hipMemsetAsync(x.xm1.p, 0, sizeof(double) * 2 * x.m_pad, w->stream) != hipSuccess ||
                   hipMemsetAsync(x.sc.p, 0, sizeof(u32x4) * 2 * XG * XKS, w->stream) != hipSuccess;
-  if (!bad) bad = hipHostMalloc((void **)&x.htolf, sizeof(double) * x.max_batch, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&x.hstat, XSTAT_N * sizeof(int), hipHostMallocDefault) != hipSuccess;
+  if (!bad) bad = hipHostMalloc((void **)&x.htolf, sizeof(double) * x.max_batch, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&x.hstat, XSTAT_N * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+                  hipHostMalloc((void **)&x.hmu_tab, sizeof(double) * XcdPlan::MU_TAB, hipHostMallocDefault) != hipSuccess ||
+                  hipHostMalloc((void **)&x.hlog, sizeof(double) * XcdPlan::LOG_CAP * XLOG_W, hipHostMallocDefault) != hipSuccess;
   if (bad) { (void)hipGetLastError(); x.release(); return; }
   if (!pcg) { // direct: the x block (-I) eliminated first, the y block's Schur complement rho I + A A' inverted densely on the device
     const int m = (int)w->m, T = x.m_pad;
@@ -932,6 +943,11 @@ void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
   }
   x.tag = 0; x.launches = 0; x.tickets_used = 0;
   x.on = true;
+  { const char *e = getenv("ABIP_HIP_XCD_OUTER"); x.outer = !(e && atoi(e) == 0); }
+  { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) x.ticks_per_ms = (double)khz; }
+#ifdef ABIP_HIP_TEST_HOOKS
+  { const char *e = getenv("ABIP_HIP_XCD_GIVEUP_AT"); x.desert_at = e ? atoi(e) : -1; }
+#endif
   // stand-alone solves (set-up, BB look-ahead) through the persistent kernel: worth it for the PCG back-end (a launch-path solve is 3 launches per PCG
   // iteration); the direct back-end's launch-path solve is 4 launches in all and wins (ABIP_HIP_XCD_SOLVES=0 / 1 forces either)
   { const char *e = getenv("ABIP_HIP_XCD_SOLVES"); w->xcd_solves = e ? atoi(e) != 0 : pcg; }
@@ -940,27 +956,20 @@ void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
            x.NZ, x.RM, x.RN, x.lds, x.minv_lds_rows);
 }
 
-int xcd_batch(W *w, int nb, int *ran, double *metric_out, double *srhs = nullptr, const double *swarm = nullptr, abip_int siter = 0);
-// K z = rhs in place by ONE launch of the persistent kernel in its solve-only mode (warm: l-vector whose y block starts the PCG, or null);
-// leaves u_t'h in the partial table like the launch path's post-solve kernels.  Returns the PCG iterations (0 for the direct back-end), < 0 on error.
-int xcd_solve(W *w, double *rhs, const double *warm, abip_int iter) {
-  int ran = 0; double metric = 0;
-  if (xcd_batch(w, 1, &ran, &metric, rhs, warm, iter)) return -1;
-  return w->linsys == ABIP_HIP_LINSYS_INDIRECT ? w->hctl->cg_it : 0;
-}
+// ---- launching the persistent kernel ---------------------------------------------------------------------------------------------
+// Persistent launches are serialised process-wide: a launch is 256 workgroups that wait for each other, and two of them dealt onto the CUs at the same
+// time (two works driven from two threads) could each hold CUs the other needs.  Held from the launch to the read-back that ends it.
+std::mutex g_xcd_mutex;
 
-// Run up to nb ADMM iterations (k, j), (k+1, j+1), ... as one launch; *ran = iterations that ran (the exit test, or the final check, stops it).
-// srhs != null: the solve-only mode (one KKT solve on srhs, nothing else).
-int xcd_batch(W *w, int nb, int *ran, double *metric_out, double *srhs, const double *swarm, abip_int siter) {
+DBuf<double> *xcd_state_vecs(W *w, int q) {
+  DBuf<double> *v[] = {&w->u, &w->v, &w->u_avg, &w->v_avg, &w->u_sum, &w->v_sum, &w->u_avgc, &w->v_avgc};
+  return v[q];
+}
+// Everything of an XcdArgs that does not depend on what the launch is asked to do
+void xcd_fill(W *w, XcdArgs &a) {
   XcdPlan &x = w->xcd;
   ABIPSettings *st = w->stgs;
   const bool pcg = (w->linsys == ABIP_HIP_LINSYS_INDIRECT);
-  nb = std::min(nb, x.max_batch);
-  if (x.tag > 0x70000000u) { // tags only ever grow within the life of the buffers: start over long before they wrap
-    HIP_OK(hipMemsetAsync(x.sc.p, 0, sizeof(u32x4) * 2 * XG * XKS, w->stream)); // (only the flags carry tags)
-    x.tag = 0;
-  }
-  XcdArgs a{};
   a.Ap = w->dA.ptr.p; a.Ai = w->dA.idx.p; a.Ax = w->dA.val.p;
   a.Tp = w->dAt.ptr.p; a.Ti = w->dAt.idx.p; a.Tx = w->dAt.val.p;
   a.mb = x.mb.p; a.nb = x.nb.p;
@@ -970,51 +979,105 @@ int xcd_batch(W *w, int nb, int *ran, double *metric_out, double *srhs, const do
   a.Mjac = pcg ? w->cg_M.p : nullptr; a.Minv = x.Minv.p; a.ldM = x.ldM; a.minv_lds_rows = x.minv_lds_rows;
   a.g_th = w->g_th;
   a.xn0 = x.xn0.p; a.xn1 = x.xn1.p; a.xm0 = x.xm0.p; a.xm1 = x.xm1.p; a.sc = x.sc.p; a.n_pad = x.n_pad; a.m_pad = x.m_pad;
-  a.tag0 = x.tag;
-  a.tickets = x.tickets.p; a.ticket_base = x.tickets_used; a.nxcd = x.nxcd;
-  x.tickets_used += (unsigned)x.G;
+  a.nxcd = x.nxcd;
   a.ctl = w->ctl.p; a.xstat = x.xstat.p;
-  a.j0 = (long)w->j; a.max_iters = nb;
+  a.j0 = (long)w->j;
   a.thr = w->gamma * w->mu; a.sentinel = (double)st->max_admm_iters;
   a.tolf = x.tolf.p; a.cg_max_its = (int)w->m_glob;
-  a.solve_only = srhs ? 1 : 0; a.srhs = srhs; a.swarm = swarm; a.part = w->part.p; a.npart = w->NB;
+  a.part = w->part.p; a.npart = w->NB;
   a.fc.on = w->final_check ? 1 : 0; a.fc.pfeasopt = (int)st->pfeasopt; a.fc.ipm_pos = w->i > 0 ? 1 : 0;
   a.fc.eps = st->eps; a.fc.den = st->normalize ? (st->scale * w->sc_c * w->sc_b) : 1.0; a.fc.nm_b = w->nm_b; a.fc.nm_c = w->nm_c;
   a.fc.k0 = (long)w->k; a.fc.max_admm = (long)st->max_admm_iters;
-  if (pcg) {
-    for (int q = 0; q < nb; ++q) x.htolf[q] = srhs ? cg_tol_factor(w, siter) : cg_tol_factor(w, w->k + q);
-    HIP_OK(hipMemcpyAsync(x.tolf.p, x.htolf, sizeof(double) * nb, hipMemcpyHostToDevice, w->stream));
+  a.outer.on = 0; a.outer.i = (long)w->i;
+  a.desert = -1;
+}
+// Launch, wait, read the control block back.  0 = the launch ran to its end; 1 = a wait inside it gave up (another kernel held CUs the launch needed, or the
+// placement the protocol relies on did not come about): the iterate is back to what it was before the launch, the persistent launch is switched off for
+// this work and the caller goes on along the launch path; < 0 = device error.  `vec` (solve-only launches): the one vector the launch overwrites.
+int xcd_launch(W *w, XcdArgs &a, double *vec) {
+  XcdPlan &x = w->xcd;
+  if (x.tag > 0x70000000u) { // tags only ever grow within the life of the buffers: start over long before they wrap
+    HIP_OK(hipMemsetAsync(x.sc.p, 0, sizeof(u32x4) * 2 * XG * XKS, w->stream)); // (only the flags carry tags)
+    x.tag = 0;
   }
+  a.tag0 = x.tag;
+  // the way back: the state the launch is about to change
+  if (vec) HIP_OK(hipMemcpyAsync(x.snap.p, vec, sizeof(double) * x.snap_len, hipMemcpyDeviceToDevice, w->stream));
+  else for (int q = 0; q < 8; ++q) HIP_OK(hipMemcpyAsync(x.snap.p + (size_t)(q + 1) * x.snap_len, xcd_state_vecs(w, q)->p, sizeof(double) * x.snap_len, hipMemcpyDeviceToDevice, w->stream));
   void *params[] = {&a};
   const double t_launch = now_ms();
   W::Ev *ev = nullptr;
-  if (((w->prof_mask >> ABIP_HIP_K_XCD) & 1u) && !srhs) { // (iteration batches only: the stand-alone solves are not iterations)
+  if (((w->prof_mask >> ABIP_HIP_K_XCD) & 1u) && !vec) { // (iteration launches only: the stand-alone solves are not iterations)
     if (w->ev_used == w->ev_pool.size()) { W::Ev e; e.cls = ABIP_HIP_K_XCD; (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); w->ev_pool.push_back(e); }
     ev = &w->ev_pool[w->ev_used++];
     ev->cls = ABIP_HIP_K_XCD; ev->tag = -1;
     (void)hipEventRecord(ev->a, w->stream);
   }
-  HIP_OK(hipLaunchKernel(x.kern, dim3(256), dim3(XTB), params, x.lds, w->stream));
-  if (ev) (void)hipEventRecord(ev->b, w->stream);
-  x.launches++; x.batches++;
-  HIP_OK(hipMemcpyAsync(x.hstat, x.xstat.p, XSTAT_N * sizeof(int), hipMemcpyDeviceToHost, w->stream));
-  if (sync_ctl(w)) return -1;
-  if (x.hstat[0]) { fprintf(stderr, "abip_hip: after %.1f ms the one-XCD persistent launch gave up waiting for an exchange (tag %d of launch base %u, rank %d, wait site %d, thread %d; found tag %d in a granule of kind %d)\n", now_ms() - t_launch, x.hstat[2], x.tag, x.hstat[3], x.hstat[4], x.hstat[5], x.hstat[7], x.hstat[6] - 2);
-    fprintf(stderr, "  exec %08x%08x ok %08x%08x nt %d na %d wave %d\n", x.hstat[81], x.hstat[80], x.hstat[83], x.hstat[82], x.hstat[84], x.hstat[85], x.hstat[86]);
-    { // the scalar areas of both parities: the tag every granule carries
-      std::vector<unsigned> hsc(2 * XG * XKS * 4);
-      if (hipMemcpy(hsc.data(), x.sc.p, hsc.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
-        for (int par = 0; par < 2; ++par)
-          for (int g = 0; g < x.G; ++g) {
-            fprintf(stderr, "  sc parity %d rank %2d:", par, g);
-            for (int k = 0; k < XKS; ++k) fprintf(stderr, " %u%s", hsc[((size_t)(par * XG + g) * XKS + k) * 4 + 1], hsc[((size_t)(par * XG + g) * XKS + k) * 4 + 1] == hsc[((size_t)(par * XG + g) * XKS + k) * 4 + 3] ? "" : "!");
-            fprintf(stderr, "\n");
-          }
-    }
-    for (int g = 0; g < x.G; ++g) fprintf(stderr, "  rank %2d: last exchange opened %d (after wait site %d)\n", g, x.hstat[8 + 2 * g], x.hstat[9 + 2 * g]);
-    return -1; }
-  x.tag += (unsigned)x.hstat[1]; x.exchanges += x.hstat[1];
-  if (srhs) return 0; // solve-only: no iteration ran
+  {
+    std::lock_guard<std::mutex> lock(g_xcd_mutex);
+    a.tickets = x.tickets.p; a.ticket_base = x.tickets_used;
+    x.tickets_used += (unsigned)x.G;
+    if (x.desert_at >= 0 && (int)x.launches == x.desert_at) a.desert = x.G - 1;
+    HIP_OK(hipLaunchKernel(x.kern, dim3(256), dim3(XTB), params, x.lds, w->stream));
+    if (ev) (void)hipEventRecord(ev->b, w->stream);
+    x.launches++;
+    HIP_OK(hipMemcpyAsync(x.hstat, x.xstat.p, XSTAT_N * sizeof(int), hipMemcpyDeviceToHost, w->stream));
+    if (sync_ctl(w)) return -1;
+  }
+  if (!x.hstat[0]) {
+    x.tag += (unsigned)x.hstat[1]; x.exchanges += x.hstat[1];
+    return 0;
+  }
+  // ---- a wait gave up: post-mortem, restore, leave the persistent launch for good ----
+  x.giveups++;
+  fprintf(stderr, "abip_hip: persistent launch %u abandoned after %.1f ms (a wait for exchange %d gave up: rank %d, wait site %d; %d of %d ranks had opened it) -- the launch path takes over\n",
+          x.launches - 1, now_ms() - t_launch, x.hstat[2], x.hstat[3], x.hstat[4],
+          [&] { int c = 0; for (int g = 0; g < x.G; ++g) c += (x.hstat[8 + 2 * g] == x.hstat[2]); return c; }(), x.G);
+  if (getenv("ABIP_HIP_XCD_VERBOSE")) {
+    for (int g = 0; g < x.G; ++g) fprintf(stderr, "  rank %3d: last exchange opened %d (wait site %d)\n", g, x.hstat[8 + 2 * g], x.hstat[9 + 2 * g]);
+  }
+  if (vec) HIP_OK(hipMemcpyAsync(vec, x.snap.p, sizeof(double) * x.snap_len, hipMemcpyDeviceToDevice, w->stream));
+  else for (int q = 0; q < 8; ++q) HIP_OK(hipMemcpyAsync(xcd_state_vecs(w, q)->p, x.snap.p + (size_t)(q + 1) * x.snap_len, sizeof(double) * x.snap_len, hipMemcpyDeviceToDevice, w->stream));
+  HIP_OK(hipMemsetAsync(x.xstat.p, 0, XSTAT_N * sizeof(int), w->stream)); // (a later work on the same buffers must not see the flag)
+  HIP_OK(hipStreamSynchronize(w->stream));
+  x.on = false;
+  w->wg_valid = false;
+  return 1;
+}
+
+// K z = rhs in place by ONE launch of the persistent kernel in its solve-only mode (warm: l-vector whose y block starts the PCG, or null);
+// leaves u_t'h in the partial table like the launch path's post-solve kernels.  Returns the PCG iterations (0 for the direct back-end), < 0 on error,
+// -2 when the launch was abandoned (rhs is intact: the caller solves on the launch path).
+int xcd_solve(W *w, double *rhs, const double *warm, abip_int iter) {
+  XcdPlan &x = w->xcd;
+  XcdArgs a{};
+  xcd_fill(w, a);
+  a.max_iters = 1; a.solve_only = 1; a.srhs = rhs; a.swarm = warm;
+  if (w->linsys == ABIP_HIP_LINSYS_INDIRECT) {
+    x.htolf[0] = cg_tol_factor(w, iter);
+    HIP_OK(hipMemcpyAsync(x.tolf.p, x.htolf, sizeof(double), hipMemcpyHostToDevice, w->stream));
+  }
+  const int rc = xcd_launch(w, a, rhs);
+  if (rc) return rc < 0 ? -1 : -2;
+  return w->linsys == ABIP_HIP_LINSYS_INDIRECT ? w->hctl->cg_it : 0;
+}
+
+// Run up to nb ADMM iterations (k, j), (k+1, j+1), ... as one launch; *ran = iterations that ran (the exit test, or the final check, stops it).
+// Returns as xcd_launch (1: abandoned, nothing ran).
+int xcd_batch(W *w, int nb, int *ran, double *metric_out) {
+  XcdPlan &x = w->xcd;
+  const bool pcg = (w->linsys == ABIP_HIP_LINSYS_INDIRECT);
+  nb = std::min(nb, x.max_batch);
+  XcdArgs a{};
+  xcd_fill(w, a);
+  a.max_iters = nb;
+  if (pcg) {
+    for (int q = 0; q < nb; ++q) x.htolf[q] = cg_tol_factor(w, w->k + q);
+    HIP_OK(hipMemcpyAsync(x.tolf.p, x.htolf, sizeof(double) * nb, hipMemcpyHostToDevice, w->stream));
+  }
+  const int rc = xcd_launch(w, a, nullptr);
+  if (rc) return rc;
+  x.batches++;
 #ifdef XCD_PROF
   { static long acc[8] = {0}; for (int q = 0; q < 8; ++q) acc[q] += (unsigned)x.hstat[600 + q];
     fprintf(stderr, "[xcd prof] cumulative us: %.0f %.0f %.0f %.0f %.0f %.0f %.0f (PCG loop: put, publish, collect, gather, rows, tail | direct: rhs+E1, E_w, all-gather, dense, E_y+E_dh, update+E_u, q+E_fin)\n", acc[0] * 0.01, acc[1] * 0.01, acc[2] * 0.01, acc[3] * 0.01, acc[4] * 0.01, acc[5] * 0.01, acc[6] * 0.01); }
@@ -1026,6 +1089,80 @@ int xcd_batch(W *w, int nb, int *ran, double *metric_out, double *srhs, const do
   if (pcg) { w->last_cg_its = w->hctl->cg_it; w->tot_cg_its += w->hctl->xcd_cg_total; w->prof.cg_iters += w->hctl->xcd_cg_total; }
   w->wg_valid = false; // the launch path's partial table does not hold S_WG
   w->stats_valid = true; w->avg_stats_valid = ((w->j + *ran) % 10 == 0);
+  return 0;
+}
+
+// ---- a launch that spans outer iterations (dev_xcd.h XcdOuter) -------------------------------------------------------------------
+// May the loop of abip.c:2102-2294 run inside the kernel for this work and these settings?  What stays outside: half_update (its clean-up pass),
+// the inner caps of dense problems (pow on the device), a PCG tolerance schedule other than 1 / k^2.
+bool xcd_outer_ok(const W *w) {
+  const ABIPSettings *st = w->stgs;
+  if (!w->xcd.on || !w->xcd.outer || w->dist || st->half_update) return false;
+  if (std::min(w->sp, st->sparsity_ratio) > 0.2) return false;                              // abip.c:2104-2115: inner_stopper = max_admm_iters only then
+  if (w->linsys == ABIP_HIP_LINSYS_INDIRECT && st->cg_rate != 2.0) return false;           // indirect.c:406-407
+  if (st->restart_fre <= 0) return false;
+  return true;
+}
+void print_summary_row(const W *w, const double *row);
+// One launch from the inner loop (phase 0: iteration (k, j) is next) or from a pending outer end (phase 1).  Updates the host's copy of the loop state from
+// what the launch hands back.  Returns as xcd_launch; *ran = ADMM iterations that ran; *reason = XR_*.
+int xcd_run(W *w, int phase, long max_steps, long *ran, int *reason) {
+  XcdPlan &x = w->xcd;
+  ABIPSettings *st = w->stgs;
+  XcdArgs a{};
+  xcd_fill(w, a);
+  a.max_iters = 0;
+  XcdOuter &o = a.outer;
+  o.on = 1; o.phase = phase; o.avg_crit = (int)st->avg_criterion;
+  o.adaptive = (int)st->adaptive; o.lookback = (int)st->adaptive_lookback; o.hybrid_mu = (int)st->hybrid_mu;
+  o.i = (long)w->i; o.fre_old = (long)w->fre_old;
+  o.mu = w->mu; o.beta = w->beta; o.sigma = w->sigma; o.gamma = w->gamma; o.dyn_sigma = st->dynamic_sigma;
+  o.max_ipm = (long)st->max_ipm_iters; o.inner_stopper = (long)w->inner_stopper; o.restart_thresh = (long)st->restart_thresh; o.restart_fre = (long)st->restart_fre;
+  // a launch is kept to about a second of device time: the iteration budget from the rate of the launches so far (a first guess from the size), the
+  // wall-clock slice looked at once per outer iteration -- also what lets max_time (abip.c:2217-2221) take effect between launches
+  const double slice_ms = 1000.0;
+  long budget = x.its_per_ms > 0.0 ? (long)std::max(64.0, x.its_per_ms * slice_ms) : ((long)w->dA.val.n + (long)w->m * (w->linsys == ABIP_HIP_LINSYS_DIRECT ? (long)w->m : 0L) < 200000L ? 8192L : 1024L);
+  if (!w->batch_ok) budget = 1; // ABIP_HIP_BATCH=0: one control read per iteration (the same kernel, the same bits)
+  o.max_steps = std::max<long>(1, std::min(max_steps, budget));
+  const double left_ms = std::max(1.0, (st->max_time - ((double)clock() - w->cpu0) / CLOCKS_PER_SEC) * 1e3);
+  o.slice_ticks = (unsigned long long)(std::min(slice_ms, left_ms) * x.ticks_per_ms);
+  o.eps_cor = st->eps_cor; o.eps_pen = st->eps_pen; o.hybrid_thresh = st->hybrid_thresh; o.dyn_sigma_second = st->dynamic_sigma_second;
+  { // update_barrier_dynamic_2 (abip.c:982-992) applied 1, 2, ... times to the current mu: pow() stays on the host
+    double mu = w->mu;
+    for (int q = 0; q < XcdPlan::MU_TAB; ++q) { mu *= std::min(st->dynamic_x * mu, std::pow(mu, st->dynamic_sigma)); x.hmu_tab[q] = mu; }
+    HIP_OK(hipMemcpyAsync(x.mu_tab.p, x.hmu_tab, sizeof(double) * XcdPlan::MU_TAB, hipMemcpyHostToDevice, w->stream));
+  }
+  o.mu_tab = x.mu_tab.p; o.mu_tab_n = XcdPlan::MU_TAB;
+  o.log = x.xlog.p; o.log_cap = XcdPlan::LOG_CAP;
+  o.a_up = w->a_up.p; o.a_vp = w->a_vp.p; o.a_u = w->a_u.p; o.a_v = w->a_v.p; o.a_un = w->a_un.p; o.a_vn = w->a_vn.p;
+  const double t0 = now_ms();
+  const int rc = xcd_launch(w, a, nullptr);
+  if (rc) return rc;
+  const double dt = now_ms() - t0;
+  x.whole_launches++;
+  const XcdOut &r = w->hctl->xo;
+  *ran = r.ran; *reason = r.reason;
+  if (getenv("ABIP_HIP_XCD_VERBOSE")) printf("[xcd] launch %u (entry phase %d, budget %ld): %.3f ms, reason %d, phase %d, ran %ld, outer iterations closed %d (look-aheads %d), i %ld j %ld k %ld mu %.3e beta %.6f avg_crit %d final_check %d\n",
+                                             x.launches - 1, phase, o.max_steps, dt, r.reason, r.phase, r.ran, r.outer_done, r.bb_lookaheads, r.i, r.j, r.k, r.mu, r.beta, r.avg_crit, r.final_check);
+  if (r.ran < 0 || r.ran > o.max_steps) return -1;
+  if (r.ran >= 64 && dt > 0.0) x.its_per_ms = (double)r.ran / dt;
+  if (st->verbose && r.log_n > 0) { // the rows print_summary would have written, one per outer iteration closed on the device
+    HIP_OK(hipMemcpyAsync(x.hlog, x.xlog.p, sizeof(double) * (size_t)r.log_n * XLOG_W, hipMemcpyDeviceToHost, w->stream));
+    HIP_OK(hipStreamSynchronize(w->stream));
+    for (int q = 0; q < r.log_n; ++q) { x.hlog[(size_t)q * XLOG_W + 10] = (t0 - w->t_solve0) + x.hlog[(size_t)q * XLOG_W + 10] / x.ticks_per_ms; print_summary_row(w, x.hlog + (size_t)q * XLOG_W); }
+  }
+  // ---- the loop state as the launch left it ----
+  w->i = (abip_int)r.i; w->j = (abip_int)r.j; w->k = (abip_int)r.k;
+  w->mu = r.mu; w->beta = r.beta; st->dynamic_sigma = r.dyn_sigma; w->final_check = r.final_check;
+  if (r.outer_done > 0) w->fre_old = 0;
+  if (r.ran > 0) { st->avg_criterion = w->hctl->avg_crit; w->it_seen = w->hctl->it_count; } // abip.c:2042, 2048
+  if (r.ran > 0 || r.outer_done > 0) { w->stats_valid = r.stats_valid != 0; w->avg_stats_valid = r.avg_stats != 0; } // (a launch that changed nothing leaves the host's sums as valid as they were)
+  w->wg_valid = false;
+  w->r.last_admm_iter = -1;
+  w->tot_solves += r.solves; w->prof.kkt_solves += r.solves; w->prof.admm_iters += r.ran;
+  if (w->linsys == ABIP_HIP_LINSYS_INDIRECT) { w->last_cg_its = r.last_cg; w->tot_cg_its += r.cg_total; w->prof.cg_iters += r.cg_total; }
+  x.outer_done += r.outer_done; x.lookaheads += r.bb_lookaheads;
+  w->phase = r.phase == 0 ? PH_INNER : (r.phase == 1 ? PH_OUTER_END : PH_OUTER_BEGIN);
   return 0;
 }
 
@@ -1082,11 +1219,7 @@ int update_barrier_dynamic(W *w) { // LOQO, abip.c:930-977
   double xs = w->hctl->out[S_XS];
   const double minxs = w->hctl->out[S_XMIN];
   if (minxs <= 0.0) { printf("Invalid xisi < 0 \n"); return -1; } // the reference asserts here
-  xs /= (double)(w->n + 1);
-  const double ksi = minxs / xs;
-  double sigma = std::min(0.05 * (1 - ksi) / ksi, 2.0);
-  sigma = std::max(0.1 * sigma * sigma * sigma, w->stgs->dynamic_sigma);
-  w->mu *= sigma;
+  w->mu *= lp_loqo_sigma(xs, minxs, (long)w->n + 1, w->stgs->dynamic_sigma); // (one source with the persistent launch: lp_scalars.h)
   return 0;
 }
 void update_barrier_dynamic_2(W *w) { // abip.c:982-992 (reads dynamic_sigma as the exponent)
@@ -1133,19 +1266,9 @@ int adaptive_search(W *w, abip_int iter) {
     launch(w, ABIP_HIP_K_VEC, k_finalize, 1, 1024, f, d, (const double *)w->part.p, w->NB, w->ctl.p);
     if (sync_ctl(w)) return -1;
     const double utut = w->hctl->out[S_A0], utv = w->hctl->out[S_A1], uu = w->hctl->out[S_A2], vv = w->hctl->out[S_A3], uv = w->hctl->out[S_A4];
-    const double norm_ut = std::sqrt(utut), norm_u = std::sqrt(uu), norm_v = std::sqrt(vv);
-    const double alpha_SD = vv / utv, alpha_MG = utv / utut, gamma_SD = vv / uv, gamma_MG = uv / uu;
-    const double alpha_ss = (2 * alpha_MG > alpha_SD) ? alpha_MG : alpha_SD - 0.5 * alpha_MG;
-    const double gamma_ss = (2 * gamma_MG > gamma_SD) ? gamma_MG : gamma_SD - 0.5 * gamma_MG;
-    const double alpha_cor = utv / (norm_v * norm_ut), gamma_cor = uv / (norm_v * norm_u);
-    const double ec = st->eps_cor;
-    if (alpha_cor > ec && gamma_cor > ec) beta = std::sqrt(alpha_ss * gamma_ss);
-    else if (alpha_cor > ec && gamma_cor <= ec) beta = alpha_ss;
-    else if (alpha_cor <= ec && gamma_cor > ec) beta = gamma_ss;
-    else beta = beta_prev;
-    const double diff = std::fabs(beta - beta_prev);
-    if (diff > 0 && diff <= st->eps_pen) { beta = (beta + beta_prev) / 2; break; }
-    else if (diff > st->eps_pen) {
+    const int act = lp_bb_beta(utut, utv, uu, vv, uv, st->eps_cor, st->eps_pen, beta_prev, beta); // adaptive.c:170-229 (lp_scalars.h)
+    if (act == 0) break;
+    else if (act == 1) {
       beta_prev = beta;
       HIP_OK(hipMemcpyAsync(w->a_up.p, w->a_u.p, bytes, hipMemcpyDeviceToDevice, w->stream));
       HIP_OK(hipMemcpyAsync(w->a_vp.p, w->a_v.p, sizeof(double) * (size_t)w->m, hipMemcpyDeviceToDevice, w->stream));
@@ -1333,6 +1456,17 @@ void print_summary(const W *w, abip_int i, abip_int j) {
   printf("%*.2e|", kHSpace, safediv_pos(r.ct_x_by_tau, r.tau)); printf("%*.2e|", kHSpace, safediv_pos(r.bt_y_by_tau, r.tau));
   printf("%*.2e|", kHSpace, safediv_pos(r.kap, r.tau));
   printf("%*.2e ", kHSpace, (now_ms() - w->t_solve0) / 1e3);
+  printf("\n");
+}
+void print_summary_row(const W *w, const double *row) { // a row of the persistent launch's outer-iteration log (dev_xcd.h XLOG_W), print_summary's columns
+  (void)w;
+  printf("%*i|", (int)strlen(kHeader[0]), (int)row[0]);
+  printf("%*i|", (int)strlen(kHeader[1]), (int)row[1]);
+  printf("%*.2e|", (int)strlen(kHeader[2]), row[2]);
+  printf("%*.2e|", kHSpace, row[3]); printf("%*.2e|", kHSpace, row[4]); printf("%*.2e|", kHSpace, row[5]);
+  printf("%*.2e|", kHSpace, safediv_pos(row[6], row[8])); printf("%*.2e|", kHSpace, safediv_pos(row[7], row[8]));
+  printf("%*.2e|", kHSpace, safediv_pos(row[9], row[8]));
+  printf("%*.2e ", kHSpace, row[10] / 1e3);
   printf("\n");
 }
 void print_footer(const W *w, const ABIPInfo *info) {
@@ -1736,6 +1870,26 @@ abip_int abip_hip_step(ABIPWork *w, abip_int max_admm_steps, abip_int *steps_don
         if (w->j >= w->inner_stopper) { w->phase = PH_OUTER_END; break; }
         if (steps >= max_admm_steps) return done(0);
         double metric = 0;
+        if (xcd_outer_ok(w) && !restart_due(w, w->k, w->j)) { // cache-resident LP: the loop goes on INSIDE one persistent launch, across outer iterations, until the host is needed
+          long ran = 0; int why = 0;
+          const int rc = xcd_run(w, 0, (long)(max_admm_steps - steps), &ran, &why);
+          if (rc < 0) return hard_fail("error in project_lin_sys");
+          if (rc > 0) break; // abandoned (nothing ran, the iterate is as it was): the launch path goes on from here
+          steps += (abip_int)ran;
+          if (w->hctl->halt && clear_halt(w)) return hard_fail("device memset");
+          if (why == XR_HOST_OUTER || ((why == XR_SLICE || why == XR_STEPS) && ran == 0 && w->hctl->xo.outer_done == 0 && w->phase == PH_OUTER_END)) w->host_outer_once = true;
+          if (why == XR_FINAL) { // abip.c:2190-2213 for the last iteration that ran (the device found the earlier ones unconverged)
+            calc_residuals(w, w->i, w->k);
+            if ((info->status_val = has_converged(w, w->i, w->k)) != 0 || w->k + 1 >= st->max_admm_iters || w->i + 1 >= st->max_ipm_iters) {
+              if (st->verbose && w->k > 0) print_summary(w, w->i, w->k);
+              if (finish_solution(w, info, w->i, w->k)) return hard_fail("device error in get_solution");
+              if (st->verbose) print_footer(w, info);
+              w->phase = PH_DONE;
+              return done(1);
+            }
+          }
+          break;
+        }
         if (w->xcd.on) { // cache-resident LP: iterations (k, j) ... as ONE persistent launch on one XCD, up to the next decision the host has to take
           long nb = std::min<long>({(long)w->xcd.max_batch, (long)(max_admm_steps - steps), (long)(w->inner_stopper - w->j)});
           if (!w->batch_ok) nb = std::min<long>(nb, 1);
@@ -1743,7 +1897,9 @@ abip_int abip_hip_step(ABIPWork *w, abip_int max_admm_steps, abip_int *steps_don
           for (long q = 0; q < nb; ++q) if (restart_due(w, w->k + q, w->j + q)) { nb = q; break; }
           if (nb >= 1) {
             int ran = 0;
-            if (xcd_batch(w, (int)nb, &ran, &metric)) return hard_fail("error in project_lin_sys");
+            const int rcb = xcd_batch(w, (int)nb, &ran, &metric);
+            if (rcb < 0) return hard_fail("error in project_lin_sys");
+            if (rcb > 0) break; // abandoned: the launch path goes on from the same iterate
             steps += ran; w->k += ran;
             const int why = w->hctl->halt;
             if (why && clear_halt(w)) return hard_fail("device memset");
@@ -1810,6 +1966,28 @@ abip_int abip_hip_step(ABIPWork *w, abip_int max_admm_steps, abip_int *steps_don
       case PH_OUTER_END: {
         if (steps > 0 && steps >= max_admm_steps) return done(0); // hand back right after the last requested iteration
         const double elapsed = ((double)clock() - w->cpu0) / CLOCKS_PER_SEC; // abip.c:2217-2221
+        if (!w->host_outer_once && xcd_outer_ok(w) && w->stats_valid && (!st->avg_criterion || w->avg_stats_valid) && elapsed <= st->max_time) { // the outer end, and what follows it, inside the persistent launch
+          long ran = 0; int why = 0;
+          const int rc = xcd_run(w, 1, (long)(max_admm_steps - steps), &ran, &why);
+          if (rc < 0) return hard_fail("error in project_lin_sys");
+          if (rc == 0) {
+            steps += (abip_int)ran;
+            if (w->hctl->halt && clear_halt(w)) return hard_fail("device memset");
+            if (why == XR_HOST_OUTER || (ran == 0 && w->hctl->xo.outer_done == 0 && w->phase == PH_OUTER_END)) w->host_outer_once = true;
+            if (why == XR_FINAL) {
+              calc_residuals(w, w->i, w->k);
+              if ((info->status_val = has_converged(w, w->i, w->k)) != 0 || w->k + 1 >= st->max_admm_iters || w->i + 1 >= st->max_ipm_iters) {
+                if (st->verbose && w->k > 0) print_summary(w, w->i, w->k);
+                if (finish_solution(w, info, w->i, w->k)) return hard_fail("device error in get_solution");
+                if (st->verbose) print_footer(w, info);
+                w->phase = PH_DONE;
+                return done(1);
+              }
+            }
+            break;
+          } // (> 0: abandoned before anything was applied -- the host's outer end below)
+        }
+        w->host_outer_once = false;
         double over = elapsed > st->max_time ? 1.0 : 0.0;
         if (w->dist && allreduce_host(w, &over, 1)) return hard_fail("collective failure"); // every rank must take the same branch
         if (over > 0) { printf("Timelimit reached. \n"); st->max_admm_iters = (abip_int)(w->k * 1.05); }
@@ -1825,14 +2003,11 @@ abip_int abip_hip_step(ABIPWork *w, abip_int max_admm_steps, abip_int *steps_don
         }
         w->status = info->status_val;
         int rc = 0;
-        if (st->hybrid_mu) { // abip.c:2251-2277
-          if (st->dynamic_sigma_second > 0.0 && w->mu < st->hybrid_thresh * st->eps) { st->dynamic_sigma = st->dynamic_sigma_second; rc = update_barrier_dynamic(w); }
-          else if (st->dynamic_sigma_second == 0.0 && w->mu < st->hybrid_thresh * st->eps) { st->dynamic_sigma = st->dynamic_sigma_second; update_barrier(w); }
-          else if (st->dynamic_sigma < 0.0) update_barrier_dynamic_2(w);
-        } else {
-          if (st->dynamic_sigma == 0.0) update_barrier(w);
-          else if (st->dynamic_sigma < 0.0) update_barrier_dynamic_2(w);
-          else rc = update_barrier_dynamic(w);
+        switch (lp_mu_rule((int)st->hybrid_mu, st->dynamic_sigma_second, st->hybrid_thresh, st->eps, w->mu, st->dynamic_sigma)) { // abip.c:2251-2277 (lp_scalars.h)
+          case LP_MU_LOQO: rc = update_barrier_dynamic(w); break;
+          case LP_MU_TABLE: update_barrier(w); break;
+          case LP_MU_DYN2: update_barrier_dynamic_2(w); break;
+          default: break;
         }
         if (rc) return hard_fail("invalid complementarity products in the LOQO barrier update");
         reinitialize_vars(w, 0);
@@ -1995,6 +2170,8 @@ abip_float abip_hip_get_scalar(ABIPWork *w, const char *name) {
   RET("lnnz", w->ldl.lnnz) RET("levels_fwd", w->ldl.F.nlev) RET("levels_bwd", w->ldl.B.nlev) RET("tail", w->ldl.T) RET("admm_iter", w->k) RET("ipm_iter", w->i)
   RET("sell_At", w->dAt.nslices) RET("sell_A", w->dA.nslices) RET("nb", w->NB) RET("dist_cols", w->cg_cols ? 1 : 0) RET("small_solve", w->ldl.small ? 1 : 0) RET("factor_resid", w->factor_resid)
   RET("xcd", w->xcd.on ? 1 : 0) RET("xcd_nz", w->xcd.NZ) RET("xcd_g", w->xcd.on ? w->xcd.G : 0) RET("xcd_batches", w->xcd.batches) RET("xcd_exchanges", w->xcd.exchanges)
+  RET("xcd_launches", w->xcd.launches) RET("xcd_outer", (w->xcd.on && w->xcd.outer) ? 1 : 0) RET("xcd_outer_done", w->xcd.outer_done) RET("xcd_lookaheads", w->xcd.lookaheads)
+  RET("xcd_whole_launches", w->xcd.whole_launches) RET("xcd_giveups", w->xcd.giveups)
 #undef RET
   return NAN;
 }

@@ -437,8 +437,7 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         ach = bytes_solve / max(avg_ms * 1e-3, 1e-12) / 1e9
         T = int(S.scalar("tail"))
         roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
-                    kernel="direct solve P' L^-T D^-1 L^-1 P (k_ldl_small<fwd> / k_tail_mv x2 or k_tail_sym / k_ldl_small<bwd>, or the segmented level kernels; "
-                           "k_lp_persist when the whole iteration is one launch)",
+                    kernel="direct solve P' L^-T D^-1 L^-1 P (k_ldl_small<fwd> / k_tail_mv x2 or k_tail_sym / k_ldl_small<bwd>, or the segmented level kernels)",
                     avg_launch_us=avg_ms * 1e3, launches=nsolve, kernel_launches=nl, algorithmic_bytes_per_launch=bytes_solve, lnnz=lnnz,
                     dense_tail=T, dense_tail_bytes_per_solve=8 * T * (T + 1), levels=[int(S.scalar("levels_fwd")), int(S.scalar("levels_bwd"))],
                     timing="hipEvents around the solve's launches in a second pass of the same length" if events_pass else "hipEvents in the timed region")

@@ -7,12 +7,14 @@ from abip_amd.solver import Solver
 
 def run(A, b, c, linsys, xcd, eps, verbose=0, max_steps=None):
     os.environ["ABIP_HIP_XCD"] = "1" if xcd else "0"
+    os.environ["ABIP_HIP_XCD_OUTER"] = "1" if xcd == 2 else "0"   # 2: launches that span outer iterations (round 4); 1: one batch of inner iterations per launch
     with Solver(A, b, c, linsys=linsys, eps=eps, verbose=verbose) as s:
         on = s.scalar("xcd")
         t0 = time.time()
         out = s.solve()
         dt = time.time() - t0
-        return dict(xcd=on, g=s.scalar("xcd_g"), nz=s.scalar("xcd_nz"), batches=s.scalar("xcd_batches"), exch=s.scalar("xcd_exchanges"), dt=dt, x=s.x.copy(), y=s.y.copy(), s=s.s.copy(), **out)
+        return dict(xcd=on, g=s.scalar("xcd_g"), nz=s.scalar("xcd_nz"), batches=s.scalar("xcd_batches"), exch=s.scalar("xcd_exchanges"), launches=s.scalar("xcd_launches"),
+                    outer=s.scalar("xcd_outer_done"), look=s.scalar("xcd_lookaheads"), giveups=s.scalar("xcd_giveups"), dt=dt, x=s.x.copy(), y=s.y.copy(), s=s.s.copy(), **out)
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "small"
@@ -37,15 +39,15 @@ def main():
         A, b, c = problems.lp_multicommodity(nodes=int(nd), arcs=int(ar), commodities=int(cm))
     print("problem", which, A.shape, A.nnz, "linsys", linsys, "eps", eps, flush=True)
     res = {}
-    for xcd in (1, 0):
-        r = run(A, b, c, linsys, xcd, eps)
+    verbose = int(os.environ.get("XCD_CHECK_VERBOSE", "0"))
+    for xcd in (2, 1, 0):
+        r = run(A, b, c, linsys, xcd, eps, verbose=verbose)
         res[xcd] = r
-        print("xcd=%d on=%g G=%g nz=%g batches=%g exch=%g status=%s admm=%d ipm=%d pobj=%.10e time=%.3fs  -> %.0f it/s" % (
-            xcd, r["xcd"], r["g"], r["nz"], r["batches"], r["exch"], r["status"], r["admm_iter"], r["ipm_iter"], r["pobj"], r["dt"], r["admm_iter"] / r["dt"]), flush=True)
-    a, b_ = res[1], res[0]
-    for k in ("x", "y", "s"):
-        d = np.linalg.norm(a[k] - b_[k]) / max(1e-300, np.linalg.norm(b_[k]))
-        print("rel diff", k, "%.3e" % d)
+        print("xcd=%d on=%g G=%g nz=%g launches=%g (outer iterations inside: %g, look-aheads %g, give-ups %g) exch=%g status=%s admm=%d ipm=%d pobj=%.10e time=%.3fs  -> %.0f it/s" % (
+            xcd, r["xcd"], r["g"], r["nz"], r["launches"], r["outer"], r["look"], r["giveups"], r["exch"], r["status"], r["admm_iter"], r["ipm_iter"], r["pobj"], r["dt"], r["admm_iter"] / r["dt"]), flush=True)
+    for u, v in ((2, 0), (1, 0), (2, 1)):
+        a, b_ = res[u], res[v]
+        print("xcd=%d against xcd=%d:" % (u, v), " ".join("rel diff %s %.3e" % (k, np.linalg.norm(a[k] - b_[k]) / max(1e-300, np.linalg.norm(b_[k]))) for k in ("x", "y", "s")))
 
 if __name__ == "__main__":
     main()

@@ -404,20 +404,30 @@ def test_iterates_follow_the_oracle(gpu, oracle_built, name, linsys):
 
 
 # ---------------------------------------------------------------------------------------------- full solves
-def _check_against_golden(S, info, z, tag, eps):
+# The one fixture on which a device path does NOT reproduce the reference's iteration counts (profiles/r04_parity_counts.txt lists every fixture x eps x
+# back-end x path: 36 of 37 rows are equal on all three paths).  lp_tiny_scale5 (60 x 150, scale = 5) is degenerate in x: the reference's own
+# eps = 1e-4 stopping point is 9.8e-2 away (relative) from the x it converges to at eps = 1e-8, while its objective is already right to 1e-5.  On it the
+# persistent launch's direct variant -- inv(rho I + A A') applied as a dense matrix where the launch path and the reference solve with LDL' -- lands on the
+# other side of one Barzilai-Borwein decision (15 or 16 outer iterations, 264 / 287 / 293 inner ones).  There the bar is what the problem determines:
+# status, objective, the reference's convergence criteria -- and (x, y, s) at eps = 1e-8, where all paths agree to 1e-6 (test_knife_edge_fixture_at_tight_eps).
+KNIFE_EDGE = {("lp_tiny_scale5", "direct_0.0001")}
+
+
+def _check_against_golden(S, info, z, tag, eps, name=None):
     """A run stopped at tolerance eps is only defined up to O(eps): the PCG stopping test (indirect.c:375) and the inner
-    stopping test (abip.c:2173) are discontinuous in sums the device forms in a different order, and one flipped decision
-    moves the iterate by O(cg_tol).  So: same status and outer-iteration count, inner count within 3 %, (x, y, s) and the
-    objectives within 10*eps of the reference's -- and the reference's own convergence criteria satisfied.  Agreement to
+    stopping test (abip.c:2173) are discontinuous in sums the device forms in a different order.  Measured (profiles/r04_parity_counts.txt):
+    identical outer AND inner iteration counts on every fixture but the one named in KNIFE_EDGE -- so the counts are asserted equal, and
+    (x, y, s) and the objectives within 10*eps of the reference's, with the reference's own convergence criteria satisfied.  Agreement to
     1e-6 is checked where it is meaningful: at tight eps (test_tight_tolerance_agreement)."""
     g = info_of(z, tag)
     assert info["status_val"] == g["status_val"]
-    assert info["ipm_iter"] == g["ipm_iter"]
-    assert abs(info["admm_iter"] - g["admm_iter"]) <= 0.03 * g["admm_iter"] + 2
-    # (a flipped inner-loop or PCG decision -- visible as a different iteration count -- moves a run stopped at eps by a few eps more)
-    tol = (10 if info["admm_iter"] == g["admm_iter"] else 30) * eps
-    for k in "xys":
-        assert rel(getattr(S, k), z[f"{tag}_{k}"]) < tol, (tag, k, info["admm_iter"], g["admm_iter"])
+    tol = 10 * eps
+    if (name, tag) in KNIFE_EDGE:
+        assert abs(info["ipm_iter"] - g["ipm_iter"]) <= 1 and abs(info["admm_iter"] - g["admm_iter"]) <= 0.12 * g["admm_iter"]
+    else:
+        assert info["ipm_iter"] == g["ipm_iter"] and info["admm_iter"] == g["admm_iter"], (tag, info["ipm_iter"], info["admm_iter"], g["ipm_iter"], g["admm_iter"])
+        for k in "xys":
+            assert rel(getattr(S, k), z[f"{tag}_{k}"]) < tol, (tag, k, info["admm_iter"], g["admm_iter"])
     assert abs(info["pobj"] - g["pobj"]) <= tol * (1 + abs(g["pobj"]))
     assert abs(info["dobj"] - g["dobj"]) <= tol * (1 + abs(g["dobj"]))
     for k in ("res_pri", "res_dual", "rel_gap"):
@@ -516,7 +526,25 @@ def test_non_default_switches_match_reference_fixture(gpu, variant, linsys):
     z, A, b, c = load("lp_tiny_" + variant)
     with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-4, **TINY_VARIANTS[variant]) as S:
         info = S.solve()
-        _check_against_golden(S, info, z, f"{linsys}_0.0001", 1e-4)
+        _check_against_golden(S, info, z, f"{linsys}_0.0001", 1e-4, name="lp_tiny_" + variant)
+
+
+def test_knife_edge_fixture_at_tight_eps(gpu, monkeypatch):
+    """lp_tiny_scale5, direct back-end (KNIFE_EDGE above): at eps = 1e-8 the three device paths -- launch path (LDL'), persistent launch in batches and
+    spanning outer iterations (dense inverse) -- reach the same (x, y, s) to the north-star bar of 1e-6, and the same objective to 1e-8."""
+    z, A, b, c = load("lp_tiny_scale5")
+    out = {}
+    for mode, env in (("path", {"ABIP_HIP_XCD": "0"}), ("batch", {"ABIP_HIP_XCD": "1", "ABIP_HIP_XCD_OUTER": "0"}), ("whole", {"ABIP_HIP_XCD": "1", "ABIP_HIP_XCD_OUTER": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with gpu.Solver(A, b, c, linsys="direct", verbose=0, eps=1e-8, **TINY_VARIANTS["scale5"]) as S:
+            info = S.solve()
+            assert info["status_val"] == 1
+            out[mode] = (info, S.x.copy(), S.y.copy(), S.s.copy())
+    for mode in ("batch", "whole"):
+        for k in (1, 2, 3):
+            assert rel(out[mode][k], out["path"][k]) < 1e-6, (mode, k)
+        assert abs(out[mode][0]["pobj"] - out["path"][0]["pobj"]) <= 1e-8 * (1 + abs(out["path"][0]["pobj"]))
 
 
 def test_matlab_surface_end_to_end(gpu):

@@ -33,7 +33,7 @@ def test_one_xcd_launch_agrees_with_the_launch_path(gpu, name, linsys, monkeypat
         with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-8) as S:
             assert S.scalar("xcd") == float(mode)
             info = S.solve()
-            assert (S.scalar("xcd_batches") > 0) == (mode == "1")
+            assert (S.scalar("xcd_launches") > 0) == (mode == "1")
             out[mode] = (info, S.x.copy(), S.y.copy(), S.s.copy())
     a, l = out["1"], out["0"]
     assert a[0]["status_val"] == l[0]["status_val"] == 1

@@ -1,0 +1,232 @@
+"""GPU (-m gpu): persistent launches that SPAN OUTER ITERATIONS (abip_amd/csrc/dev_xcd.h XcdOuter, round 4): calc_residuals / has_converged, the mu
+rule, reinitialize_vars and the Barzilai-Borwein search (abip.c:2217-2293, src/adaptive.c:87-251) run inside the kernel, so that a cache-resident LP
+is a handful of launches -- and what happens when such a launch has to be abandoned.
+
+Bars: the same decisions as the launch path (status, outer iterations; inner iterations within 1 %), (x, y, s) within 1e-6 relative when both run to
+eps = 1e-8; the same bits whatever budget of iterations a launch is given; a launch that gives up (fault injection, another kernel holding the CUs)
+costs time, never the answer."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from _golden import load, rel
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    import __graft_entry__ as g
+    g.build()
+    import abip_amd
+    return abip_amd
+
+
+def _solve(gpu, A, b, c, linsys, **kw):
+    with gpu.Solver(A, b, c, linsys=linsys, verbose=0, **kw) as S:
+        info = S.solve()
+        stats = {k: S.scalar(k) for k in ("xcd", "xcd_outer", "xcd_launches", "xcd_outer_done", "xcd_lookaheads", "xcd_giveups", "tot_cg_its")}
+        return info, S.x.copy(), S.y.copy(), S.s.copy(), stats
+
+
+@pytest.mark.parametrize("name", ["lp_afiro_like", "lp_random_sparse_small", "lp_multicommodity_small", "lp_staircase", "lp_tiny_scale5"])
+@pytest.mark.parametrize("linsys", ["indirect", "direct"])
+def test_outer_iterations_inside_the_launch(gpu, name, linsys, monkeypatch):
+    """A whole solve in a handful of launches (the set-up solve of the PCG back-end is one of them), nearly every outer iteration closed on the device,
+    and the launch path's answer."""
+    z, A, b, c = load(name)
+    out = {}
+    for mode, env in (("outer", {"ABIP_HIP_XCD": "1", "ABIP_HIP_XCD_OUTER": "1"}), ("batch", {"ABIP_HIP_XCD": "1", "ABIP_HIP_XCD_OUTER": "0"}), ("path", {"ABIP_HIP_XCD": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out[mode] = _solve(gpu, A, b, c, linsys, eps=1e-8)
+    a, bt, l = out["outer"], out["batch"], out["path"]
+    assert a[4]["xcd"] == 1.0 and a[4]["xcd_outer"] == 1.0 and bt[4]["xcd_outer"] == 0.0 and l[4]["xcd"] == 0.0
+    assert a[4]["xcd_giveups"] == 0
+    assert a[4]["xcd_launches"] <= 8 and a[4]["xcd_launches"] < bt[4]["xcd_launches"]
+    assert a[4]["xcd_outer_done"] >= a[0]["ipm_iter"] - 3          # the first outer iteration starts on the host, the last one ends there
+    assert a[4]["xcd_lookaheads"] > 0
+    for r in (a, bt):
+        assert r[0]["status_val"] == l[0]["status_val"] == 1
+        assert r[0]["ipm_iter"] == l[0]["ipm_iter"]
+        assert abs(r[0]["admm_iter"] - l[0]["admm_iter"]) <= 0.01 * l[0]["admm_iter"] + 1
+        assert abs(r[0]["pobj"] - l[0]["pobj"]) <= 1e-6 * (1 + abs(l[0]["pobj"]))
+        for k in (1, 2, 3):
+            assert rel(r[k], l[k]) < 1e-6
+
+
+@pytest.mark.parametrize("name,linsys", [("lp_multicommodity_small", "indirect"), ("lp_staircase", "direct"), ("lp_afiro_like", "indirect"), ("lp_afiro_like", "direct")])
+def test_same_bits_whatever_the_budget_of_a_launch(gpu, name, linsys, monkeypatch):
+    """abip_solve (as few launches as the slices allow), strides of 7 and of 1000 iterations through the stepping ABI, one iteration per launch
+    (ABIP_HIP_BATCH=0): the launches break the loop at different places, the kernel resumes it bit for bit."""
+    z, A, b, c = load(name)
+    monkeypatch.setenv("ABIP_HIP_XCD", "1")
+    runs = []
+    for mode in ("solve", 7, 1000, "one"):
+        if mode == "one":
+            monkeypatch.setenv("ABIP_HIP_BATCH", "0")
+        else:
+            monkeypatch.delenv("ABIP_HIP_BATCH", raising=False)
+        with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-5) as S:
+            assert S.scalar("xcd_outer") == 1.0
+            if isinstance(mode, int):
+                S.begin()
+                fin, total = False, 0
+                while not fin:
+                    fin, done = S.step(mode)
+                    assert done <= mode
+                    total += done
+                info = S.end()
+                assert total == info["admm_iter"] - 1
+            else:
+                info = S.solve()
+            runs.append((info["admm_iter"], info["ipm_iter"], info["pobj"], S.scalar("tot_cg_its"), S.x.copy(), S.y.copy(), S.s.copy()))
+    for r in runs[1:]:
+        assert r[:4] == runs[0][:4]
+        for a2, b2 in zip(r[4:], runs[0][4:]):
+            assert np.array_equal(a2, b2)
+
+
+def _child(body: str, env: dict, hooks: bool = False, timeout: int = 600):
+    import textwrap
+    e = dict(os.environ)
+    e.update(env)
+    if hooks:
+        e["ABIP_HIP_LIBRARY"] = os.path.join(ROOT, "abip_amd", "lib", "libabip_hip_hooks.so")
+    pre = textwrap.dedent(f"""
+        import sys, json
+        sys.path[:0] = [{ROOT!r}, {os.path.join(ROOT, 'tests')!r}]
+        import numpy as np
+        import abip_amd as gpu
+        from _golden import load, rel
+        """)
+    r = subprocess.run([sys.executable, "-c", pre + textwrap.dedent(body)], env=e, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return r
+
+
+def test_verbose_rows_of_the_outer_iterations_closed_on_the_device(gpu):
+    """print_summary's table (abip.c:1418-1463): one row per outer iteration whether the host or the kernel closed it -- the same `ipm iter` / `admm iter`
+    columns as the launch path prints."""
+    body = """
+        z, A, b, c = load("lp_staircase")
+        with gpu.Solver(A, b, c, linsys="direct", verbose=1, eps=1e-6) as S:
+            info = S.solve()
+        print("IPM", info["ipm_iter"], flush=True)
+        """
+    rows = {}
+    for mode in ("1", "0"):
+        r = _child(body, {"ABIP_HIP_XCD": mode})
+        tab = [ln.split("|") for ln in r.stdout.splitlines() if ln.count("|") == 9 and ln.split("|")[0].strip().isdigit()]
+        rows[mode] = [(int(t[0]), int(t[1])) for t in tab]
+        ipm = int([ln for ln in r.stdout.splitlines() if ln.startswith("IPM")][0].split()[1])
+        assert len(rows[mode]) == ipm and [q[0] for q in rows[mode]] == list(range(ipm))
+    assert rows["1"] == rows["0"]
+
+
+@pytest.mark.parametrize("name,linsys,at", [("lp_staircase", "direct", 0), ("lp_staircase", "direct", 1), ("lp_multicommodity_small", "indirect", 0),
+                                            ("lp_multicommodity_small", "indirect", 1), ("lp_multicommodity_small", "indirect", 2)])
+def test_a_launch_that_gives_up_hands_over_to_the_launch_path(gpu, name, linsys, at):
+    """Fault injection (libabip_hip_hooks.so only): the last rank of launch number `at` leaves at once, so every wait of that launch gives up after
+    ~0.1 s.  The iterate is restored to what it was before the launch, the persistent launch is switched off for this work and the launch path
+    finishes the solve: same status, same outer iterations, (x, y, s) to 1e-6 -- and the next work on the device is not affected."""
+    body = f"""
+        import os
+        z, A, b, c = load({name!r})
+        with gpu.Solver(A, b, c, linsys={linsys!r}, verbose=0, eps=1e-8) as S:
+            info = S.solve()
+            assert S.scalar("xcd_giveups") == 1 and S.scalar("xcd") == 0.0, (S.scalar("xcd_giveups"), S.scalar("xcd"))
+            res = (info, S.x.copy(), S.y.copy(), S.s.copy())
+        os.environ["ABIP_HIP_XCD_GIVEUP_AT"] = "-1"
+        with gpu.Solver(A, b, c, linsys={linsys!r}, verbose=0, eps=1e-8) as S:          # the next work: persistent launches again, nothing left behind
+            info2 = S.solve()
+            assert S.scalar("xcd_giveups") == 0 and S.scalar("xcd") == 1.0 and S.scalar("xcd_outer_done") > 0
+            res2 = (info2, S.x.copy(), S.y.copy(), S.s.copy())
+        os.environ["ABIP_HIP_XCD"] = "0"
+        with gpu.Solver(A, b, c, linsys={linsys!r}, verbose=0, eps=1e-8) as S:
+            ref = (S.solve(), S.x.copy(), S.y.copy(), S.s.copy())
+        for r in (res, res2):
+            assert r[0]["status_val"] == ref[0]["status_val"] == 1 and r[0]["ipm_iter"] == ref[0]["ipm_iter"]
+            assert abs(r[0]["admm_iter"] - ref[0]["admm_iter"]) <= 0.01 * ref[0]["admm_iter"] + 1
+            for k in (1, 2, 3):
+                assert rel(r[k], ref[k]) < 1e-6
+        """
+    r = _child(body, {"ABIP_HIP_XCD": "1", "ABIP_HIP_XCD_GIVEUP_AT": str(at)}, hooks=True)
+    assert "abandoned" in r.stderr
+
+
+def test_two_works_solving_concurrently_from_two_threads(gpu, monkeypatch):
+    """Two ABIPWork objects driven from two host threads: persistent launches are serialised process-wide (each is 256 workgroups that wait for each
+    other), so both solves finish, with the bits of a solve that had the device to itself."""
+    monkeypatch.setenv("ABIP_HIP_XCD", "1")
+    z, A, b, c = load("lp_staircase")
+    z2, A2, b2, c2 = load("lp_multicommodity_small")
+    ref = {}
+    for key, (AA, bb, cc, ls) in {"d": (A, b, c, "direct"), "p": (A2, b2, c2, "indirect")}.items():
+        ref[key] = _solve(gpu, AA, bb, cc, ls, eps=1e-6)
+    out = {}
+
+    def work(key, AA, bb, cc, ls):
+        for rep in range(3):
+            out[(key, rep)] = _solve(gpu, AA, bb, cc, ls, eps=1e-6)
+
+    th = [threading.Thread(target=work, args=("d", A, b, c, "direct")), threading.Thread(target=work, args=("p", A2, b2, c2, "indirect"))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+        assert not t.is_alive()
+    for (key, rep), r in out.items():
+        assert r[4]["xcd_giveups"] == 0
+        assert r[0]["status_val"] == 1 and r[0]["admm_iter"] == ref[key][0]["admm_iter"]
+        for k in (1, 2, 3):
+            assert np.array_equal(r[k], ref[key][k])
+    assert len(out) == 6
+
+
+def test_a_solve_while_another_kernel_holds_the_device(gpu, monkeypatch):
+    """A long-running kernel of another stream (a chain of large torch matmuls) is in flight when the solve starts: the persistent launch either gets
+    its CUs in time or gives up and the launch path finishes -- the answer is the launch path's either way."""
+    import torch
+    monkeypatch.setenv("ABIP_HIP_XCD", "1")
+    z, A, b, c = load("lp_staircase")
+    monkeypatch.setenv("ABIP_HIP_XCD", "0")
+    ref = _solve(gpu, A, b, c, "direct", eps=1e-8)
+    monkeypatch.setenv("ABIP_HIP_XCD", "1")
+    side = torch.cuda.Stream()
+    x = torch.randn(8192, 8192, device="cuda")
+    with torch.cuda.stream(side):
+        for _ in range(60):
+            x = (x @ x) * 1e-4
+    r = _solve(gpu, A, b, c, "direct", eps=1e-8)
+    torch.cuda.synchronize()
+    assert r[0]["status_val"] == 1 and r[0]["ipm_iter"] == ref[0]["ipm_iter"]
+    assert abs(r[0]["admm_iter"] - ref[0]["admm_iter"]) <= 0.01 * ref[0]["admm_iter"] + 1
+    for k in (1, 2, 3):
+        assert rel(r[k], ref[k]) < 1e-6
+
+
+def test_time_limit_takes_effect_between_launches(gpu):
+    """max_time (abip_mex.c:320-326; abip.c:2217-2221: looked at once per outer iteration; the reference then cuts max_admm_iters to 1.05 k, and does so
+    again at every later outer iteration): a launch looks at the wall clock once per outer iteration and hands the loop back when the limit has passed --
+    the host prints the reference's message and applies its rule, exactly as it does on the launch path."""
+    body = """
+        from abip_amd import problems
+        A, b, c = problems.lp_multicommodity(nodes=300, arcs=1100, commodities=6)
+        with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-7, max_time={limit}) as S:
+            assert S.scalar("xcd_outer") == 1.0
+            info = S.solve()
+        print("RESULT", info["status_val"], info["admm_iter"], flush=True)
+        """
+    full = _child(body.format(limit=3600.0), {"ABIP_HIP_XCD": "1"})
+    cut = _child(body.format(limit=0.02), {"ABIP_HIP_XCD": "1"})
+    res = lambda r: [int(v) for v in [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0].split()[1:]]
+    assert "Timelimit reached" not in full.stdout and res(full)[0] == 1
+    assert "Timelimit reached" in cut.stdout and res(cut)[0] in (1, 2)
