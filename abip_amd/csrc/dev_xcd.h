@@ -328,12 +328,22 @@ __device__ __forceinline__ void x_prox(const UpdArgs &a, double uo, double vo, d
 #define XP_DECL unsigned long long xp_t = 0, xp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define XP_START xp_t = wall_clock64();
 #define XP_LAP(k) { const unsigned long long xp_n = wall_clock64(); xp_acc[k] += xp_n - xp_t; xp_t = xp_n; }
-#define XP_DUMP if (rank == 0 && t == 0) for (int q = 0; q < 8; ++q) a.xstat[600 + q] = (int)xp_acc[q];
+#define XP_DUMP if (rank == 0 && t == 0) { for (int q = 0; q < 8; ++q) a.xstat[600 + q] = (int)xp_acc[q]; for (int q = 0; q < 8; ++q) a.xstat[610 + q] = (int)xq_acc[q]; }
+// coarse counters of a launch that spans outer iterations: [0] the launch, [1] ADMM iterations, [2] look-ahead steps of the search, [3] outer end / begin,
+// [4] / [5] the PCG loops inside [1] / [2], [6] / [7] their PCG iterations
+#define XQ_DECL unsigned long long xq_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xq_t = 0, xq_c = 0, xq_0 = wall_clock64();
+#define XQ_MARK(v) v = wall_clock64();
+#define XQ_ADD(k, v) xq_acc[k] += wall_clock64() - v;
+#define XQ_CNT(k, n) xq_acc[k] += (unsigned long long)(n);
 #else
 #define XP_DECL
 #define XP_START
 #define XP_LAP(k)
 #define XP_DUMP
+#define XQ_DECL
+#define XQ_MARK(v)
+#define XQ_ADD(k, v)
+#define XQ_CNT(k, n)
 #endif
 
 
@@ -467,6 +477,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   }
   if (t < 96) outs[t] = a.ctl->out[t]; // slots this launch does not refresh keep what the last finalize left (as on the launch path)
   XP_DECL
+  XQ_DECL
 
   // ---- the loop state of abip.c:2102-2294 (uniform: every workgroup carries the same values and takes the same branches).  What only the outer
   //      iterations touch lives in the LDS (cs[]: written by thread 0, read by everybody after a barrier); the inner loop's share in registers ----
@@ -491,6 +502,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   for (;;) {
     // (an index the optimiser cannot see through: otherwise it hoists the element addresses of an iteration out of this loop and spills them)
     unsigned tb = t; asm volatile("" : "+v"(tb));
+    XQ_MARK(xq_c)
     // ================================================================================================================================
     // outer end (abip.c:2217-2293): time, final_check, residuals, convergence, mu, reinitialize_vars; then the search or the next outer iteration
     // ================================================================================================================================
@@ -636,6 +648,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       mode = XM_MAIN; need_pre = true; stage = XS_PROJECT;
       __syncthreads(); // (cs[] complete before anybody reads it again)
     }
+    XQ_ADD(3, xq_c)
     // ---- may this launch start another ADMM iteration? (abip_hip_step's budget; abip.c:608-609: a restart is the launch path's) ----
     if (mode == XM_MAIN && !solo) {
       if (whole) {
@@ -692,6 +705,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     int leave = 0;
     for (;;) {
     unsigned tb = t; asm volatile("" : "+v"(tb)); // (see the outer loop)
+    XQ_MARK(xq_t)
     const bool avg_stats = ((jj + 1) % 10 == 0); // abip.c:2000
     if (mode == XM_MAIN) { up.dom = (double)(jj + 1); up.avg_stats = avg_stats ? 1 : 0; }
     // ---- right-hand side (k_rhs, abip.c:552-558) ----
@@ -777,6 +791,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       for (int q = 0; q < RN; ++q) ctmp[q] = 0.0;
       int cgit = 0;
       double zr_prev = 0.0;
+      XQ_MARK(xq_c)
       XP_START
       for (;;) {
         // ---- z and (|r|^2, z'r) out; convergence test; tmp = A'z + beta tmp (k_cg_spmv_At) ----
@@ -859,6 +874,8 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         ++cgit;
       }
       XP_LAP(5)
+      XQ_ADD(mode == XM_MAIN ? 4 : 5, xq_c)
+      XQ_CNT(mode == XM_MAIN ? 7 : 6, cgit)
       last_cg = cgit; cg_total += cgit;
 #pragma unroll
       for (int q = 0; q < RM; ++q) y[q] = cx[q];
@@ -1129,6 +1146,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     ++ran;
     stats_valid = true; avg_stats_last = avg_stats ? 1 : 0;
     if (!PCG) { XP_LAP(6) }
+    XQ_ADD(1, xq_t)
     if (__builtin_expect(metric < thr, 0)) { // abip.c:2173-2188: the inner loop is left (j is not advanced)
       if (!whole) { halt = 1; leave = 1; break; }
       stage = XS_OUTER_END;
@@ -1183,6 +1201,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         x_bbstep(al, mob, utq_t, bup_t, bvp_t, un, vn);
         csw(CS_BUT, un); csw(CS_BVT, vn);
         mode = XM_BB2; need_pre = true;
+        XQ_ADD(2, xq_t)
         continue;
       }
       // (u, v) -> (u_next, v_next), and the inner products of the three difference vectors
@@ -1245,6 +1264,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         }
         csw(CS_BBPREV, bb_prev); csw(CS_BUPT, bu_t); csw(CS_BVPT, (act == 1) ? mob2 / bu_t : bv_t); csw(CS_BBIT, (double)(bb_it + 1));
         mode = XM_BB1; need_pre = true;
+        XQ_ADD(2, xq_t)
         continue;
       }
       // the search is over (adaptive.c:253): w->beta; reinitialize_vars(2) (abip.c:2291) on the vectors the outer end rescaled
@@ -1261,10 +1281,11 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         if (!av) { u_tau = r_ut; v_tau = r_vt; }
       }
       stage = XS_OUTER_BEGIN;
+      XQ_ADD(2, xq_t)
       continue;
     }
-
   }
+  XQ_ADD(0, xq_0)
   __syncthreads();
   if (rank == 0 && t < 96 && ran > 0) a.ctl->out[t] = outs[t];
   if (rank == 0 && t == 0) {

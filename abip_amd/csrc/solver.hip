@@ -1142,6 +1142,11 @@ int xcd_run(W *w, int phase, long max_steps, long *ran, int *reason) {
   x.whole_launches++;
   const XcdOut &r = w->hctl->xo;
   *ran = r.ran; *reason = r.reason;
+#ifdef XCD_PROF
+  { static double acc[8] = {0}; for (int q = 0; q < 8; ++q) acc[q] += (unsigned)x.hstat[610 + q];
+    fprintf(stderr, "[xcd prof] cumulative: launches %.0f us | ADMM iterations %.0f us (their PCG loops %.0f us, %.0f PCG iterations) | look-ahead steps %.0f us (PCG loops %.0f us, %.0f PCG iterations) | outer end / begin %.0f us\n",
+            acc[0] * 0.01, acc[1] * 0.01, acc[4] * 0.01, acc[7], acc[2] * 0.01, acc[5] * 0.01, acc[6], acc[3] * 0.01); }
+#endif
   if (getenv("ABIP_HIP_XCD_VERBOSE")) printf("[xcd] launch %u (entry phase %d, budget %ld): %.3f ms, reason %d, phase %d, ran %ld, outer iterations closed %d (look-aheads %d), i %ld j %ld k %ld mu %.3e beta %.6f avg_crit %d final_check %d\n",
                                              x.launches - 1, phase, o.max_steps, dt, r.reason, r.phase, r.ran, r.outer_done, r.bb_lookaheads, r.i, r.j, r.k, r.mu, r.beta, r.avg_crit, r.final_check);
   if (r.ran < 0 || r.ran > o.max_steps) return -1;

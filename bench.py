@@ -336,6 +336,7 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
     elif args.events_in_timed_region:
         S.profile_enable(("sptrsv",))
     S.profile_read(reset=True)
+    xstat0 = {k: S.scalar(k) for k in ("xcd_exchanges", "xcd_launches", "xcd_outer_done", "xcd_lookaheads")} if xcd else None
 
     def barrier():
         if dist is not None:
@@ -385,7 +386,10 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         its = max(prof["admm_iters"], 1)
         ms = prof["ms"]["xcd"]
         ach = b_iter * its / max(ms * 1e-3, 1e-12) / 1e9
-        exch = (2 * cg_step + 6) if linsys == "indirect" else 6.0
+        # exchanges counted by the kernel itself (every rendez-vous of the window's launches, the look-ahead solves of the Barzilai-Borwein search included:
+        # since round 4 the search runs inside the launch, so its time is inside `ms` as well)
+        xd = {k: S.scalar(k) - xstat0[k] for k in xstat0}
+        exch = xd["xcd_exchanges"] / its if xd["xcd_exchanges"] > 0 else ((2 * cg_step + 7) if linsys == "indirect" else 6.0)
         # HBM bytes per launch from the committed counter passes (per inner iteration there, FETCH_SIZE / WRITE_SIZE summed over the kernel's dispatches)
         tpi = pmc_traffic(name).get("k_lp_xcd", {}).get("traffic_bytes_per_iteration") if pmc and world == 1 else None
         roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=(tpi * its / nl) if tpi else None,
@@ -393,7 +397,7 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
                     kernel="k_lp_xcd: the whole inner ADMM loop as one persistent launch, one workgroup per CU on %d XCD(s) (slices of A and A' per workgroup; operands "
                            "handed over through the L2%s: stores, acknowledged, partial-sum granules as flags, L1-bypassing gathers); bound by the latency "
                            "of its exchanges -- a chain of L2 round trips and two workgroup barriers -- not by HBM" % (xg // 32, " (written through between XCDs)" if xg > 32 else ""),
-                    workgroups=xg,
+                    workgroups=xg, outer_iterations_inside_the_launches=int(xd["xcd_outer_done"]), lookahead_steps_inside_the_launches=int(xd["xcd_lookaheads"]),
                     avg_launch_us=1e3 * ms / nl, launches=nl, iterations_per_launch=its / nl, algorithmic_bytes_per_launch=b_iter * its / nl,
                     algorithmic_bytes_per_iteration=b_iter, us_per_iteration=1e3 * ms / its, exchanges_per_iteration=exch, us_per_exchange=1e3 * ms / its / exch,
                     timing="hipEvents around every launch inside the timed region")
@@ -467,6 +471,9 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
                   status=info["status"], admm_iter=info["admm_iter"], ipm_iter=info["ipm_iter"],
                   res_pri=info["res_pri"], res_dual=info["res_dual"], rel_gap=info["rel_gap"],
                   cg_iters_per_step=S2.scalar("tot_cg_its") / max(info["admm_iter"], 1) if linsys == "indirect" else None)
+        if S2.scalar("xcd") == 1.0:   # how many launches the whole solve took, and how much of the outer loop ran inside them (dev_xcd.h XcdOuter)
+            tt.update(launches=int(S2.scalar("xcd_launches")), outer_iterations_inside_the_launches=int(S2.scalar("xcd_outer_done")),
+                      lookahead_steps_inside_the_launches=int(S2.scalar("xcd_lookaheads")), launches_abandoned=int(S2.scalar("xcd_giveups")))
         S2.close()
 
     cpu_rec = None
