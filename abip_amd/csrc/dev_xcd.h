@@ -35,16 +35,24 @@
 
 namespace abip {
 
-constexpr int XTB = 768;           // threads per workgroup: 12 wavefronts, 3 per SIMD -> 168 VGPRs each: the NZ = 2 variants need no scratch (at 1024 threads /
-                                   // 128 VGPRs they spilled 100-190 bytes per lane); measured +3 % on c2 / c3 (profiles/r03f_xcd_gather_experiments.txt (g))
+#ifndef XCD_TB
+#define XCD_TB 512
+#endif
+constexpr int XTB = XCD_TB;        // threads per workgroup: 8 wavefronts, 2 per SIMD -> 256 VGPRs each.  Round 3 ran 768 (168 VGPRs, no scratch then); with the outer
+                                   // iterations and the search inside the kernel 768 spills (13 scratch loads per iteration of the direct variant), 512 does not:
+                                   // c2 317.7 -> 276.5 ms, c3 6.03 -> 5.88 s per solve, same iteration and PCG counts (profiles/r04f_threads_per_workgroup.txt)
 constexpr int XWAVES = XTB / 64;
 constexpr int XG = 256;            // most workgroups taking part: the CUs of one XCD (32), or of 2, 4, 8 XCDs
 constexpr int XQ = XG / 64;        // flags a polling lane looks after
 constexpr int XKS = 16;            // granule slots per workgroup per exchange: sums 0..11 (wavefront k handles sum k), slots 12..15 the tau entries
 constexpr int XSTAT_N = 1024;       // ints of the status / post-mortem record
+#ifndef XCD_SLEEP
+#define XCD_SLEEP 2
+#endif
+constexpr int XSLEEP = XCD_SLEEP;   // s_sleep between two polling rounds of a wavefront (units of 64 clocks)
 constexpr int XSPIN = 1 << 17;     // polling rounds before a wavefront gives up (a round is ~1 us: about a tenth of a second, then the launch path takes over)
 constexpr int XCD_LDS_MIN = 84 * 1024; // more than half a CU's LDS: one workgroup per CU
-static_assert(12 <= XWAVES, "one wavefront per sum of an exchange (at most 12; the granule slots 12..15 carry the tau entries)");
+static_assert(XTB % 64 == 0 && XWAVES >= 4 && XWAVES <= 16, "wavefront k handles the sums k, k + XWAVES, ... of an exchange (at most 12 sums; the granule slots 12..15 carry the tau entries)");
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -195,7 +203,7 @@ __device__ __forceinline__ bool x_spin(XWait &w, int &spins, unsigned found, int
 // (4) x_gather: the entries this thread's non-zeros name.
 template <int K, int SA>
 __device__ __forceinline__ void x_publish(double (&v)[K], double *red, xrsrc sc, unsigned sc_off /* byte offset of this rank's granules */, unsigned tag) {
-  static_assert(K >= 1 && K <= 12 && K <= XWAVES, "wavefront k handles sum k: at most 12 sums per exchange");
+  static_assert(K >= 1 && K <= 12, "at most 12 sums per exchange (granule slots 12..15 carry the tau entries)");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] = x_wave_sum63(v[k]); // (while the stores travel)
@@ -205,14 +213,21 @@ __device__ __forceinline__ void x_publish(double (&v)[K], double *red, xrsrc sc,
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my entries have been acknowledged by the L2
   __syncthreads(); // ... and so have everybody's of this workgroup
-  if (wave < K) { // wavefront k adds the XWAVES partials of scalar k and raises the flag
-    const double s = x_wave_sum63(lane < XWAVES ? red[wave * XWAVES + lane] : 0.0);
-    if (lane == 63) x_putg<SA>(sc, sc_off + (unsigned)wave * 16u, s, tag);
+#pragma unroll
+  for (int kk = 0; kk < K; kk += XWAVES) { // wavefront k adds the XWAVES partials of scalar k (and k + XWAVES) and raises the flag
+    const int k = kk + wave;
+    if (k < K) {
+      const double s = x_wave_sum63(lane < XWAVES ? red[k * XWAVES + lane] : 0.0);
+      if (lane == 63) x_putg<SA>(sc, sc_off + (unsigned)k * 16u, s, tag);
+    }
   }
 }
 template <int K>
 __device__ __forceinline__ void x_collect(XWait &w, int G, double *tot, double (&out)[K]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int kk = 0; kk < K; kk += XWAVES) {
+  const int wave = kk + (int)(threadIdx.x >> 6); // (the scalar this wavefront looks after in this pass)
   if (wave < K) {
     u32x4 g[XQ];
 #pragma unroll
@@ -231,7 +246,7 @@ __device__ __forceinline__ void x_collect(XWait &w, int G, double *tot, double (
       const unsigned long long miss = __ballot(ok ? 0 : 1);
       const int src = miss ? (int)__builtin_ctzll(miss) : 0;
       if (!x_spin(w, spins, (unsigned)__builtin_amdgcn_readlane((int)g[0].y, src), 1000 + src)) break;
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(XSLEEP);
     }
     double s = 0.0; // rank order: 64 ranks at a time, lane order inside
 #pragma unroll
@@ -241,10 +256,42 @@ __device__ __forceinline__ void x_collect(XWait &w, int G, double *tot, double (
     }
     if (lane == 63) tot[wave] = s;
   }
+  }
   __syncthreads();
   if (__hip_atomic_load(w.xstat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) w.dead = true; // (one wavefront gave up: everybody leaves)
 #pragma unroll
   for (int k = 0; k < K; ++k) out[k] = x_uni(tot[k]);
+}
+// An exchange that carries entries but no sum: the flag alone.  The same rendez-vous (stores acknowledged, barrier, one granule per rank; wavefront 0 polls
+// them all; barrier) without the partial sums around it.
+template <int SA>
+__device__ __forceinline__ void x_flag(xrsrc sc, unsigned sc_off, unsigned tag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) x_putg<SA>(sc, sc_off, 0.0, tag);
+}
+__device__ __forceinline__ void x_wait(XWait &w, int G) {
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+    int spins = 0;
+    for (;;) {
+      asm volatile("" ::: "memory"); // (the loads are issued anew every round)
+      bool ok = true;
+      unsigned seen = w.tag;
+#pragma unroll
+      for (int q = 0; q < XQ; ++q) {
+        if (q * 64 >= G) break; // (uniform)
+        if (q * 64 + lane < G) { const u32x4 g = x_ldg(w.sc, (unsigned)((q * 64 + lane) * XKS) * 16u); ok = ok && x_ok(g, w.tag); if (q == 0) seen = g.y; }
+      }
+      if (__all(ok ? 1 : 0)) break;
+      const unsigned long long miss = __ballot(ok ? 0 : 1);
+      const int src = miss ? (int)__builtin_ctzll(miss) : 0;
+      if (!x_spin(w, spins, (unsigned)__builtin_amdgcn_readlane((int)seen, src), 1000 + src)) break;
+      __builtin_amdgcn_s_sleep(XSLEEP);
+    }
+  }
+  __syncthreads();
+  if (__hip_atomic_load(w.xstat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) w.dead = true; // (one wavefront gave up: everybody leaves)
 }
 template <int NZ>
 __device__ __forceinline__ void x_gather(xrsrc r, const unsigned (&idx)[NZ], double (&v)[NZ]) {
@@ -309,6 +356,30 @@ __device__ __forceinline__ void xs_x(const UpdArgs &a, unsigned q /* MP + j */, 
     st.cx += a.xw * (cj * un);
     if (a.avg_stats) st.cxa += a.xw * (cj * ua);
   }
+}
+// the same with the element's old values already in registers (every load of the update is issued before its first store); the averaged u entry is returned
+struct XLd { double u, v, ua, va, us, vs, g, bc; }; // u, v, the restart sums, the running sums, g, and b_i or c_j of one element
+__device__ __forceinline__ double xs_y2(const UpdArgs &a, const XLd &L, double un, double vn, Stat &st) {
+  const double us = L.us + un, vs = L.vs + vn; // compute_avg, abip.c:649-656
+  const double ua = us / a.dom, va = vs / a.dom;
+  const double bi = L.bc;
+  st.wg += a.rho * (un + vn) * L.g;
+  st.nu += un * un; st.nv += vn * vn; st.by += bi * un;
+  if (a.avg_stats) { st.nua += ua * ua; st.nva += va * va; st.bya += bi * ua; }
+  return ua;
+}
+__device__ __forceinline__ double xs_x2(const UpdArgs &a, const XLd &L, bool tail, double un, double vn, Stat &st) {
+  const double us = L.us + un, vs = L.vs + vn;
+  const double ua = us / a.dom, va = vs / a.dom;
+  st.nu += a.xw * (un * un); st.nv += a.xw * (vn * vn);
+  if (a.avg_stats) { st.nua += a.xw * (ua * ua); st.nva += a.xw * (va * va); }
+  if (!tail) {
+    const double cj = L.bc;
+    st.wg += a.xw * ((un + vn) * L.g);
+    st.cx += a.xw * (cj * un);
+    if (a.avg_stats) st.cxa += a.xw * (cj * ua);
+  }
+  return ua;
 }
 __device__ __forceinline__ void x_prox(const UpdArgs &a, double uo, double vo, double utq, double &un, double &vn) {
   if (!a.half_update) {
@@ -474,6 +545,19 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       const double *row = a.Minv + (long)(m0 + rl) * a.ldM;
       for (unsigned c = lane; c < (unsigned)a.m_pad; c += 64) mrow[(size_t)rl * a.m_pad + c] = x_at(row, c);
     }
+  }
+  // ... and, while a row is at most XMR doubles per lane, each wavefront keeps ONE more row in registers and its lanes hold their share of w for all of a
+  // wavefront's rows (c2: 19 rows in the LDS + 7 in registers = all 26 of a workgroup, nothing streamed from the L2 inside the loop)
+  constexpr int XMR = 16;
+  const bool dsmall = !PCG && a.m_pad <= 64 * XMR;
+  double mreg[XMR];
+#pragma unroll
+  for (int k = 0; k < XMR; ++k) mreg[k] = 0.0;
+  const unsigned rl_reg = (unsigned)a.minv_lds_rows + (unsigned)wave; // (local index of the row this wavefront keeps)
+  if (dsmall && m0 + rl_reg < m1) {
+    const double *row = a.Minv + (long)(m0 + rl_reg) * a.ldM;
+#pragma unroll
+    for (int k = 0; k < XMR; ++k) { const unsigned c = 64u * k + lane; if (c < (unsigned)a.m) mreg[k] = x_at(row, c); }
   }
   if (t < 96) outs[t] = a.ctl->out[t]; // slots this launch does not refresh keep what the last finalize left (as on the launch path)
   XP_DECL
@@ -702,6 +786,47 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     // step of the search (and the solve-only mode) leaves after the projection; what they do with it follows the loop.
     // ================================================================================================================================
     double y[RM], zx[RN], dhS[1], tsum; // what a projection leaves behind: the solution's y and x blocks, u_t'h, the tau entry of the right-hand side
+    double rhs_y[RM], rhs_x[RN];        // the right-hand side of the projection in flight (k_rhs, abip.c:552-558)
+    // the entries this workgroup owns, from the iterate (srcU, srcV) -- or the caller's vector in the solve-only mode --; the x block goes out to the exchange
+    // area of the exchange that is open (and with it, for the PCG back-end, A'u_y of the warm start)
+    auto build_rhs = [&](unsigned tb_, double ts_, double cf_, double (&bn_)[1]) {
+#pragma unroll
+      for (int q = 0; q < RM; ++q) {
+        const unsigned i = m0 + tb_ + q * XTB;
+        rhs_y[q] = 0.0;
+        if (i < m1) {
+          double r;
+          if (solo) r = x_at(a.srhs, i);
+          else {
+            const double hi = x_at(a.h, i);
+            r = (x_at(srcU, i) + x_at(srcV, i)) * rho;
+            r += -ts_ * hi;
+            r += -cf_ * hi;
+          }
+          rhs_y[q] = r;
+          bn_[0] += r * r;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < RN; ++q) {
+        const unsigned j2 = n0 + tb_ + q * XTB;
+        rhs_x[q] = 0.0;
+        if (j2 < n1) {
+          double r;
+          if (solo) r = -x_at(a.srhs, MP + j2);
+          else {
+            const double hj = x_at(a.h, MP + j2);
+            r = x_at(srcU, MP + j2) + x_at(srcV, MP + j2);
+            r += -ts_ * hj;
+            r += -cf_ * hj;
+          }
+          rhs_x[q] = -r;
+          x_putd<SA>(pn0, j2 * 8u, -r);
+          if (PCG) x_putd<SA>(pn1, j2 * 8u, aty[q]);
+        }
+      }
+    };
+    bool have_rhs = false;
     int leave = 0;
     for (;;) {
     unsigned tb = t; asm volatile("" : "+v"(tb)); // (see the outer loop)
@@ -712,48 +837,15 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     tsum = (mode == XM_MAIN) ? (u_tau + v_tau) : (mode == XM_BB1 ? (csr(CS_BUPT) + csr(CS_BVPT)) : (csr(CS_BUT) + csr(CS_BVT)));
     const double coef = (wg - tsum * a.g_th) / (a.g_th + 1.0);
     if (!PCG) { XP_START }
-    double rhs_y[RM], rhs_x[RN];
-    double bn[1] = {0.0};
-    open(2);
-#pragma unroll
-    for (int q = 0; q < RM; ++q) {
-      const unsigned i = m0 + tb + q * XTB;
-      rhs_y[q] = 0.0;
-      if (i < m1) {
-        double r;
-        if (solo) r = x_at(a.srhs, i);
-        else {
-          const double hi = x_at(a.h, i);
-          r = (x_at(srcU, i) + x_at(srcV, i)) * rho;
-          r += -tsum * hi;
-          r += -coef * hi;
-        }
-        rhs_y[q] = r;
-        bn[0] += r * r;
-      }
+    double bn[1] = {0.0}, bnS[1] = {0.0};
+    if (!have_rhs) {
+      open(2);
+      build_rhs(tb, tsum, coef, bn);
+      x_publish<1, SA>(bn, red, psc, sc_off, tag);
+      x_collect<1>(w, G, tot, bnS);
+      if (__builtin_expect(w.dead, 0)) return;
     }
-#pragma unroll
-    for (int q = 0; q < RN; ++q) {
-      const unsigned j2 = n0 + tb + q * XTB;
-      rhs_x[q] = 0.0;
-      if (j2 < n1) {
-        double r;
-        if (solo) r = -x_at(a.srhs, MP + j2);
-        else {
-          const double hj = x_at(a.h, MP + j2);
-          r = x_at(srcU, MP + j2) + x_at(srcV, MP + j2);
-          r += -tsum * hj;
-          r += -coef * hj;
-        }
-        rhs_x[q] = -r;
-        x_putd<SA>(pn0, j2 * 8u, -r);
-        if (PCG) x_putd<SA>(pn1, j2 * 8u, aty[q]);
-      }
-    }
-    x_publish<1, SA>(bn, red, psc, sc_off, tag);
-    double bnS[1];
-    x_collect<1>(w, G, tot, bnS);
-    if (__builtin_expect(w.dead, 0)) return;
+    have_rhs = false; // (the right-hand side this trip works on was built, and handed round, by the previous iteration's last exchange -- see there)
     if (PCG) {
       // ---- PCG set-up (k_cg_init_A, indirect.c:345-365, 415) ----
       double sA[RM], sB[RM];
@@ -892,33 +984,70 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       open(5);
 #pragma unroll
       for (int q = 0; q < RM; ++q) { const unsigned i = m0 + tb + q * XTB; if (i < m1) x_putd<SA>(pm0, i * 8u, rhs_y[q] + sA[q]); }
-      double dz[1] = {0.0}, dzS[1];
-      x_publish<1, SA>(dz, red, psc, sc_off, tag);
-      x_collect<1>(w, G, tot, dzS);
+      x_flag<SA>(psc, sc_off, tag);
+      x_wait(w, G);
       if (__builtin_expect(w.dead, 0)) return;
       XP_LAP(1)
       for (unsigned i = t; i < (unsigned)a.m; i += XTB) wv[i] = x_ldd(pm0, i * 8u); // every workgroup needs the whole w
       __syncthreads();
       XP_LAP(2)
       double *yv = wv + a.m_pad;
-      for (unsigned r = m0 + wave; r < m1; r += XWAVES) { // one wavefront per owned row: the first rows from the LDS, the others from the L2 (8 loads in flight)
-        const unsigned rl = r - m0;
+      // one wavefront per owned row; a lane adds its columns lane, lane + 64, ... in that order whichever way the row is held, then the wavefront sum
+      auto stream_row = [&](unsigned r) { // a row from the L2 (8 loads in flight)
+        const double *row = a.Minv + (long)r * a.ldM;
         double acc = 0.0;
-        if ((int)rl < a.minv_lds_rows) {
-          const double *row = mrow + (size_t)rl * a.m_pad;
-          for (unsigned c = lane; c < (unsigned)a.m; c += 64) acc += row[c] * wv[c];
-        } else {
-          const double *row = a.Minv + (long)r * a.ldM;
-          for (unsigned c0 = 0; c0 < (unsigned)a.m; c0 += 512) {
-            double mv[8];
+        for (unsigned c0 = 0; c0 < (unsigned)a.m; c0 += 512) {
+          double mv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const unsigned c = c0 + 64u * u + lane; mv[u] = c < (unsigned)a.m ? x_at(row, c) : 0.0; }
+          for (int u = 0; u < 8; ++u) { const unsigned c = c0 + 64u * u + lane; mv[u] = c < (unsigned)a.m ? x_at(row, c) : 0.0; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const unsigned c = c0 + 64u * u + lane; if (c < (unsigned)a.m) acc += mv[u] * wv[c]; }
-          }
+          for (int u = 0; u < 8; ++u) { const unsigned c = c0 + 64u * u + lane; if (c < (unsigned)a.m) acc += mv[u] * wv[c]; }
         }
-        acc = x_wave_sum63(acc);
-        if (lane == 63) yv[rl] = acc;
+        return acc;
+      };
+      const unsigned nrows = m1 - m0, nlds = min((unsigned)a.minv_lds_rows, nrows);
+      if (dsmall) {
+        double wreg[XMR]; // this lane's columns of w: read once, used for every row of the wavefront
+#pragma unroll
+        for (int k = 0; k < XMR; ++k) { const unsigned c = 64u * k + lane; wreg[k] = c < (unsigned)a.m ? wv[c] : 0.0; }
+        unsigned rl = wave;
+        for (; rl + XWAVES < nlds; rl += 2 * XWAVES) { // rows resident in the LDS, two at a time (independent chains)
+          const double *r0 = mrow + (size_t)rl * a.m_pad, *r1 = r0 + (size_t)XWAVES * a.m_pad;
+          double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+          for (int k = 0; k < XMR; ++k) { const unsigned c = 64u * k + lane; if (c < (unsigned)a.m) { a0 += r0[c] * wreg[k]; a1 += r1[c] * wreg[k]; } }
+          a0 = x_wave_sum63(a0); a1 = x_wave_sum63(a1);
+          if (lane == 63) { yv[rl] = a0; yv[rl + XWAVES] = a1; }
+        }
+        if (rl < nlds) {
+          const double *r0 = mrow + (size_t)rl * a.m_pad;
+          double a0 = 0.0;
+#pragma unroll
+          for (int k = 0; k < XMR; ++k) { const unsigned c = 64u * k + lane; if (c < (unsigned)a.m) a0 += r0[c] * wreg[k]; }
+          a0 = x_wave_sum63(a0);
+          if (lane == 63) yv[rl] = a0;
+        }
+        if (rl_reg < nrows) { // the row in registers
+          double a0 = 0.0;
+#pragma unroll
+          for (int k = 0; k < XMR; ++k) { const unsigned c = 64u * k + lane; if (c < (unsigned)a.m) a0 += mreg[k] * wreg[k]; }
+          a0 = x_wave_sum63(a0);
+          if (lane == 63) yv[rl_reg] = a0;
+        }
+        for (unsigned r2 = (unsigned)a.minv_lds_rows + XWAVES + wave; r2 < nrows; r2 += XWAVES) { // whatever is left streams from the L2
+          const double acc = x_wave_sum63(stream_row(m0 + r2));
+          if (lane == 63) yv[r2] = acc;
+        }
+      } else {
+        for (unsigned rl = wave; rl < nrows; rl += XWAVES) {
+          double acc = 0.0;
+          if (rl < nlds) {
+            const double *row = mrow + (size_t)rl * a.m_pad;
+            for (unsigned c = lane; c < (unsigned)a.m; c += 64) acc += row[c] * wv[c];
+          } else acc = stream_row(m0 + rl);
+          acc = x_wave_sum63(acc);
+          if (lane == 63) yv[rl] = acc;
+        }
       }
       __syncthreads();
 #pragma unroll
@@ -932,16 +1061,16 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     for (int q = 0; q < RM; ++q) {
       const unsigned i = m0 + tb + q * XTB;
       if (i < m1) {
+        const double hi = x_at(a.h, i); // (before the stores: see the element-wise update)
         x_putd<SA>(pm0, i * 8u, y[q]);
         if (solo) x_at(a.srhs, i) = y[q];
         else if (mode == XM_MAIN) x_at(up.ut, i) = y[q];
-        dh[0] += y[q] * x_at(a.h, i);
+        dh[0] += y[q] * hi;
       }
     }
     {
-      double dz[1] = {0.0}, dzS[1];
-      x_publish<1, SA>(dz, red, psc, sc_off, tag);
-      x_collect<1>(w, G, tot, dzS);
+      x_flag<SA>(psc, sc_off, tag);
+      x_wait(w, G);
       if (__builtin_expect(w.dead, 0)) return;
       double tx[NZ], vt[NZ], tq[RN];
       x_mat<NZ>(gT, nt, tx);
@@ -961,22 +1090,54 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     if (!PCG) { XP_LAP(4) }
     if (__builtin_expect(solo || mode != XM_MAIN, 0)) break; // (not an ADMM iteration: see below the loop)
     // ---- element-wise update (k_admm_update): barrier prox, dual update, running sums, averages, statistics ----
+    // Every load of the phase is issued before its first store: on this chip loads and stores share one in-order counter (vmcnt), so a load issued behind a
+    // store is not handed over before that store has been acknowledged by the L2 -- read-modify-write stream after read-modify-write stream (the round-3
+    // form: nine of them per element, which the compiler must keep in order because the arrays may alias) is a chain of that many L2 round trips.
     Stat sst = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double tau4[4] = {0.0, 0.0, 0.0, 0.0};
     open(8);
+    XLd Ly[RM], Lx[RN], Lt;
+#pragma unroll
+    for (int q = 0; q < RM; ++q) {
+      const unsigned i = m0 + tb + q * XTB;
+      Ly[q] = XLd{0, 0, 0, 0, 0, 0, 0, 0};
+      if (i < m1) {
+        Ly[q].v = x_at(up.v, i); if (up.half_update) Ly[q].u = x_at(up.u, i);
+        Ly[q].ua = x_at(up.u_avg, i); Ly[q].va = x_at(up.v_avg, i); Ly[q].us = x_at(up.u_sum, i); Ly[q].vs = x_at(up.v_sum, i);
+        Ly[q].g = x_at(up.g, i); Ly[q].bc = x_at(up.b, i);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RN; ++q) {
+      const unsigned j2 = n0 + tb + q * XTB;
+      Lx[q] = XLd{0, 0, 0, 0, 0, 0, 0, 0};
+      if (j2 < n1) {
+        const unsigned qq = MP + j2;
+        Lx[q].u = x_at(up.u, qq); Lx[q].v = x_at(up.v, qq);
+        Lx[q].ua = x_at(up.u_avg, qq); Lx[q].va = x_at(up.v_avg, qq); Lx[q].us = x_at(up.u_sum, qq); Lx[q].vs = x_at(up.v_sum, qq);
+        Lx[q].g = x_at(up.g, qq); Lx[q].bc = x_at(up.c, j2);
+      }
+    }
+    Lt = XLd{0, 0, 0, 0, 0, 0, 0, 0};
+    if (rank == 0 && t == 0) {
+      Lt.u = x_at(up.u, tail); Lt.v = x_at(up.v, tail);
+      Lt.ua = x_at(up.u_avg, tail); Lt.va = x_at(up.v_avg, tail); Lt.us = x_at(up.u_sum, tail); Lt.vs = x_at(up.v_sum, tail);
+    }
 #pragma unroll
     for (int q = 0; q < RM; ++q) {
       const unsigned i = m0 + tb + q * XTB;
       if (i < m1) {
         double un, vn;
         const double uti = y[q];
-        if (!up.half_update) { vn = x_at(up.v, i); un = uti - vn; }
-        else { double vh = x_at(up.v, i) + 0.5 * (x_at(up.u, i) - uti); un = uti - vh; vn = vh + (un - uti); }
+        if (!up.half_update) { vn = Ly[q].v; un = uti - vn; }
+        else { double vh = Ly[q].v + 0.5 * (Ly[q].u - uti); un = uti - vh; vn = vh + (un - uti); }
+        const double ua = xs_y2(up, Ly[q], un, vn, sst);
         x_at(up.u, i) = un; x_at(up.v, i) = vn;
-        x_at(up.u_avg, i) += un; x_at(up.v_avg, i) += vn;
-        xs_y(up, i, un, vn, sst);
+        x_at(up.u_avg, i) = Ly[q].ua + un; x_at(up.v_avg, i) = Ly[q].va + vn;
+        x_at(up.u_sum, i) = Ly[q].us + un; x_at(up.v_sum, i) = Ly[q].vs + vn;
+        x_at(up.u_avgc, i) = ua; x_at(up.v_avgc, i) = (Ly[q].vs + vn) / up.dom;
         x_putd<SA>(pm0, i * 8u, un);
-        if (avg_stats) x_putd<SA>(pm1, i * 8u, x_at(up.u_avgc, i));
+        if (avg_stats) x_putd<SA>(pm1, i * 8u, ua);
       }
     }
 #pragma unroll
@@ -984,25 +1145,29 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       const unsigned j2 = n0 + tb + q * XTB;
       if (j2 < n1) {
         const unsigned qq = MP + j2;
-        x_at(up.ut, qq) = zx[q];
         double un, vn;
-        x_prox(up, x_at(up.u, qq), x_at(up.v, qq), zx[q], un, vn);
+        x_prox(up, Lx[q].u, Lx[q].v, zx[q], un, vn);
+        const double ua = xs_x2(up, Lx[q], false, un, vn, sst);
+        x_at(up.ut, qq) = zx[q];
         x_at(up.u, qq) = un; x_at(up.v, qq) = vn;
-        x_at(up.u_avg, qq) += un; x_at(up.v_avg, qq) += vn;
-        xs_x(up, qq, j2, false, un, vn, sst);
+        x_at(up.u_avg, qq) = Lx[q].ua + un; x_at(up.v_avg, qq) = Lx[q].va + vn;
+        x_at(up.u_sum, qq) = Lx[q].us + un; x_at(up.v_sum, qq) = Lx[q].vs + vn;
+        x_at(up.u_avgc, qq) = ua; x_at(up.v_avgc, qq) = (Lx[q].vs + vn) / up.dom;
         x_putd<SA>(pn0, j2 * 8u, un);
-        if (avg_stats) x_putd<SA>(pn1, j2 * 8u, x_at(up.u_avgc, qq));
+        if (avg_stats) x_putd<SA>(pn1, j2 * 8u, ua);
       }
     }
     if (rank == 0 && t == 0) { // the tau / kappa entry
       const double utq = tsum + dhS[0];
-      x_at(up.ut, tail) = utq;
       double un, vn;
-      x_prox(up, x_at(up.u, tail), x_at(up.v, tail), utq, un, vn);
+      x_prox(up, Lt.u, Lt.v, utq, un, vn);
+      const double ua = xs_x2(up, Lt, true, un, vn, sst), va = (Lt.vs + vn) / up.dom;
+      x_at(up.ut, tail) = utq;
       x_at(up.u, tail) = un; x_at(up.v, tail) = vn;
-      x_at(up.u_avg, tail) += un; x_at(up.v_avg, tail) += vn;
-      xs_x(up, tail, (unsigned)a.n, true, un, vn, sst);
-      tau4[0] = un; tau4[1] = vn; tau4[2] = x_at(up.u_avgc, tail); tau4[3] = x_at(up.v_avgc, tail);
+      x_at(up.u_avg, tail) = Lt.ua + un; x_at(up.v_avg, tail) = Lt.va + vn;
+      x_at(up.u_sum, tail) = Lt.us + un; x_at(up.v_sum, tail) = Lt.vs + vn;
+      x_at(up.u_avgc, tail) = ua; x_at(up.v_avgc, tail) = va;
+      tau4[0] = un; tau4[1] = vn; tau4[2] = ua; tau4[3] = va;
       // the tau / kappa entries are nobody's sum: they travel as granules of rank 0 behind the sums' (slots 12..15), acknowledged before its flags go out
 #pragma unroll
       for (int q = 0; q < 4; ++q) x_putg<SA>(psc, sc_off + (unsigned)(12 + q) * 16u, tau4[q], tag);
@@ -1103,6 +1268,17 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     }
     if (!PCG) { XP_LAP(5) }
     open(9);
+    if (!PCG) {
+      // Direct back-end: the NEXT iteration's right-hand side rides on this exchange -- everything it needs (S_WG, the tau entries, the new iterate) is
+      // known since the previous one, its x block goes out with the sums of the stopping test, and the next trip starts at its first product: five
+      // rendez-vous per iteration instead of six.  If the exit test below ends the inner loop the entries are simply not used.  (The PCG back-end's first
+      // exchange also carries |rhs_y|^2 for its tolerance -- a thirteenth sum on the iterations that test the averaged iterate; it keeps the exchange.)
+      const double ts_n = S13[9] + S13[10];
+      const double cf_n = (S13[0] - ts_n * a.g_th) / (a.g_th + 1.0);
+      double bn_n[1] = {0.0};
+      build_rhs(tb, ts_n, cf_n, bn_n);
+      have_rhs = true;
+    }
     double Q[12];
     if (avg_stats) {
       x_publish<12, SA>(q6, red, psc, sc_off, tag);

@@ -1143,6 +1143,8 @@ int xcd_run(W *w, int phase, long max_steps, long *ran, int *reason) {
   const XcdOut &r = w->hctl->xo;
   *ran = r.ran; *reason = r.reason;
 #ifdef XCD_PROF
+  { static long lap[8] = {0}; for (int q = 0; q < 8; ++q) lap[q] += (unsigned)x.hstat[600 + q];
+    fprintf(stderr, "[xcd prof] laps, cumulative us: %.0f %.0f %.0f %.0f %.0f %.0f %.0f (PCG loop: put, publish, collect, gather, rows, tail | direct: rhs+E1, E_w, all-gather, dense, E_y+E_dh, update+E_u, q+E_fin)\n", lap[0] * 0.01, lap[1] * 0.01, lap[2] * 0.01, lap[3] * 0.01, lap[4] * 0.01, lap[5] * 0.01, lap[6] * 0.01); }
   { static double acc[8] = {0}; for (int q = 0; q < 8; ++q) acc[q] += (unsigned)x.hstat[610 + q];
     fprintf(stderr, "[xcd prof] cumulative: launches %.0f us | ADMM iterations %.0f us (their PCG loops %.0f us, %.0f PCG iterations) | look-ahead steps %.0f us (PCG loops %.0f us, %.0f PCG iterations) | outer end / begin %.0f us\n",
             acc[0] * 0.01, acc[1] * 0.01, acc[4] * 0.01, acc[7], acc[2] * 0.01, acc[5] * 0.01, acc[6], acc[3] * 0.01); }

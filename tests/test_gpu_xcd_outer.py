@@ -172,10 +172,15 @@ def test_two_works_solving_concurrently_from_two_threads(gpu, monkeypatch):
     for key, (AA, bb, cc, ls) in {"d": (A, b, c, "direct"), "p": (A2, b2, c2, "indirect")}.items():
         ref[key] = _solve(gpu, AA, bb, cc, ls, eps=1e-6)
     out = {}
+    init = threading.Lock()   # the back-end is a process-wide choice (abip_hip_set_linsys: the reference picks it at link time), so the works are SET UP one at a time ...
 
     def work(key, AA, bb, cc, ls):
         for rep in range(3):
-            out[(key, rep)] = _solve(gpu, AA, bb, cc, ls, eps=1e-6)
+            with init:
+                S = gpu.Solver(AA, bb, cc, linsys=ls, verbose=0, eps=1e-6)
+            with S:                                                            # ... and SOLVED concurrently
+                info = S.solve()
+                out[(key, rep)] = (info, S.x.copy(), S.y.copy(), S.s.copy(), {"xcd_giveups": S.scalar("xcd_giveups")})
 
     th = [threading.Thread(target=work, args=("d", A, b, c, "direct")), threading.Thread(target=work, args=("p", A2, b2, c2, "indirect"))]
     for t in th:
