@@ -69,6 +69,7 @@ EXPORTS = (
     "abip_hip_accum_by_A", "abip_hip_accum_by_Atrans", "abip_hip_kkt_solve", "abip_hip_get_vector",
     "abip_hip_get_scalar", "abip_hip_profile_enable", "abip_hip_profile_read", "abip_hip_sync",
     "abip_hip_dist_get_unique_id", "abip_hip_dist_init_rccl", "abip_hip_dist_init_callback", "abip_hip_dist_finalize",
+    "abip_hip_dist_peer_capacity", "abip_hip_dist_peer_prepare", "abip_hip_dist_init_peer",
     "abip_hip_dist_partition", "abip_hip_dist_rows", "abip_hip_host_factor_solve", "abip_hip_host_normalize_A",
     "abip_hip_dist_comm_count", "abip_hip_profile_enable_stamps", "abip_hip_set_copy_a_matrix", "abip_hip_get_copy_a_matrix", "abip_hip_ldl_solve", "abip_hip_xcd_plan",
     "abip_qcp", "abip_qcp_set_default_settings", "abip_hip_qcp_last_stats", "abip_hip_qcp_phase_times", "abip_hip_qcp_cone_prox", "abip_hip_qcp_dist_partition", "abip_hip_qcp_host_probe",
@@ -159,6 +160,12 @@ def load() -> C.CDLL:
     L.abip_hip_dist_init_rccl.argtypes = [C.c_int, C.c_int, C.c_void_p]
     L.abip_hip_dist_init_callback.restype = C.c_int
     L.abip_hip_dist_init_callback.argtypes = [C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
+    L.abip_hip_dist_peer_capacity.restype = C.c_long
+    L.abip_hip_dist_peer_capacity.argtypes = [C.c_long, C.c_long]
+    L.abip_hip_dist_peer_prepare.restype = C.c_int
+    L.abip_hip_dist_peer_prepare.argtypes = [C.c_long, C.c_void_p]
+    L.abip_hip_dist_init_peer.restype = C.c_int
+    L.abip_hip_dist_init_peer.argtypes = [C.c_int, C.c_int, C.c_void_p]
     L.abip_hip_dist_finalize.restype = None
     L.abip_hip_dist_comm_count.restype = C.c_int
     L.abip_hip_profile_enable_stamps.restype = C.c_int

@@ -27,6 +27,7 @@
 #include "dev_kernels.h"
 #include "dev_ldl.h"
 #include "dev_xcd.h"
+#include "dev_peer.h"
 #include "dist_internal.h"
 #include "host_setup.h"
 #include "dev_host_util.h"
@@ -62,8 +63,16 @@ struct RcclApi {
   int (*CommAbort)(rcclComm_t) = nullptr;       // optional
   int (*CommCount)(rcclComm_t, int *) = nullptr; // optional
 };
+struct PeerHost { // dev_peer.h: the hand-rolled exchange over peer-mapped mailboxes
+  abip::PeerCtx ctx{};
+  void *mine = nullptr; void *mapped[abip::PEER_MAX] = {nullptr};
+  unsigned *sync = nullptr; int *hstatus = nullptr;
+  unsigned long long epoch = 0;
+  long cap = 0;
+};
 struct DistCtx {
-  int kind = 0; // 0 none, 1 RCCL, 2 host callback (tests)
+  int kind = 0; // 0 none, 1 RCCL, 2 host callback (tests), 3 peer-mapped mailboxes (dev_peer.h)
+  PeerHost peer;
   int rank = 0, world = 1;
   rcclComm_t comm = nullptr;
   abip_hip_allreduce_fn fn = nullptr;
@@ -129,6 +138,14 @@ int dist_allreduce(double *buf, size_t count, hipStream_t s, std::vector<double>
     const int rc = g_dist.api.AllReduce(buf, buf, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, g_dist.comm, s);
     if (rc != 0) { fprintf(stderr, "abip_hip: ncclAllReduce failed (%d)\n", rc); return -1; }
     return 0;
+  }
+  if (g_dist.kind == 3) { // dev_peer.h: one launch, every chunk reduced in one place in rank order
+    PeerHost &p = g_dist.peer;
+    if ((long)count > p.cap) { fprintf(stderr, "abip_hip: all-reduce of %zu doubles exceeds the mailbox capacity %ld (abip_hip_dist_peer_prepare)\n", count, p.cap); return -1; }
+    if (*p.hstatus) { fprintf(stderr, "abip_hip: rank %d: an earlier peer exchange gave up waiting for rank %d\n", g_dist.rank, *p.hstatus - 1); return -1; }
+    ++p.epoch;
+    hipLaunchKernelGGL(abip::k_peer_allreduce, dim3(64), dim3(256), 0, s, p.ctx, buf, (long)count, p.epoch);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
   }
   if (g_dist.kind != 2) return -1;
   // host-staged callback (test backend): D2H, reduce on the host through the caller's collective, H2D
@@ -345,6 +362,7 @@ int sync_ctl(W *w) { // the once-per-iteration control read
   HIP_OK(hipStreamSynchronize(w->stream));
   harvest_events(w);
   if (hi > lo) harvest_stamps(w, lo, hi);
+  if (w->dist && g_dist.kind == 3 && *g_dist.peer.hstatus) { fprintf(stderr, "abip_hip: rank %d: a peer exchange gave up waiting for rank %d\n", g_dist.rank, *g_dist.peer.hstatus - 1); return -1; }
   return 0;
 }
 
@@ -2307,8 +2325,49 @@ int abip_hip_dist_init_callback(int rank, int world, abip_hip_allreduce_fn fn, v
   g_dist.kind = 2; g_dist.rank = rank; g_dist.world = world; g_dist.fn = fn; g_dist.fn_ctx = ctx;
   return 0;
 }
+// ---- the peer-mapped transport (dev_peer.h).  Step 1 on every rank: allocate the mailbox, hand out its IPC handle (64 bytes); the host program gathers the
+// handles of all ranks (any collective it has); step 2: map the peers' mailboxes.  cap_doubles = the longest vector the solve will all-reduce
+// (LP, row form: n + 64 padded to 32, + the packed scalars; abip_hip_dist_peer_capacity gives a safe figure).
+long abip_hip_dist_peer_capacity(long m, long n) { return ((std::max(m, n) + 63) / 32 * 32) * 2 + 4096; }
+int abip_hip_dist_peer_prepare(long cap_doubles, void *handle_out64) {
+  if (cap_doubles < 1 || !handle_out64) return -1;
+  PeerHost &p = g_dist.peer;
+  if (p.mine) return -2;
+  const size_t bytes = sizeof(double) * (size_t)(abip::PEER_HEAD + 2 * cap_doubles + 64);
+  if (hipMalloc(&p.mine, bytes) != hipSuccess || hipMemset(p.mine, 0, bytes) != hipSuccess) { (void)hipGetLastError(); return -3; }
+  if (hipMalloc((void **)&p.sync, 64) != hipSuccess || hipMemset(p.sync, 0, 64) != hipSuccess) return -3;
+  if (hipHostMalloc((void **)&p.hstatus, sizeof(int), hipHostMallocMapped) != hipSuccess) return -3;
+  *p.hstatus = 0;
+  p.cap = cap_doubles;
+  hipIpcMemHandle_t h;
+  if (hipIpcGetMemHandle(&h, p.mine) != hipSuccess) { fprintf(stderr, "abip_hip: hipIpcGetMemHandle failed (%s)\n", hipGetErrorString(hipGetLastError())); return -4; }
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
+  memcpy(handle_out64, &h, 64);
+  return hipDeviceSynchronize() == hipSuccess ? 0 : -3;
+}
+int abip_hip_dist_init_peer(int rank, int world, const void *handles /* world x 64 bytes, in rank order */) {
+  PeerHost &p = g_dist.peer;
+  if (world < 1 || world > abip::PEER_MAX || rank < 0 || rank >= world || !handles || !p.mine) return -1;
+  for (int r = 0; r < world; ++r) {
+    if (r == rank) { p.mapped[r] = p.mine; continue; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const char *)handles + 64 * (size_t)r, 64);
+    if (hipIpcOpenMemHandle(&p.mapped[r], h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+      fprintf(stderr, "abip_hip: rank %d cannot map the mailbox of rank %d (%s)\n", rank, r, hipGetErrorString(hipGetLastError()));
+      return -2;
+    }
+  }
+  p.ctx.rank = rank; p.ctx.world = world; p.ctx.cap = p.cap; p.ctx.sync = p.sync;
+  for (int r = 0; r < world; ++r) p.ctx.mail[r] = (double *)p.mapped[r];
+  int *dstatus = nullptr;
+  if (hipHostGetDevicePointer((void **)&dstatus, p.hstatus, 0) != hipSuccess) return -3;
+  p.ctx.status = dstatus;
+  p.epoch = 0;
+  g_dist.kind = 3; g_dist.rank = rank; g_dist.world = world;
+  return 0;
+}
 int abip_hip_dist_comm_count(void) { // ranks of the live communicator as RCCL reports them (callback transport: the world it was given; none: 0)
-  if (g_dist.kind == 2) return g_dist.world;
+  if (g_dist.kind == 2 || g_dist.kind == 3) return g_dist.world;
   if (g_dist.kind != 1 || !g_dist.comm) return 0;
   int cnt = g_dist.world;
   if (g_dist.api.CommCount && g_dist.api.CommCount(g_dist.comm, &cnt) != 0) return -1;
@@ -2316,6 +2375,15 @@ int abip_hip_dist_comm_count(void) { // ranks of the live communicator as RCCL r
 }
 void abip_hip_dist_finalize(void) {
   if (g_dist.kind == 1 && g_dist.comm) g_dist.api.CommDestroy(g_dist.comm);
+  {
+    PeerHost &p = g_dist.peer;
+    if (p.mine) {
+      (void)hipDeviceSynchronize();
+      for (int r = 0; r < abip::PEER_MAX; ++r) if (p.mapped[r] && p.mapped[r] != p.mine) (void)hipIpcCloseMemHandle(p.mapped[r]);
+      (void)hipFree(p.mine); (void)hipFree(p.sync); (void)hipHostFree(p.hstatus);
+      p = PeerHost();
+    }
+  }
   g_dist_aborted = false;
   g_dist.kind = 0; g_dist.rank = 0; g_dist.world = 1; g_dist.comm = nullptr; g_dist.fn = nullptr; g_dist.fn_ctx = nullptr;
 }

@@ -3,6 +3,7 @@
     dist.init_rccl(rank, world, broadcast)   # production: RCCL over xGMI; `broadcast(bytes_or_None) -> bytes` moves the id
     dist.init_torch(process_group=None)      # the same, using torch.distributed for the 128-byte id exchange
     dist.init_callback(rank, world, allreduce)  # tests: host-staged sum through any collective (e.g. gloo)
+    dist.init_peer(rank, world, m, n, allgather) # the hand-rolled deterministic exchange over peer-mapped buffers (dev_peer.h); init_peer_torch: over torch.distributed
     dist.finalize()
 """
 from __future__ import annotations
@@ -69,6 +70,36 @@ def init_callback(rank: int, world: int, allreduce) -> None:
     _keepalive.append(fn)
     if L.abip_hip_dist_init_callback(rank, world, fn, None) != 0:
         raise RuntimeError("abip_hip_dist_init_callback failed")
+
+
+def init_peer(rank: int, world: int, m: int, n: int, allgather) -> None:
+    """The hand-rolled exchange over peer-mapped mailboxes (abip_amd/csrc/dev_peer.h).  `allgather(bytes) -> list[bytes]` (in rank order) moves the
+    64-byte IPC handles, e.g. over torch.distributed.all_gather_object; (m, n) size the mailbox for the LP about to be solved."""
+    L = _lib.load()
+    cap = int(L.abip_hip_dist_peer_capacity(int(m), int(n)))
+    buf = C.create_string_buffer(64)
+    rc = L.abip_hip_dist_peer_prepare(cap, buf)
+    if rc != 0:
+        raise RuntimeError(f"abip_hip_dist_peer_prepare failed ({rc})")
+    handles = allgather(buf.raw)
+    if len(handles) != world or any(len(h) != 64 for h in handles):
+        raise RuntimeError("the handle exchange did not return one 64-byte handle per rank")
+    allh = C.create_string_buffer(b"".join(handles), 64 * world)
+    rc = L.abip_hip_dist_init_peer(rank, world, allh)
+    if rc != 0:
+        raise RuntimeError(f"abip_hip_dist_init_peer failed ({rc})")
+
+
+def init_peer_torch(m: int, n: int, process_group=None) -> None:
+    import torch.distributed as dist
+    rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+
+    def gather(payload):
+        box = [None] * world
+        dist.all_gather_object(box, payload, group=process_group)
+        return box
+
+    init_peer(rank, world, m, n, gather)
 
 
 def comm_count() -> int:

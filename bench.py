@@ -73,8 +73,8 @@ def spawn_ranks(args) -> None:
     """--gpus N > 1 outside a launcher: start the ranks as children of this (GPU-free) process and relay rank 0's line."""
     import torch  # device_count() does not initialise the GPU on this image
     transport = os.environ.get("ABIP_BENCH_TRANSPORT", "rccl")
-    if transport not in ("rccl", "gloo-callback"):
-        die(f"unknown ABIP_BENCH_TRANSPORT={transport!r} (rccl | gloo-callback)")
+    if transport not in ("rccl", "gloo-callback", "peer"):
+        die(f"unknown ABIP_BENCH_TRANSPORT={transport!r} (rccl | gloo-callback | peer)")
     ndev = torch.cuda.device_count()
     if transport == "rccl" and ndev < args.gpus:
         die(f"--gpus {args.gpus} needs {args.gpus} GPUs on this node, found {ndev}: not launching (one process per GPU over RCCL; "
@@ -543,7 +543,10 @@ def main():
         die("needs a GPU (libabip_hip has no CPU path)")
     if transport == "rccl" and world > torch.cuda.device_count():
         die(f"{world} ranks but {torch.cuda.device_count()} GPUs visible")
-    torch.cuda.set_device(local_rank if transport == "rccl" else 0)
+    # rccl: one GPU per rank.  peer (the hand-rolled exchange over IPC-mapped mailboxes, dev_peer.h): one GPU per rank where the node has them, else every rank on
+    # cuda:0 (a functional dry run).  gloo-callback: every rank on cuda:0, host-staged sums.
+    peer_one_gpu = transport == "peer" and torch.cuda.device_count() < world
+    torch.cuda.set_device(local_rank if (transport == "rccl" or (transport == "peer" and not peer_one_gpu)) else 0)
     dist = None
     if world > 1 or force_shard:
         import torch.distributed as dist
@@ -565,6 +568,9 @@ def main():
         if sharded:   # communicator for the solver; rows of A are split over the ranks inside abip_init.  Failure here is fatal (no replica fall-back).
             if transport == "rccl":
                 adist.init_torch()
+            elif transport == "peer":
+                shape = {"c4": (200_000, 500_000), "c3": (16_390, 48_400), "c2": (816, 1_879)}[args.workload]
+                adist.init_peer_torch(*shape)
             else:
                 adist.init_callback(rank, world, lambda arr: dist.all_reduce(torch.from_numpy(arr)))
         if sharded and "ABIP_HIP_DIST_CG" not in os.environ:
@@ -583,7 +589,9 @@ def main():
             rows = [None] * world
             dist.all_gather_object(rows, rec["extra"]["rows"])
             rec["rank_rows"] = rows
-            rec["transport"] = ("rccl" if transport == "rccl" else "gloo-callback (host-staged sums, every rank on cuda:0: a plumbing dry run, NOT a scaling number)") if sharded else "none (replicas)"
+            rec["transport"] = ({"rccl": "rccl", "peer": "peer-mapped mailboxes (dev_peer.h: one-shot reduce-scatter + all-gather, every chunk summed in one place in rank order)"
+                                         + (" -- every rank on cuda:0: a functional dry run, NOT a scaling number" if peer_one_gpu else "")}.get(
+                                             transport, "gloo-callback (host-staged sums, every rank on cuda:0: a plumbing dry run, NOT a scaling number)")) if sharded else "none (replicas)"
             rec["rccl_ranks"] = adist.comm_count() if sharded else 0
             # form of the sharded solve: "cols" (default: the solve's m-space gathered and replicated, A by column blocks, one all-reduce of m doubles per PCG
             # iteration) or "rows" (ABIP_HIP_DIST_CG=rows: one all-reduce of n doubles + packed scalars per PCG iteration)

@@ -79,6 +79,14 @@ typedef void (*abip_hip_allreduce_fn)(void *ctx, double *host_buf, long count); 
 int abip_hip_dist_get_unique_id(void *out128);
 int abip_hip_dist_init_rccl(int rank, int world, const void *unique_id128);
 int abip_hip_dist_init_callback(int rank, int world, abip_hip_allreduce_fn fn, void *ctx);
+/* A third transport: a hand-rolled all-reduce over peer-mapped device buffers (abip_amd/csrc/dev_peer.h: one-shot reduce-scatter + all-gather, every chunk
+ * summed in ONE place in rank order -- deterministic, the same bits on every rank -- one kernel launch per collective, no library in between; what SURVEY 8(e)
+ * prices for xGMI).  Every rank: abip_hip_dist_peer_prepare (allocates its mailbox for vectors of up to cap_doubles -- abip_hip_dist_peer_capacity(m, n) is
+ * enough for an LP -- and returns the 64-byte IPC handle); the host program gathers the handles of all ranks in rank order; every rank:
+ * abip_hip_dist_init_peer.  At most 8 ranks (one node).  Selected by the host program; RCCL stays the default of bench.py until hardware says otherwise. */
+long abip_hip_dist_peer_capacity(long m, long n);
+int abip_hip_dist_peer_prepare(long cap_doubles, void *handle_out64);
+int abip_hip_dist_init_peer(int rank, int world, const void *handles64_by_rank);
 void abip_hip_dist_finalize(void);
 /* Ranks in the live communicator as the transport reports them (RCCL: ncclCommCount; callback: the world given; none: 0). */
 int abip_hip_dist_comm_count(void);

@@ -3,6 +3,7 @@
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 --master-port P tests/dist_worker.py MODE FIXTURE EPS
 
 MODE = gloo-callback : every rank uses cuda:0 and the host-staged collective over gloo (runs on a 1-GPU box)
+MODE = peer          : every rank uses cuda:0 and the hand-rolled exchange over peer-mapped mailboxes (abip_amd/csrc/dev_peer.h; IPC handles over gloo)
 MODE = rccl          : one GPU per rank, RCCL communicator bootstrapped over torch.distributed
 Rank 0 prints a JSON line with the result."""
 import json
@@ -49,6 +50,10 @@ def main():
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         adist.init_callback(rank, world, lambda arr: dist.all_reduce(torch.from_numpy(arr)))
+    elif mode == "peer":          # the hand-rolled exchange over peer-mapped mailboxes (dev_peer.h): every rank on cuda:0, the IPC handles travel over gloo
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        adist.init_peer_torch(A.shape[0], A.shape[1])
     else:
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl", rank=rank, world_size=world)
@@ -61,7 +66,7 @@ def main():
     # every rank must hold the same full solution, BIT for bit (replicated n-space state and every host decision derive from all-reduced
     # values and from reductions whose grid is the same on every rank), and the same persistent grid NB
     t = torch.from_numpy(np.concatenate([extra, S.x, S.y, S.s]).astype(np.float64))
-    if mode != "gloo-callback":
+    if mode == "rccl":
         t = t.cuda()
     gathered = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(gathered, t)
