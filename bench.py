@@ -166,9 +166,12 @@ def cpu_baseline(A, b, c, linsys, budget_s=12.0, window=None):
 # ---------------------------------------------------------------------------------------------------------
 # the conic workload
 # ---------------------------------------------------------------------------------------------------------
+PMC_FILE = "r04_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) else "r03_pmc_traffic.json"
+
+
 def pmc_traffic(case):
-    """Per-kernel HBM traffic of the committed counter passes (scripts/r03_pmc.sh -> profiles/r03_pmc_traffic.json), or {}."""
-    f = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    """Per-kernel HBM traffic of the committed counter passes (scripts/r04_pmc.sh -> profiles/r04_pmc_traffic.json; round 3's file before that), or {}."""
+    f = os.path.join(ROOT, "profiles", PMC_FILE)
     try:
         return json.load(open(f)).get(case, {})
     except Exception:  # noqa: BLE001
@@ -244,7 +247,7 @@ def run_conic(workload, linsys, no_cpu, rank, world, dist, torch):
     tr = pmc_traffic("c5_direct") if not ml else {}
     traffic = (tr["k_tail_sym"]["traffic_bytes"] + tr.get("k_tail_sym_fin", {}).get("traffic_bytes", 0) + 2 * tr.get("k_tri_wide", {}).get("traffic_bytes", 0)) if "k_tail_sym" in tr else None
     roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic,
-                traffic_source="profiles/r03_pmc_traffic.json: k_tail_sym + k_tail_sym_fin + 2 k_tri_wide per solve (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
+                traffic_source="profiles/" + PMC_FILE + ": k_tail_sym + k_tail_sym_fin + 2 k_tri_wide per solve (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
                 effective_frac=bytes_solve / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 explanation="achieved / frac count the bytes this back-end streams per KKT solve; effective_frac prices the same time against SURVEY 8(d)'s B_solve_direct "
                             "(the two triangular sweeps of the reference's algorithm): the symmetric tail halves the bytes, so the effective figure can exceed the real one",
@@ -261,7 +264,7 @@ def run_conic(workload, linsys, no_cpu, rank, world, dist, torch):
         ka = "kq_pcg_Aty_lds" if "kq_pcg_Aty_lds" in tr else "kq_pcg_Aty"
         traffic = int((cg + 2.5) * (tr[ka]["traffic_bytes"] + tr["kq_pcg_Gp"]["traffic_bytes"]) + cg * tr.get("kq_pcg_update", {}).get("traffic_bytes", 0)) if ka in tr and "kq_pcg_Gp" in tr else None
         roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic,
-                    traffic_source=f"profiles/r03_pmc_traffic.json: (cg + 2.5) x ({ka} + kq_pcg_Gp) + cg x kq_pcg_update per solve" if traffic else None,
+                    traffic_source=f"profiles/{PMC_FILE}: (cg + 2.5) x ({ka} + kq_pcg_Gp) + cg x kq_pcg_update per solve" if traffic else None,
                     kernel="KKT solve of the conic projection by y-space PCG: kq_pcg_prep, kq_pcg_Aty/_Gp (set-up), {kq_pcg_Aty (m-vector in LDS where it fits: kq_pcg_Aty_lds), kq_pcg_Gp, kq_pcg_update} x cg, kq_pcg_post; one host round trip per solve",
                     avg_launch_us=avg_ms * 1e3, launches=f["solves_timed"], algorithmic_bytes_per_launch=bytes_solve, avg_cg_iters=cg)
     # cpu_baseline: the conic reference does not build here (its sources include MKL headers unconditionally; a stand-in build is not allowed) and the scalar
@@ -403,7 +406,7 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         # HBM bytes per launch from the committed counter passes (per inner iteration there, FETCH_SIZE / WRITE_SIZE summed over the kernel's dispatches)
         tpi = pmc_traffic(name).get("k_lp_xcd", {}).get("traffic_bytes_per_iteration") if pmc and world == 1 else None
         roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=(tpi * its / nl) if tpi else None,
-                    traffic_source="profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; per inner iteration x iterations per launch)" if tpi else None,
+                    traffic_source="profiles/" + PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; per inner iteration x iterations per launch)" if tpi else None,
                     kernel="k_lp_xcd: the whole inner ADMM loop as one persistent launch, one workgroup per CU on %d XCD(s) (slices of A and A' per workgroup; operands "
                            "handed over through the L2%s: stores, acknowledged, partial-sum granules as flags, L1-bypassing gathers); bound by the latency "
                            "of its exchanges -- a chain of L2 round trips and two workgroup barriers -- not by HBM" % (xg // 32, " (written through between XCDs)" if xg > 32 else ""),
@@ -423,7 +426,7 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         traffic, tsrc = None, None
         if pmc and name == "c4" and world == 1:   # PMC counters need rocprofv3: measured in separate passes (scripts/r03_pmc.sh), committed
             rec = pmc_traffic("c4").get("k_cg_" + kname, {})
-            traffic, tsrc = rec.get("traffic_bytes"), "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            traffic, tsrc = rec.get("traffic_bytes"), "profiles/" + PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         # The driver-parsed figures (achieved, frac, avg_launch_us) are the ones `profiles/` reproduces: kernel-trace durations (dispatch to drain).  The
         # device-side stamps of this run leave out dispatch and drain; they are scaled by the ratio trace / stamp that ONE profiled run measured for the
         # same kernel (scripts/r04_trace.sh -> profiles/r04_trace_durations.json) and kept, unscaled, under `stamps`.
