@@ -2,6 +2,7 @@
 // the 32-bit CSR/CSC images the kernels stream, their row blocks, the Jacobi preconditioner, and the
 // sparse LDL' factorisation + level schedule for the direct back-end.
 #include "host_setup.h"
+#include "host_par.h"
 
 #include <algorithm>
 #include <cmath>
@@ -70,15 +71,18 @@ void normalize_A(ABIPMatrix *A, const ABIPSettings *stgs, std::vector<double> &D
   std::vector<double> D_pc(m, 1.0), E_pc(n, 1.0), D_or(m, 1.0), E_or(n, 1.0), D_rz(m, 1.0), E_rz(n, 1.0), D_qp(m, 1.0), E_qp(n, 1.0);
   const double min_row = kMinScale * std::sqrt((double)n), max_row = kMaxScale * std::sqrt((double)n); // common.c:172-175
   const double min_col = kMinScale * std::sqrt((double)m), max_col = kMaxScale * std::sqrt((double)m);
-  auto rows_div = [&](const std::vector<double> &R) { for (abip_int q = 0; q < A->p[n]; ++q) A->x[q] /= R[A->i[q]]; };
+  // A few host threads (host_par.h): a thread owns a range of columns (or of entries for the element-wise divisions); the sums down a ROW keep their sequential
+  // pass (their order is the reference's), the row maxima of the Ruiz passes are folded from per-thread tables (a maximum has no order).
+  auto rows_div = [&](const std::vector<double> &R) { par_ranges((long)A->p[n], 400000, [&](long lo, long hi, int) { for (long q = lo; q < hi; ++q) A->x[q] /= R[A->i[q]]; }); };
+  auto cols = [&](auto body) { par_by_entries(A->p, (long)n, 400000, [&](long lo, long hi, int) { for (long j = lo; j < hi; ++j) body((abip_int)j); }); };
 
   if (stgs->pc_ruiz_rescale) { // common.c:217-266
-    for (abip_int j = 0; j < n; ++j) {
+    cols([&](abip_int j) {
       const abip_int len = A->p[j + 1] - A->p[j];
       const double e = clamp_scale(std::sqrt(col_norm1(&A->x[A->p[j]], len)), min_col, max_col);
       col_scale(&A->x[A->p[j]], 1.0 / e, len);
       E_pc[j] = e;
-    }
+    });
     std::fill(Dk.begin(), Dk.end(), 0.0);
     for (abip_int q = 0; q < A->p[n]; ++q) Dk[A->i[q]] += std::fabs(A->x[q]);
     for (abip_int i = 0; i < m; ++i) D_pc[i] = clamp_scale(std::sqrt(Dk[i]), min_row, max_row);
@@ -100,14 +104,23 @@ void normalize_A(ABIPMatrix *A, const ABIPSettings *stgs, std::vector<double> &D
   }
   if (stgs->pc_ruiz_rescale) { // common.c:339-413
     for (abip_int it = 0; it < stgs->ruiz_iter; ++it) {
-      for (abip_int j = 0; j < n; ++j) {
+      cols([&](abip_int j) {
         const abip_int len = A->p[j + 1] - A->p[j];
         const double e = clamp_scale(std::sqrt(col_norminf(&A->x[A->p[j]], len)), min_col, max_col);
         col_scale(&A->x[A->p[j]], 1.0 / e, len);
         Ek[j] = e;
-      }
+      });
       std::fill(Dk.begin(), Dk.end(), 0.0);
-      for (abip_int q = 0; q < A->p[n]; ++q) { const double w = std::fabs(A->x[q]); if (w >= Dk[A->i[q]]) Dk[A->i[q]] = w; }
+      {
+        const long nz = (long)A->p[n];
+        const int T = (int)std::max<long>(1, std::min<long>(par_threads(), nz / par_grain(400000)));
+        if (T <= 1) { for (abip_int q = 0; q < A->p[n]; ++q) { const double w = std::fabs(A->x[q]); if (w >= Dk[A->i[q]]) Dk[A->i[q]] = w; } }
+        else {
+          std::vector<std::vector<double>> part(T, std::vector<double>(m, 0.0));
+          par_ranges(nz, nz / T, [&](long lo, long hi, int t) { std::vector<double> &P = part[t]; for (long q = lo; q < hi; ++q) { const double w = std::fabs(A->x[q]); if (w >= P[A->i[q]]) P[A->i[q]] = w; } });
+          for (int t = 0; t < T; ++t) for (abip_int i = 0; i < m; ++i) if (part[t][i] >= Dk[i]) Dk[i] = part[t][i];
+        }
+      }
       for (abip_int i = 0; i < m; ++i) Dk[i] = clamp_scale(std::sqrt(Dk[i]), min_row, max_row);
       rows_div(Dk);
       for (abip_int j = 0; j < n; ++j) E_rz[j] = E_rz[j] * Ek[j];
@@ -163,12 +176,8 @@ void csc_as_csr(const ABIPMatrix *A, HostCsr &out) {
 void transpose_to_csr(const ABIPMatrix *A, HostCsr &out) {
   const abip_int m = A->m, n = A->n, nnz = A->p[n];
   out.nrows = (int)m; out.ncols = (int)n;
-  out.ptr.assign(m + 1, 0); out.idx.resize(nnz); out.val.resize(nnz);
-  for (abip_int q = 0; q < nnz; ++q) out.ptr[A->i[q] + 1]++;
-  for (abip_int i = 0; i < m; ++i) out.ptr[i + 1] += out.ptr[i];
-  std::vector<int> pos(out.ptr.begin(), out.ptr.end() - 1);
-  for (abip_int j = 0; j < n; ++j)
-    for (abip_int q = A->p[j]; q < A->p[j + 1]; ++q) { const int dst = pos[A->i[q]]++; out.idx[dst] = (int)j; out.val[dst] = A->x[q]; }
+  (void)nnz;
+  par_transpose((long)m, (long)n, A->p, A->i, A->x, out.ptr, out.idx, out.val); // (host_par.h)
 }
 
 void build_row_blocks(HostCsr &M, int chunk) {

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 
+#include "host_par.h"
 #include "qcp_work.h"
 
 namespace abip {
@@ -26,15 +27,18 @@ inline void apply_pass(QWk *w, std::vector<double> &Dp, std::vector<double> &Ep)
   const double min_col = kMinScale * std::sqrt((double)m), max_col = kMaxScale * std::sqrt((double)m);
   HMat &A = w->A, &Q = w->Q;
   for (int i = 0; i < m; ++i) { if (Dp[i] < min_row) Dp[i] = 1; else if (Dp[i] > max_row) Dp[i] = max_row; }
-  for (int i = 0; i < n; ++i) {
-    if (Ep[i] < min_col) Ep[i] = 1; else if (Ep[i] > max_col) Ep[i] = max_col;
-    for (int j = A.p[i]; j < A.p[i + 1]; ++j) A.x[j] /= Ep[i];
-  }
+  // (column ranges on a few host threads, host_par.h: every entry is touched by one thread, the arithmetic per entry is the sequential code's)
+  host::par_by_entries(A.p.data(), n, 400000, [&](long lo, long hi, int) {
+    for (long i = lo; i < hi; ++i) {
+      if (Ep[i] < min_col) Ep[i] = 1; else if (Ep[i] > max_col) Ep[i] = max_col;
+      for (int j = A.p[i]; j < A.p[i + 1]; ++j) A.x[j] /= Ep[i];
+    }
+  });
   if (w->hasQ) {
     for (int i = 0; i < n; ++i) for (int j = Q.p[i]; j < Q.p[i + 1]; ++j) Q.x[j] /= Ep[i];
     for (int q = 0; q < Q.p[n]; ++q) Q.x[q] /= Ep[Q.i[q]];
   }
-  for (int q = 0; q < A.p[n]; ++q) A.x[q] /= Dp[A.i[q]];
+  host::par_ranges((long)A.p[n], 400000, [&](long lo, long hi, int) { for (long q = lo; q < hi; ++q) A.x[q] /= Dp[A.i[q]]; });
   for (int i = 0; i < n; ++i) w->E[i] *= Ep[i];
   for (int i = 0; i < m; ++i) w->D[i] *= Dp[i];
 }
@@ -49,11 +53,19 @@ inline void scale_passes(QWk *w, const QCPCone *k) {
   if (w->st->ruiz_scaling) {
     for (int it = 0; it < 10; ++it) {
       std::fill(E2.begin(), E2.end(), 0.0); std::fill(Dp.begin(), Dp.end(), 0.0);
-      for (int j = 0; j < n; ++j) E1[j] = (A.p[j] == A.p[j + 1]) ? 0 : std::sqrt(col_inf(A, j));
+      host::par_by_entries(A.p.data(), n, 400000, [&](long lo, long hi, int) { for (long j = lo; j < hi; ++j) E1[j] = (A.p[j] == A.p[j + 1]) ? 0 : std::sqrt(col_inf(A, (int)j)); });
       if (w->hasQ) for (int j = 0; j < n; ++j) E2[j] = (Q.p[j] == Q.p[j + 1]) ? 0 : std::sqrt(col_inf(Q, j));
       for (int j = 0; j < n; ++j) Ep[j] = E1[j] < E2[j] ? E2[j] : E1[j];
       cone_average(Ep, k);
-      for (int q = 0; q < A.p[n]; ++q) if (Dp[A.i[q]] < std::fabs(A.x[q])) Dp[A.i[q]] = std::fabs(A.x[q]);
+      { // row maxima: a maximum does not depend on the order, so every thread takes a range of entries into a table of its own and the tables are folded
+        const int T = (int)std::max<long>(1, std::min<long>(host::par_threads(), (long)A.p[n] / host::par_grain(400000)));
+        if (T <= 1) { for (int q = 0; q < A.p[n]; ++q) if (Dp[A.i[q]] < std::fabs(A.x[q])) Dp[A.i[q]] = std::fabs(A.x[q]); }
+        else {
+          std::vector<std::vector<double>> part(T, std::vector<double>(m, 0.0));
+          host::par_ranges((long)A.p[n], (long)A.p[n] / T, [&](long lo, long hi, int t) { std::vector<double> &P = part[t]; for (long q = lo; q < hi; ++q) { const double a = std::fabs(A.x[q]); if (P[A.i[q]] < a) P[A.i[q]] = a; } });
+          for (int t = 0; t < T; ++t) for (int i = 0; i < m; ++i) if (Dp[i] < part[t][i]) Dp[i] = part[t][i];
+        }
+      }
       for (int i = 0; i < m; ++i) Dp[i] = std::sqrt(Dp[i]);
       apply_pass(w, Dp, Ep);
     }
@@ -143,14 +155,14 @@ inline void build_lasso(QWk *w, const QCPData *d) {
         E[i] = 1 / (E[i] * L.sc);
       }
     }
-    for (int i = 0; i < dn; ++i) for (int j = X->p[i]; j < X->p[i + 1]; ++j) xs[j] *= E[i];
+    host::par_by_entries(X->p, (long)dn, 400000, [&](long lo, long hi, int) { for (long i = lo; i < hi; ++i) for (int j = X->p[i]; j < X->p[i + 1]; ++j) xs[j] *= E[i]; });
   }
   for (int k = 0; k < xnnz; ++k) D[X->i[k]] += xs[k] * xs[k]; // :212-230
   double avg = 0;
   for (int i = 0; i < dm; ++i) avg += std::sqrt(2 * D[i] + L.sc_cone2);
   avg /= dm;
   for (int i = 0; i < dm; ++i) D[i] = avg / std::sqrt(2 * D[i] + L.sc_cone2);
-  for (int k = 0; k < xnnz; ++k) xs[k] *= D[X->i[k]];
+  host::par_ranges((long)xnnz, 400000, [&](long lo, long hi, int) { for (long k = lo; k < hi; ++k) xs[k] *= D[X->i[k]]; });
   L.y.assign(d->b, d->b + dm);
   w->b.assign(p, 0.0); w->c.assign(q, 0.0); // :232-250
   w->b[0] = L.sc_cone1;
@@ -161,17 +173,19 @@ inline void build_lasso(QWk *w, const QCPData *d) {
   for (double &t : w->c) t *= L.sc_c;
   // the operator of lasso_A_times (:99-110) as a p x q CSC matrix
   HMat &A = w->A;
-  A.m = p; A.n = q; A.p.assign(q + 1, 0); A.i.clear(); A.x.clear();
-  A.i.reserve((size_t)1 + dm + 2 * (size_t)xnnz); A.x.reserve(A.i.capacity());
+  A.m = p; A.n = q; A.p.assign(q + 1, 0);
+  A.i.assign((size_t)1 + dm + 2 * (size_t)xnnz, 0); A.x.assign(A.i.size(), 0.0);
   const double sq2 = std::sqrt(L.sc_cone2);
-  A.i.push_back(0); A.x.push_back(1.0); A.p[1] = 1; // column 0
-  A.p[2] = 1;                                         // column 1 is empty
-  for (int i = 0; i < dm; ++i) { A.i.push_back(1 + i); A.x.push_back(D[i] * sq2); A.p[3 + i] = (int)A.i.size(); }
-  for (int sign = 0; sign < 2; ++sign)
-    for (int j = 0; j < dn; ++j) {
-      for (int k = X->p[j]; k < X->p[j + 1]; ++k) { A.i.push_back(1 + X->i[k]); A.x.push_back(sign ? -xs[k] : xs[k]); }
-      A.p[dm + 2 + sign * dn + j + 1] = (int)A.i.size();
-    }
+  A.i[0] = 0; A.x[0] = 1.0; A.p[1] = 1; // column 0
+  A.p[2] = 1;                           // column 1 is empty
+  for (int i = 0; i < dm; ++i) { A.i[1 + i] = 1 + i; A.x[1 + i] = D[i] * sq2; A.p[3 + i] = 2 + i; }
+  for (int sign = 0; sign < 2; ++sign) { // [X~ | -X~]: the column pointers first, then the two copies filled by column ranges (host_par.h)
+    const int base = 1 + dm + sign * xnnz;
+    for (int j = 0; j < dn; ++j) A.p[dm + 2 + sign * dn + j + 1] = base + (int)X->p[j + 1];
+    host::par_by_entries(X->p, (long)dn, 400000, [&](long lo, long hi, int) {
+      for (long j = lo; j < hi; ++j) for (int k = X->p[j]; k < X->p[j + 1]; ++k) { A.i[base + k] = 1 + (int)X->i[k]; A.x[base + k] = sign ? -xs[k] : xs[k]; }
+    });
+  }
   w->D.assign(p, 1.0); w->E.assign(q, 1.0); w->sc_b = 1; w->sc_c = 1; // (neutral for the generic sums kq_resid still provides: certificates)
 }
 

@@ -36,11 +36,9 @@ void hcsr_from(const HMat &M, host::HostCsr &out, bool transpose_to_rows) {
   if (!transpose_to_rows) {
     out.nrows = M.n; out.ncols = M.m; out.ptr = M.p; out.idx = M.i; out.val = M.x;
   } else {
-    out.nrows = M.m; out.ncols = M.n; out.ptr.assign(M.m + 1, 0); out.idx.resize(nnz); out.val.resize(nnz);
-    for (int q = 0; q < nnz; ++q) out.ptr[M.i[q] + 1]++;
-    for (int i = 0; i < M.m; ++i) out.ptr[i + 1] += out.ptr[i];
-    std::vector<int> pos(out.ptr.begin(), out.ptr.end() - 1);
-    for (int j = 0; j < M.n; ++j) for (int q = M.p[j]; q < M.p[j + 1]; ++q) { const int dst = pos[M.i[q]]++; out.idx[dst] = j; out.val[dst] = M.x[q]; }
+    out.nrows = M.m; out.ncols = M.n;
+    (void)nnz;
+    host::par_transpose((long)M.m, (long)M.n, M.p.data(), M.i.data(), M.x.data(), out.ptr, out.idx, out.val); // (host_par.h: the counting sort on a few threads, entry for entry the same result)
   }
   host::build_row_blocks(out, CHUNK);
 }
