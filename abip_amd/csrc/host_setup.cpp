@@ -489,17 +489,18 @@ void complete_schur_on_host(LdlHost &F) {
 int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, const std::vector<double> &Kx, LdlHost &out) {
   out.N = N;
   const long kk = Kp[N];
-  // symmetric adjacency (no diagonal)
-  std::vector<int> Gp(N + 1, 0);
-  for (int j = 0; j < N; ++j) for (int q = Kp[j]; q < Kp[j + 1]; ++q) if (Ki[q] != j) { Gp[Ki[q] + 1]++; Gp[j + 1]++; }
-  for (int i = 0; i < N; ++i) Gp[i + 1] += Gp[i];
-  std::vector<int> Gi(Gp[N]), pos(Gp.begin(), Gp.end() - 1);
-  for (int j = 0; j < N; ++j) for (int q = Kp[j]; q < Kp[j + 1]; ++q) if (Ki[q] != j) { Gi[pos[Ki[q]]++] = j; Gi[pos[j]++] = Ki[q]; }
   const bool tm = getenv("ABIP_HIP_SETUP_TIMES") != nullptr;
   auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tq = clk();
   if (g_order_hint && (int)g_order_hint->size() == N) { out.P = *g_order_hint; if (tm) printf("[setup] ordering: the caller's elimination order\n"); }
-  else min_degree(N, Gp, Gi, out.P);
+  else { // symmetric adjacency (no diagonal) for the minimum-degree pass (not built when the caller brings the order: two passes over the matrix)
+    std::vector<int> Gp(N + 1, 0);
+    for (int j = 0; j < N; ++j) for (int q = Kp[j]; q < Kp[j + 1]; ++q) if (Ki[q] != j) { Gp[Ki[q] + 1]++; Gp[j + 1]++; }
+    for (int i = 0; i < N; ++i) Gp[i + 1] += Gp[i];
+    std::vector<int> Gi(Gp[N]), pos(Gp.begin(), Gp.end() - 1);
+    for (int j = 0; j < N; ++j) for (int q = Kp[j]; q < Kp[j + 1]; ++q) if (Ki[q] != j) { Gi[pos[Ki[q]]++] = j; Gi[pos[j]++] = Ki[q]; }
+    min_degree(N, Gp, Gi, out.P);
+  }
   if (tm) { printf("[setup] ordering %.3f s\n", clk() - tq); tq = clk(); }
   std::vector<int> Pinv(N);
   for (int i = 0; i < N; ++i) Pinv[out.P[i]] = i;
@@ -513,27 +514,19 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
     const int a = Pinv[Ki[q]], b = Pinv[j], r = std::min(a, b), c = std::max(a, b);
     Ci[cpos[c]] = r; Cx[cpos[c]] = Kx[q]; cpos[c]++;
   }
-  // elimination tree + column counts
+  // elimination tree
   std::vector<int> parent(N, -1), anc(N, -1), flag(N, -1), lnz(N, 0);
   for (int j = 0; j < N; ++j)
     for (int q = Cp[j]; q < Cp[j + 1]; ++q) {
       int r = Ci[q];
       while (r != -1 && r < j) { const int nx = anc[r]; anc[r] = j; if (nx == -1) parent[r] = j; r = nx; }
     }
-  for (int j = 0; j < N; ++j) {
-    flag[j] = j;
-    for (int q = Cp[j]; q < Cp[j + 1]; ++q) { int r = Ci[q]; while (r < j && flag[r] != j) { lnz[r]++; flag[r] = j; r = parent[r]; } }
-  }
-  std::vector<long> Lp(N + 1, 0);
-  for (int j = 0; j < N; ++j) Lp[j + 1] = Lp[j] + lnz[j];
-  if (tm) { printf("[setup] symbolic %.3f s (nnz(L) = %ld)\n", clk() - tq, Lp[N]); tq = clk(); }
-  out.lnnz = Lp[N];
 
   // ---- head / dense-tail split -----------------------------------------------------------------------------------
   // With a fill-reducing ordering the last pivots form a (nearly) dense trailing block whose rows are one level each:
   // the sequential part of a level-scheduled solve.  Columns >= t0 are therefore not kept as a sparse factor: the host
   // computes only the Schur complement S onto them (sparse arithmetic), the device factors S densely and applies
-  // inv(L22) as two dense triangular mat-vecs (dev_ldl.h).
+  // inv(L22) as two dense triangular mat-vecs (dev_ldl.h).  (Chosen from the tree alone, before the column counts: see below.)
   int T = 0;
   {
     const int Tmax = std::min(N - 1, tail_cap());
@@ -555,8 +548,21 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
       }
     }
   }
-  out.S.clear(); out.k22_row.clear(); out.k22_col.clear(); out.k22_val.clear();
   const int t0 = N - T;
+  // column counts (LDL_symbolic, ldl.c:70-120): row j's pattern = the tree paths from its entries up to j.  Nothing ever reads the pattern of a LARGE dense tail
+  // (it is factored as a dense block on the device), and walking it is T^2 / 2 steps (C5: 5e7 of the 5.45e7 entries of L, 0.1 s): from T = 2048 on the walks stop
+  // at the first tail column and the tail is counted as the dense triangle it is stored as.
+  const bool skip_tail_pattern = T >= 2048;
+  const int lim = skip_tail_pattern ? t0 : N;
+  for (int j = 0; j < N; ++j) {
+    flag[j] = j;
+    for (int q = Cp[j]; q < Cp[j + 1]; ++q) { int r = Ci[q]; while (r < j && r < lim && flag[r] != j) { lnz[r]++; flag[r] = j; r = parent[r]; } }
+  }
+  std::vector<long> Lp(N + 1, 0);
+  for (int j = 0; j < N; ++j) Lp[j + 1] = Lp[j] + lnz[j];
+  out.lnnz = Lp[N] + (skip_tail_pattern ? (long)T * (T - 1) / 2 : 0L);
+  if (tm) { printf("[setup] symbolic %.3f s (nnz(L) = %ld%s)\n", clk() - tq, out.lnnz, skip_tail_pattern ? ", the tail counted as dense" : ""); tq = clk(); }
+  out.S.clear(); out.k22_row.clear(); out.k22_col.clear(); out.k22_val.clear();
   out.t0 = t0; out.T = T;
 
   // numeric, up-looking: row k of L by a sparse triangular solve against the leading block.  For a tail row only the head
@@ -578,7 +584,7 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
       if (r >= t0) { out.k22_row.push_back(k - t0); out.k22_col.push_back(r - t0); out.k22_val.push_back(Cx[q]); continue; } // tail-tail: an entry of K22 (its etree path stays in the tail)
       Y[r] += Cx[q];
       int len = 0;
-      while (flag[r] != k) { pat[len++] = r; flag[r] = k; r = parent[r]; }
+      while (r < t0 && flag[r] != k) { pat[len++] = r; flag[r] = k; r = parent[r]; } // (a tail column's ancestors are tail columns, and those are skipped below: the walk ends at the head's edge)
       while (len > 0) stack[--top] = pat[--len];
     }
     if (k == t0) hfill = fill; // from here on only tail rows arrive: a head column's first hfill entries are its head rows
