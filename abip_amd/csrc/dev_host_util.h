@@ -39,6 +39,9 @@ struct DBuf { // device buffer
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+// dev_transpose.hip: CSC -> CSR on the device (a stable sort of the entry numbers by row); 0 = done and synchronised
+int dev_csc_to_csr(int nrows, int ncols, long nnz, const int *cp, const int *ri, const double *cx, int *out_ptr, int *out_col, double *out_val, hipStream_t s);
+
 struct DevCsr {
   DBuf<int> ptr, idx, rbd; // rbd: 4 ints per row block, read as int4
   DBuf<double> val;
@@ -54,6 +57,22 @@ struct DevCsr {
       if (sval.upload(h.sval, s) || sidx.upload(h.sidx, s) || slen.upload(h.slen, s) || soff.upload(h.soff, s)) return -1;
       nslices = (int)h.slen.size();
     }
+    return 0;
+  }
+  // the row form of an operator whose column form C (= the CSR of its transpose: ncols rows) is already resident: transposed on the device (dev_transpose.hip),
+  // only the row pointers come back for the row blocks.  != 0: nothing kept, the caller builds and uploads the host's form instead
+  int from_columns(const DevCsr &C, int nrows_, long nnz, int chunk, hipStream_t s) {
+    nrows = nrows_; nslices = 0;
+    if (ptr.alloc((size_t)nrows + 1) || idx.alloc((size_t)nnz) || val.alloc((size_t)nnz)) { release(); return -1; }
+    if (dev_csc_to_csr(nrows, C.nrows, nnz, C.ptr.p, C.idx.p, C.val.p, ptr.p, idx.p, val.p, s)) { release(); (void)hipGetLastError(); return -1; }
+    host::HostCsr h;
+    h.nrows = nrows; h.ptr.resize((size_t)nrows + 1);
+    if (hipMemcpyAsync(h.ptr.data(), ptr.p, sizeof(int) * ((size_t)nrows + 1), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { release(); (void)hipGetLastError(); return -1; }
+    host::build_row_blocks(h, chunk);
+    nrb = (int)h.rb.size() - 1;
+    std::vector<int> d4((size_t)4 * std::max(nrb, 1), 0);
+    for (int q = 0; q < nrb; ++q) { d4[4 * q] = h.rb[q]; d4[4 * q + 1] = h.rb[q + 1]; d4[4 * q + 2] = h.ptr[h.rb[q]]; d4[4 * q + 3] = h.ptr[h.rb[q + 1]]; }
+    if (rbd.upload(d4, s)) { release(); return -1; }
     return 0;
   }
   Csr view() const { return Csr{ptr.p, idx.p, val.p, (const int4 *)rbd.p, nrb, nrows, sval.p, sidx.p, soff.p, slen.p, nslices}; }

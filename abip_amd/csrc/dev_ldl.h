@@ -17,6 +17,7 @@
 // Set-up kernels: the two that carry the flops (the trailing update of the dense LDL' and the Schur complement's rank-k update) run on the matrix cores
 // (v_mfma_f64_16x16x4_f64, 64 x 64 tiles through LDS); the rest is LDS-tiled fp64 FMA code.
 #pragma once
+#include "host_par.h"
 #include <algorithm>
 #include <chrono>
 #include <functional>
@@ -641,14 +642,25 @@ struct DevLdl {
     auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tq = clk();
     auto lap = [&](const char *what) { if (tms) { (void)hipStreamSynchronize(s); const double t = clk(); printf("[setup]   device: %s %.3f s\n", what, t - tq); tq = t; } };
+    if (Pmap.upload(pmap, s) || D.upload(H.D, s) || xw.alloc(N)) return -1;
+    // the dense tail first: the host may still be building the level-ordered forms of the head (LdlHost::forms_job), which nothing below needs
+    const int rt = T > 0 ? setup_tail(H, s, tms) : 0;
+    H.wait_forms();
+    if (rt) return rt;
+    tq = clk();
     // small systems: the whole sparse part in one workgroup (x in LDS), whatever the shape of the levels
     const bool one_wg = N <= XL_MAX && H.fwd.idx.size() <= 32768 && H.bwd.idx.size() <= 32768;
-    if (Pmap.upload(pmap, s) || D.upload(H.D, s) || xw.alloc(N) || F.upload(H.fwd, s, one_wg) || B.upload(H.bwd, s, one_wg)) return -1;
+    if (F.upload(H.fwd, s, one_wg) || B.upload(H.bwd, s, one_wg)) return -1;
     small = F.single_workgroup() && B.single_workgroup() && N <= 65536;
     xl = small && N <= XL_MAX;
     if (xl && !allow_lds<NoFuse>()) xl = false;
     lap("upload of the sparse head (forward / backward forms)");
-    if (T == 0) return 0;
+    return 0;
+  }
+  int setup_tail(const host::LdlHost &H, hipStream_t s, bool tms) {
+    auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tq = clk();
+    auto lap = [&](const char *what) { if (tms) { (void)hipStreamSynchronize(s); const double t = clk(); printf("[setup]   device: %s %.3f s\n", what, t - tq); tq = t; } };
 #ifdef ABIP_HIP_TEST_HOOKS // fault injection exists only in the library variant the tests build (libabip_hip_hooks.so): the shipped one ignores these variables
     if (getenv("ABIP_HIP_TAIL_FAIL")) return -1; // pretend the dense set-up failed (the callers fall back to T = 0)
 #endif
@@ -670,14 +682,12 @@ struct DevLdl {
     lap("upload of S (K22), allocations");
     const bool use_mfma = !(getenv("ABIP_HIP_MFMA") && atoi(getenv("ABIP_HIP_MFMA")) == 0); // the dense set-up products on the matrix cores (0: the LDS-tiled FMA kernels)
     if (H.dev_schur && H.schur_rows) { // sparse L21: the row-wise kernel (LDS accumulator of T doubles per wavefront)
-      std::vector<long> rptr((size_t)T + 1, 0), cposv(H.l21_row.size());
+      // L21 by tail row: (head column, position in the column form) of every entry, columns ascending inside a row (host_par.h: a stable bucket pass)
+      std::vector<int> rp32;
+      std::vector<long> cposv(H.l21_row.size());
       std::vector<int> rcol(H.l21_row.size());
-      for (size_t q = 0; q < H.l21_row.size(); ++q) rptr[H.l21_row[q] + 1]++;
-      for (int i = 0; i < T; ++i) rptr[i + 1] += rptr[i];
-      {
-        std::vector<long> pos(rptr.begin(), rptr.end() - 1);
-        for (int c = 0; c < t0; ++c) for (long q = H.l21_ptr[c]; q < H.l21_ptr[c + 1]; ++q) { const long dst = pos[H.l21_row[q]]++; rcol[dst] = c; cposv[dst] = q; }
-      }
+      host::par_bucket((long)t0, H.l21_ptr.data(), (long)T, rp32, 1000000, [&](long, long q) { return (long)H.l21_row[q]; }, [&](long dst, long c, long q) { rcol[dst] = (int)c; cposv[dst] = q; });
+      std::vector<long> rptr(rp32.begin(), rp32.end());
       DBuf<long> drp, dcp, dpos; DBuf<int> drc, dcr; DBuf<double> dcv;
       auto drop = [&]() { drp.release(); dcp.release(); dpos.release(); drc.release(); dcr.release(); dcv.release(); };
       if (drp.upload(rptr, s) || drc.upload(rcol, s) || dpos.upload(cposv, s) || dcp.upload(H.l21_ptr, s) || dcr.upload(H.l21_row, s) || dcv.upload(H.l21_val, s)) { drop(); return -1; }

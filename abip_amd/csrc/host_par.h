@@ -92,33 +92,43 @@ inline void par_by_entries(const P *ptr, long n, long grain_entries, F fn) {
 }
 inline int par_threads() { return Pool::get().threads(); }
 
-// CSC (ncols columns, row indices ri, nrows rows) -> CSR: out_ptr (nrows + 1), out_col, out_val, entries of a row in ascending column order -- what the
-// sequential counting sort produces, entry for entry.  Threads own column ranges for the counts and the scatter (a row's slots are dealt to the
-// threads in column order), so no two threads write the same slot.
-template <class PI, class RI>
-inline void par_transpose(long nrows, long ncols, const PI *cp, const RI *ri, const double *cx, std::vector<int> &out_ptr, std::vector<int> &out_col, std::vector<double> &out_val) {
-  const long nnz = (long)cp[ncols];
-  out_ptr.assign(nrows + 1, 0); out_col.resize(nnz); out_val.resize(nnz);
-  const int T = (int)std::max<long>(1, std::min<long>(std::min<long>(par_threads(), ncols), nnz / par_grain(2000000)));
+// A stable bucket pass over the entries of a compressed matrix (ncols columns, cp): entry q of column j goes to bucket key(j, q) in [0, nb); inside a bucket the
+// entries keep the order of the sequential double loop (j ascending, q ascending).  out_ptr (nb + 1) receives the bucket extents, emit(dst, j, q) stores
+// entry q at slot dst.  Threads own column ranges for the counts and for the scatter (a bucket's slots are dealt to the threads in column order), so no two
+// threads write the same slot and the result is the sequential counting sort's, entry for entry.
+template <class PI, class Key, class Emit>
+inline void par_bucket(long ncols, const PI *cp, long nb, std::vector<int> &out_ptr, long grain, Key key, Emit emit) {
+  const long nnz = (long)cp[ncols] - (long)cp[0];
+  out_ptr.assign(nb + 1, 0);
+  const int T = (int)std::max<long>(1, std::min<long>(std::min<long>(par_threads(), ncols), nnz / par_grain(grain)));
   if (T <= 1) {
-    for (long q = 0; q < nnz; ++q) out_ptr[ri[q] + 1]++;
-    for (long i = 0; i < nrows; ++i) out_ptr[i + 1] += out_ptr[i];
+    for (long j = 0; j < ncols; ++j) for (long q = cp[j]; q < (long)cp[j + 1]; ++q) out_ptr[key(j, q) + 1]++;
+    for (long i = 0; i < nb; ++i) out_ptr[i + 1] += out_ptr[i];
     std::vector<int> pos(out_ptr.begin(), out_ptr.end() - 1);
-    for (long j = 0; j < ncols; ++j) for (long q = cp[j]; q < (long)cp[j + 1]; ++q) { const int dst = pos[ri[q]]++; out_col[dst] = (int)j; out_val[dst] = cx[q]; }
+    for (long j = 0; j < ncols; ++j) for (long q = cp[j]; q < (long)cp[j + 1]; ++q) emit((long)pos[key(j, q)]++, j, q);
     return;
   }
   std::vector<long> cut(T + 1, ncols);
   cut[0] = 0;
-  for (int t = 1; t < T; ++t) cut[t] = std::max<long>(cut[t - 1], std::lower_bound(cp, cp + ncols + 1, (PI)(nnz * t / T)) - cp);
-  std::vector<std::vector<int>> cnt(T, std::vector<int>(nrows, 0)); // entries of row i among thread t's columns
-  Pool::get().run(T, [&](int t) { for (long q = cp[cut[t]]; q < (long)cp[cut[t + 1]]; ++q) cnt[t][ri[q]]++; });
-  for (long i = 0; i < nrows; ++i) { int s = 0; for (int t = 0; t < T; ++t) { const int c = cnt[t][i]; cnt[t][i] = s; s += c; } out_ptr[i + 1] = s; } // -> offset of thread t inside row i
-  for (long i = 0; i < nrows; ++i) out_ptr[i + 1] += out_ptr[i];
+  for (int t = 1; t < T; ++t) cut[t] = std::max<long>(cut[t - 1], std::lower_bound(cp, cp + ncols + 1, (PI)((long)cp[0] + nnz * t / T)) - cp);
+  std::vector<std::vector<int>> cnt(T); // entries of bucket i among thread t's columns
+  Pool::get().run(T, [&](int t) { cnt[t].assign(nb, 0); for (long j = cut[t]; j < cut[t + 1]; ++j) for (long q = cp[j]; q < (long)cp[j + 1]; ++q) cnt[t][key(j, q)]++; });
+  par_ranges(nb, 1 << 16, [&](long lo, long hi, int) { for (long i = lo; i < hi; ++i) { int s = 0; for (int t = 0; t < T; ++t) { const int c = cnt[t][i]; cnt[t][i] = s; s += c; } out_ptr[i + 1] = s; } }); // -> offset of thread t inside bucket i
+  for (long i = 0; i < nb; ++i) out_ptr[i + 1] += out_ptr[i];
   Pool::get().run(T, [&](int t) {
     std::vector<int> &off = cnt[t];
     for (long j = cut[t]; j < cut[t + 1]; ++j)
-      for (long q = cp[j]; q < (long)cp[j + 1]; ++q) { const long i = ri[q]; const int dst = out_ptr[i] + off[i]++; out_col[dst] = (int)j; out_val[dst] = cx[q]; }
+      for (long q = cp[j]; q < (long)cp[j + 1]; ++q) { const long i = key(j, q); emit((long)out_ptr[i] + off[i]++, j, q); }
   });
+}
+
+// CSC (ncols columns, row indices ri, nrows rows) -> CSR: out_ptr (nrows + 1), out_col, out_val, entries of a row in ascending column order -- what the
+// sequential counting sort produces, entry for entry.
+template <class PI, class RI>
+inline void par_transpose(long nrows, long ncols, const PI *cp, const RI *ri, const double *cx, std::vector<int> &out_ptr, std::vector<int> &out_col, std::vector<double> &out_val) {
+  const long nnz = (long)cp[ncols];
+  out_col.resize(nnz); out_val.resize(nnz);
+  par_bucket(ncols, cp, nrows, out_ptr, 2000000, [&](long, long q) { return (long)ri[q]; }, [&](long dst, long j, long q) { out_col[dst] = (int)j; out_val[dst] = cx[q]; });
 }
 
 } // namespace host

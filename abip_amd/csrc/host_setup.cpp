@@ -370,11 +370,13 @@ void level_sets(int N, TriHost &T, bool backward) {
   std::vector<double> v2;
   for (int r = 0; r < npos; ++r) p2[r + 1] = p2[r] + (T.ptr[T.lev_rows[r] + 1] - T.ptr[T.lev_rows[r]]);
   i2.resize(p2[npos]); v2.resize(p2[npos]);
-  for (int r = 0; r < npos; ++r) {
-    const int row = T.lev_rows[r];
-    std::copy(T.idx.begin() + T.ptr[row], T.idx.begin() + T.ptr[row + 1], i2.begin() + p2[r]);
-    std::copy(T.val.begin() + T.ptr[row], T.val.begin() + T.ptr[row + 1], v2.begin() + p2[r]);
-  }
+  par_by_entries(p2.data(), (long)npos, 500000, [&](long r0, long r1, int) {
+    for (long r = r0; r < r1; ++r) {
+      const int row = T.lev_rows[r];
+      std::copy(T.idx.begin() + T.ptr[row], T.idx.begin() + T.ptr[row + 1], i2.begin() + p2[r]);
+      std::copy(T.val.begin() + T.ptr[row], T.val.begin() + T.ptr[row + 1], v2.begin() + p2[r]);
+    }
+  });
   T.ptr.swap(p2); T.idx.swap(i2); T.val.swap(v2);
 }
 
@@ -385,6 +387,7 @@ namespace { const std::vector<int> *g_order_hint = nullptr; }
 void set_order_hint(const std::vector<int> *P) { g_order_hint = P; }
 
 int host_solve(const LdlHost &F, std::vector<double> &b) {
+  F.wait_forms();
   const int N = F.N, t0 = F.t0, T = F.T;
   if ((int)b.size() != N) return -1;
   std::vector<double> x(N);
@@ -487,6 +490,7 @@ void complete_schur_on_host(LdlHost &F) {
 }
 
 int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, const std::vector<double> &Kx, LdlHost &out) {
+  out.wait_forms(); out.forms_job = std::shared_future<void>(); // (a second factorisation into the same object: the first one's forms thread is through)
   out.N = N;
   const long kk = Kp[N];
   const bool tm = getenv("ABIP_HIP_SETUP_TIMES") != nullptr;
@@ -504,16 +508,11 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
   if (tm) { printf("[setup] ordering %.3f s\n", clk() - tq); tq = clk(); }
   std::vector<int> Pinv(N);
   for (int i = 0; i < N; ++i) Pinv[out.P[i]] = i;
-  // C = upper triangle of P K P' by columns (cs_symperm, direct.c:259-260)
-  std::vector<int> Cp(N + 1, 0);
-  for (int j = 0; j < N; ++j) for (int q = Kp[j]; q < Kp[j + 1]; ++q) Cp[std::max(Pinv[Ki[q]], Pinv[j]) + 1]++;
-  for (int i = 0; i < N; ++i) Cp[i + 1] += Cp[i];
-  std::vector<int> Ci(kk), cpos(Cp.begin(), Cp.end() - 1);
+  // C = upper triangle of P K P' by columns (cs_symperm, direct.c:259-260): a stable bucket pass over the entries of K (host_par.h)
+  std::vector<int> Cp, Ci(kk);
   std::vector<double> Cx(kk);
-  for (int j = 0; j < N; ++j) for (int q = Kp[j]; q < Kp[j + 1]; ++q) {
-    const int a = Pinv[Ki[q]], b = Pinv[j], r = std::min(a, b), c = std::max(a, b);
-    Ci[cpos[c]] = r; Cx[cpos[c]] = Kx[q]; cpos[c]++;
-  }
+  par_bucket((long)N, Kp.data(), (long)N, Cp, 1000000, [&](long j, long q) { return (long)std::max(Pinv[Ki[q]], Pinv[j]); },
+             [&](long dst, long j, long q) { Ci[dst] = std::min(Pinv[Ki[q]], Pinv[j]); Cx[dst] = Kx[q]; });
   // elimination tree
   std::vector<int> parent(N, -1), anc(N, -1), flag(N, -1), lnz(N, 0);
   for (int j = 0; j < N; ++j)
@@ -639,19 +638,31 @@ int factor_upper(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, 
     }
     if (tm) { printf("[setup] Schur complement L21 D L21' (%.2e multiply-adds): %s %.3f s\n", cost, out.dev_schur ? (out.schur_rows ? "left to the device (row-wise, sparse)" : "left to the device (dense panels)") : "host", clk() - tq); tq = clk(); }
   }
-  // backward form = CSC of the head columns of L (all rows); forward form = CSR of [L11; L21]
-  out.bwd.ptr.assign(N + 1, 0);
-  for (int j = 0; j <= N; ++j) out.bwd.ptr[j] = (int)Lp[std::min(j, t0)];
-  out.bwd.idx.assign(Li.begin(), Li.begin() + Lhead); out.bwd.val.assign(Lx.begin(), Lx.begin() + Lhead);
-  out.fwd.ptr.assign(N + 1, 0);
-  for (long q = 0; q < Lhead; ++q) out.fwd.ptr[Li[q] + 1]++;
-  for (int i = 0; i < N; ++i) out.fwd.ptr[i + 1] += out.fwd.ptr[i];
-  out.fwd.idx.resize(Lhead); out.fwd.val.resize(Lhead);
-  std::vector<int> rpos(out.fwd.ptr.begin(), out.fwd.ptr.end() - 1);
-  for (int j = 0; j < t0; ++j) for (long q = Lp[j]; q < Lp[j + 1]; ++q) { const int dst = rpos[Li[q]]++; out.fwd.idx[dst] = j; out.fwd.val[dst] = Lx[q]; }
-  level_sets(N, out.fwd, false);
-  level_sets(N, out.bwd, true);
-  if (tm) printf("[setup] forward / backward forms + level sets %.3f s\n", clk() - tq);
+  // backward form = CSC of the head columns of L (all rows); forward form = CSR of [L11; L21].  The two are independent: the backward one is built on
+  // a thread of its own while this one transposes (host_par.h) and levels the forward one.  Nothing of the dense tail's set-up reads them: with a tail
+  // and a large head the whole job runs behind the caller's back (LdlHost::forms_job), the device starts on the Schur complement meanwhile
+  struct Head { std::vector<long> Lp; std::vector<int> Li; std::vector<double> Lx; };
+  auto head = std::make_shared<Head>();
+  head->Lp.swap(Lp); head->Li.swap(Li); head->Lx.swap(Lx);
+  LdlHost *o = &out;
+  const char *fe = getenv("ABIP_HIP_FORMS_ASYNC"); // 0: never, 1: always (tests), unset: large heads in front of a dense tail
+  const bool async = fe ? atoi(fe) != 0 : (T > 0 && Lhead >= 1000000);
+  auto forms = [head, o, N, t0, Lhead, tm, clk, async]() {
+    const double ts = clk();
+    const std::vector<long> &Lp = head->Lp; const std::vector<int> &Li = head->Li; const std::vector<double> &Lx = head->Lx;
+    std::thread back([&] {
+      o->bwd.ptr.assign(N + 1, 0);
+      for (int j = 0; j <= N; ++j) o->bwd.ptr[j] = (int)Lp[std::min(j, t0)];
+      o->bwd.idx.assign(Li.begin(), Li.begin() + Lhead); o->bwd.val.assign(Lx.begin(), Lx.begin() + Lhead);
+      level_sets(N, o->bwd, true);
+    });
+    par_transpose(N, t0, Lp.data(), Li.data(), Lx.data(), o->fwd.ptr, o->fwd.idx, o->fwd.val);
+    level_sets(N, o->fwd, false);
+    back.join();
+    if (tm) printf("[setup] forward / backward forms + level sets %.3f s%s\n", clk() - ts, async ? " (beside the device's work on the tail)" : "");
+  };
+  if (async) out.forms_job = std::async(std::launch::async, forms).share();
+  else forms();
   return 0;
 }
 

@@ -1,5 +1,6 @@
 // host_setup.h -- one-off host-side preparation for the device solver (runs once per abip_init).
 #pragma once
+#include <future>
 #include <vector>
 
 #include "../../include/abip.h"
@@ -48,7 +49,11 @@ struct LdlHost {
   long lnnz = 0;         // strictly-lower non-zeros of the complete factor (head + tail), as LDL_symbolic counts them
   std::vector<int> P;    // P[k] = original KKT index of pivot k
   std::vector<double> D; // pivots of the head [0, t0); the tail's come from the device factorisation
-  TriHost fwd, bwd;      // sparse part: columns < t0 of L (rows of the tail included)
+  TriHost fwd, bwd;      // sparse part: columns < t0 of L (rows of the tail included).  On large factors with a dense tail factor_upper returns BEFORE these two are
+                         // built: a thread of its own fills them in while the device already works on the tail (dev_ldl.h) -- wait_forms() before reading them
+  std::shared_future<void> forms_job;
+  void wait_forms() const { if (forms_job.valid()) forms_job.wait(); }
+  ~LdlHost() { wait_forms(); }
   int t0 = 0, T = 0;     // head size, dense-tail size (T % 64 == 0, t0 + T = N)
   std::vector<double> S; // T x T row-major, lower triangle: Schur complement of the head onto the tail -- EMPTY when dev_schur: then K22 arrives as the triplets below
   std::vector<int> k22_row, k22_col; std::vector<double> k22_val; // K22 (tail-local indices, row >= col): what S is before L21 D1 L21' is subtracted

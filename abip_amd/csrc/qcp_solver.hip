@@ -495,8 +495,19 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   for (hipEvent_t &e : w->ev_ph) if (hipEventCreate(&e) != hipSuccess) return bail("hipEventCreate failed");
   { // matrices
     host::HostCsr hAt, hA, hQ;
-    hcsr_from(w->A, hAt, false); hcsr_from(w->A, hA, true);
-    if (w->dAt.upload(hAt, w->stream) || w->dA.upload(hA, w->stream)) return bail("device allocation failure");
+    // the column form IS the work's copy of A: lent to the upload instead of copied (22 M entries on the LASSO protocol)
+    hAt.nrows = w->A.n; hAt.ncols = w->A.m; hAt.ptr.swap(w->A.p); hAt.idx.swap(w->A.i); hAt.val.swap(w->A.x);
+    host::build_row_blocks(hAt, CHUNK);
+    bool up_bad = w->dAt.upload(hAt, w->stream) != 0;
+    hAt.ptr.swap(w->A.p); hAt.idx.swap(w->A.i); hAt.val.swap(w->A.x);
+    // the row form: large operators are transposed on the device from the column form just uploaded (dev_transpose.hip: the same arrays entry for entry, no second
+    // pass over the matrix on the host and half the upload); small ones, or a device transpose that found no room, take the host's counting sort
+    const long nnzA = w->A.p[w->A.n];
+    const char *dt = getenv("ABIP_HIP_DEV_TRANSPOSE"); // 0: never, 1: always (tests)
+    bool on_dev = !up_bad && nnzA > 0 && (dt ? atoi(dt) != 0 : nnzA >= 2000000);
+    if (on_dev && w->dA.from_columns(w->dAt, w->A.m, nnzA, CHUNK, w->stream)) on_dev = false;
+    if (!up_bad && !on_dev) { hcsr_from(w->A, hA, true); up_bad = w->dA.upload(hA, w->stream) != 0; }
+    if (up_bad) return bail("device allocation failure");
     long nrb = std::max<long>(std::max<long>(w->dAt.nrb, w->dA.nrb), (std::max(m, nl) + 4 * BS - 1) / (4 * BS));
     if (w->hasQ) { hcsr_from(w->Q, hQ, false); if (w->dQ.upload(hQ, w->stream)) return bail("device allocation failure"); nrb = std::max<long>(nrb, w->dQ.nrb); }
     if (w->dist) // the replicated m-space kernels must sum in the same order on every rank: a grid that depends on global quantities only
@@ -557,20 +568,34 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
     const int N = m + nl;
     const double rho_y = st->rho_y, rho_x = w->kkt_rho_x;
     std::vector<int> Kp(N + 1), Ki; std::vector<double> Kx;
-    Ki.reserve(N + w->A.p[nl] + (w->hasQ ? w->Q.p[nl] : 0)); Kx.reserve(Ki.capacity());
-    for (int i = 0; i < m; ++i) { Kp[i] = (int)Ki.size(); Ki.push_back(i); Kx.push_back(-rho_y); }
-    for (int i = 0; i < nl; ++i) {
-      Kp[m + i] = (int)Ki.size();
-      for (int j = w->A.p[i]; j < w->A.p[i + 1]; ++j) { Ki.push_back(w->A.i[j]); Kx.push_back(-w->A.x[j]); }
-      if (!w->hasQ || w->Q.p[i] == w->Q.p[i + 1]) { Ki.push_back(m + i); Kx.push_back(rho_x); }
-      else for (int j = w->Q.p[i]; j < w->Q.p[i + 1]; ++j) {
-        if (w->Q.i[j] > i) continue;
-        const double t = (w->Q.i[j] == i) ? w->Q.x[j] + rho_x : w->Q.x[j];
-        if (t == 0) continue; // cs_dropzeros
-        Ki.push_back(m + w->Q.i[j]); Kx.push_back(t);
+    if (!w->hasQ) { // column m + i = -A(:, i) on top of rho_x: the extents are known up front, the columns filled by ranges of equal work (host_par.h)
+      const long kk = (long)m + w->A.p[nl] + nl;
+      Ki.resize(kk); Kx.resize(kk);
+      for (int i = 0; i < m; ++i) { Kp[i] = i; Ki[i] = i; Kx[i] = -rho_y; }
+      for (int i = 0; i <= nl; ++i) Kp[m + i] = m + w->A.p[i] + i;
+      host::par_by_entries(w->A.p.data(), (long)nl, 500000, [&](long lo, long hi, int) {
+        for (long i = lo; i < hi; ++i) {
+          long dst = Kp[m + i];
+          for (int j = w->A.p[i]; j < w->A.p[i + 1]; ++j, ++dst) { Ki[dst] = w->A.i[j]; Kx[dst] = -w->A.x[j]; }
+          Ki[dst] = m + (int)i; Kx[dst] = rho_x;
+        }
+      });
+    } else {
+      Ki.reserve(N + w->A.p[nl] + w->Q.p[nl]); Kx.reserve(Ki.capacity());
+      for (int i = 0; i < m; ++i) { Kp[i] = (int)Ki.size(); Ki.push_back(i); Kx.push_back(-rho_y); }
+      for (int i = 0; i < nl; ++i) {
+        Kp[m + i] = (int)Ki.size();
+        for (int j = w->A.p[i]; j < w->A.p[i + 1]; ++j) { Ki.push_back(w->A.i[j]); Kx.push_back(-w->A.x[j]); }
+        if (w->Q.p[i] == w->Q.p[i + 1]) { Ki.push_back(m + i); Kx.push_back(rho_x); }
+        else for (int j = w->Q.p[i]; j < w->Q.p[i + 1]; ++j) {
+          if (w->Q.i[j] > i) continue;
+          const double t = (w->Q.i[j] == i) ? w->Q.x[j] + rho_x : w->Q.x[j];
+          if (t == 0) continue; // cs_dropzeros
+          Ki.push_back(m + w->Q.i[j]); Kx.push_back(t);
+        }
       }
+      Kp[N] = (int)Ki.size();
     }
-    Kp[N] = (int)Ki.size();
     host::LdlHost F;
     std::vector<int> pmap(N);
     // x block diagonal and the Schur complement onto the y block dense anyway (pairs of non-zeros per column >= a quarter of the m (m - 1) / 2 entries):

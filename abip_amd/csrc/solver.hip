@@ -2210,9 +2210,12 @@ int abip_hip_host_factor_solve(const ABIPMatrix *A, double rho_y, int tail, doub
   const int rc = host::factor_kkt(A, rho_y, F);
   host::set_tail_request(-2);
   if (rc < 0) return -2;
-  std::vector<double> b(rhs, rhs + F.N);
-  if (host::host_solve(F, b)) return -3;
-  std::copy(b.begin(), b.end(), rhs);
+  F.wait_forms();
+  if (!getenv("ABIP_HIP_HOST_FACTOR_ONLY")) { // (set by scripts/host_setup_time.py: times the set-up passes of a large matrix without the host's dense LDL' of its tail)
+    std::vector<double> b(rhs, rhs + F.N);
+    if (host::host_solve(F, b)) return -3;
+    std::copy(b.begin(), b.end(), rhs);
+  }
   stats8[0] = F.N; stats8[1] = (double)F.lnnz; stats8[2] = F.T; stats8[3] = (double)F.fwd.lev_ptr.size() - 1; stats8[4] = (double)F.bwd.lev_ptr.size() - 1;
   stats8[5] = (double)F.fwd.idx.size(); stats8[6] = 0; stats8[7] = 0;
   return 0;
@@ -2241,6 +2244,26 @@ int abip_hip_xcd_plan(abip_int m, abip_int n, const abip_int *Ap, const abip_int
   if (ok && nb_out) std::copy(nb.begin(), nb.end(), nb_out);
   return 0;
 }
+int abip_hip_csc_to_csr(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax, int *out_ptr, int *out_col, double *out_val) {
+  if (nrows <= 0 || ncols <= 0 || !Ap || !Ai || !Ax || !out_ptr || !out_col || !out_val || Ap[ncols] <= 0) return -1;
+  char devname[128];
+  if (abip_hip_device_info(devname, sizeof(devname), nullptr, nullptr) != 0) return -4;
+  const long nnz = Ap[ncols];
+  hipStream_t st = nullptr;
+  if (hipStreamCreate(&st) != hipSuccess) return -4;
+  DBuf<int> cp, ri, op, oc; DBuf<double> cx, ov;
+  int ret = 0;
+  if (cp.alloc((size_t)ncols + 1) || ri.alloc(nnz) || cx.alloc(nnz) || op.alloc((size_t)nrows + 1) || oc.alloc(nnz) || ov.alloc(nnz) ||
+      hipMemcpyAsync(cp.p, Ap, sizeof(int) * ((size_t)ncols + 1), hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(ri.p, Ai, sizeof(int) * nnz, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(cx.p, Ax, sizeof(double) * nnz, hipMemcpyHostToDevice, st) != hipSuccess) ret = -5;
+  if (!ret && dev_csc_to_csr(nrows, ncols, nnz, cp.p, ri.p, cx.p, op.p, oc.p, ov.p, st)) ret = -6;
+  if (!ret && (hipMemcpyAsync(out_ptr, op.p, sizeof(int) * ((size_t)nrows + 1), hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(out_col, oc.p, sizeof(int) * nnz, hipMemcpyDeviceToHost, st) != hipSuccess ||
+               hipMemcpyAsync(out_val, ov.p, sizeof(double) * nnz, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) ret = -7;
+  (void)hipGetLastError();
+  cp.release(); ri.release(); cx.release(); op.release(); oc.release(); ov.release();
+  (void)hipStreamDestroy(st);
+  return ret;
+}
 int abip_hip_ldl_solve(int N, const int *Kp, const int *Ki, const double *Kx, int tail, int on_device, double *rhs, double *stats4) {
   if (N <= 0 || !Kp || !Ki || !Kx || !rhs) return -1;
   std::vector<int> kp(Kp, Kp + N + 1), ki(Ki, Ki + Kp[N]);
@@ -2250,6 +2273,7 @@ int abip_hip_ldl_solve(int N, const int *Kp, const int *Ki, const double *Kx, in
   const int rc = host::factor_upper(N, kp, ki, kx, F);
   host::set_tail_request(-2);
   if (rc < 0) return -2;
+  F.wait_forms();
   if (stats4) { stats4[0] = F.T; stats4[1] = (double)F.lnnz; stats4[2] = (double)F.fwd.lev_ptr.size() - 1; stats4[3] = (double)F.bwd.lev_ptr.size() - 1; }
   if (!on_device) {
     if (F.dev_schur) host::complete_schur_on_host(F);

@@ -118,6 +118,11 @@ int abip_hip_xcd_plan(abip_int m, abip_int n, const abip_int *Ap, const abip_int
  * the solve applied on the device.  tail: -1 automatic, 0 none, T forced.  stats4 (may be NULL) = {T, nnz(L), forward levels, backward levels}.
  * Held against the reference's QDLDL (src/external/qdldl/src/qdldl.c: QDLDL_factor / QDLDL_solve, the conic solve of linsys.c:310-316) by tests/test_qdldl_pin*.py. */
 int abip_hip_ldl_solve(int N, const int *Kp, const int *Ki, const double *Kx, int tail, int on_device, double *rhs, double *stats4);
+/* Unit-level access to the device-side transposition the conic set-up uses for large operators (abip_amd/csrc/dev_transpose.hip): the CSC arrays of an
+ * nrows x ncols matrix (32-bit indices) are uploaded, transposed on the device, and the CSR arrays copied back -- out_ptr (nrows + 1), out_col / out_val
+ * (Ap[ncols]), the entries of a row in ascending column order, exactly as the host's counting sort (reference: indirect.c:81-139) leaves them.
+ * 0 on success, < 0: invalid arguments or no device. */
+int abip_hip_csc_to_csr(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax, int *out_ptr, int *out_col, double *out_val);
 
 /* --- measurement ------------------------------------------------------------ */
 /* Kernel classes timed with hipEvents on the solver's own stream. */

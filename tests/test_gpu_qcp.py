@@ -315,3 +315,43 @@ def test_conic_batched_iterations_equal_stepwise(gpu, case, monkeypatch):
         assert runs[0][:3] == other[:3]
         for a2, b2 in zip(runs[0][3:], other[3:]):
             assert np.array_equal(a2, b2)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1.0), (7, 5, 0.6), (300, 900, 0.05), (5001, 3000, 0.01), (64, 70000, 0.002), (70000, 64, 0.002)])
+def test_device_transpose_equals_the_host(gpu, shape):
+    """dev_transpose.hip: the row form of an operator built on the device from its column form (a stable sort of the entry numbers by row) is, entry for entry,
+    what the host's counting sort (host_par.h; reference: indirect.c:81-139) leaves: row pointers, columns ascending inside a row, the values bit for bit.
+    Empty rows and columns, one row, one column, more rows than columns and the other way round."""
+    import ctypes as C
+    from abip_amd import _lib
+    L = _lib.load()
+    m, n, dens = shape
+    rng = np.random.default_rng(m * 31 + n)
+    A = sp.random(m, n, density=dens, random_state=rng, data_rvs=rng.standard_normal, format="csc")
+    if A.nnz == 0:
+        A = sp.csc_matrix(np.ones((m, n)))
+    A.sort_indices()
+    Ap, Ai, Ax = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    ptr, col, val = np.zeros(m + 1, np.int32), np.zeros(A.nnz, np.int32), np.zeros(A.nnz)
+    PI32 = C.POINTER(C.c_int)
+    L.abip_hip_csc_to_csr.restype = C.c_int
+    L.abip_hip_csc_to_csr.argtypes = [C.c_int, C.c_int, PI32, PI32, _lib.PF, PI32, PI32, _lib.PF]
+    rc = L.abip_hip_csc_to_csr(m, n, Ap.ctypes.data_as(PI32), Ai.ctypes.data_as(PI32), Ax.ctypes.data_as(_lib.PF), ptr.ctypes.data_as(PI32), col.ctypes.data_as(PI32), val.ctypes.data_as(_lib.PF))
+    assert rc == 0, rc
+    R = A.tocsr(); R.sort_indices()
+    assert np.array_equal(ptr, R.indptr) and np.array_equal(col, R.indices) and np.array_equal(val, R.data)
+
+
+@pytest.mark.parametrize("ls", [1, 3])
+def test_conic_solve_is_the_same_with_the_device_transpose(gpu, ls, monkeypatch):
+    """The conic set-up transposes large operators on the device (from 2e6 non-zeros; forced here on a small one): the same arrays reach the kernels, so the solve is
+    bit-identical to the one over the host's row form."""
+    data, K = lasso_socp(400, 1500, 3, density=0.02)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ABIP_HIP_DEV_TRANSPOSE", mode)
+        out[mode] = gpu.abip_qcp(data, K, dict(eps=1e-5, linsys_solver=ls, verbose=0))
+    (s0, i0), (s1, i1) = out["0"], out["1"]
+    assert i0["status_val"] == 1 and i0["admm_iter"] == i1["admm_iter"] and i0["ipm_iter"] == i1["ipm_iter"]
+    for k in "xys":
+        assert np.array_equal(s0[k], s1[k])

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_oracle_parity_of_the_host_code_with_threads():
-    env = dict(os.environ, ABIP_HIP_HOST_THREADS="8", ABIP_HIP_HOST_GRAIN_DIV="100000")
+    # ABIP_HIP_FORMS_ASYNC=1: the level-ordered forms of the factor built behind factor_upper's back (LdlHost::forms_job), as on large factors with a dense tail
+    env = dict(os.environ, ABIP_HIP_HOST_THREADS="8", ABIP_HIP_HOST_GRAIN_DIV="100000", ABIP_HIP_FORMS_ASYNC="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_host_factor_cpu.py"),
                         os.path.join(ROOT, "tests", "test_qcp_host_cpu.py")], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
