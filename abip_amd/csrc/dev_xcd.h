@@ -541,6 +541,9 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   };
 
   if (!PCG) { // this workgroup's first rows of the dense inverse stay in the LDS for the whole launch
+    // (small systems read every row out to 64 XMR columns, see the dense product: rows this workgroup does not fill and the pad behind the last one are zero)
+    for (unsigned c = (unsigned)a.m + t; c < (unsigned)a.m_pad; c += XTB) wv[c] = 0.0; // the pad of w stays zero: the all-gather writes [0, m)
+    if (a.m_pad <= 64 * 16) { for (unsigned c = t; c < (unsigned)a.minv_lds_rows * (unsigned)a.m_pad + (64u * 16u - (unsigned)a.m_pad); c += XTB) mrow[c] = 0.0; __syncthreads(); }
     for (unsigned rl = wave; (int)rl < a.minv_lds_rows && m0 + rl < m1; rl += XWAVES) {
       const double *row = a.Minv + (long)(m0 + rl) * a.ldM;
       for (unsigned c = lane; c < (unsigned)a.m_pad; c += 64) mrow[(size_t)rl * a.m_pad + c] = x_at(row, c);
@@ -1007,30 +1010,49 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       };
       const unsigned nrows = m1 - m0, nlds = min((unsigned)a.minv_lds_rows, nrows);
       if (dsmall) {
+        // Branch-free: a lane's column 64 k + lane may lie beyond m (the last k of a row, every k >= m_pad / 64).  A guard per element makes every LDS read a
+        // basic block of its own -- read, wait, multiply, sixteen times in a row: 3.5 us of a 17.5 us iteration on c2 (profiles/r04l_*).  Instead every lane
+        // reads all XMR columns at their natural addresses (one base register per row, the column in the instruction's offset field) and its entry of w is
+        // ZERO beyond m: the term is an exact zero, the sum keeps its bits, and the reads go out back to back.  What lies behind a row's end is the next row,
+        // or the zeroed pad behind the last one (finite either way: 0 x finite = 0).
+        const unsigned mlast = (unsigned)a.m - 1u;
         double wreg[XMR]; // this lane's columns of w: read once, used for every row of the wavefront
 #pragma unroll
-        for (int k = 0; k < XMR; ++k) { const unsigned c = 64u * k + lane; wreg[k] = c < (unsigned)a.m ? wv[c] : 0.0; }
+        for (int k = 0; k < XMR; ++k) { const double wk = wv[64u * k + lane]; wreg[k] = 64u * k + lane <= mlast ? wk : 0.0; } // (behind w: y of the last trip, discarded)
+        constexpr int KC = 4; // columns per lane whose reads are in flight together
         unsigned rl = wave;
         for (; rl + XWAVES < nlds; rl += 2 * XWAVES) { // rows resident in the LDS, two at a time (independent chains)
-          const double *r0 = mrow + (size_t)rl * a.m_pad, *r1 = r0 + (size_t)XWAVES * a.m_pad;
+          const double *r0 = mrow + (size_t)rl * a.m_pad + lane, *r1 = r0 + (size_t)XWAVES * a.m_pad;
           double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-          for (int k = 0; k < XMR; ++k) { const unsigned c = 64u * k + lane; if (c < (unsigned)a.m) { a0 += r0[c] * wreg[k]; a1 += r1[c] * wreg[k]; } }
+          for (int k0 = 0; k0 < XMR; k0 += KC) {
+            double v0[KC], v1[KC];
+#pragma unroll
+            for (int k = 0; k < KC; ++k) { v0[k] = r0[64 * (k0 + k)]; v1[k] = r1[64 * (k0 + k)]; }
+#pragma unroll
+            for (int k = 0; k < KC; ++k) { a0 += v0[k] * wreg[k0 + k]; a1 += v1[k] * wreg[k0 + k]; }
+          }
           a0 = x_wave_sum63(a0); a1 = x_wave_sum63(a1);
           if (lane == 63) { yv[rl] = a0; yv[rl + XWAVES] = a1; }
         }
         if (rl < nlds) {
-          const double *r0 = mrow + (size_t)rl * a.m_pad;
+          const double *r0 = mrow + (size_t)rl * a.m_pad + lane;
           double a0 = 0.0;
 #pragma unroll
-          for (int k = 0; k < XMR; ++k) { const unsigned c = 64u * k + lane; if (c < (unsigned)a.m) a0 += r0[c] * wreg[k]; }
+          for (int k0 = 0; k0 < XMR; k0 += 2 * KC) {
+            double v0[2 * KC];
+#pragma unroll
+            for (int k = 0; k < 2 * KC; ++k) v0[k] = r0[64 * (k0 + k)];
+#pragma unroll
+            for (int k = 0; k < 2 * KC; ++k) a0 += v0[k] * wreg[k0 + k];
+          }
           a0 = x_wave_sum63(a0);
           if (lane == 63) yv[rl] = a0;
         }
-        if (rl_reg < nrows) { // the row in registers
+        if (rl_reg < nrows) { // the row in registers (zero beyond m, like w)
           double a0 = 0.0;
 #pragma unroll
-          for (int k = 0; k < XMR; ++k) { const unsigned c = 64u * k + lane; if (c < (unsigned)a.m) a0 += mreg[k] * wreg[k]; }
+          for (int k = 0; k < XMR; ++k) a0 += mreg[k] * wreg[k];
           a0 = x_wave_sum63(a0);
           if (lane == 63) yv[rl_reg] = a0;
         }
@@ -1041,9 +1063,15 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       } else {
         for (unsigned rl = wave; rl < nrows; rl += XWAVES) {
           double acc = 0.0;
-          if (rl < nlds) {
-            const double *row = mrow + (size_t)rl * a.m_pad;
-            for (unsigned c = lane; c < (unsigned)a.m; c += 64) acc += row[c] * wv[c];
+          if (rl < nlds) { // four columns per lane in flight; the pad of w is zero and the row's is finite: the terms behind m are exact zeros, added in the same order
+            const double *row = mrow + (size_t)rl * a.m_pad + lane, *wl = wv + lane;
+            for (unsigned c0 = 0; c0 < (unsigned)a.m_pad; c0 += 256) {
+              double rv[4], wq[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) { const bool in = c0 + 64u * u < (unsigned)a.m_pad; rv[u] = in ? row[c0 + 64u * u] : 0.0; wq[u] = in ? wl[c0 + 64u * u] : 0.0; } // (uniform)
+#pragma unroll
+              for (int u = 0; u < 4; ++u) acc += rv[u] * wq[u];
+            }
           } else acc = stream_row(m0 + rl);
           acc = x_wave_sum63(acc);
           if (lane == 63) yv[rl] = acc;

@@ -886,6 +886,7 @@ bool xcd_plan(XcdPlan &x, const host::HostCsr &hA, const host::HostCsr &hAt, boo
   x.n_pad = (int)((n + 63) / 64 * 64); x.m_pad = (int)((m + 63) / 64 * 64);
   size_t words = 2 * (size_t)x.NZ * XTB + XKS + XWAVES * XKS + 96 + 16 + 32;
   if (!pcg) words += (size_t)x.m_pad + (size_t)x.RM * XTB;
+  if (!pcg && x.m_pad <= 64 * 16) words += (size_t)(64 * 16 - x.m_pad); // the zeroed pad behind the last LDS row of the dense inverse (dev_xcd.h: every row is read out to 1024 columns)
   constexpr size_t kLdsWords = (160 * 1024 - 512) / sizeof(double); // (the kernel's one static word lives in the remaining 512 bytes)
   if (words > kLdsWords) return false;
   x.minv_lds_rows = 0;
