@@ -178,6 +178,7 @@ struct XWait { // the exchange in flight
   int *xstat;
   bool dead;
   int site, rank; // which exchange of the iteration this is / whose: recorded when a wavefront gives up
+  double *ldead;  // LDS: != 0 once a wavefront of this workgroup has given up (or seen another workgroup do so) -- how the wavefronts that do not poll learn of it
 };
 // spin bookkeeping of one WAVEFRONT (its lanes poll together): true = keep polling
 __device__ __forceinline__ bool x_spin(XWait &w, int &spins, unsigned found, int what) {
@@ -192,7 +193,7 @@ __device__ __forceinline__ bool x_spin(XWait &w, int &spins, unsigned found, int
     dead = __hip_atomic_load(w.xstat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   dead = __builtin_amdgcn_readfirstlane(dead);
-  if (dead) { w.dead = true; return false; }
+  if (dead) { w.dead = true; if ((threadIdx.x & 63) == 0) *w.ldead = 1.0; return false; }
   return true;
 }
 
@@ -222,7 +223,7 @@ __device__ __forceinline__ void x_publish(double (&v)[K], double *red, xrsrc sc,
     }
   }
 }
-template <int K>
+template <int K, bool WIDE /* more than 64 ranks (several XCDs): several loads per polling round */>
 __device__ __forceinline__ void x_collect(XWait &w, int G, double *tot, double (&out)[K]) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -235,12 +236,18 @@ __device__ __forceinline__ void x_collect(XWait &w, int G, double *tot, double (
     int spins = 0;
     for (;;) {
       asm volatile("" ::: "memory"); // (the loads are issued anew every round)
+      // all the loads of a round first, the tags afterwards: a test behind each load (`ok = ok && ...`) makes the compiler wait for it before the next one goes
+      // out -- four memory round trips per polling round on 256 workgroups instead of one
       bool ok = true;
+      if (!WIDE) { // one XCD's worth of ranks: one load per round
+        if (lane < G) g[0] = x_ldg(w.sc, (unsigned)(lane * XKS + wave) * 16u);
+        ok = x_ok(g[0], w.tag);
+      } else {
 #pragma unroll
-      for (int q = 0; q < XQ; ++q) {
-        if (q * 64 >= G) break; // (uniform)
-        if (q * 64 + lane < G) g[q] = x_ldg(w.sc, (unsigned)((q * 64 + lane) * XKS + wave) * 16u);
-        ok = ok && x_ok(g[q], w.tag);
+        for (int q = 0; q < XQ; ++q)
+          if (q * 64 < G && q * 64 + lane < G) g[q] = x_ldg(w.sc, (unsigned)((q * 64 + lane) * XKS + wave) * 16u);
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) ok = ok & x_ok(g[q], w.tag); // (slots past G keep the tag they were initialised with)
       }
       if (__all(ok ? 1 : 0)) break;
       const unsigned long long miss = __ballot(ok ? 0 : 1);
@@ -258,7 +265,7 @@ __device__ __forceinline__ void x_collect(XWait &w, int G, double *tot, double (
   }
   }
   __syncthreads();
-  if (__hip_atomic_load(w.xstat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) w.dead = true; // (one wavefront gave up: everybody leaves)
+  if (*w.ldead != 0.0) w.dead = true; // (a polling wavefront gave up -- it, or whoever it saw in xstat: everybody leaves.  Read from the LDS: the global flag costs an L2 round trip per exchange)
 #pragma unroll
   for (int k = 0; k < K; ++k) out[k] = x_uni(tot[k]);
 }
@@ -270,19 +277,28 @@ __device__ __forceinline__ void x_flag(xrsrc sc, unsigned sc_off, unsigned tag) 
   __syncthreads();
   if (threadIdx.x == 0) x_putg<SA>(sc, sc_off, 0.0, tag);
 }
+template <bool WIDE>
 __device__ __forceinline__ void x_wait(XWait &w, int G) {
   const int lane = threadIdx.x & 63;
   if (threadIdx.x < 64) {
     int spins = 0;
     for (;;) {
       asm volatile("" ::: "memory"); // (the loads are issued anew every round)
-      bool ok = true;
-      unsigned seen = w.tag;
+      u32x4 g[XQ];
 #pragma unroll
-      for (int q = 0; q < XQ; ++q) {
-        if (q * 64 >= G) break; // (uniform)
-        if (q * 64 + lane < G) { const u32x4 g = x_ldg(w.sc, (unsigned)((q * 64 + lane) * XKS) * 16u); ok = ok && x_ok(g, w.tag); if (q == 0) seen = g.y; }
+      for (int q = 0; q < XQ; ++q) { g[q].x = 0; g[q].y = w.tag; g[q].z = 0; g[q].w = w.tag; }
+      bool ok = true;
+      if (!WIDE) {
+        if (lane < G) g[0] = x_ldg(w.sc, (unsigned)(lane * XKS) * 16u);
+        ok = x_ok(g[0], w.tag);
+      } else {
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) // (all the loads of a round first: see x_collect)
+          if (q * 64 < G && q * 64 + lane < G) g[q] = x_ldg(w.sc, (unsigned)((q * 64 + lane) * XKS) * 16u);
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) ok = ok & x_ok(g[q], w.tag);
       }
+      const unsigned seen = g[0].y;
       if (__all(ok ? 1 : 0)) break;
       const unsigned long long miss = __ballot(ok ? 0 : 1);
       const int src = miss ? (int)__builtin_ctzll(miss) : 0;
@@ -291,7 +307,7 @@ __device__ __forceinline__ void x_wait(XWait &w, int G) {
     }
   }
   __syncthreads();
-  if (__hip_atomic_load(w.xstat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) w.dead = true; // (one wavefront gave up: everybody leaves)
+  if (*w.ldead != 0.0) w.dead = true; // (see x_collect)
 }
 template <int NZ>
 __device__ __forceinline__ void x_gather(xrsrc r, const unsigned (&idx)[NZ], double (&v)[NZ]) {
@@ -489,6 +505,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       if (r < 0 || r >= a.G) r = -1;
     }
     s_rank = r;
+    mnb[15] = 0.0; // XWait::ldead
     cs[CS_MU] = a.outer.mu; cs[CS_BETA] = a.outer.beta; cs[CS_DYNS] = a.outer.dyn_sigma; cs[CS_OI] = (double)a.outer.i; cs[CS_FRE] = (double)a.outer.fre_old;
     cs[CS_BBPREV] = 1.0; cs[CS_BUPT] = 0.0; cs[CS_BVPT] = 0.0; cs[CS_BUT] = 0.0; cs[CS_BVT] = 0.0; cs[CS_RUT] = 0.0; cs[CS_RVT] = 0.0;
     cs[CS_ODONE] = 0.0; cs[CS_DYN2] = 0.0; cs[CS_LOGN] = 0.0; cs[CS_BBTOT] = 0.0; cs[CS_BBIT] = 0.0; cs[CS_AV] = 0.0; cs[CS_PHASE] = 0.0; cs[CS_REASON] = (double)XR_BATCH;
@@ -526,7 +543,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   const bool whole = a.outer.on != 0 && !solo;
   unsigned tag = a.tag0;
   int flip = 0;
-  XWait w; w.xstat = a.xstat; w.dead = false; w.site = 0; w.rank = rank;
+  XWait w; w.xstat = a.xstat; w.dead = false; w.site = 0; w.rank = rank; w.ldead = mnb + 15; // (x_block_min uses the first XWAVES of the 16)
   xrsrc pn0, pn1, pm0, pm1, psc; // the exchange areas of the parity in use
   const unsigned sc_off = (unsigned)rank * XKS * 16u;
   auto open = [&](int site) { // next exchange: tag and the areas of its parity
@@ -622,7 +639,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       if (t == 0) x_putg<SA>(psc, sc_off + 12u * 16u, mn, tag); // (acknowledged before this rank's flags go out)
       x_publish<2, SA>(p2, red, psc, sc_off, tag);
       double P2[2];
-      x_collect<2>(w, G, tot, P2);
+      x_collect<2, CROSS>(w, G, tot, P2);
       if (__builtin_expect(w.dead, 0)) return;
       double gmin = 1e+10;
       if ((int)t < G) gmin = x_val(x_ldg(psc, (t * XKS + 12u) * 16u));
@@ -771,7 +788,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       if (rank == 0 && t == 0 && !solo && mode == XM_MAIN) { p[1] = x_at(up.u, tail); p[2] = x_at(up.v, tail); }
       x_publish<3, SA>(p, red, psc, sc_off, tag);
       double s3[3];
-      x_collect<3>(w, G, tot, s3);
+      x_collect<3, CROSS>(w, G, tot, s3);
       if (__builtin_expect(w.dead, 0)) return;
       if (PCG) {
         double tx[NZ], vt[NZ];
@@ -845,7 +862,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       open(2);
       build_rhs(tb, tsum, coef, bn);
       x_publish<1, SA>(bn, red, psc, sc_off, tag);
-      x_collect<1>(w, G, tot, bnS);
+      x_collect<1, CROSS>(w, G, tot, bnS);
       if (__builtin_expect(w.dead, 0)) return;
     }
     have_rhs = false; // (the right-hand side this trip works on was built, and handed round, by the previous iteration's last exchange -- see there)
@@ -899,7 +916,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         double tx[NZ];
         x_mat<NZ>(gT, nt, tx); // (on their way while the flags are awaited)
         double rzS[2];
-        x_collect<2>(w, G, tot, rzS);
+        x_collect<2, CROSS>(w, G, tot, rzS);
         if (__builtin_expect(w.dead, 0)) return;
         XP_LAP(2)
         const double nr = sqrt(rzS[0]);
@@ -940,7 +957,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         double ax[NZ];
         x_mat<NZ>(gA, na, ax);
         double tpS[2];
-        x_collect<2>(w, G, tot, tpS);
+        x_collect<2, CROSS>(w, G, tot, tpS);
         if (__builtin_expect(w.dead, 0)) return;
         XP_LAP(2)
         double gq[RM];
@@ -988,10 +1005,16 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
 #pragma unroll
       for (int q = 0; q < RM; ++q) { const unsigned i = m0 + tb + q * XTB; if (i < m1) x_putd<SA>(pm0, i * 8u, rhs_y[q] + sA[q]); }
       x_flag<SA>(psc, sc_off, tag);
-      x_wait(w, G);
+      x_wait<CROSS>(w, G);
       if (__builtin_expect(w.dead, 0)) return;
       XP_LAP(1)
-      for (unsigned i = t; i < (unsigned)a.m; i += XTB) wv[i] = x_ldd(pm0, i * 8u); // every workgroup needs the whole w
+      for (unsigned i0 = t; i0 < (unsigned)a.m; i0 += 4 * XTB) { // every workgroup needs the whole w (four loads in flight)
+        double tv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const unsigned i = i0 + (unsigned)u * XTB; tv[u] = i < (unsigned)a.m ? x_ldd(pm0, i * 8u) : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const unsigned i = i0 + (unsigned)u * XTB; if (i < (unsigned)a.m) wv[i] = tv[u]; }
+      }
       __syncthreads();
       XP_LAP(2)
       double *yv = wv + a.m_pad;
@@ -999,12 +1022,12 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       auto stream_row = [&](unsigned r) { // a row from the L2 (8 loads in flight)
         const double *row = a.Minv + (long)r * a.ldM;
         double acc = 0.0;
-        for (unsigned c0 = 0; c0 < (unsigned)a.m; c0 += 512) {
-          double mv[8];
+        for (unsigned c0 = 0; c0 < (unsigned)a.m_pad; c0 += 512) { // (to m_pad: the pad of w is zero, the row's finite -- exact zeros, added in the same order; no guard per element)
+          double mv[8], wq[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { const unsigned c = c0 + 64u * u + lane; mv[u] = c < (unsigned)a.m ? x_at(row, c) : 0.0; }
+          for (int u = 0; u < 8; ++u) { const bool in = c0 + 64u * u < (unsigned)a.m_pad; const unsigned c = c0 + 64u * u + lane; mv[u] = in ? x_at(row, c) : 0.0; wq[u] = in ? wv[c] : 0.0; } // (uniform)
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { const unsigned c = c0 + 64u * u + lane; if (c < (unsigned)a.m) acc += mv[u] * wv[c]; }
+          for (int u = 0; u < 8; ++u) acc += mv[u] * wq[u];
         }
         return acc;
       };
@@ -1098,7 +1121,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     }
     {
       x_flag<SA>(psc, sc_off, tag);
-      x_wait(w, G);
+      x_wait<CROSS>(w, G);
       if (__builtin_expect(w.dead, 0)) return;
       double tx[NZ], vt[NZ], tq[RN];
       x_mat<NZ>(gT, nt, tx);
@@ -1113,7 +1136,12 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     }
     open(7);
     x_publish<1, SA>(dh, red, psc, sc_off, tag);
-    x_collect<1>(w, G, tot, dhS);
+    // In an ADMM iteration u_t'h has ONE reader: rank 0's thread 0, for the tau entry of the update.  The other ranks do not wait for it: they go on to the
+    // update and meet rank 0 again at its exchange (whose granules carry the tau entries) -- rank 0's wait here overlaps with their element-wise work.  (Rank r
+    // writes this granule slot again two exchanges on, behind rank 0's next flag: not before rank 0 has read it.)  The search's steps and the solve-only mode
+    // use the sum in every workgroup.
+    if (mode == XM_MAIN && !solo && rank != 0) { dhS[0] = 0.0; __syncthreads(); } // (the barrier: `red` is written again by the next publish)
+    else x_collect<1, CROSS>(w, G, tot, dhS);
     if (__builtin_expect(w.dead, 0)) return;
     if (!PCG) { XP_LAP(4) }
     if (__builtin_expect(solo || mode != XM_MAIN, 0)) break; // (not an ADMM iteration: see below the loop)
@@ -1207,13 +1235,13 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     if (avg_stats) {
       double s9[9] = {sst.wg, sst.nu, sst.nv, sst.cx, sst.by, sst.nua, sst.nva, sst.cxa, sst.bya}, S9[9];
       x_publish<9, SA>(s9, red, psc, sc_off, tag);
-      x_collect<9>(w, G, tot, S9);
+      x_collect<9, CROSS>(w, G, tot, S9);
 #pragma unroll
       for (int q = 0; q < 9; ++q) S13[q] = S9[q];
     } else {
       double s5[5] = {sst.wg, sst.nu, sst.nv, sst.cx, sst.by}, S5[5];
       x_publish<5, SA>(s5, red, psc, sc_off, tag);
-      x_collect<5>(w, G, tot, S5);
+      x_collect<5, CROSS>(w, G, tot, S5);
 #pragma unroll
       for (int q = 0; q < 5; ++q) S13[q] = S5[q];
       S13[5] = 0.0; S13[6] = 0.0; S13[7] = 0.0; S13[8] = 0.0;
@@ -1310,11 +1338,11 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     double Q[12];
     if (avg_stats) {
       x_publish<12, SA>(q6, red, psc, sc_off, tag);
-      x_collect<12>(w, G, tot, Q);
+      x_collect<12, CROSS>(w, G, tot, Q);
     } else {
       double q[6] = {q6[0], q6[1], q6[2], q6[3], q6[4], q6[5]}, Q6[6];
       x_publish<6, SA>(q, red, psc, sc_off, tag);
-      x_collect<6>(w, G, tot, Q6);
+      x_collect<6, CROSS>(w, G, tot, Q6);
 #pragma unroll
       for (int k = 0; k < 6; ++k) { Q[k] = Q6[k]; Q[6 + k] = 0.0; }
     }
@@ -1440,7 +1468,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       open(12);
       x_publish<5, SA>(d5, red, psc, sc_off, tag);
       double D5[5];
-      x_collect<5>(w, G, tot, D5);
+      x_collect<5, CROSS>(w, G, tot, D5);
       if (__builtin_expect(w.dead, 0)) return;
       const int bb_it = (int)csr(CS_BBIT);
       const double bb_tot = csr(CS_BBTOT);
