@@ -1136,12 +1136,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     }
     open(7);
     x_publish<1, SA>(dh, red, psc, sc_off, tag);
-    // In an ADMM iteration u_t'h has ONE reader: rank 0's thread 0, for the tau entry of the update.  The other ranks do not wait for it: they go on to the
-    // update and meet rank 0 again at its exchange (whose granules carry the tau entries) -- rank 0's wait here overlaps with their element-wise work.  (Rank r
-    // writes this granule slot again two exchanges on, behind rank 0's next flag: not before rank 0 has read it.)  The search's steps and the solve-only mode
-    // use the sum in every workgroup.
-    if (mode == XM_MAIN && !solo && rank != 0) { dhS[0] = 0.0; __syncthreads(); } // (the barrier: `red` is written again by the next publish)
-    else x_collect<1, CROSS>(w, G, tot, dhS);
+    x_collect<1, CROSS>(w, G, tot, dhS);
     if (__builtin_expect(w.dead, 0)) return;
     if (!PCG) { XP_LAP(4) }
     if (__builtin_expect(solo || mode != XM_MAIN, 0)) break; // (not an ADMM iteration: see below the loop)
@@ -1153,25 +1148,35 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     double tau4[4] = {0.0, 0.0, 0.0, 0.0};
     open(8);
     XLd Ly[RM], Lx[RN], Lt;
+    // What the phases behind the update need of the owned elements rides in registers from here: the scale factors and h with this batch of loads, the new
+    // (u, v) and the averaged v as they are computed -- the stopping test and the next right-hand side then start without a round trip to the L2 of their own
+    // (the arrays are written all the same: everything outside this loop reads them there).
+    double wsy[RM], wsx[RN], hy[RM], hx[RN], nuy[RM], nvy[RM], nux[RN], nvx[RN], vacx[RN];
 #pragma unroll
     for (int q = 0; q < RM; ++q) {
       const unsigned i = m0 + tb + q * XTB;
       Ly[q] = XLd{0, 0, 0, 0, 0, 0, 0, 0};
+      wsy[q] = 1.0; hy[q] = 0.0; nuy[q] = 0.0; nvy[q] = 0.0;
       if (i < m1) {
         Ly[q].v = x_at(up.v, i); if (up.half_update) Ly[q].u = x_at(up.u, i);
         Ly[q].ua = x_at(up.u_avg, i); Ly[q].va = x_at(up.v_avg, i); Ly[q].us = x_at(up.u_sum, i); Ly[q].vs = x_at(up.v_sum, i);
         Ly[q].g = x_at(up.g, i); Ly[q].bc = x_at(up.b, i);
+        if (a.wD) wsy[q] = x_at(a.wD, i);
+        hy[q] = x_at(a.h, i);
       }
     }
 #pragma unroll
     for (int q = 0; q < RN; ++q) {
       const unsigned j2 = n0 + tb + q * XTB;
       Lx[q] = XLd{0, 0, 0, 0, 0, 0, 0, 0};
+      wsx[q] = 1.0; hx[q] = 0.0; nux[q] = 0.0; nvx[q] = 0.0; vacx[q] = 0.0;
       if (j2 < n1) {
         const unsigned qq = MP + j2;
         Lx[q].u = x_at(up.u, qq); Lx[q].v = x_at(up.v, qq);
         Lx[q].ua = x_at(up.u_avg, qq); Lx[q].va = x_at(up.v_avg, qq); Lx[q].us = x_at(up.u_sum, qq); Lx[q].vs = x_at(up.v_sum, qq);
         Lx[q].g = x_at(up.g, qq); Lx[q].bc = x_at(up.c, j2);
+        if (a.wE) wsx[q] = x_at(a.wE, j2);
+        hx[q] = x_at(a.h, qq);
       }
     }
     Lt = XLd{0, 0, 0, 0, 0, 0, 0, 0};
@@ -1192,6 +1197,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         x_at(up.u_avg, i) = Ly[q].ua + un; x_at(up.v_avg, i) = Ly[q].va + vn;
         x_at(up.u_sum, i) = Ly[q].us + un; x_at(up.v_sum, i) = Ly[q].vs + vn;
         x_at(up.u_avgc, i) = ua; x_at(up.v_avgc, i) = (Ly[q].vs + vn) / up.dom;
+        nuy[q] = un; nvy[q] = vn;
         x_putd<SA>(pm0, i * 8u, un);
         if (avg_stats) x_putd<SA>(pm1, i * 8u, ua);
       }
@@ -1208,7 +1214,9 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         x_at(up.u, qq) = un; x_at(up.v, qq) = vn;
         x_at(up.u_avg, qq) = Lx[q].ua + un; x_at(up.v_avg, qq) = Lx[q].va + vn;
         x_at(up.u_sum, qq) = Lx[q].us + un; x_at(up.v_sum, qq) = Lx[q].vs + vn;
-        x_at(up.u_avgc, qq) = ua; x_at(up.v_avgc, qq) = (Lx[q].vs + vn) / up.dom;
+        const double vac = (Lx[q].vs + vn) / up.dom;
+        x_at(up.u_avgc, qq) = ua; x_at(up.v_avgc, qq) = vac;
+        nux[q] = un; nvx[q] = vn; vacx[q] = vac;
         x_putd<SA>(pn0, j2 * 8u, un);
         if (avg_stats) x_putd<SA>(pn1, j2 * 8u, ua);
       }
@@ -1247,31 +1255,30 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       S13[5] = 0.0; S13[6] = 0.0; S13[7] = 0.0; S13[8] = 0.0;
     }
     if (__builtin_expect(w.dead, 0)) return;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) S13[9 + q] = x_uni(x_val(x_ldg(psc, (unsigned)(12 + q) * 16u))); // (rank 0's granules: there since its flags are)
     // ---- stopping-test products (k_q_both): A u_x and A'u_y, residual sums; A'u_y is also the next solve's warm-start product ----
+    // One round trip for everything the phase reads from the L2: rank 0's tau granules (there since its flags are), the matrix values and the gathered entries
+    // of both products; b, c, the scale factors, v and the averaged v of the owned elements come from the update in registers.
     {
+      u32x4 tg[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tg[q] = x_ldg(psc, (unsigned)(12 + q) * 16u);
+      double ax[NZ], va[NZ], tx[NZ], vt[NZ];
+      x_mat<NZ>(gA, na, ax);
+      x_gather<NZ>(pn0, ai, va);
+      x_mat<NZ>(gT, nt, tx);
+      x_gather<NZ>(pm0, ti, vt);
       double pri[RM];
-      {
-        double ax[NZ], va[NZ];
-        x_mat<NZ>(gA, na, ax);
-        x_gather<NZ>(pn0, ai, va);
-        x_rows<NZ, RM>(prod, flip, ax, va, na, sa, ea, pri);
-      }
-      {
-        double tx[NZ], vt[NZ];
-        x_mat<NZ>(gT, nt, tx);
-        x_gather<NZ>(pm0, ti, vt);
-        x_rows<NZ, RN>(prod, flip, tx, vt, nt, st, et, aty);
-      }
+      x_rows<NZ, RM>(prod, flip, ax, va, na, sa, ea, pri);
+      x_rows<NZ, RN>(prod, flip, tx, vt, nt, st, et, aty);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S13[9 + q] = x_uni(x_val(tg[q]));
       const double tau = S13[9];
 #pragma unroll
       for (int q = 0; q < RM; ++q) {
         const unsigned i = m0 + tb + q * XTB;
         if (i < m1) {
-          const double e = pri[q] - x_at(up.b, i) * tau;
-          double sc = a.wD ? x_at(a.wD, i) : 1.0;
-          sc = sc * sc;
+          const double e = pri[q] - Ly[q].bc * tau;
+          const double sc = wsy[q] * wsy[q];
           q6[0] += e * e; q6[1] += (e * e) * sc; q6[2] += (pri[q] * pri[q]) * sc;
         }
       }
@@ -1279,9 +1286,8 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       for (int q = 0; q < RN; ++q) {
         const unsigned j2 = n0 + tb + q * XTB;
         if (j2 < n1) {
-          const double drj = aty[q] + x_at(up.v, MP + j2), e = drj - x_at(up.c, j2) * tau;
-          double sc = a.wE ? x_at(a.wE, j2) : 1.0;
-          sc = sc * sc;
+          const double drj = aty[q] + nvx[q], e = drj - Lx[q].bc * tau;
+          const double sc = wsx[q] * wsx[q];
           q6[3] += e * e; q6[4] += (e * e) * sc; q6[5] += (drj * drj) * sc;
         }
       }
@@ -1289,15 +1295,12 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     if (avg_stats) { // the same on the averaged iterate (its entries went out with the same exchange)
       double pri[RM], atya[RN];
       {
-        double ax[NZ], va[NZ];
+        double ax[NZ], va[NZ], tx[NZ], vt[NZ];
         x_mat<NZ>(gA, na, ax);
         x_gather<NZ>(pn1, ai, va);
-        x_rows<NZ, RM>(prod, flip, ax, va, na, sa, ea, pri);
-      }
-      {
-        double tx[NZ], vt[NZ];
         x_mat<NZ>(gT, nt, tx);
         x_gather<NZ>(pm1, ti, vt);
+        x_rows<NZ, RM>(prod, flip, ax, va, na, sa, ea, pri);
         x_rows<NZ, RN>(prod, flip, tx, vt, nt, st, et, atya);
       }
       const double tau = S13[11];
@@ -1305,9 +1308,8 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       for (int q = 0; q < RM; ++q) {
         const unsigned i = m0 + tb + q * XTB;
         if (i < m1) {
-          const double e = pri[q] - x_at(up.b, i) * tau;
-          double sc = a.wD ? x_at(a.wD, i) : 1.0;
-          sc = sc * sc;
+          const double e = pri[q] - Ly[q].bc * tau;
+          const double sc = wsy[q] * wsy[q];
           q6[6] += e * e; q6[7] += (e * e) * sc; q6[8] += (pri[q] * pri[q]) * sc;
         }
       }
@@ -1315,9 +1317,8 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       for (int q = 0; q < RN; ++q) {
         const unsigned j2 = n0 + tb + q * XTB;
         if (j2 < n1) {
-          const double drj = atya[q] + x_at(up.v_avgc, MP + j2), e = drj - x_at(up.c, j2) * tau;
-          double sc = a.wE ? x_at(a.wE, j2) : 1.0;
-          sc = sc * sc;
+          const double drj = atya[q] + vacx[q], e = drj - Lx[q].bc * tau;
+          const double sc = wsx[q] * wsx[q];
           q6[9] += e * e; q6[10] += (e * e) * sc; q6[11] += (drj * drj) * sc;
         }
       }
@@ -1331,8 +1332,30 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       // exchange also carries |rhs_y|^2 for its tolerance -- a thirteenth sum on the iterations that test the averaged iterate; it keeps the exchange.)
       const double ts_n = S13[9] + S13[10];
       const double cf_n = (S13[0] - ts_n * a.g_th) / (a.g_th + 1.0);
-      double bn_n[1] = {0.0};
-      build_rhs(tb, ts_n, cf_n, bn_n);
+      // (build_rhs with the iterate and h in registers: the same expressions, no loads)
+#pragma unroll
+      for (int q = 0; q < RM; ++q) {
+        const unsigned i = m0 + tb + q * XTB;
+        rhs_y[q] = 0.0;
+        if (i < m1) {
+          double r = (nuy[q] + nvy[q]) * rho;
+          r += -ts_n * hy[q];
+          r += -cf_n * hy[q];
+          rhs_y[q] = r;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < RN; ++q) {
+        const unsigned j2 = n0 + tb + q * XTB;
+        rhs_x[q] = 0.0;
+        if (j2 < n1) {
+          double r = nux[q] + nvx[q];
+          r += -ts_n * hx[q];
+          r += -cf_n * hx[q];
+          rhs_x[q] = -r;
+          x_putd<SA>(pn0, j2 * 8u, -r);
+        }
+      }
       have_rhs = true;
     }
     double Q[12];
