@@ -848,6 +848,11 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     };
     bool have_rhs = false;
     int leave = 0;
+    double hy[RM], hx[RN]; // h of the owned elements: constant, read by three phases of every trip
+#pragma unroll
+    for (int q = 0; q < RM; ++q) { const unsigned i = m0 + t + q * XTB; hy[q] = i < m1 ? x_at(a.h, i) : 0.0; }
+#pragma unroll
+    for (int q = 0; q < RN; ++q) { const unsigned j2 = n0 + t + q * XTB; hx[q] = j2 < n1 ? x_at(a.h, MP + j2) : 0.0; }
     for (;;) {
     unsigned tb = t; asm volatile("" : "+v"(tb)); // (see the outer loop)
     XQ_MARK(xq_t)
@@ -1112,11 +1117,10 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     for (int q = 0; q < RM; ++q) {
       const unsigned i = m0 + tb + q * XTB;
       if (i < m1) {
-        const double hi = x_at(a.h, i); // (before the stores: see the element-wise update)
         x_putd<SA>(pm0, i * 8u, y[q]);
         if (solo) x_at(a.srhs, i) = y[q];
         else if (mode == XM_MAIN) x_at(up.ut, i) = y[q];
-        dh[0] += y[q] * hi;
+        dh[0] += y[q] * hy[q];
       }
     }
     {
@@ -1131,7 +1135,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       for (int q = 0; q < RN; ++q) {
         const unsigned j2 = n0 + tb + q * XTB;
         zx[q] = 0.0;
-        if (j2 < n1) { zx[q] = tq[q] - rhs_x[q]; dh[0] += zx[q] * x_at(a.h, MP + j2); }
+        if (j2 < n1) { zx[q] = tq[q] - rhs_x[q]; dh[0] += zx[q] * hx[q]; }
       }
     }
     open(7);
@@ -1148,35 +1152,33 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     double tau4[4] = {0.0, 0.0, 0.0, 0.0};
     open(8);
     XLd Ly[RM], Lx[RN], Lt;
-    // What the phases behind the update need of the owned elements rides in registers from here: the scale factors and h with this batch of loads, the new
+    // What the phases behind the update need of the owned elements rides in registers from here: the scale factors with this batch of loads, the new
     // (u, v) and the averaged v as they are computed -- the stopping test and the next right-hand side then start without a round trip to the L2 of their own
     // (the arrays are written all the same: everything outside this loop reads them there).
-    double wsy[RM], wsx[RN], hy[RM], hx[RN], nuy[RM], nvy[RM], nux[RN], nvx[RN], vacx[RN];
+    double wsy[RM], wsx[RN], nuy[RM], nvy[RM], nux[RN], nvx[RN], vacx[RN];
 #pragma unroll
     for (int q = 0; q < RM; ++q) {
       const unsigned i = m0 + tb + q * XTB;
       Ly[q] = XLd{0, 0, 0, 0, 0, 0, 0, 0};
-      wsy[q] = 1.0; hy[q] = 0.0; nuy[q] = 0.0; nvy[q] = 0.0;
+      wsy[q] = 1.0; nuy[q] = 0.0; nvy[q] = 0.0;
       if (i < m1) {
         Ly[q].v = x_at(up.v, i); if (up.half_update) Ly[q].u = x_at(up.u, i);
         Ly[q].ua = x_at(up.u_avg, i); Ly[q].va = x_at(up.v_avg, i); Ly[q].us = x_at(up.u_sum, i); Ly[q].vs = x_at(up.v_sum, i);
         Ly[q].g = x_at(up.g, i); Ly[q].bc = x_at(up.b, i);
         if (a.wD) wsy[q] = x_at(a.wD, i);
-        hy[q] = x_at(a.h, i);
       }
     }
 #pragma unroll
     for (int q = 0; q < RN; ++q) {
       const unsigned j2 = n0 + tb + q * XTB;
       Lx[q] = XLd{0, 0, 0, 0, 0, 0, 0, 0};
-      wsx[q] = 1.0; hx[q] = 0.0; nux[q] = 0.0; nvx[q] = 0.0; vacx[q] = 0.0;
+      wsx[q] = 1.0; nux[q] = 0.0; nvx[q] = 0.0; vacx[q] = 0.0;
       if (j2 < n1) {
         const unsigned qq = MP + j2;
         Lx[q].u = x_at(up.u, qq); Lx[q].v = x_at(up.v, qq);
         Lx[q].ua = x_at(up.u_avg, qq); Lx[q].va = x_at(up.v_avg, qq); Lx[q].us = x_at(up.u_sum, qq); Lx[q].vs = x_at(up.v_sum, qq);
         Lx[q].g = x_at(up.g, qq); Lx[q].bc = x_at(up.c, j2);
         if (a.wE) wsx[q] = x_at(a.wE, j2);
-        hx[q] = x_at(a.h, qq);
       }
     }
     Lt = XLd{0, 0, 0, 0, 0, 0, 0, 0};
