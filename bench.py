@@ -431,7 +431,7 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         # device-side stamps of this run leave out dispatch and drain; they are scaled by the ratio trace / stamp that ONE profiled run measured for the
         # same kernel (scripts/r04_trace.sh -> profiles/r04_trace_durations.json) and kept, unscaled, under `stamps`.
         ratio, tsrc2, tr = 1.0, None, None
-        for trf in ("r04_trace_durations.json", "r03_trace_durations.json"):
+        for trf in ("r04w_trace_durations.json", "r04_trace_durations.json", "r03_trace_durations.json"):
             path = os.path.join(ROOT, "profiles", trf)
             if name == "c4" and world == 1 and os.path.exists(path):
                 tr = json.load(open(path)).get("k_cg_" + kname)
