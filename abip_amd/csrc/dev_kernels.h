@@ -15,6 +15,7 @@
 // All reductions go through the partials table (dev_common.h); no atomics, no fences.
 #pragma once
 #include "dev_common.h"
+#include "lp_scalars.h"
 
 namespace abip {
 
@@ -50,9 +51,12 @@ __global__ __launch_bounds__(BS) void k_norm_y(const double *__restrict__ x, Dim
 // k_rhs: u_t <- rhs of the KKT system (abip.c:552-558).
 //   u_t = u + v; u_t[y] *= rho; u_t[0:l-1) -= tau~ h; u_t[0:l-1) -= (u_t'g/(g_th+1)) h; u_t[x] *= -1
 // ---------------------------------------------------------------------------------------------
+// `aty` / `pair` (PCG back-end, one GPU; both or neither): A'u_y of the current iterate is already known -- the previous iteration's back-substitution left it
+// (k_post_At) -- so the pairs (rhs_x[j], (A's)[j]) that k_cg_init_A gathers are written here and k_cg_init_At's product is not repeated.
 __global__ __launch_bounds__(BS) void k_rhs(const double *__restrict__ u, const double *__restrict__ v, double *__restrict__ ut,
                                             const double *__restrict__ h, double rho, double g_th, Dims d,
-                                            double *part, int nb, const Ctl *ctl, const double *gs) {
+                                            double *part, int nb, const Ctl *ctl, const double *gs,
+                                            const double *__restrict__ aty, double2 *__restrict__ pair) {
   ABIP_GATE_HALT(ctl);
   __shared__ double sm[WAVES];
   double wg[1];
@@ -75,6 +79,7 @@ __global__ __launch_bounds__(BS) void k_rhs(const double *__restrict__ u, const 
     t += -tsum * h[d.MP + j];
     t += -coef * h[d.MP + j];
     ut[d.MP + j] = -t;
+    if (pair) pair[j] = make_double2(-t, aty[j]);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) ut[tail] = tsum;
   const int ws[1] = {S_BN};
@@ -289,9 +294,11 @@ __global__ __launch_bounds__(BS) void k_cg_update(double *__restrict__ x, double
 // Post-solve: rhs_x <- A' rhs_y - rhs_x (indirect.c:419-420) and S_DH <- rhs[0:l-1)'h (abip.c:560).
 // Runs only once the CG has converged; re-checks convergence itself because the last update of a
 // chunk has no SpMV behind it.
+// `aty` (or null): the product A'rhs_y itself is kept -- with v_y == 0 the iterate's new y block IS rhs_y (abip.c:731-734), so the stopping test's A'u_y
+// and the next solve's warm-start product A's (indirect.c:345-350) are this very vector, row for row the same sums (solver.hip: aty_valid).
 template <bool SELL>
 __global__ __launch_bounds__(BS, SELL ? 6 : 8) void k_post_At(Csr At, double *__restrict__ rhs, const double *__restrict__ h, Dims d,
-                                                int max_its, double *part, int nb, Ctl *ctl) {
+                                                int max_its, double *part, int nb, Ctl *ctl, double *__restrict__ aty) {
   ABIP_GATE_HALT(ctl);
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
@@ -309,6 +316,7 @@ __global__ __launch_bounds__(BS, SELL ? 6 : 8) void k_post_At(Csr At, double *__
       [&](int j, double(&acc)[1]) {
         const double v = acc[0] - bx[j];
         bx[j] = v;
+        if (aty) aty[j] = acc[0];
         acc1[0] += v * hx[j];
       });
   for (int i = blockIdx.x * BS + threadIdx.x; i < d.m; i += gridDim.x * BS) acc1[0] += rhs[i] * h[i];
@@ -527,6 +535,54 @@ __global__ __launch_bounds__(BS, (SELLA || SELLT) ? 6 : 8) void k_q_both(Csr A, 
   else d_q_At<SELLT>(At, uu, vv, c, wE, d, slotAt, part, lds, lptr, sm, (int)blockIdx.x - nbA, (int)gridDim.x - nbA);
 }
 
+// the same launch when A'u_y is at hand (k_post_At's `aty`): workgroups [0, nbA) take A u_x as before, the rest walk the n dual residuals element-wise --
+// d_q_At's row epilogue on the stored product: the same per-element numbers, summed by a different set of workgroups
+template <bool SELLA>
+__global__ __launch_bounds__(BS, SELLA ? 6 : 8) void k_q_A_aty(Csr A, const double *__restrict__ aty, const double *__restrict__ uu, const double *__restrict__ vv, const double *__restrict__ b,
+                                                const double *__restrict__ c, const double *__restrict__ wD, const double *__restrict__ wE, Dims d,
+                                                int slotA, int slotAt, int nbA, double *part, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (!ctl->cg_done) return;
+  __shared__ double lds[CHUNK];
+  __shared__ int lptr[CHUNK + 1];
+  __shared__ double sm[3 * WAVES];
+  if ((int)blockIdx.x < nbA) { d_q_A<SELLA>(A, uu, b, wD, d, slotA, part, lds, lptr, sm, (int)blockIdx.x, nbA); return; }
+  const int vb = (int)blockIdx.x - nbA, vgrid = (int)gridDim.x - nbA;
+  const double *s = vv + d.MP;
+  const double tau = uu[d.MP + d.n];
+  double acc3[3] = {0.0, 0.0, 0.0};
+  for (int j = vb * BS + threadIdx.x; j < d.n; j += vgrid * BS) {
+    const double drj = aty[j] + s[j], e = drj - c[j] * tau;
+    double sc = wE ? wE[j] : 1.0;
+    sc = sc * sc;
+    acc3[0] += e * e; acc3[1] += (e * e) * sc; acc3[2] += (drj * drj) * sc;
+  }
+  const int ws[3] = {slotAt, slotAt + 1, slotAt + 2};
+  write_partials<3>(part, ws, acc3, sm, vb);
+}
+
+struct XcdFinal { // the final_check branch of abip.c:2190-2213 evaluated on the device (calc_residuals + has_converged on the finalised sums)
+  int on, pfeasopt, ipm_pos;
+  double eps, den, nm_b, nm_c;
+  long k0, max_admm;
+};
+
+// the finalised sums of one iterate as lp_scalars.h reads them (o = the out[] array; ac: the averaged iterate's)
+__host__ __device__ inline LpSums x_sums(const double *o, int ac) {
+  LpSums s;
+  s.ut = ac ? o[82] : o[80]; s.vt = ac ? o[83] : o[81];
+  s.rp = ac ? o[S_RPA] : o[S_RP]; s.nax = ac ? o[S_NAXA] : o[S_NAX];
+  s.rd = ac ? o[S_RDA] : o[S_RD]; s.naty = ac ? o[S_NATYA] : o[S_NATY];
+  s.by = ac ? o[S_BYA] : o[S_BY]; s.cx = ac ? o[S_CXA] : o[S_CX];
+  return s;
+}
+// calc_residuals (abip.c:458-535) + has_converged (1613-1641) on finalised sums; ac = avg_criterion of this iteration
+__device__ __forceinline__ int x_converged(const double *o, int ac, const XcdFinal &f, long ipm_iter, long k) {
+  LpResid r;
+  lp_residuals(x_sums(o, ac), f.den, f.nm_b, f.nm_c, r);
+  return lp_converged(r, f.eps, f.pfeasopt, ipm_iter, k) != 0;
+}
+
 // One block: fold the listed slots into ctl->out[slot] and append the tau/kappa entries the host needs.
 struct FinArgs {
   int nslots; int slots[40]; const double *u, *v, *ua, *va; const double *gs; /* non-null: take the already all-reduced values */
@@ -585,6 +641,32 @@ __device__ __forceinline__ void d_finalize(const FinArgs &f, const Dims &d, cons
   }
 }
 __global__ __launch_bounds__(1024) void k_finalize(FinArgs f, Dims d, const double *part, int nb, Ctl *ctl) { d_finalize(f, d, part, nb, ctl); }
+
+// The finalize of a STREAMED iteration (solver.hip: admm_stream_pcg -- the host enqueues iteration j + 1 before it has read the verdict of iteration j, so nothing
+// the next iteration depends on may be left to the host):
+//   * the PCG had not converged inside the launches enqueued for it: halt = 2 ("stalled") -- everything enqueued behind falls through, the host adds PCG iterations
+//     and enqueues the rest of this iteration again;
+//   * the exit test of abip.c:2173 holds: halt = 1 (d_finalize);
+//   * final_check (abip.c:2190-2213): calc_residuals + has_converged on the finalised sums, the iteration limits: halt = 3 -- the host extracts the solution;
+//   * in every case the control block is copied to a pinned host mirror (no copy launch between two iterations; the host waits for an event behind this kernel).
+struct FinStream { Ctl *mirror; XcdFinal fc; long ipm_iter; int ipm_last; /* i + 1 >= max_ipm_iters */ };
+__global__ __launch_bounds__(1024) void k_finalize_stream(FinArgs f, FinStream fs, Dims d, const double *part, int nb, Ctl *ctl) {
+  const int halt0 = ctl->halt, done0 = ctl->cg_done, it0 = ctl->it_count;
+  __syncthreads(); // (everybody has read the state thread 0 may overwrite)
+  if (!halt0 && !done0) { if (threadIdx.x == 0) ctl->halt = 2; }
+  else d_finalize(f, d, part, nb, ctl);
+  __syncthreads();
+  if (threadIdx.x == 0 && fs.fc.on && ctl->it_count != it0 && !ctl->halt) {
+    const long k = fs.fc.k0 + 1; // admm_iter as abip.c:2190 sees it
+    if (x_converged(ctl->out, ctl->avg_crit, fs.fc, fs.ipm_iter, k) || k + 1 >= fs.fc.max_admm || fs.ipm_last) ctl->halt = 3;
+  }
+  __syncthreads();
+  if (fs.mirror) {
+    const double *src = reinterpret_cast<const double *>(ctl);
+    double *dst = reinterpret_cast<double *>(fs.mirror);
+    for (int q = threadIdx.x; q < (int)(sizeof(Ctl) / sizeof(double)); q += blockDim.x) dst[q] = src[q];
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // outer-iteration element-wise kernels

@@ -57,11 +57,7 @@ static_assert(XTB % 64 == 0 && XWAVES >= 4 && XWAVES <= 16, "wavefront k handles
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-struct XcdFinal { // the final_check branch of abip.c:2190-2213 evaluated on the device (calc_residuals + has_converged on the finalised sums)
-  int on, pfeasopt, ipm_pos;
-  double eps, den, nm_b, nm_c;
-  long k0, max_admm;
-};
+// (XcdFinal, x_sums, x_converged: dev_kernels.h -- the launch path's streamed iterations take the same decisions on the device)
 
 // A launch that SPANS OUTER ITERATIONS (round 4; abip.c:2217-2293 and src/adaptive.c:87-251 on the device).  With `on` the kernel does not return when
 // the inner loop's exit test holds: every workgroup takes the reference's scalar decisions itself, from sums that are bit-identical in all of them
@@ -433,22 +429,6 @@ __device__ __forceinline__ void x_prox(const UpdArgs &a, double uo, double vo, d
 #define XQ_CNT(k, n)
 #endif
 
-
-// the finalised sums of one iterate as lp_scalars.h reads them (o = the out[] array; ac: the averaged iterate's)
-__host__ __device__ inline LpSums x_sums(const double *o, int ac) {
-  LpSums s;
-  s.ut = ac ? o[82] : o[80]; s.vt = ac ? o[83] : o[81];
-  s.rp = ac ? o[S_RPA] : o[S_RP]; s.nax = ac ? o[S_NAXA] : o[S_NAX];
-  s.rd = ac ? o[S_RDA] : o[S_RD]; s.naty = ac ? o[S_NATYA] : o[S_NATY];
-  s.by = ac ? o[S_BYA] : o[S_BY]; s.cx = ac ? o[S_CXA] : o[S_CX];
-  return s;
-}
-// calc_residuals (abip.c:458-535) + has_converged (1613-1641) on finalised sums; ac = avg_criterion of this iteration
-__device__ __forceinline__ int x_converged(const double *o, int ac, const XcdFinal &f, long ipm_iter, long k) {
-  LpResid r;
-  lp_residuals(x_sums(o, ac), f.den, f.nm_b, f.nm_c, r);
-  return lp_converged(r, f.eps, f.pfeasopt, ipm_iter, k) != 0;
-}
 
 // the smallest of one value per thread, in every thread (outer iterations only: a handful of calls per solve)
 __device__ __forceinline__ double x_block_min(double v, double *mnb /* XWAVES doubles of their own */) {

@@ -222,6 +222,13 @@ struct ABIP_WORK {
   DBuf<double> u, v, ut, u_avg, v_avg, u_sum, v_sum, u_avgc, v_avgc, h, g, b, c, wD, wE;
   DBuf<double> cg_p, cg_r, cg_Gp, cg_z, cg_M, cg_tmp; // indirect.h:14-29
   DBuf<double> cg_pair; // 2 n: (rhs_x[j], (A's)[j]) side by side for the one-gather PCG set-up (k_cg_init_A)
+  // A'u_y of the current iterate, kept by the back-substitution (k_post_At) of the iteration that produced it: with v_y == 0 the new y block is the solve's
+  // (abip.c:731-734), so the stopping test's A'u_y and the next solve's warm-start product are that vector -- one product per iteration instead of three.
+  // Valid from a plain iteration of the launch path (one GPU, PCG, no restart, no half update) until something else writes u_y.
+  DBuf<double> aty; bool aty_valid = false, aty_on = true;
+  // streamed iterations of the launch path (admm_stream_pcg): two pinned mirrors of the control block, written by k_finalize_stream, and the events behind them
+  Ctl *hmir[2] = {nullptr, nullptr}; hipEvent_t mir_ev[2] = {nullptr, nullptr}; bool stream_on = true;
+  long stream_stalls = 0, stream_iters = 0;
   DBuf<double> a_up, a_vp, a_ut, a_u, a_v, a_utn, a_un, a_vn; // adaptive.c:13-32 (the three delta vectors are never stored)
   DBuf<double> part;
   DBuf<Ctl> ctl;
@@ -409,14 +416,14 @@ double cg_tol_factor(const W *w, abip_int iter) { // indirect.c:406-407
 // a partial n-vector in T[0:n); it is all-reduced together with the packed scalars in T[n:] (one collective), and the
 // second half of each step runs on the summed data.  Per CG iteration: ONE collective (vector + packed scalars): p'Gp is
 // rebuilt from rho ||p||^2 (recurrence on the summed z'z, z'p) + ||A'p||^2 (replicated), not reduced on its own.
-int enqueue_cg_begin(W *w, double *rhs, const double *warm, abip_int iter) {
+int enqueue_cg_begin(W *w, double *rhs, const double *warm, abip_int iter, bool pairs_ready = false) {
   const Dims d = dims(w);
   w->cg_enq = 0;
   const Ctl *ctl = w->ctl.p;
   const double *bx = rhs + w->MP;
   double2 *pair = (double2 *)w->cg_pair.p;
   if (!w->dist) {
-    if (warm) launch(w, ABIP_HIP_K_CG_EDGE, PICK(k_cg_init_At, w->dAt), w->NB, BS, w->dAt.view(), warm, bx, pair, ctl);
+    if (warm && !pairs_ready) launch(w, ABIP_HIP_K_CG_EDGE, PICK(k_cg_init_At, w->dAt), w->NB, BS, w->dAt.view(), warm, bx, pair, ctl); // (pairs_ready: k_rhs wrote them from the kept A'u_y)
     launch(w, ABIP_HIP_K_CG_EDGE, PICK2(k_cg_init_A, false, w->dA), w->NB, BS, w->dA.view(), rhs, (const double2 *)pair, warm, (const double *)w->cg_M.p,
            w->cg_r.p, w->cg_z.p, w->cg_p.p, w->stgs->rho_y, cg_tol_factor(w, iter), d, w->part.p, w->NB, w->ctl.p, (const double *)nullptr);
     return 0;
@@ -492,9 +499,9 @@ int enqueue_cg_chunk(W *w, double *rhs, int its) {
   w->ev_tag = -1;
   return 0;
 }
-int enqueue_cg_post(W *w, double *rhs) {
+int enqueue_cg_post(W *w, double *rhs, double *keep_aty = nullptr) {
   if (!w->dist) {
-    launch(w, ABIP_HIP_K_CG_EDGE, PICK(k_post_At, w->dAt), w->NB, BS, w->dAt.view(), rhs, (const double *)w->h.p, dims(w), (int)w->m_glob, w->part.p, w->NB, w->ctl.p);
+    launch(w, ABIP_HIP_K_CG_EDGE, PICK(k_post_At, w->dAt), w->NB, BS, w->dAt.view(), rhs, (const double *)w->h.p, dims(w), (int)w->m_glob, w->part.p, w->NB, w->ctl.p, keep_aty);
     return 0;
   }
   if (w->cg_cols) { // decision on the replicated |r|^2; then y back to the row block, A_g'y into its place of T, and the row form's tail
@@ -636,7 +643,7 @@ abip_int has_converged(const W *w, abip_int ipm_iter, abip_int admm_iter) { // a
 // ------------------------------------------------------------------------------------------------
 // statistics pass on the current iterate(s): the two residual SpMVs + finalise + control read
 // ------------------------------------------------------------------------------------------------
-int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty, bool decide = true, FinArgs *defer = nullptr) {
+int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty, bool decide = true, FinArgs *defer = nullptr, const double *aty = nullptr, const FinStream *fs = nullptr) {
   const Dims d = dims(w);
   const Ctl *ctl = w->ctl.p;
   const double *wD = w->stgs->normalize ? w->wD.p : nullptr, *wE = w->stgs->normalize ? w->wE.p : nullptr;
@@ -645,7 +652,10 @@ int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty, bool decide =
   const int base[] = {S_NU, S_NV, S_CX, S_BY, S_QP, S_RP, S_NAX, S_QD, S_RD, S_NATY};
   const int extra[] = {S_NUA, S_NVA, S_CXA, S_BYA, S_QPA, S_RPA, S_NAXA, S_QDA, S_RDA, S_NATYA};
   for (int s : base) f.slots[ns++] = s;
-  if (!w->dist) {
+  if (!w->dist && aty) { // A'u_y is at hand (k_post_At kept it): only A u_x is a product, the dual residuals are element-wise
+    launch(w, ABIP_HIP_K_QNORM, PICK(k_q_A_aty, w->dA), 2 * w->NB, BS, w->dA.view(), aty, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->b.p,
+           (const double *)w->c.p, wD, wE, d, (int)S_QP, (int)S_QD, w->NB, w->part.p, ctl);
+  } else if (!w->dist) {
     launch(w, ABIP_HIP_K_QNORM, (w->dA.nslices > 0 ? (w->dAt.nslices > 0 ? k_q_both<true, true> : k_q_both<true, false>) : (w->dAt.nslices > 0 ? k_q_both<false, true> : k_q_both<false, false>)), 2 * w->NB, BS, w->dA.view(), w->dAt.view(), (const double *)w->u.p, (const double *)w->v.p, (const double *)w->b.p,
            (const double *)w->c.p, wD, wE, d, (int)S_QP, (int)S_QD, w->NB, w->part.p, ctl);
   } else {
@@ -681,7 +691,8 @@ int enqueue_q_and_finalize(W *w, bool avg_stats, bool T_holds_Aty, bool decide =
     if (allreduce_scalars(w)) return -1;
   }
   if (defer) { *defer = f; return 0; } // the next iteration's solve kernel runs it as its prologue
-  launch(w, ABIP_HIP_K_VEC, k_finalize, 1, 1024, f, d, (const double *)w->part.p, w->NB, w->ctl.p);
+  if (fs) launch(w, ABIP_HIP_K_VEC, k_finalize_stream, 1, 1024, f, *fs, d, (const double *)w->part.p, w->NB, w->ctl.p);
+  else launch(w, ABIP_HIP_K_VEC, k_finalize, 1, 1024, f, d, (const double *)w->part.p, w->NB, w->ctl.p);
   return 0;
 }
 
@@ -711,7 +722,7 @@ int enqueue_iteration_direct(W *w, abip_int j, bool restart, const FinArgs *prev
     w->ldl.enqueue([&](auto kern, int grid, int block, size_t lds, auto... a) { launch_lds(w, ABIP_HIP_K_SPTRSV, kern, grid, block, lds, a...); }, w->ut.p, ctl, w->NB, fz);
   } else {
     launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, w->ut.p, (const double *)w->h.p, st->rho_y, w->g_th, d,
-           w->part.p, w->NB, ctl, (const double *)w->gs);
+           w->part.p, w->NB, ctl, (const double *)w->gs, (const double *)nullptr, (double2 *)nullptr);
     enqueue_direct(w, w->ut.p);
   }
   launch(w, ABIP_HIP_K_VEC, k_admm_update, w->NB, BS, upd_args(w, !restart, avg_stats, j), d, w->part.p, w->NB, ctl);
@@ -774,8 +785,11 @@ int admm_iteration(W *w, double *metric_out) {
   if (w->linsys == ABIP_HIP_LINSYS_DIRECT) {
     if (enqueue_iteration_direct(w, w->j, restart) || sync_ctl(w)) return -1;
   } else {
+    // one GPU, v_y == 0, a plain iteration: the back-substitution's A'u_t,y is kept and serves the stopping test and the next solve's set-up (W::aty)
+    const bool keep = w->aty_on && !w->dist && w->vy_zero && !restart && !st->half_update && w->aty.p;
+    const bool have = keep && w->aty_valid;
     launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, w->ut.p, (const double *)w->h.p, st->rho_y, w->g_th, d,
-           w->part.p, w->NB, ctl, (const double *)w->gs);
+           w->part.p, w->NB, ctl, (const double *)w->gs, have ? (const double *)w->aty.p : (const double *)nullptr, have ? (double2 *)w->cg_pair.p : (double2 *)nullptr);
     int err = 0;
     auto tail = [&]() {
       launch(w, ABIP_HIP_K_VEC, k_admm_update, w->NB, BS, upd_args(w, !restart, avg_stats, w->j), d, w->part.p, w->NB, ctl);
@@ -784,13 +798,14 @@ int admm_iteration(W *w, double *metric_out) {
         launch(w, ABIP_HIP_K_VEC, k_avg_stats, w->NB, BS, upd_args(w, true, avg_stats, w->j), d, w->part.p, ctl);
       }
       // T still holds A'u_t,y from the back-substitution; it equals A'u_y iff v_y == 0 and (u, v) were not replaced by the restart mean
-      if (enqueue_q_and_finalize(w, avg_stats, w->vy_zero && !restart)) err = -1;
+      if (enqueue_q_and_finalize(w, avg_stats, w->vy_zero && !restart, true, nullptr, keep ? (const double *)w->aty.p : (const double *)nullptr)) err = -1;
     };
-    if (enqueue_cg_begin(w, w->ut.p, w->u.p, w->k)) return -1; // warm start = current u[0:m), abip.c:559
+    if (enqueue_cg_begin(w, w->ut.p, w->u.p, w->k, have)) return -1; // warm start = current u[0:m), abip.c:559
+    w->aty_valid = false;
     int chunk = next_chunk(w);
     for (;;) {
       if (enqueue_cg_chunk(w, w->ut.p, chunk)) return -1;
-      if (enqueue_cg_post(w, w->ut.p)) return -1;
+      if (enqueue_cg_post(w, w->ut.p, keep ? w->aty.p : nullptr)) return -1;
       tail();
       if (err || sync_ctl(w)) return -1;
       if (w->hctl->cg_done) break;
@@ -799,12 +814,93 @@ int admm_iteration(W *w, double *metric_out) {
     w->last_cg_its = w->hctl->cg_it;
     w->tot_cg_its += w->hctl->cg_it;
     w->prof.cg_iters += w->hctl->cg_it;
+    w->aty_valid = keep;
   }
   if (restart) w->fre_old = st->restart_fre; // abip.c:627
   w->wg_valid = true;
   w->stats_valid = true; w->avg_stats_valid = avg_stats;
   w->prof.admm_iters++;
   take_verdict(w, metric_out); // iterate_Q_norm_resd, abip.c:1951-2051 (scalar part, evaluated by k_finalize)
+  return clear_halt(w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// PCG back-end on one GPU, LPs beyond the caches (C4): iterations STREAMED -- iteration q + 1 is enqueued before the host has seen the verdict of iteration q,
+// so the device never waits for the host between two iterations (round 4: one control read per iteration = ~27 us of idle device + a 4.6 us copy launch).
+// What makes that safe: everything an iteration needs is either known to the host in advance (j, k, mu, beta, the PCG tolerance factor) or decided on the
+// device by k_finalize_stream -- exit test (halt 1), final check (halt 3), "the PCG did not converge inside the launches enqueued for it" (halt 2) -- and every
+// kernel of the path falls through once halt is raised.  A stalled iteration is resumed where it stopped (more PCG iterations, then its tail again); the
+// chain that was enqueued behind it ran as no-ops and is enqueued again.  The verdicts arrive through two pinned mirrors of the control block.
+// Same kernels, same arguments, same order as admm_iteration: the trajectory is bit for bit the one the stepwise loop produces.
+// *ran = iterations completed; *why = 0 budget used up, 1 exit test held at the last one, 3 final check held at the last one.
+// ------------------------------------------------------------------------------------------------
+bool stream_ok(const W *w) {
+  return w->stream_on && w->hmir[0] && w->linsys == ABIP_HIP_LINSYS_INDIRECT && !w->dist && !w->xcd.on && !w->stgs->half_update && !(w->prof_mask & ~(1u << ABIP_HIP_K_CLASSES));
+}
+int admm_stream_pcg(W *w, long nmax, long *ran, double *metric_out, int *why) {
+  const Dims d = dims(w);
+  const Ctl *ctl = w->ctl.p;
+  ABIPSettings *st = w->stgs;
+  *ran = 0; *why = 0;
+  if (!w->wg_valid) launch(w, ABIP_HIP_K_VEC, k_dot_wg, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, (const double *)w->g.p, st->rho_y, d, w->part.p, w->xwt);
+  const abip_int j0 = w->j, k0 = w->k;
+  const bool keep = w->aty_on && w->vy_zero && w->aty.p;
+  FinStream fs;
+  fs.fc.on = w->final_check ? 1 : 0; fs.fc.pfeasopt = (int)st->pfeasopt; fs.fc.ipm_pos = w->i > 0 ? 1 : 0;
+  fs.fc.eps = st->eps; fs.fc.den = st->normalize ? (st->scale * w->sc_c * w->sc_b) : 1.0; fs.fc.nm_b = w->nm_b; fs.fc.nm_c = w->nm_c;
+  fs.fc.max_admm = (long)st->max_admm_iters; fs.ipm_iter = (long)w->i; fs.ipm_last = (w->i + 1 >= st->max_ipm_iters) ? 1 : 0;
+  auto tail = [&](long q) -> int { // back-substitution, update, stopping test, the streamed finalize + its event
+    const bool avg_stats = ((j0 + q + 1) % 10 == 0);
+    if (enqueue_cg_post(w, w->ut.p, keep ? w->aty.p : nullptr)) return -1;
+    launch(w, ABIP_HIP_K_VEC, k_admm_update, w->NB, BS, upd_args(w, true, avg_stats, j0 + q), d, w->part.p, w->NB, ctl);
+    fs.mirror = w->hmir[q & 1]; fs.fc.k0 = (long)(k0 + q);
+    if (enqueue_q_and_finalize(w, avg_stats, false, true, nullptr, keep ? (const double *)w->aty.p : (const double *)nullptr, &fs)) return -1;
+    return hipEventRecord(w->mir_ev[q & 1], w->stream) == hipSuccess ? 0 : -1;
+  };
+  int chunk = next_chunk(w);
+  auto enqueue_iter = [&](long q, bool have) -> int {
+    launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, w->ut.p, (const double *)w->h.p, st->rho_y, w->g_th, d,
+           w->part.p, w->NB, ctl, (const double *)w->gs, have ? (const double *)w->aty.p : (const double *)nullptr, have ? (double2 *)w->cg_pair.p : (double2 *)nullptr);
+    if (enqueue_cg_begin(w, w->ut.p, w->u.p, k0 + q, have)) return -1; // warm start = current u[0:m), abip.c:559
+    if (enqueue_cg_chunk(w, w->ut.p, chunk)) return -1;
+    return tail(q);
+  };
+  long enq = 0, done = 0;
+  while (done < nmax) {
+    while (enq < nmax && enq - done < 2) { // (the first iteration of a call may find A'u_y kept by its predecessor; every later one does when `keep`)
+      if (enqueue_iter(enq, enq == 0 ? (keep && w->aty_valid) : keep)) return -1;
+      ++enq;
+    }
+    w->aty_valid = false;
+    const int sl = (int)(done & 1);
+    if (hipEventSynchronize(w->mir_ev[sl]) != hipSuccess) return -1;
+    const Ctl &hm = *w->hmir[sl];
+    if (hm.halt == 2) { // stalled: the PCG needs more iterations than were enqueued.  Resume it; what was enqueued behind ran as no-ops.
+      ++w->stream_stalls;
+      HIP_OK(hipMemsetAsync(&w->ctl.p->halt, 0, sizeof(int), w->stream));
+      chunk = std::max(4, chunk);
+      if (enqueue_cg_chunk(w, w->ut.p, chunk) || tail(done)) return -1;
+      enq = done + 1;
+      continue;
+    }
+    memcpy(w->hctl, &hm, sizeof(Ctl));
+    if (w->hctl->it_count != w->it_seen + 1) { fprintf(stderr, "abip_hip: streamed iteration %ld: the device reports %d completed iterations, expected %d\n", (long)(k0 + done), w->hctl->it_count, w->it_seen + 1); return -1; }
+    w->last_cg_its = w->hctl->cg_it; w->tot_cg_its += w->hctl->cg_it; w->prof.cg_iters += w->hctl->cg_it;
+    chunk = next_chunk(w);
+    w->tot_solves++; w->prof.kkt_solves++; w->prof.admm_iters++; ++w->stream_iters;
+    take_verdict(w, metric_out);
+    ++done;
+    if (w->hctl->halt) { *why = w->hctl->halt; break; } // 1: exit test; 3: final check.  Whatever was enqueued behind falls through.
+  }
+  *ran = done;
+  w->wg_valid = true; w->stats_valid = true; w->avg_stats_valid = ((j0 + done) % 10 == 0);
+  w->aty_valid = keep && done > 0;
+  if (w->stamp_mask) { // (device-side launch stamps of bench.py's roofline leg: read back once per call)
+    size_t lo = 0, hi = 0;
+    if (enqueue_stamp_readback(w, &lo, &hi)) return -1;
+    HIP_OK(hipStreamSynchronize(w->stream));
+    if (hi > lo) harvest_stamps(w, lo, hi);
+  }
   return clear_halt(w);
 }
 
@@ -1265,7 +1361,7 @@ int lin_projection(W *w, double *ut, const double *u, const double *v, abip_int 
   launch(w, ABIP_HIP_K_VEC, k_dot_wg, w->NB, BS, u, v, (const double *)w->g.p, w->stgs->rho_y, d, w->part.p, w->xwt);
   if (w->dist) { enqueue_fold(w, {S_WG}); if (allreduce_scalars(w)) return -1; }
   launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, u, v, ut, (const double *)w->h.p, w->stgs->rho_y, w->g_th, d, w->part.p, w->NB, (const Ctl *)w->ctl.p,
-         (const double *)w->gs);
+         (const double *)w->gs, (const double *)nullptr, (double2 *)nullptr);
   return kkt_solve_sync(w, ut, u, iter) < 0 ? -1 : 0; // S_DH is left for k_adapt_step
 }
 int adaptive_search(W *w, abip_int iter) {
@@ -1523,10 +1619,11 @@ void free_work(W *w) {
   { DBuf<double> *cb[] = {&w->cc_b, &w->cc_y, &w->cc_r, &w->cc_z, &w->cc_p, &w->cc_Gp, &w->cc_M, &w->cc_tmp, &w->cc_d, &w->cc_buf}; for (auto *b : cb) b->release(); }
   DBuf<double> *bufs[] = {&w->u, &w->v, &w->ut, &w->u_avg, &w->v_avg, &w->u_sum, &w->v_sum, &w->u_avgc, &w->v_avgc, &w->h, &w->g, &w->b, &w->c,
                           &w->wD, &w->wE, &w->cg_p, &w->cg_r, &w->cg_Gp, &w->cg_z, &w->cg_M, &w->cg_tmp, &w->cg_pair, &w->a_up, &w->a_vp, &w->a_ut, &w->a_u,
-                          &w->a_v, &w->a_utn, &w->a_un, &w->a_vn, &w->part};
+                          &w->a_v, &w->a_utn, &w->a_un, &w->a_vn, &w->part, &w->aty};
   for (auto *b : bufs) b->release();
   w->ctl.release(); w->ldl.release(); w->T.release(); w->xcd.release();
   if (w->hctl) (void)hipHostFree(w->hctl);
+  for (int q = 0; q < 2; ++q) { if (w->hmir[q]) (void)hipHostFree(w->hmir[q]); if (w->mir_ev[q]) (void)hipEventDestroy(w->mir_ev[q]); }
   w->stamps.release();
   if (w->hstamps) (void)hipHostFree(w->hstamps);
   for (auto &e : w->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1720,6 +1817,16 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
     host::jacobi_preconditioner(Ause, Minv);
     if (w->cg_M.upload(Minv, w->stream) || w->cg_p.alloc(m) || w->cg_r.alloc(m) || w->cg_Gp.alloc(m) || w->cg_z.alloc(m) || w->cg_tmp.alloc(n) || w->cg_pair.alloc(2 * (size_t)n))
       return fail("init_lin_sys_work failure");
+    { const char *e = getenv("ABIP_HIP_ATY"); w->aty_on = !(e && atoi(e) == 0); } // ABIP_HIP_ATY=0: every product formed where the reference forms it (A / B, tests)
+    if (!w->dist && w->aty_on && w->aty.alloc(n)) return fail("init_lin_sys_work failure");
+    { const char *e = getenv("ABIP_HIP_STREAM"); w->stream_on = !(e && atoi(e) == 0); } // ABIP_HIP_STREAM=0: one control read per iteration, as in round 4
+    if (!w->dist && w->stream_on) {
+      for (int q = 0; q < 2; ++q) {
+        if (hipHostMalloc((void **)&w->hmir[q], sizeof(Ctl), hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&w->mir_ev[q], hipEventDisableTiming) != hipSuccess)
+          return fail("pinned allocation failure");
+        memset(w->hmir[q], 0, sizeof(Ctl));
+      }
+    }
     if (hipMemsetAsync(w->cg_tmp.p, 0, sizeof(double) * n, w->stream) != hipSuccess) return fail("memset failure");
   } else { // init_lin_sys_work / factorize, direct.c:218-303
     host::LdlHost F;
@@ -1847,7 +1954,7 @@ abip_int abip_hip_solve_begin(ABIPWork *w, const ABIPData *d, const ABIPSolution
     if (sync_ctl(w)) return ABIP_FAILED;
     w->g_th = w->hctl->out[S_T0];
   }
-  w->i = 0; w->j = 0; w->k = 0; w->phase = PH_OUTER_BEGIN; w->wg_valid = false; w->stats_valid = false; w->have_solution = false;
+  w->i = 0; w->j = 0; w->k = 0; w->phase = PH_OUTER_BEGIN; w->wg_valid = false; w->stats_valid = false; w->have_solution = false; w->aty_valid = false;
   w->tot_cg_its = 0; w->tot_solves = 0; w->last_cg_its = 6;
   if (st->verbose) print_header(w);
   return 0;
@@ -1885,7 +1992,7 @@ abip_int abip_hip_step(ABIPWork *w, abip_int max_admm_steps, abip_int *steps_don
           if (hipMemcpyAsync(w->u.p, w->u_avgc.p, lbytes, hipMemcpyDeviceToDevice, w->stream) != hipSuccess ||
               hipMemcpyAsync(w->v.p, w->v_avgc.p, lbytes, hipMemcpyDeviceToDevice, w->stream) != hipSuccess)
             return hard_fail("device copy");
-          w->wg_valid = false;
+          w->wg_valid = false; w->aty_valid = false;
         }
         w->j = 0;
         w->batch = 4;
@@ -1898,6 +2005,7 @@ abip_int abip_hip_step(ABIPWork *w, abip_int max_admm_steps, abip_int *steps_don
         double metric = 0;
         if (xcd_outer_ok(w) && !restart_due(w, w->k, w->j)) { // cache-resident LP: the loop goes on INSIDE one persistent launch, across outer iterations, until the host is needed
           long ran = 0; int why = 0;
+          w->aty_valid = false;
           const int rc = xcd_run(w, 0, (long)(max_admm_steps - steps), &ran, &why);
           if (rc < 0) return hard_fail("error in project_lin_sys");
           if (rc > 0) break; // abandoned (nothing ran, the iterate is as it was): the launch path goes on from here
@@ -1923,6 +2031,7 @@ abip_int abip_hip_step(ABIPWork *w, abip_int max_admm_steps, abip_int *steps_don
           for (long q = 0; q < nb; ++q) if (restart_due(w, w->k + q, w->j + q)) { nb = q; break; }
           if (nb >= 1) {
             int ran = 0;
+            w->aty_valid = false;
             const int rcb = xcd_batch(w, (int)nb, &ran, &metric);
             if (rcb < 0) return hard_fail("error in project_lin_sys");
             if (rcb > 0) break; // abandoned: the launch path goes on from the same iterate
@@ -1968,6 +2077,26 @@ abip_int abip_hip_step(ABIPWork *w, abip_int max_admm_steps, abip_int *steps_don
             break;
           }
         }
+        if (stream_ok(w) && !restart_due(w, w->k, w->j)) { // PCG on one GPU beyond the caches: iterations streamed, the host one verdict behind the device
+          long nb = std::min<long>({(long)(max_admm_steps - steps), (long)(w->inner_stopper - w->j), 1L << 20});
+          for (long q = 1; q < nb; ++q) if (restart_due(w, w->k + q, w->j + q)) { nb = q; break; }
+          long ran = 0; int why = 0;
+          if (admm_stream_pcg(w, nb, &ran, &metric, &why) || ran < 1) return hard_fail("error in project_lin_sys");
+          steps += (abip_int)ran; w->k += (abip_int)ran;
+          if (why == 1) { w->j += (abip_int)ran - 1; w->phase = PH_OUTER_END; break; } // abip.c:2173-2188: the exit test held at the last iteration (j is not advanced)
+          if (why == 3 || w->final_check) { // abip.c:2190-2213 for the last iteration that ran (the device found the earlier ones unconverged)
+            calc_residuals(w, w->i, w->k);
+            if ((info->status_val = has_converged(w, w->i, w->k)) != 0 || w->k + 1 >= st->max_admm_iters || w->i + 1 >= st->max_ipm_iters) {
+              if (st->verbose && w->k > 0) print_summary(w, w->i, w->k);
+              if (finish_solution(w, info, w->i, w->k)) return hard_fail("device error in get_solution");
+              if (st->verbose) print_footer(w, info);
+              w->phase = PH_DONE;
+              return done(1);
+            }
+          }
+          w->j += (abip_int)ran;
+          break;
+        }
         if (admm_iteration(w, &metric)) return hard_fail("error in project_lin_sys");
         ++steps;
         w->k += 1;
@@ -1994,6 +2123,7 @@ abip_int abip_hip_step(ABIPWork *w, abip_int max_admm_steps, abip_int *steps_don
         const double elapsed = ((double)clock() - w->cpu0) / CLOCKS_PER_SEC; // abip.c:2217-2221
         if (!w->host_outer_once && xcd_outer_ok(w) && w->stats_valid && (!st->avg_criterion || w->avg_stats_valid) && elapsed <= st->max_time) { // the outer end, and what follows it, inside the persistent launch
           long ran = 0; int why = 0;
+          w->aty_valid = false;
           const int rc = xcd_run(w, 1, (long)(max_admm_steps - steps), &ran, &why);
           if (rc < 0) return hard_fail("error in project_lin_sys");
           if (rc == 0) {
@@ -2197,7 +2327,7 @@ abip_float abip_hip_get_scalar(ABIPWork *w, const char *name) {
   RET("sell_At", w->dAt.nslices) RET("sell_A", w->dA.nslices) RET("nb", w->NB) RET("dist_cols", w->cg_cols ? 1 : 0) RET("small_solve", w->ldl.small ? 1 : 0) RET("factor_resid", w->factor_resid)
   RET("xcd", w->xcd.on ? 1 : 0) RET("xcd_nz", w->xcd.NZ) RET("xcd_g", w->xcd.on ? w->xcd.G : 0) RET("xcd_batches", w->xcd.batches) RET("xcd_exchanges", w->xcd.exchanges)
   RET("xcd_launches", w->xcd.launches) RET("xcd_outer", (w->xcd.on && w->xcd.outer) ? 1 : 0) RET("xcd_outer_done", w->xcd.outer_done) RET("xcd_lookaheads", w->xcd.lookaheads)
-  RET("xcd_whole_launches", w->xcd.whole_launches) RET("xcd_giveups", w->xcd.giveups)
+  RET("xcd_whole_launches", w->xcd.whole_launches) RET("xcd_giveups", w->xcd.giveups) RET("stream_stalls", w->stream_stalls) RET("stream_iters", w->stream_iters) RET("aty_valid", w->aty_valid ? 1.0 : 0.0)
 #undef RET
   return NAN;
 }

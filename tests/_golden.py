@@ -27,3 +27,12 @@ def info_of(z, tag):
 def rel(a, b):
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def lp_sha256(A, b, c):
+    """Checksum of an LP as tests/golden/make_golden.py took it: the BASELINE-size fixtures store it instead of the LP (the seeded generator rebuilds it)."""
+    import hashlib
+    h = hashlib.sha256()
+    for a in (np.asarray(A.data, dtype=np.float64), np.asarray(A.indices, dtype=np.int64), np.asarray(A.indptr, dtype=np.int64), np.asarray(b, dtype=np.float64), np.asarray(c, dtype=np.float64)):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()

@@ -56,7 +56,7 @@ def test_abip_main_from_c(prog, tmp_path, linsys):
     assert "2.0.0" in p.stdout
     (info, x, y, s), = _read_out(ob, A.shape[0], A.shape[1], 1)
     g = info_of(z, f"{linsys}_1e-06")
-    assert info[0] == 1 and info[1] == g["ipm_iter"] and abs(info[2] - g["admm_iter"]) <= 0.03 * g["admm_iter"] + 2
+    assert info[0] == 1 and info[1] == g["ipm_iter"] and info[2] == g["admm_iter"]
     for got, k in ((x, "x"), (y, "y"), (s, "s")):
         assert rel(got, z[f"{linsys}_1e-06_{k}"]) < 1e-5, k
     assert abs(info[3] - g["pobj"]) <= 1e-5 * (1 + abs(g["pobj"]))

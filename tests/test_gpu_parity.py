@@ -256,16 +256,17 @@ def test_edge_shapes_and_sparsity_branches(gpu, oracle_built, shape, linsys):
         assert 0.2 < sp_ratio <= 0.5
     if shape == "dense_full":
         assert sp_ratio > 0.5
-    o = oracle_built.solve("oracle", A, b, c, linsys=linsys, eps=1e-6, max_admm_iters=100000)
-    with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-6, max_admm_iters=100000) as S:
+    cap = 20000 if shape == "tall_warned" else 100000   # (the PCG back-end runs `tall_warned` into its cap: no need for a long one)
+    o = oracle_built.solve("oracle", A, b, c, linsys=linsys, eps=1e-6, max_admm_iters=cap)
+    with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-6, max_admm_iters=cap) as S:
         info = S.solve()
         assert info["status_val"] == o.info["status_val"], (shape, info["status"], o.info["status"])
         if o.info["status_val"] == 1:       # (the PCG back-end stalls on `tall_warned` at its 1e-7 CG floor -- reference, oracle and device
             assert info["ipm_iter"] == o.info["ipm_iter"]   # all end "Solved/Inaccurate" at the iteration cap; nothing finer to compare there)
-            assert abs(info["admm_iter"] - o.info["admm_iter"]) <= 0.03 * o.info["admm_iter"] + 2
+            assert info["admm_iter"] == o.info["admm_iter"], (shape, linsys, info["admm_iter"], o.info["admm_iter"])
             assert abs(info["pobj"] - o.info["pobj"]) <= 1e-5 * (1 + abs(o.info["pobj"]))
             for k in "xys":
-                assert rel(getattr(S, k), getattr(o, k)) < 1e-4, (shape, linsys, k)
+                assert rel(getattr(S, k), getattr(o, k)) < 1e-5, (shape, linsys, k)
 
 
 @pytest.mark.parametrize("linsys", ["indirect", "direct"])
@@ -282,9 +283,9 @@ def test_restart_path_follows_the_oracle(gpu, oracle_built, linsys):
     with gpu.Solver(A, b, c, linsys=linsys, verbose=0, **kw) as S:
         info = S.solve()
         assert info["status_val"] == o.info["status_val"] and info["ipm_iter"] == o.info["ipm_iter"]
-        assert abs(info["admm_iter"] - o.info["admm_iter"]) <= 0.03 * o.info["admm_iter"] + 2
+        assert info["admm_iter"] == o.info["admm_iter"], (linsys, info["admm_iter"], o.info["admm_iter"])
         for k in "xys":
-            assert rel(getattr(S, k), getattr(o, k)) < (1e-6 if info["admm_iter"] == o.info["admm_iter"] else 1e-4), (linsys, k)
+            assert rel(getattr(S, k), getattr(o, k)) < 1e-6, (linsys, k)
 
 
 def test_dense_tail_failure_falls_back_to_the_level_scheduled_factor(gpu, monkeypatch):
@@ -379,7 +380,7 @@ def test_sliced_ell_layout(gpu, oracle_built, monkeypatch):
                 assert rel(S.vector(nm), o.trace[t, col]) < 1e-9, (t + 1, nm)
     with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-6) as S:
         info = S.solve()
-        _check_against_golden_loose((info, S.x, S.y, S.s), z, "indirect_1e-06", 1e-6, "lp_random_sparse_small")
+        _check_run_against_golden((info, S.x, S.y, S.s), z, "indirect_1e-06", 1e-6)
     monkeypatch.setenv("ABIP_HIP_SELL", "0")
     with gpu.Solver(A, b, c, linsys="indirect", verbose=0) as S:
         assert S.scalar("sell_At") == 0
@@ -409,7 +410,8 @@ def test_iterates_follow_the_oracle(gpu, oracle_built, name, linsys):
 # eps = 1e-4 stopping point is 9.8e-2 away (relative) from the x it converges to at eps = 1e-8, while its objective is already right to 1e-5.  On it the
 # persistent launch's direct variant -- inv(rho I + A A') applied as a dense matrix where the launch path and the reference solve with LDL' -- lands on the
 # other side of one Barzilai-Borwein decision (15 or 16 outer iterations, 264 / 287 / 293 inner ones).  There the bar is what the problem determines:
-# status, objective, the reference's convergence criteria -- and (x, y, s) at eps = 1e-8, where all paths agree to 1e-6 (test_knife_edge_fixture_at_tight_eps).
+# status, objective, the reference's convergence criteria -- and (x, y, s) against the reference's own eps = 1e-8 solution (test_knife_edge_fixture_at_tight_eps).
+# The exemption is the persistent launch's alone: the launch path (sparse LDL', as the reference) takes the reference's counts here too and is held to them.
 KNIFE_EDGE = {("lp_tiny_scale5", "direct_0.0001")}
 
 
@@ -422,7 +424,7 @@ def _check_against_golden(S, info, z, tag, eps, name=None):
     g = info_of(z, tag)
     assert info["status_val"] == g["status_val"]
     tol = 10 * eps
-    if (name, tag) in KNIFE_EDGE:
+    if (name, tag) in KNIFE_EDGE and S.scalar("xcd") == 1.0:
         assert abs(info["ipm_iter"] - g["ipm_iter"]) <= 1 and abs(info["admm_iter"] - g["admm_iter"]) <= 0.12 * g["admm_iter"]
     else:
         assert info["ipm_iter"] == g["ipm_iter"] and info["admm_iter"] == g["admm_iter"], (tag, info["ipm_iter"], info["admm_iter"], g["ipm_iter"], g["admm_iter"])
@@ -434,15 +436,15 @@ def _check_against_golden(S, info, z, tag, eps, name=None):
         assert info[k] < eps
 
 
-def _check_against_golden_loose(run, z, tag, eps, name):
+def _check_run_against_golden(run, z, tag, eps):
+    """The same bar for a run handed over as (info, x, y, s): the reference's counts, (x, y, s) and objectives within 10 eps."""
     info, x, y, s_ = run
     g = info_of(z, tag)
-    assert info["status_val"] == g["status_val"] and info["ipm_iter"] == g["ipm_iter"]
-    assert abs(info["admm_iter"] - g["admm_iter"]) <= 0.03 * g["admm_iter"] + 2
+    assert info["status_val"] == g["status_val"]
+    assert (info["ipm_iter"], info["admm_iter"]) == (g["ipm_iter"], g["admm_iter"]), (tag, info["ipm_iter"], info["admm_iter"], g["ipm_iter"], g["admm_iter"])
     assert abs(info["pobj"] - g["pobj"]) <= 10 * eps * (1 + abs(g["pobj"]))
-    if name != "lp_staircase":
-        for got, k in ((x, "x"), (y, "y"), (s_, "s")):
-            assert rel(got, z[f"{tag}_{k}"]) < 10 * eps, k
+    for got, k in ((x, "x"), (y, "y"), (s_, "s")):
+        assert rel(got, z[f"{tag}_{k}"]) < 10 * eps, k
 
 
 @pytest.mark.parametrize("name", ["lp_afiro_like", "lp_random_sparse_small", "lp_multicommodity_small"])
@@ -474,77 +476,71 @@ def test_north_star_agreement_with_the_reference_itself(gpu, name, linsys):
     assert g["status_val"] == 1
     with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-8, max_admm_iters=400000) as S:
         info = S.solve()
-        assert info["status_val"] == 1 and info["ipm_iter"] == g["ipm_iter"]
-        assert abs(info["admm_iter"] - g["admm_iter"]) <= 0.03 * g["admm_iter"] + 2
-        # lp_staircase is degenerate (a face of optimal solutions; profiles/README.md r01h): the objectives and residuals pin it, (x, y, s) at 1e-4
-        tol = 1e-4 if name == "lp_staircase" else 1e-6
-        for k in "xys":
-            assert rel(getattr(S, k), z[f"{tag}_{k}"]) < tol, (name, linsys, k)
+        assert info["status_val"] == 1
+        assert (info["ipm_iter"], info["admm_iter"]) == (g["ipm_iter"], g["admm_iter"]), (name, linsys, info["ipm_iter"], info["admm_iter"], g["ipm_iter"], g["admm_iter"])
+        for k in "xys":   # (lp_staircase -- the C2 workload, a degenerate LP -- included: profiles/r04w_parity_counts.txt has it at 3e-9)
+            assert rel(getattr(S, k), z[f"{tag}_{k}"]) < 1e-6, (name, linsys, k)
         assert abs(info["pobj"] - g["pobj"]) <= 1e-6 * (1 + abs(g["pobj"]))
         assert abs(info["dobj"] - g["dobj"]) <= 1e-6 * (1 + abs(g["dobj"]))
         for k in ("res_pri", "res_dual", "rel_gap"):
             assert info[k] < 1e-8
 
 
-@pytest.mark.parametrize("name,eps_list", [("lp_afiro_like", (1e-3, 1e-6)), ("lp_random_sparse_small", (1e-3, 1e-6)),
-                                           ("lp_multicommodity_small", (1e-4,)), ("lp_staircase", (1e-3, 1e-6))])
-@pytest.mark.parametrize("linsys", ["indirect", "direct"])
-def test_final_solution_matches_reference_fixture(gpu, name, eps_list, linsys):
-    z, A, b, c = load(name)
-    for eps in eps_list:
-        with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=eps) as S:
-            info = S.solve()
-            _check_against_golden(S, info, z, f"{linsys}_{eps:g}", eps)
-
-
 @pytest.mark.parametrize("xcd", ["1", "0"])
+@pytest.mark.parametrize("linsys", ["indirect", "direct"])
 @pytest.mark.parametrize("name,eps_list", [("lp_afiro_like", (1e-3, 1e-6, 1e-8)), ("lp_random_sparse_small", (1e-3, 1e-6, 1e-8)),
                                            ("lp_multicommodity_small", (1e-4, 1e-8)), ("lp_staircase", (1e-3, 1e-6))])
-def test_direct_back_end_exact_iteration_counts(gpu, monkeypatch, name, eps_list, xcd):
-    """The direct back-end has no inner stopping test to flip (the KKT solve is exact to rounding), so its runs are held to the reference's
-    fixtures at the EXACT inner and outer iteration counts, and (x, y, s) at 10 eps -- through the one-XCD launch (the dense inverse of
-    rho I + A A') and through the launch-per-operation path (the sparse LDL' solve) alike."""
+def test_exact_iteration_counts_on_both_paths(gpu, monkeypatch, name, eps_list, linsys, xcd):
+    """Every main fixture x eps x back-end, through the persistent launch (PCG inside the kernel; the direct variant's dense inverse of rho I + A A') and through
+    the launch-per-operation path (the C4 path: PCG kernel by kernel; the sparse LDL' solve): the reference's EXACT inner and outer iteration counts, (x, y, s) and
+    the objectives within 10 eps, its convergence criteria (profiles/r04w_parity_counts.txt is this table).  lp_staircase is the C2 workload.
+    (The launch path skips the two longest PCG runs -- 40 000 iterations of lp_multicommodity_small / lp_staircase at 1e-8, ~18 s each; the persistent launch and
+    test_north_star_agreement_with_the_reference_itself cover those.)"""
     monkeypatch.setenv("ABIP_HIP_XCD", xcd)
     z, A, b, c = load(name)
     for eps in eps_list:
-        tag = f"direct_{eps:g}"
-        g = info_of(z, tag)
-        with gpu.Solver(A, b, c, linsys="direct", verbose=0, eps=eps, max_admm_iters=400000) as S:
+        if xcd == "0" and linsys == "indirect" and eps == 1e-8 and name == "lp_multicommodity_small":
+            continue
+        with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=eps, max_admm_iters=400000) as S:
             assert S.scalar("xcd") == float(xcd)
             info = S.solve()
-            assert info["status_val"] == g["status_val"] and info["ipm_iter"] == g["ipm_iter"]
-            assert info["admm_iter"] == g["admm_iter"], (name, eps, info["admm_iter"], g["admm_iter"])
-            if name != "lp_staircase":
-                for k in "xys":
-                    assert rel(getattr(S, k), z[f"{tag}_{k}"]) < 10 * eps, (name, eps, k)
-            assert abs(info["pobj"] - g["pobj"]) <= 10 * eps * (1 + abs(g["pobj"]))
+            _check_against_golden(S, info, z, f"{linsys}_{eps:g}", eps, name=name)
 
 
+@pytest.mark.parametrize("xcd", ["1", "0"])
 @pytest.mark.parametrize("variant", sorted(TINY_VARIANTS))
 @pytest.mark.parametrize("linsys", ["indirect", "direct"])
-def test_non_default_switches_match_reference_fixture(gpu, variant, linsys):
+def test_non_default_switches_match_reference_fixture(gpu, variant, linsys, xcd, monkeypatch):
+    """half_update, origin / qp scaling, no normalisation, no adaptive search, scale = 5, the "tedious" mu table: both device paths at the reference's counts
+    (the persistent launch on the KNIFE_EDGE fixture excepted; the launch path is held to it there too)."""
+    monkeypatch.setenv("ABIP_HIP_XCD", xcd)
     z, A, b, c = load("lp_tiny_" + variant)
     with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-4, **TINY_VARIANTS[variant]) as S:
+        assert S.scalar("xcd") == float(xcd)
         info = S.solve()
         _check_against_golden(S, info, z, f"{linsys}_0.0001", 1e-4, name="lp_tiny_" + variant)
 
 
 def test_knife_edge_fixture_at_tight_eps(gpu, monkeypatch):
-    """lp_tiny_scale5, direct back-end (KNIFE_EDGE above): at eps = 1e-8 the three device paths -- launch path (LDL'), persistent launch in batches and
-    spanning outer iterations (dense inverse) -- reach the same (x, y, s) to the north-star bar of 1e-6, and the same objective to 1e-8."""
+    """lp_tiny_scale5, direct back-end (KNIFE_EDGE above) against the REFERENCE's eps = 1e-8 solution (fixture tags direct_1e-08_*, written by make_golden.py
+    from oracle/_ref): the three device paths -- launch path (LDL'), persistent launch in batches and spanning outer iterations (dense inverse) -- reach the
+    reference's (x, y, s) to the north-star bar of 1e-6 and its objective to 1e-8; the launch path also takes the reference's iteration counts."""
     z, A, b, c = load("lp_tiny_scale5")
-    out = {}
+    g = info_of(z, "direct_1e-08")
+    assert g["status_val"] == 1
     for mode, env in (("path", {"ABIP_HIP_XCD": "0"}), ("batch", {"ABIP_HIP_XCD": "1", "ABIP_HIP_XCD_OUTER": "0"}), ("whole", {"ABIP_HIP_XCD": "1", "ABIP_HIP_XCD_OUTER": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         with gpu.Solver(A, b, c, linsys="direct", verbose=0, eps=1e-8, **TINY_VARIANTS["scale5"]) as S:
             info = S.solve()
-            assert info["status_val"] == 1
-            out[mode] = (info, S.x.copy(), S.y.copy(), S.s.copy())
-    for mode in ("batch", "whole"):
-        for k in (1, 2, 3):
-            assert rel(out[mode][k], out["path"][k]) < 1e-6, (mode, k)
-        assert abs(out[mode][0]["pobj"] - out["path"][0]["pobj"]) <= 1e-8 * (1 + abs(out["path"][0]["pobj"]))
+            assert info["status_val"] == 1 and info["ipm_iter"] == g["ipm_iter"], (mode, info["ipm_iter"], g["ipm_iter"])
+            if mode == "path":
+                assert info["admm_iter"] == g["admm_iter"], (mode, info["admm_iter"], g["admm_iter"])
+            for k in "xys":
+                assert rel(getattr(S, k), z[f"direct_1e-08_{k}"]) < 1e-6, (mode, k)
+            assert abs(info["pobj"] - g["pobj"]) <= 1e-8 * (1 + abs(g["pobj"])) and abs(info["dobj"] - g["dobj"]) <= 1e-8 * (1 + abs(g["dobj"]))
+            for k in ("res_pri", "res_dual", "rel_gap"):
+                assert info[k] < 1e-8
 
 
 def test_matlab_surface_end_to_end(gpu):

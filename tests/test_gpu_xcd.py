@@ -1,14 +1,15 @@
 """GPU (-m gpu): the one-XCD persistent launch (abip_amd/csrc/dev_xcd.h) -- the whole inner ADMM loop of a cache-resident LP in one kernel on
-the 32 CUs of one XCD -- against the launch path (one kernel per step of the iteration, dev_kernels.h), which the rest of the suite holds against
-the reference's fixtures and the oracle.  (With the launch on by default the fixture / oracle tests of test_gpu_parity.py run through it too.)
+the 32 CUs of one XCD (or of 2, 4, 8 XCDs) -- against the REFERENCE's eps = 1e-8 fixtures (tests/golden, written from oracle/_ref) where a fixture exists, and
+against the launch path (one kernel per step of the iteration, dev_kernels.h; held to the same fixtures by test_gpu_parity.py) on generated LPs.  (With the
+launch on by default the fixture / oracle tests of test_gpu_parity.py run through it too.)
 
-Bars: the same decisions (status, outer iterations; inner iterations within 1 %), (x, y, s) within 1e-6 relative when both run to eps = 1e-8 (the
-north-star bar: the two paths add in different orders and the direct variant applies inv(rho I + A A') where the launch path solves with LDL');
-bit-identical results whatever the batching of the iterations."""
+Bars: the reference's outer AND inner iteration counts, (x, y, s) within 1e-6 relative at eps = 1e-8 (the north-star bar: the paths add in different orders and
+the direct variant applies inv(rho I + A A') where the reference solves with LDL'); bit-identical results whatever the batching of the iterations.
+(Round 4 compared the persistent launch with a launch-path run of the same LP; the fixture is the stronger bar and costs no second solve.)"""
 import numpy as np
 import pytest
 
-from _golden import load, rel
+from _golden import info_of, load, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -23,25 +24,27 @@ def gpu():
     return abip_amd
 
 
+def _against_the_reference_at_1e8(S, info, z, linsys):
+    """The reference's own eps = 1e-8 run of this LP: its counts, its (x, y, s) to 1e-6, its objective."""
+    tag = f"{linsys}_1e-08"
+    g = info_of(z, tag)
+    assert info["status_val"] == g["status_val"] == 1
+    assert (info["ipm_iter"], info["admm_iter"]) == (g["ipm_iter"], g["admm_iter"]), (info["ipm_iter"], info["admm_iter"], g["ipm_iter"], g["admm_iter"])
+    assert abs(info["pobj"] - g["pobj"]) <= 1e-6 * (1 + abs(g["pobj"]))
+    for k in "xys":
+        assert rel(getattr(S, k), z[f"{tag}_{k}"]) < 1e-6, k
+
+
 @pytest.mark.parametrize("name", ["lp_afiro_like", "lp_random_sparse_small", "lp_multicommodity_small", "lp_staircase"])
 @pytest.mark.parametrize("linsys", ["indirect", "direct"])
-def test_one_xcd_launch_agrees_with_the_launch_path(gpu, name, linsys, monkeypatch):
+def test_one_xcd_launch_matches_the_reference_at_tight_eps(gpu, name, linsys, monkeypatch):
     z, A, b, c = load(name)
-    out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("ABIP_HIP_XCD", mode)
-        with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-8) as S:
-            assert S.scalar("xcd") == float(mode)
-            info = S.solve()
-            assert (S.scalar("xcd_launches") > 0) == (mode == "1")
-            out[mode] = (info, S.x.copy(), S.y.copy(), S.s.copy())
-    a, l = out["1"], out["0"]
-    assert a[0]["status_val"] == l[0]["status_val"] == 1
-    assert a[0]["ipm_iter"] == l[0]["ipm_iter"]
-    assert abs(a[0]["admm_iter"] - l[0]["admm_iter"]) <= 0.01 * l[0]["admm_iter"] + 1
-    assert abs(a[0]["pobj"] - l[0]["pobj"]) <= 1e-6 * (1 + abs(l[0]["pobj"]))
-    for k in (1, 2, 3):
-        assert rel(a[k], l[k]) < 1e-6
+    monkeypatch.setenv("ABIP_HIP_XCD", "1")
+    with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-8) as S:
+        assert S.scalar("xcd") == 1.0
+        info = S.solve()
+        assert S.scalar("xcd_launches") > 0
+        _against_the_reference_at_1e8(S, info, z, linsys)
 
 
 @pytest.mark.parametrize("name,linsys", [("lp_multicommodity_small", "indirect"), ("lp_staircase", "direct"), ("lp_afiro_like", "indirect")])
@@ -108,45 +111,23 @@ def test_problems_that_do_not_fit_stay_on_the_launch_path(gpu, monkeypatch):
         assert info["admm_iter"] >= 20
 
 
-def test_full_size_c2_and_c3_on_the_one_xcd_launch(gpu, monkeypatch):
-    """BASELINE configs[1] / configs[2] surrogates at full size: the persistent launch and the launch path reach the same optimum with the same
-    number of outer iterations (eps 1e-4: seconds)."""
-    from abip_amd import problems
-    for (A, b, c), linsys in ((problems.lp_staircase(), "direct"), (problems.lp_multicommodity(nodes=1200, arcs=4400, commodities=10), "indirect")):
-        out = {}
-        for mode in ("1", "0"):
-            monkeypatch.setenv("ABIP_HIP_XCD", mode)
-            with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-4) as S:
-                assert S.scalar("xcd") == float(mode)
-                out[mode] = S.solve()
-        assert out["1"]["status_val"] == out["0"]["status_val"] == 1
-        assert out["1"]["ipm_iter"] == out["0"]["ipm_iter"]
-        assert abs(out["1"]["admm_iter"] - out["0"]["admm_iter"]) <= 0.02 * out["0"]["admm_iter"] + 2
-        assert abs(out["1"]["pobj"] - out["0"]["pobj"]) <= 1e-3 * (1 + abs(out["0"]["pobj"]))
+# (BASELINE configs[1] / configs[2] at full size on both paths: tests/test_gpu_baseline_size.py and the lp_staircase fixture tests -- against the reference.)
 
 
 @pytest.mark.parametrize("G", [64, 128, 256])
 @pytest.mark.parametrize("name,linsys", [("lp_multicommodity_small", "indirect"), ("lp_random_sparse_small", "indirect"), ("lp_staircase", "direct"),
                                          ("lp_random_sparse_small", "direct")])
-def test_launch_spread_over_several_xcds_agrees_with_the_launch_path(gpu, name, linsys, G, monkeypatch):
+def test_launch_spread_over_several_xcds_matches_the_reference(gpu, name, linsys, G, monkeypatch):
     """The workgroups may sit on 2, 4 or 8 XCDs (G = 64, 128, 256; chosen from the non-zero count -- PCG -- or from m -- direct --, here forced): the
-    stores of an exchange are then written through (the L2s of two XCDs are not coherent with each other).  Same bars as on one XCD, and the same
-    bits whatever the batching -- the partial sums are added in rank order, 64 ranks at a time."""
+    stores of an exchange are then written through (the L2s of two XCDs are not coherent with each other).  Same bar as on one XCD -- the reference's eps 1e-8
+    fixture, counts included -- and the same bits whatever the batching: the partial sums are added in rank order, 64 ranks at a time."""
     z, A, b, c = load(name)
     monkeypatch.setenv("ABIP_HIP_XCD_G", str(G))
-    out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("ABIP_HIP_XCD", mode)
-        with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-8) as S:
-            assert S.scalar("xcd") == float(mode) and S.scalar("xcd_g") == (float(G) if mode == "1" else 0.0)
-            info = S.solve()
-            out[mode] = (info, S.x.copy(), S.y.copy(), S.s.copy())
-    a, l = out["1"], out["0"]
-    assert a[0]["status_val"] == l[0]["status_val"] == 1 and a[0]["ipm_iter"] == l[0]["ipm_iter"]
-    assert abs(a[0]["admm_iter"] - l[0]["admm_iter"]) <= 0.01 * l[0]["admm_iter"] + 1
-    for k in (1, 2, 3):
-        assert rel(a[k], l[k]) < 1e-6
     monkeypatch.setenv("ABIP_HIP_XCD", "1")
+    with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-8) as S:
+        assert S.scalar("xcd") == 1.0 and S.scalar("xcd_g") == float(G)
+        info = S.solve()
+        _against_the_reference_at_1e8(S, info, z, linsys)
     runs = []
     for batch in ("1", "0"):
         monkeypatch.setenv("ABIP_HIP_BATCH", batch)
@@ -173,6 +154,6 @@ def test_direct_variant_row_counts_around_its_paddings(gpu, m, monkeypatch):
             out[mode] = (info, S.x.copy(), S.y.copy(), S.s.copy())
     a, l = out["1"], out["0"]
     assert a[0]["status_val"] == l[0]["status_val"] == 1 and a[0]["ipm_iter"] == l[0]["ipm_iter"]
-    assert abs(a[0]["admm_iter"] - l[0]["admm_iter"]) <= 0.01 * l[0]["admm_iter"] + 1
+    assert a[0]["admm_iter"] == l[0]["admm_iter"], (a[0]["admm_iter"], l[0]["admm_iter"])
     for k in (1, 2, 3):
         assert rel(a[k], l[k]) < 1e-6

@@ -2,8 +2,8 @@
 rule, reinitialize_vars and the Barzilai-Borwein search (abip.c:2217-2293, src/adaptive.c:87-251) run inside the kernel, so that a cache-resident LP
 is a handful of launches -- and what happens when such a launch has to be abandoned.
 
-Bars: the same decisions as the launch path (status, outer iterations; inner iterations within 1 %), (x, y, s) within 1e-6 relative when both run to
-eps = 1e-8; the same bits whatever budget of iterations a launch is given; a launch that gives up (fault injection, another kernel holding the CUs)
+Bars: the REFERENCE's fixtures (tests/golden, from oracle/_ref) -- its outer and inner iteration counts, (x, y, s) within 1e-6 relative at eps = 1e-8, 10 eps at
+the looser tolerances; the same bits whatever budget of iterations a launch is given; a launch that gives up (fault injection, another kernel holding the CUs)
 costs time, never the answer."""
 import os
 import subprocess
@@ -13,7 +13,7 @@ import threading
 import numpy as np
 import pytest
 
-from _golden import load, rel
+from _golden import TINY_VARIANTS, info_of, load, rel
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,26 +40,31 @@ def _solve(gpu, A, b, c, linsys, **kw):
 @pytest.mark.parametrize("linsys", ["indirect", "direct"])
 def test_outer_iterations_inside_the_launch(gpu, name, linsys, monkeypatch):
     """A whole solve in a handful of launches (the set-up solve of the PCG back-end is one of them), nearly every outer iteration closed on the device,
-    and the launch path's answer."""
+    and the reference's answer at eps 1e-8: its iteration counts (the knife-edge fixture lp_tiny_scale5 / direct -- tests/test_gpu_parity.py KNIFE_EDGE -- keeps
+    the outer count and the solution) and its (x, y, s) to 1e-6, for the launches that span outer iterations and for round 3's one-batch-per-launch form."""
     z, A, b, c = load(name)
+    kw = TINY_VARIANTS["scale5"] if name == "lp_tiny_scale5" else {}
+    tag = f"{linsys}_1e-08"
+    g = info_of(z, tag)
     out = {}
-    for mode, env in (("outer", {"ABIP_HIP_XCD": "1", "ABIP_HIP_XCD_OUTER": "1"}), ("batch", {"ABIP_HIP_XCD": "1", "ABIP_HIP_XCD_OUTER": "0"}), ("path", {"ABIP_HIP_XCD": "0"})):
+    for mode, env in (("outer", {"ABIP_HIP_XCD": "1", "ABIP_HIP_XCD_OUTER": "1"}), ("batch", {"ABIP_HIP_XCD": "1", "ABIP_HIP_XCD_OUTER": "0"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        out[mode] = _solve(gpu, A, b, c, linsys, eps=1e-8)
-    a, bt, l = out["outer"], out["batch"], out["path"]
-    assert a[4]["xcd"] == 1.0 and a[4]["xcd_outer"] == 1.0 and bt[4]["xcd_outer"] == 0.0 and l[4]["xcd"] == 0.0
+        out[mode] = _solve(gpu, A, b, c, linsys, eps=1e-8, **kw)
+    a, bt = out["outer"], out["batch"]
+    assert a[4]["xcd"] == 1.0 and a[4]["xcd_outer"] == 1.0 and bt[4]["xcd_outer"] == 0.0
     assert a[4]["xcd_giveups"] == 0
     assert a[4]["xcd_launches"] <= 8 and a[4]["xcd_launches"] < bt[4]["xcd_launches"]
     assert a[4]["xcd_outer_done"] >= a[0]["ipm_iter"] - 3          # the first outer iteration starts on the host, the last one ends there
     assert a[4]["xcd_lookaheads"] > 0
     for r in (a, bt):
-        assert r[0]["status_val"] == l[0]["status_val"] == 1
-        assert r[0]["ipm_iter"] == l[0]["ipm_iter"]
-        assert abs(r[0]["admm_iter"] - l[0]["admm_iter"]) <= 0.01 * l[0]["admm_iter"] + 1
-        assert abs(r[0]["pobj"] - l[0]["pobj"]) <= 1e-6 * (1 + abs(l[0]["pobj"]))
-        for k in (1, 2, 3):
-            assert rel(r[k], l[k]) < 1e-6
+        assert r[0]["status_val"] == g["status_val"] == 1
+        assert r[0]["ipm_iter"] == g["ipm_iter"]
+        if (name, linsys) != ("lp_tiny_scale5", "direct"):
+            assert r[0]["admm_iter"] == g["admm_iter"], (r[0]["admm_iter"], g["admm_iter"])
+        assert abs(r[0]["pobj"] - g["pobj"]) <= 1e-6 * (1 + abs(g["pobj"]))
+        for k, nm in ((1, "x"), (2, "y"), (3, "s")):
+            assert rel(r[k], z[f"{tag}_{nm}"]) < 1e-6, nm
 
 
 @pytest.mark.parametrize("name,linsys", [("lp_multicommodity_small", "indirect"), ("lp_staircase", "direct"), ("lp_afiro_like", "indirect"), ("lp_afiro_like", "direct")])
@@ -105,7 +110,7 @@ def _child(body: str, env: dict, hooks: bool = False, timeout: int = 600):
         sys.path[:0] = [{ROOT!r}, {os.path.join(ROOT, 'tests')!r}]
         import numpy as np
         import abip_amd as gpu
-        from _golden import load, rel
+        from _golden import TINY_VARIANTS, info_of, load, rel
         """)
     r = subprocess.run([sys.executable, "-c", pre + textwrap.dedent(body)], env=e, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
@@ -131,32 +136,32 @@ def test_verbose_rows_of_the_outer_iterations_closed_on_the_device(gpu):
     assert rows["1"] == rows["0"]
 
 
-@pytest.mark.parametrize("name,linsys,at", [("lp_staircase", "direct", 0), ("lp_staircase", "direct", 1), ("lp_multicommodity_small", "indirect", 0),
-                                            ("lp_multicommodity_small", "indirect", 1), ("lp_multicommodity_small", "indirect", 2)])
-def test_a_launch_that_gives_up_hands_over_to_the_launch_path(gpu, name, linsys, at):
+@pytest.mark.parametrize("name,linsys,eps,at", [("lp_staircase", "direct", 1e-6, 0), ("lp_staircase", "direct", 1e-6, 1), ("lp_multicommodity_small", "indirect", 1e-4, 0),
+                                                ("lp_multicommodity_small", "indirect", 1e-4, 1), ("lp_multicommodity_small", "indirect", 1e-8, 2)])
+def test_a_launch_that_gives_up_hands_over_to_the_launch_path(gpu, name, linsys, eps, at):
     """Fault injection (libabip_hip_hooks.so only): the last rank of launch number `at` leaves at once, so every wait of that launch gives up after
     ~0.1 s.  The iterate is restored to what it was before the launch, the persistent launch is switched off for this work and the launch path
-    finishes the solve: same status, same outer iterations, (x, y, s) to 1e-6 -- and the next work on the device is not affected."""
+    finishes the solve: the reference's status, iteration counts and (x, y, s) within 10 eps (the fixture's bar) -- and the next work on the device is not affected."""
     body = f"""
         import os
+        from _golden import info_of
         z, A, b, c = load({name!r})
-        with gpu.Solver(A, b, c, linsys={linsys!r}, verbose=0, eps=1e-8) as S:
+        tag = "{linsys}_{eps:g}"
+        g = info_of(z, tag)
+        with gpu.Solver(A, b, c, linsys={linsys!r}, verbose=0, eps={eps!r}) as S:
             info = S.solve()
             assert S.scalar("xcd_giveups") == 1 and S.scalar("xcd") == 0.0, (S.scalar("xcd_giveups"), S.scalar("xcd"))
             res = (info, S.x.copy(), S.y.copy(), S.s.copy())
         os.environ["ABIP_HIP_XCD_GIVEUP_AT"] = "-1"
-        with gpu.Solver(A, b, c, linsys={linsys!r}, verbose=0, eps=1e-8) as S:          # the next work: persistent launches again, nothing left behind
+        with gpu.Solver(A, b, c, linsys={linsys!r}, verbose=0, eps={eps!r}) as S:          # the next work: persistent launches again, nothing left behind
             info2 = S.solve()
             assert S.scalar("xcd_giveups") == 0 and S.scalar("xcd") == 1.0 and S.scalar("xcd_outer_done") > 0
             res2 = (info2, S.x.copy(), S.y.copy(), S.s.copy())
-        os.environ["ABIP_HIP_XCD"] = "0"
-        with gpu.Solver(A, b, c, linsys={linsys!r}, verbose=0, eps=1e-8) as S:
-            ref = (S.solve(), S.x.copy(), S.y.copy(), S.s.copy())
         for r in (res, res2):
-            assert r[0]["status_val"] == ref[0]["status_val"] == 1 and r[0]["ipm_iter"] == ref[0]["ipm_iter"]
-            assert abs(r[0]["admm_iter"] - ref[0]["admm_iter"]) <= 0.01 * ref[0]["admm_iter"] + 1
-            for k in (1, 2, 3):
-                assert rel(r[k], ref[k]) < 1e-6
+            assert r[0]["status_val"] == g["status_val"] == 1
+            assert (r[0]["ipm_iter"], r[0]["admm_iter"]) == (g["ipm_iter"], g["admm_iter"]), (r[0]["ipm_iter"], r[0]["admm_iter"], g["ipm_iter"], g["admm_iter"])
+            for k, nm in ((1, "x"), (2, "y"), (3, "s")):
+                assert rel(r[k], z[tag + "_" + nm]) < max(10 * {eps!r}, 1e-6), nm
         """
     r = _child(body, {"ABIP_HIP_XCD": "1", "ABIP_HIP_XCD_GIVEUP_AT": str(at)}, hooks=True)
     assert "abandoned" in r.stderr
@@ -198,13 +203,11 @@ def test_two_works_solving_concurrently_from_two_threads(gpu, monkeypatch):
 
 def test_a_solve_while_another_kernel_holds_the_device(gpu, monkeypatch):
     """A long-running kernel of another stream (a chain of large torch matmuls) is in flight when the solve starts: the persistent launch either gets
-    its CUs in time or gives up and the launch path finishes -- the answer is the launch path's either way."""
+    its CUs in time or gives up and the launch path finishes -- the answer is the reference's either way (its eps 1e-8 fixture, counts included)."""
     import torch
     monkeypatch.setenv("ABIP_HIP_XCD", "1")
     z, A, b, c = load("lp_staircase")
-    monkeypatch.setenv("ABIP_HIP_XCD", "0")
-    ref = _solve(gpu, A, b, c, "direct", eps=1e-8)
-    monkeypatch.setenv("ABIP_HIP_XCD", "1")
+    g = info_of(z, "direct_1e-08")
     side = torch.cuda.Stream()
     x = torch.randn(8192, 8192, device="cuda")
     with torch.cuda.stream(side):
@@ -212,10 +215,9 @@ def test_a_solve_while_another_kernel_holds_the_device(gpu, monkeypatch):
             x = (x @ x) * 1e-4
     r = _solve(gpu, A, b, c, "direct", eps=1e-8)
     torch.cuda.synchronize()
-    assert r[0]["status_val"] == 1 and r[0]["ipm_iter"] == ref[0]["ipm_iter"]
-    assert abs(r[0]["admm_iter"] - ref[0]["admm_iter"]) <= 0.01 * ref[0]["admm_iter"] + 1
-    for k in (1, 2, 3):
-        assert rel(r[k], ref[k]) < 1e-6
+    assert r[0]["status_val"] == 1 and (r[0]["ipm_iter"], r[0]["admm_iter"]) == (g["ipm_iter"], g["admm_iter"])
+    for k, nm in ((1, "x"), (2, "y"), (3, "s")):
+        assert rel(r[k], z[f"direct_1e-08_{nm}"]) < 1e-6, nm
 
 
 def test_time_limit_takes_effect_between_launches(gpu):
