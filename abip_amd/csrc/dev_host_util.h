@@ -64,6 +64,9 @@ struct DevCsr {
   int from_columns(const DevCsr &C, int nrows_, long nnz, int chunk, hipStream_t s) {
     nrows = nrows_; nslices = 0;
     if (ptr.alloc((size_t)nrows + 1) || idx.alloc((size_t)nnz) || val.alloc((size_t)nnz)) { release(); return -1; }
+#ifdef ABIP_HIP_TEST_HOOKS
+    if (getenv("ABIP_HIP_DEV_TRANSPOSE_FAIL")) { release(); return -1; } // as if the library sort (hipcub, dev_transpose.hip) had refused: the caller's host transpose takes over
+#endif
     if (dev_csc_to_csr(nrows, C.nrows, nnz, C.ptr.p, C.idx.p, C.val.p, ptr.p, idx.p, val.p, s)) { release(); (void)hipGetLastError(); return -1; }
     host::HostCsr h;
     h.nrows = nrows; h.ptr.resize((size_t)nrows + 1);

@@ -15,6 +15,7 @@
 // All reductions go through the partials table (dev_common.h); no atomics, no fences.
 #pragma once
 #include "dev_common.h"
+#include "dev_peer.h"
 #include "lp_scalars.h"
 
 namespace abip {
@@ -808,22 +809,44 @@ __device__ __forceinline__ void fold_slots(const FoldArgs &f, const double *part
   }
 }
 __global__ __launch_bounds__(BS) void k_fold(FoldArgs f, const double *part, int nb, double *gs) { fold_slots(f, part, nb, gs); }
-// out = M x on the rows of this rank; FOLD: the last workgroup also folds the partials of the previous kernel into gs
+// out = M x on the rows of this rank; FOLD: the last workgroup also folds the partials of the previous kernel into gs.
+// pp.on (the peer-mapped transport, dev_peer.h): `out` is one rank's contribution to an all-reduce, so every row goes straight into the inbox of the rank that
+// reduces it (step 1 of the exchange: no local vector, no copy launch) -- and so do the folded scalars, which ride behind the vector at index `scal0`.
 template <bool FOLD, bool SELL>
 __global__ __launch_bounds__(BS, SELL ? 6 : 8) void k_spmv_set_t(Csr M, const double *__restrict__ x, double *__restrict__ out, int mode, const Ctl *ctl,
-                                                   FoldArgs f, const double *part, int nb, double *gs, Stamp *st) {
+                                                   FoldArgs f, const double *part, int nb, double *gs, Stamp *st, PeerPush pp, long scal0) {
   ABIP_GATE_HALT(ctl);
-  if (FOLD && blockIdx.x == gridDim.x - 1) fold_slots(f, part, nb, gs); // (before the gates: the convergence test needs the sums)
+  if (FOLD && blockIdx.x == gridDim.x - 1) { // (before the gates: the convergence test needs the sums)
+    fold_slots(f, part, nb, gs);
+    if (pp.on && !(mode == 1 && ctl->cg_done) && !(mode == 2 && !ctl->cg_done)) {
+      __syncthreads();
+      for (int q = threadIdx.x; q < f.nslots; q += BS) d_peer_put(pp, scal0 + f.slots[q], gs[f.slots[q]]);
+    }
+  }
   if (mode == 1 && ctl->cg_done) return;
   if (mode == 2 && !ctl->cg_done) return;
   stamp_begin(st);
   __shared__ double lds[CHUNK];
   __shared__ int lptr[CHUNK + 1];
   __shared__ double sm[WAVES];
-  spmv_rows<1, SELL>(
-      M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
-      [&](int row, double(&acc)[1]) { out[row] = acc[0]; });
+  if (pp.on) {
+    spmv_rows<1, SELL>(
+        M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
+        [&](int row, double(&acc)[1]) { d_peer_put(pp, (long)row, acc[0]); });
+    d_peer_push_done(pp);
+  } else {
+    spmv_rows<1, SELL>(
+        M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
+        [&](int row, double(&acc)[1]) { out[row] = acc[0]; });
+  }
   stamp_end(st);
+}
+// steps 2 + 3 of the exchange behind such a producer, under the producer's own gates (every rank takes them alike: the control state is replicated)
+__global__ __launch_bounds__(256) void k_peer_reduce_gather_gated(PeerCtx c, double *buf, long count, unsigned long long epoch, int mode, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  if (mode == 1 && ctl->cg_done) return;
+  if (mode == 2 && !ctl->cg_done) return;
+  d_peer_reduce_gather(c, buf, count, epoch);
 }
 template <bool SELL>
 __global__ __launch_bounds__(BS, SELL ? 6 : 8) void k_spmv_set(Csr M, const double *__restrict__ x, double *__restrict__ out, int mode, const Ctl *ctl) {

@@ -624,7 +624,8 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       double gmin = 1e+10;
       if ((int)t < G) gmin = x_val(x_ldg(psc, (t * XKS + 12u) * 16u));
       gmin = x_block_min(gmin, mnb);
-      if (P2[0] > 0.0) { csw(CS_REASON, (double)XR_SLICE); break; } // (nothing of this outer end has been applied: the next launch enters here again)
+      if (P2[0] > 0.0 || log_n >= xo.log_cap) { csw(CS_REASON, (double)XR_SLICE); break; } // (nothing of this outer end has been applied: the next launch enters here again.
+                                                                                          //  A full log -- LOQO rule on a tiny LP: no mu-table limit -- ends the launch the same way: the host prints its rows)
       if (mu < a.fc.eps) final_check = 1;                          // abip.c:2224-2227
       __syncthreads();                                             // outs complete
       LpResid r;
@@ -1514,6 +1515,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         for (int q = 0; q < RN; ++q) { const unsigned j2 = n0 + tb + q * XTB; if (j2 < n1) { x_at(RU, MP + j2) = sq * x_at(RU, MP + j2); x_at(RV, MP + j2) = sq * x_at(RV, MP + j2); } }
         const double r_ut = x_uni(sq * csr(CS_RUT)), r_vt = x_uni(sq * csr(CS_RVT));
         if (rank == 0 && t == 0) { x_at(RU, tail) = r_ut; x_at(RV, tail) = r_vt; }
+        __syncthreads(); // (every wavefront has read CS_RUT / CS_RVT before thread 0 rewrites them)
         csw(CS_RUT, r_ut); csw(CS_RVT, r_vt);
         if (!av) { u_tau = r_ut; v_tau = r_vt; }
       }

@@ -75,6 +75,14 @@ inline void par_ranges(long n, long grain, F fn) {
   if (T <= 1) { fn(0L, n, 0); return; }
   Pool::get().run(T, [&](int t) { fn(n * t / T, n * (t + 1) / T, t); });
 }
+// the same with the number of parts GIVEN (T <= par_threads()): for callers that size per-part tables first -- going through a grain again may come out
+// with a different count (ABIP_HIP_HOST_GRAIN_DIV on a tiny matrix: ADVICE r4) and index past the tables
+template <class F>
+inline void par_ranges_T(long n, int T, F fn) {
+  T = std::max(1, std::min(T, Pool::get().threads()));
+  if (T <= 1) { fn(0L, n, 0); return; }
+  Pool::get().run(T, [&](int t) { fn(n * t / T, n * (t + 1) / T, t); });
+}
 // the same for the columns (rows) of a compressed matrix, cut so that every part holds about the same number of entries: ptr has n + 1 entries
 template <class P, class F>
 inline void par_by_entries(const P *ptr, long n, long grain_entries, F fn) {

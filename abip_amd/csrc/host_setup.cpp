@@ -117,7 +117,7 @@ void normalize_A(ABIPMatrix *A, const ABIPSettings *stgs, std::vector<double> &D
         if (T <= 1) { for (abip_int q = 0; q < A->p[n]; ++q) { const double w = std::fabs(A->x[q]); if (w >= Dk[A->i[q]]) Dk[A->i[q]] = w; } }
         else {
           std::vector<std::vector<double>> part(T, std::vector<double>(m, 0.0));
-          par_ranges(nz, nz / T, [&](long lo, long hi, int t) { std::vector<double> &P = part[t]; for (long q = lo; q < hi; ++q) { const double w = std::fabs(A->x[q]); if (w >= P[A->i[q]]) P[A->i[q]] = w; } });
+          par_ranges_T(nz, T, [&](long lo, long hi, int t) { std::vector<double> &P = part[t]; for (long q = lo; q < hi; ++q) { const double w = std::fabs(A->x[q]); if (w >= P[A->i[q]]) P[A->i[q]] = w; } });
           for (int t = 0; t < T; ++t) for (abip_int i = 0; i < m; ++i) if (part[t][i] >= Dk[i]) Dk[i] = part[t][i];
         }
       }

@@ -62,7 +62,7 @@ inline void scale_passes(QWk *w, const QCPCone *k) {
         if (T <= 1) { for (int q = 0; q < A.p[n]; ++q) if (Dp[A.i[q]] < std::fabs(A.x[q])) Dp[A.i[q]] = std::fabs(A.x[q]); }
         else {
           std::vector<std::vector<double>> part(T, std::vector<double>(m, 0.0));
-          host::par_ranges((long)A.p[n], (long)A.p[n] / T, [&](long lo, long hi, int t) { std::vector<double> &P = part[t]; for (long q = lo; q < hi; ++q) { const double a = std::fabs(A.x[q]); if (P[A.i[q]] < a) P[A.i[q]] = a; } });
+          host::par_ranges_T((long)A.p[n], T, [&](long lo, long hi, int t) { std::vector<double> &P = part[t]; for (long q = lo; q < hi; ++q) { const double a = std::fabs(A.x[q]); if (P[A.i[q]] < a) P[A.i[q]] = a; } });
           for (int t = 0; t < T; ++t) for (int i = 0; i < m; ++i) if (Dp[i] < part[t][i]) Dp[i] = part[t][i];
         }
       }

@@ -27,7 +27,6 @@
 #include "dev_kernels.h"
 #include "dev_ldl.h"
 #include "dev_xcd.h"
-#include "dev_peer.h"
 #include "dist_internal.h"
 #include "host_setup.h"
 #include "dev_host_util.h"
@@ -69,6 +68,8 @@ struct PeerHost { // dev_peer.h: the hand-rolled exchange over peer-mapped mailb
   unsigned *sync = nullptr; int *hstatus = nullptr;
   unsigned long long epoch = 0;
   long cap = 0;
+  bool fused = true;      // the product kernels of the sharded PCG push their rows themselves (ABIP_HIP_PEER_FUSED=0: every all-reduce is the stand-alone kernel)
+  bool fine = false;      // the mailbox is fine-grained device memory (else plain device memory: see dev_peer.h "Coherence")
 };
 struct DistCtx {
   int kind = 0; // 0 none, 1 RCCL, 2 host callback (tests), 3 peer-mapped mailboxes (dev_peer.h)
@@ -396,6 +397,21 @@ int allreduce_dev(W *w, double *buf, size_t count) {
   if (ev) (void)hipEventRecord(ev->b, w->stream);
   return rc;
 }
+// The peer-mapped transport (dev_peer.h) lets a producer kernel push its result straight into the reducing ranks' mailboxes: peer_push_begin hands the kernel
+// what it needs (and takes the epoch of this exchange); peer_finish enqueues steps 2 + 3 behind it under the producer's gate `mode`.  pp.on == 0: any other
+// transport -- the producer stores locally and the caller runs the collective as before.
+PeerPush peer_push_begin(W *w, size_t count) {
+  PeerPush pp{};
+  pp.on = 0;
+  if (!w->dist || g_dist.kind != 3 || *g_dist.peer.hstatus || (long)count > g_dist.peer.cap || !g_dist.peer.fused) return pp;
+  pp.on = 1; pp.c = g_dist.peer.ctx; pp.chunk = abip::peer_chunk((long)count, g_dist.world); pp.epoch = ++g_dist.peer.epoch;
+  return pp;
+}
+int peer_finish(W *w, const PeerPush &pp, double *buf, size_t count, int mode) {
+  w->prof.allreduce_calls++; w->prof.allreduce_bytes += (double)(sizeof(double) * count);
+  hipLaunchKernelGGL(abip::k_peer_reduce_gather_gated, dim3(64), dim3(256), 0, w->stream, pp.c, buf, (long)count, pp.epoch, mode, (const Ctl *)w->ctl.p);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 void enqueue_fold(W *w, std::initializer_list<int> slots) {
   FoldArgs f; f.nslots = 0;
   for (int sl : slots) f.slots[f.nslots++] = sl;
@@ -464,8 +480,15 @@ int enqueue_cg_chunk(W *w, double *rhs, int its) {
     for (int q = 0; q < its; ++q) {
       w->ev_tag = w->cg_enq++;
       launch(w, ABIP_HIP_K_SPMV_AT, k_cg_spmv_At<false>, w->NB, BS, w->dAct.view(), (const double *)w->cc_z.p, w->cc_tmp.p, max_its, w->part.p, w->NB, w->ctl.p, next_stamp(w, ABIP_HIP_K_SPMV_AT));
-      launch(w, ABIP_HIP_K_SPMV_A, k_spmv_set<false>, w->NB, BS, w->dAc.view(), (const double *)w->cc_tmp.p, w->cc_buf.p, 1, (const Ctl *)w->ctl.p);
-      if (allreduce_dev(w, w->cc_buf.p, (size_t)mg)) return -1;
+      const PeerPush pp = peer_push_begin(w, (size_t)mg);
+      if (pp.on) {
+        launch(w, ABIP_HIP_K_SPMV_A, k_spmv_set_t<false, false>, w->NB, BS, w->dAc.view(), (const double *)w->cc_tmp.p, w->cc_buf.p, 1, (const Ctl *)w->ctl.p,
+               FoldArgs{}, (const double *)w->part.p, w->NB, w->gs, (Stamp *)nullptr, pp, 0L);
+        if (peer_finish(w, pp, w->cc_buf.p, (size_t)mg, 1)) return -1;
+      } else {
+        launch(w, ABIP_HIP_K_SPMV_A, k_spmv_set<false>, w->NB, BS, w->dAc.view(), (const double *)w->cc_tmp.p, w->cc_buf.p, 1, (const Ctl *)w->ctl.p);
+        if (allreduce_dev(w, w->cc_buf.p, (size_t)mg)) return -1;
+      }
       launch(w, ABIP_HIP_K_CG_VEC, k_cols_Gp_fin, w->NB, BS, (const double *)w->cc_buf.p, (const double *)w->cc_z.p, w->cc_p.p, w->cc_Gp.p, w->stgs->rho_y, mg, w->part.p, (const Ctl *)w->ctl.p);
       launch(w, ABIP_HIP_K_CG_VEC, k_cg_update<false>, gv, BS, w->cc_y.p, w->cc_r.p, w->cc_z.p, (const double *)w->cc_p.p, (const double *)w->cc_Gp.p,
              (const double *)w->cc_M.p, mg, w->stgs->rho_y, w->part.p, w->NB, w->ctl.p, (const double *)nullptr);
@@ -481,9 +504,10 @@ int enqueue_cg_chunk(W *w, double *rhs, int its) {
     } else {
       FoldArgs fo; fo.nslots = 0;
       for (int sl : {S_RR0, S_RR1, S_ZR0, S_ZR1, S_ZZ, S_ZP}) fo.slots[fo.nslots++] = sl;
+      const PeerPush pp = peer_push_begin(w, w->n_pad + S_COUNT);
       launch(w, ABIP_HIP_K_SPMV_AT, PICK2(k_spmv_set_t, true, w->dAt), w->NB, BS, w->dAt.view(), (const double *)w->cg_z.p, w->T.p, 1, (const Ctl *)w->ctl.p,
-             fo, (const double *)w->part.p, w->NB, w->gs, next_stamp(w, ABIP_HIP_K_SPMV_AT));
-      if (allreduce_vec_and_scalars(w)) return -1;
+             fo, (const double *)w->part.p, w->NB, w->gs, next_stamp(w, ABIP_HIP_K_SPMV_AT), pp, (long)w->n_pad);
+      if (pp.on ? peer_finish(w, pp, w->T.p, w->n_pad + S_COUNT, 1) : allreduce_vec_and_scalars(w)) return -1;
       launch(w, ABIP_HIP_K_CG_VEC, k_dist_cg_step, w->NB, BS, (const double *)w->T.p, w->cg_tmp.p, (int)w->n, max_its, 1, (const double *)w->gs, w->part.p, w->ctl.p);
     }
     launch(w, ABIP_HIP_K_SPMV_A, PICK(k_cg_spmv_A, w->dA), w->NB, BS, w->dA.view(), (const double *)w->cg_tmp.p, (const double *)w->cg_z.p, w->cg_p.p,
@@ -1746,10 +1770,11 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
         if (w->A->i[q] >= r0 && w->A->i[q] < r1) { w->Aloc_i[t] = w->A->i[q] - r0; w->Aloc_x[t] = w->A->x[q]; ++t; }
     w->Aloc.x = w->Aloc_x.data(); w->Aloc.i = w->Aloc_i.data(); w->Aloc.p = w->Aloc_p.data(); w->Aloc.m = w->m; w->Aloc.n = n;
     Ause = &w->Aloc;
-    // form of the sharded solve: rows (default: north_star's contract -- row blocks, one all-reduce of the A'-partials + packed scalars per PCG iteration) or
-    // columns (ABIP_HIP_DIST_CG=cols: inside the solve the m-space is gathered and replicated, the exchange per PCG iteration is the m-vector -- C4: 1.6 MB
-    // against 4 MB).  Neither has run on two GPUs yet; bench.py --gpus N measures both in one invocation, and the default follows a measurement, not a model.
-    { const char *e = getenv("ABIP_HIP_DIST_CG"); w->cg_cols = (e && !strcmp(e, "cols")); }
+    // form of the sharded solve: rows (north_star's wording -- row blocks, one all-reduce of the A'-partials + packed scalars per PCG iteration) or columns
+    // (inside the solve the m-space is gathered and replicated, the exchange per PCG iteration is the m-vector -- C4: 1.6 MB against 4 MB; the iteration around
+    // the solve keeps its row blocks either way).  Neither has run on two GPUs yet; bench.py --gpus N measures both in one invocation.
+    // Default since round 5: the form that exchanges less -- columns whenever m < n; ABIP_HIP_DIST_CG=rows|cols names one.
+    { const char *e = getenv("ABIP_HIP_DIST_CG"); w->cg_cols = e ? !strcmp(e, "cols") : (mg < n); }
     if (w->cg_cols) { // column block of the scaled matrix, balanced by non-zeros (+1 per column), and the whole Jacobi preconditioner
       if (n < w->world) return fail("fewer columns than ranks");
       std::vector<abip_int> cb(w->world + 1, 0);
@@ -2488,17 +2513,37 @@ int abip_hip_dist_peer_prepare(long cap_doubles, void *handle_out64) {
   if (cap_doubles < 1 || !handle_out64) return -1;
   PeerHost &p = g_dist.peer;
   if (p.mine) return -2;
-  const size_t bytes = sizeof(double) * (size_t)(abip::PEER_HEAD + 2 * cap_doubles + 64);
-  if (hipMalloc(&p.mine, bytes) != hipSuccess || hipMemset(p.mine, 0, bytes) != hipSuccess) { (void)hipGetLastError(); return -3; }
-  if (hipMalloc((void **)&p.sync, 64) != hipSuccess || hipMemset(p.sync, 0, 64) != hipSuccess) return -3;
-  if (hipHostMalloc((void **)&p.hstatus, sizeof(int), hipHostMallocMapped) != hipSuccess) return -3;
+  auto undo = [&](int rc) { // nothing half-made is left behind: a later call starts from scratch
+    if (p.mine) (void)hipFree(p.mine);
+    if (p.sync) (void)hipFree(p.sync);
+    if (p.hstatus) (void)hipHostFree(p.hstatus);
+    p = PeerHost();
+    (void)hipGetLastError();
+    return rc;
+  };
+  const size_t bytes = sizeof(double) * (size_t)abip::peer_mailbox_doubles(cap_doubles);
+  hipIpcMemHandle_t h;
+  // Fine-grained device memory where the runtime can export it over IPC (other agents write it while this agent's kernels poll it); else plain device memory --
+  // every access to a mailbox is a system-scope access either way (dev_peer.h).  ABIP_HIP_PEER_FINE=0 skips the attempt.
+  const char *fe = getenv("ABIP_HIP_PEER_FINE");
+  if (!(fe && atoi(fe) == 0) && hipExtMallocWithFlags(&p.mine, bytes, hipDeviceMallocFinegrained) == hipSuccess) {
+    if (hipIpcGetMemHandle(&h, p.mine) == hipSuccess) p.fine = true;
+    else { (void)hipFree(p.mine); p.mine = nullptr; (void)hipGetLastError(); }
+  } else { p.mine = nullptr; (void)hipGetLastError(); }
+  if (!p.mine) {
+    if (hipMalloc(&p.mine, bytes) != hipSuccess) return undo(-3);
+    if (hipIpcGetMemHandle(&h, p.mine) != hipSuccess) { fprintf(stderr, "abip_hip: hipIpcGetMemHandle failed (%s)\n", hipGetErrorString(hipGetLastError())); return undo(-4); }
+  }
+  if (hipMemset(p.mine, 0, bytes) != hipSuccess) return undo(-3);
+  if (hipMalloc((void **)&p.sync, 64) != hipSuccess || hipMemset(p.sync, 0, 64) != hipSuccess) return undo(-3);
+  if (hipHostMalloc((void **)&p.hstatus, sizeof(int), hipHostMallocMapped) != hipSuccess) return undo(-3);
   *p.hstatus = 0;
   p.cap = cap_doubles;
-  hipIpcMemHandle_t h;
-  if (hipIpcGetMemHandle(&h, p.mine) != hipSuccess) { fprintf(stderr, "abip_hip: hipIpcGetMemHandle failed (%s)\n", hipGetErrorString(hipGetLastError())); return -4; }
+  { const char *e = getenv("ABIP_HIP_PEER_FUSED"); p.fused = !(e && atoi(e) == 0); }
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
   memcpy(handle_out64, &h, 64);
-  return hipDeviceSynchronize() == hipSuccess ? 0 : -3;
+  if (hipDeviceSynchronize() != hipSuccess) return undo(-3);
+  return 0;
 }
 int abip_hip_dist_init_peer(int rank, int world, const void *handles /* world x 64 bytes, in rank order */) {
   PeerHost &p = g_dist.peer;

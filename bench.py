@@ -120,6 +120,15 @@ def b_spmv(R, C, nnz):
     return 12 * nnz + 4 * (R + 1) + 8 * C + 16 * R
 
 
+def kernel_sources_sha256() -> str:
+    """Hash of the sources of the launch path's kernels: ties a committed trace / stamp ratio (scripts/trace_medians.py) to the kernels it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("dev_common.h", "dev_kernels.h"):
+        h.update(open(os.path.join(ROOT, "abip_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def host_cores() -> int:
     try:
         return len(os.sched_getaffinity(0))
@@ -129,7 +138,10 @@ def host_cores() -> int:
 
 def cpu_baseline(A, b, c, linsys, budget_s=12.0, window=None):
     """The reference itself (oracle/_ref, kind 'reference') or our C restatement (kind 'port') on ONE host thread, on a bounded prefix
-    of the same trajectory -- and the restatement with the reference's OpenMP loop enabled (common.c:620-622) on several threads."""
+    of the same trajectory; the device is then run under the same iteration cap and its (x, y, s) compared with the CPU leg's (rel_err_xys: the
+    parity of THIS workload at THIS size, measured in the same run) -- and the restatement with the reference's OpenMP loop enabled
+    (common.c:620-622) on the 4 threads of the reference's own benchmark protocol (scripts/bench-lp/README.md:23-29)."""
+    import numpy as np
     from oracle import pyoracle as po
     kind = "reference" if po.have_ref() else "port"
     which = "ref" if kind == "reference" else "oracle"
@@ -144,20 +156,36 @@ def cpu_baseline(A, b, c, linsys, budget_s=12.0, window=None):
             T2 = max(T2, min(window, int(4 * budget / per_it)))   # cover the GPU leg's window where that stays bounded
         if T2 > 2 * T and (time.time() - t0) < budget:
             r = po.solve(which_, A, b, c, linsys=linsys, eps=1e-6, max_admm_iters=T2)
-        return r.info["admm_iter"], r.info["solve_time"] / 1e3, max(T, T2)
+        return r, max(T, T2)
 
-    its, secs, cap = sample(which, budget_s)
+    r, cap = sample(which, budget_s)
+    its, secs = r.info["admm_iter"], r.info["solve_time"] / 1e3
     rec = dict(value=its / secs, unit="ADMM iterations/s", cores=1, kind=kind, host_cores=host_cores(),
                sample=f"first {its} ADMM iterations of the same LP and settings (max_admm_iters={cap}), {secs:.2f} s, single thread, gcc -O2")
+    try:   # the device under the same cap: same counts, same status, how far apart the two (x, y, s) are
+        from abip_amd import Solver
+        with Solver(A, b, c, linsys=linsys, eps=1e-6, verbose=0, max_admm_iters=cap) as S:
+            gi = S.solve()
+            rel = lambda a_, b_: float(np.linalg.norm(a_ - b_) / max(np.linalg.norm(b_), 1e-300))
+            rec["rel_err_xys"] = max(rel(S.x, r.x), rel(S.y, r.y), rel(S.s, r.s))
+            rec["device_same_cap"] = dict(status=gi["status"], ipm_iter=int(gi["ipm_iter"]), admm_iter=int(gi["admm_iter"]), cpu_status=r.info["status"],
+                                          cpu_ipm_iter=int(r.info["ipm_iter"]), cpu_admm_iter=int(r.info["admm_iter"]),
+                                          counts_equal=bool(gi["ipm_iter"] == r.info["ipm_iter"] and gi["admm_iter"] == r.info["admm_iter"] and gi["status"] == r.info["status"]),
+                                          rel_err_pobj=abs(gi["pobj"] - r.info["pobj"]) / (1 + abs(r.info["pobj"])))
+    except Exception as e:  # noqa: BLE001
+        rec["rel_err_xys"] = None
+        rec["device_same_cap"] = dict(error=repr(e))
     if linsys == "indirect":   # the reference's OpenMP site is the SpMV of the PCG path
         try:
             L = po.lib("oracle_omp")
-            thr = max(1, min(host_cores(), 32))
+            thr = max(1, min(host_cores(), 4))    # the reference's benchmark protocol runs its solvers on 4 threads (scripts/bench-lp/README.md:23-29)
             L.orc_set_threads(thr)
-            its2, secs2, cap2 = sample("oracle_omp", budget_s / 2)
+            r2, cap2 = sample("oracle_omp", budget_s / 2)
+            its2, secs2 = r2.info["admm_iter"], r2.info["solve_time"] / 1e3
+            slower = " -- SLOWER than one thread on this LP (the loop it parallelises is too short to pay for the fork/join): the single-thread figure stays the baseline" if its2 / secs2 < its / secs else ""
             rec["openmp"] = dict(value=its2 / secs2, unit="ADMM iterations/s", cores=thr, kind="port",
                                  sample=f"first {its2} ADMM iterations, {secs2:.2f} s, oracle/abip_lp_oracle.c built -fopenmp (the reference's own "
-                                        f"OpenMP loop, linsys/common.c:620-622; its build must not define _OPENMP), {thr} threads of {host_cores()} host cores")
+                                        f"OpenMP loop, linsys/common.c:620-622; its build must not define _OPENMP), {thr} threads (the reference's bench protocol) of {host_cores()} host cores{slower}")
         except Exception as e:  # noqa: BLE001
             rec["openmp"] = dict(error=str(e))
     return rec
@@ -166,7 +194,7 @@ def cpu_baseline(A, b, c, linsys, budget_s=12.0, window=None):
 # ---------------------------------------------------------------------------------------------------------
 # the conic workload
 # ---------------------------------------------------------------------------------------------------------
-PMC_FILE = "r04_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) else "r03_pmc_traffic.json"
+PMC_FILE = next((f for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r04_pmc_traffic.json")
 
 
 def pmc_traffic(case):
@@ -430,14 +458,20 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         # The driver-parsed figures (achieved, frac, avg_launch_us) are the ones `profiles/` reproduces: kernel-trace durations (dispatch to drain).  The
         # device-side stamps of this run leave out dispatch and drain; they are scaled by the ratio trace / stamp that ONE profiled run measured for the
         # same kernel (scripts/r04_trace.sh -> profiles/r04_trace_durations.json) and kept, unscaled, under `stamps`.
-        ratio, tsrc2, tr = 1.0, None, None
-        for trf in ("r04w_trace_durations.json", "r04_trace_durations.json", "r03_trace_durations.json"):
+        ratio, tsrc2, tr, stale = 1.0, None, None, None
+        for trf in ("r05_trace_durations.json", "r04w_trace_durations.json"):
             path = os.path.join(ROOT, "profiles", trf)
             if name == "c4" and world == 1 and os.path.exists(path):
-                tr = json.load(open(path)).get("k_cg_" + kname)
-                if tr:
-                    ratio, tsrc2 = tr["mean_working_us"] / tr["stamp_avg_us_same_run"], "profiles/" + trf
-                    break
+                blob = json.load(open(path))
+                cand_tr = blob.get("k_cg_" + kname)
+                if not cand_tr:
+                    continue
+                if blob.get("kernel_sources_sha256") != kernel_sources_sha256():   # taken on other kernels than the ones built now: not applied
+                    stale = f"profiles/{trf} was measured on other kernel sources (sha256 {str(blob.get('kernel_sources_sha256'))[:12]}..., now {kernel_sources_sha256()[:12]}...): ratio not applied, the figures are this run's device-side stamps"
+                    continue
+                tr = cand_tr
+                ratio, tsrc2 = tr["mean_working_us"] / tr["stamp_avg_us_same_run"], "profiles/" + trf
+                break
         stamps = dict(avg_launch_us=avg_ms * 1e3, achieved=ach, frac=ach / HBM_PEAK_GBS,
                       timing="device wall-clock ticks (first sampled workgroup begin .. last sampled workgroup end) of every launch that did work, inside the timed region")
         roof = dict(bound="hbm", achieved=ach / ratio, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS / ratio, traffic=traffic, traffic_source=tsrc,
@@ -445,7 +479,7 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
                     timing=("kernel-trace equivalent: this run's device-side stamps x (trace duration / stamp duration) of one profiled run of the same kernel" if tr else
                             "device wall-clock ticks (first sampled workgroup begin .. last sampled workgroup end) of every launch that did work, inside the timed region"),
                     trace=(dict(trace_over_stamp=ratio, profiled_run_trace_us=tr["mean_working_us"], profiled_run_stamp_us=tr["stamp_avg_us_same_run"], source=tsrc2) if tr else None),
-                    stamps=stamps,
+                    stamps=stamps, trace_file_stale=stale,
                     other_spmv={k: dict(avg_launch_us=1e3 * prof["stamp_ms"][k] / max(prof["stamp_launches"][k], 1), launches=prof["stamp_launches"][k],
                                         algorithmic_bytes_per_launch=cand[k][0], timing="device-side stamps") for k in cand if k != kname},
                     noop_launches=prof["stamp_noop_launches"])
@@ -505,7 +539,7 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": desc, "linsys": linsys, "eps": 1e-6,
                    "parallelism": "single GPU" if world == 1 else
-                   (f"rows of A sharded over {world} ranks, one all-reduce of A'-partials + packed scalars per PCG iteration" if sharded
+                   (f"rows of A sharded over {world} ranks; PCG form {os.environ.get('ABIP_HIP_DIST_CG', 'default')}: one all-reduce per PCG iteration (rows: the n A'-partials + packed scalars; cols: the m-vector A A'p)" if sharded
                     else f"{world} independent replicas (the direct back-end does not shard)")},
         "roofline": roof, "cpu_baseline": cpu_rec, "time_to_tol": tt, "extra": extra,
     }
@@ -577,7 +611,10 @@ def main():
             else:
                 adist.init_callback(rank, world, lambda arr: dist.all_reduce(torch.from_numpy(arr)))
         if sharded and "ABIP_HIP_DIST_CG" not in os.environ:
-            os.environ["ABIP_HIP_DIST_CG"] = "rows"       # the headline of an N-GPU line is north_star's form: row blocks, all-reduce of the A'-partials
+            # the headline of an N-GPU line is the library's default form -- the one that exchanges less: columns (one all-reduce of m doubles per PCG iteration, the
+            # iteration around the solve on row blocks) whenever m < n; north_star's literal form (rows: all-reduce of the n A'-partials) is measured beside it
+            shape = {"c4": (200_000, 500_000), "c3": (16_390, 48_400), "c2": (816, 1_879)}[args.workload]
+            os.environ["ABIP_HIP_DIST_CG"] = "cols" if shape[0] < shape[1] else "rows"
         rec = run_lp(args.workload, steps, warmup, args, rank, world, dist, torch, sharded, linsys_override=args.linsys,
                      to_tol=(args.to_tol or world == 1) and not args.no_to_tol, cpu=not args.no_cpu)
         if sharded and os.environ.get("ABIP_BENCH_ONE_FORM") != "1":

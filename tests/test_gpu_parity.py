@@ -522,25 +522,30 @@ def test_non_default_switches_match_reference_fixture(gpu, variant, linsys, xcd,
 
 
 def test_knife_edge_fixture_at_tight_eps(gpu, monkeypatch):
-    """lp_tiny_scale5, direct back-end (KNIFE_EDGE above) against the REFERENCE's eps = 1e-8 solution (fixture tags direct_1e-08_*, written by make_golden.py
-    from oracle/_ref): the three device paths -- launch path (LDL'), persistent launch in batches and spanning outer iterations (dense inverse) -- reach the
-    reference's (x, y, s) to the north-star bar of 1e-6 and its objective to 1e-8; the launch path also takes the reference's iteration counts."""
+    """lp_tiny_scale5 (KNIFE_EDGE above) against the REFERENCE's eps = 1e-8 solution (fixture tags <linsys>_1e-08_*, written by make_golden.py from oracle/_ref),
+    both back-ends, the three device paths -- launch path, persistent launch in batches and spanning outer iterations.  What this LP determines is held to the
+    north-star bar: status, (x, y, s) to 1e-6, the objectives to 1e-8, the reference's convergence criteria.  What it does not determine is its iteration count:
+    profiles/r05c_knife_edge_trace_*.txt follows oracle and device outer iteration by outer iteration -- after the FIRST Barzilai-Borwein search the iterates agree
+    to 3e-16 and the penalties beta to 1.4e-11 (the search divides inner products of differences of nearly equal vectors, adaptive.c:154-229), five searches later to
+    3e-8, by the 13th beta is 2.94 against 3.00 and the 14th 2.02 against 3.87: any other summation order than the reference's own ends elsewhere (15 or 16 outer
+    iterations, 1832 / 1833-1842 inner ones with LDL'; 1964 / 1954 with PCG).  Hence +-1 outer and 2 % inner iterations here, and only here."""
     z, A, b, c = load("lp_tiny_scale5")
-    g = info_of(z, "direct_1e-08")
-    assert g["status_val"] == 1
-    for mode, env in (("path", {"ABIP_HIP_XCD": "0"}), ("batch", {"ABIP_HIP_XCD": "1", "ABIP_HIP_XCD_OUTER": "0"}), ("whole", {"ABIP_HIP_XCD": "1", "ABIP_HIP_XCD_OUTER": "1"})):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        with gpu.Solver(A, b, c, linsys="direct", verbose=0, eps=1e-8, **TINY_VARIANTS["scale5"]) as S:
-            info = S.solve()
-            assert info["status_val"] == 1 and info["ipm_iter"] == g["ipm_iter"], (mode, info["ipm_iter"], g["ipm_iter"])
-            if mode == "path":
-                assert info["admm_iter"] == g["admm_iter"], (mode, info["admm_iter"], g["admm_iter"])
-            for k in "xys":
-                assert rel(getattr(S, k), z[f"direct_1e-08_{k}"]) < 1e-6, (mode, k)
-            assert abs(info["pobj"] - g["pobj"]) <= 1e-8 * (1 + abs(g["pobj"])) and abs(info["dobj"] - g["dobj"]) <= 1e-8 * (1 + abs(g["dobj"]))
-            for k in ("res_pri", "res_dual", "rel_gap"):
-                assert info[k] < 1e-8
+    for linsys in ("direct", "indirect"):
+        tag = f"{linsys}_1e-08"
+        g = info_of(z, tag)
+        assert g["status_val"] == 1
+        for mode, env in (("path", {"ABIP_HIP_XCD": "0"}), ("batch", {"ABIP_HIP_XCD": "1", "ABIP_HIP_XCD_OUTER": "0"}), ("whole", {"ABIP_HIP_XCD": "1", "ABIP_HIP_XCD_OUTER": "1"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            with gpu.Solver(A, b, c, linsys=linsys, verbose=0, eps=1e-8, **TINY_VARIANTS["scale5"]) as S:
+                info = S.solve()
+                assert info["status_val"] == 1, (linsys, mode)
+                assert abs(info["ipm_iter"] - g["ipm_iter"]) <= 1 and abs(info["admm_iter"] - g["admm_iter"]) <= 0.02 * g["admm_iter"], (linsys, mode, info["ipm_iter"], info["admm_iter"])
+                for k in "xys":
+                    assert rel(getattr(S, k), z[f"{tag}_{k}"]) < 1e-6, (linsys, mode, k)
+                assert abs(info["pobj"] - g["pobj"]) <= 1e-8 * (1 + abs(g["pobj"])) and abs(info["dobj"] - g["dobj"]) <= 1e-8 * (1 + abs(g["dobj"]))
+                for k in ("res_pri", "res_dual", "rel_gap"):
+                    assert info[k] < 1e-8
 
 
 def test_matlab_surface_end_to_end(gpu):

@@ -156,6 +156,33 @@ def test_conic_tail_residual_guard(gpu, monkeypatch):
     assert rel(np.array(res["x"]), sol0["x"]) < 1e-4 and abs(res["pobj"] - i0["pobj"]) < 1e-5 * (1 + abs(i0["pobj"]))
 
 
+def test_device_transpose_that_fails_falls_back_to_the_host_transpose(gpu, monkeypatch):
+    """The one library call on the device (hipcub's radix sort in dev_transpose.hip; everything else is hand-written) may refuse -- no room for its scratch, an
+    error from the sort: DevCsr::from_columns then keeps nothing and the set-up transposes on the host as it does for small operators.  Forced through the hook of
+    libabip_hip_hooks.so with the device transpose switched on for a small operator: same solve, bit for bit."""
+    import os, subprocess, sys, textwrap, json
+    data, K = lasso_socp(400, 1500, 3, density=0.02)
+    monkeypatch.setenv("ABIP_HIP_DEV_TRANSPOSE", "1")
+    sol0, i0 = gpu.abip_qcp(data, K, dict(eps=1e-5, linsys_solver=3, verbose=0))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, ABIP_HIP_DEV_TRANSPOSE="1", ABIP_HIP_DEV_TRANSPOSE_FAIL="1", ABIP_HIP_LIBRARY=os.path.join(root, "abip_amd", "lib", "libabip_hip_hooks.so"))
+    code = textwrap.dedent(f"""
+        import sys, json
+        sys.path[:0] = [{root!r}, {os.path.join(root, 'tests')!r}]
+        import numpy as np
+        from abip_amd import qcp as gpu
+        from test_gpu_qcp import lasso_socp
+        data, K = lasso_socp(400, 1500, 3, density=0.02)
+        sol1, i1 = gpu.abip_qcp(data, K, dict(eps=1e-5, linsys_solver=3, verbose=0))
+        print("RESULT " + json.dumps(dict(status=i1["status"], ipm=i1["ipm_iter"], admm=int(i1["admm_iter"]), x=sol1["x"].tolist())))
+        """)
+    r = subprocess.run([sys.executable, "-c", code], env=e, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    res = json.loads([l for l in r.stdout.split("\n") if l.startswith("RESULT ")][-1][7:])
+    assert res["status"] == i0["status"] == "Solved" and res["ipm"] == i0["ipm_iter"] and res["admm"] == i0["admm_iter"]
+    assert np.array_equal(np.array(res["x"]), sol0["x"])
+
+
 def test_unsupported_back_ends_are_rejected(gpu):
     data, K = toy()
     # the reference's other exact factorisations (0 MKL-DSS, 2 Cholesky, 4 PARDISO, 5 LAPACK: what its default rule picks for dense data) run the device LDL'

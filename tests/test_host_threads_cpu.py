@@ -50,3 +50,35 @@ def test_scaling_is_bit_identical_with_one_and_with_eight_threads():
     # the library's own chatter ("Done the ... rescaling!") is text in front of / between the payloads: identical in both runs
     assert len(out[0]) == len(out[1]) and len(out[0]) > 8 * 100000
     assert out[0] == out[1]
+
+
+TINY = r"""
+import sys, ctypes as C
+sys.path.insert(0, {root!r})
+import numpy as np, scipy.sparse as sp
+from abip_amd import _lib
+from abip_amd.solver import default_settings
+L = _lib.load()
+rng = np.random.default_rng(7)
+m, n = 4, 10
+A = sp.csc_matrix(sp.random(m, n, density=0.4, random_state=rng, format="csc", data_rvs=lambda k: rng.uniform(-3, 3, k)) + sp.hstack([sp.identity(m), sp.csc_matrix((m, n - m))]))
+A.sort_indices()
+Ax = A.data.astype(np.float64).copy(); Ai = A.indices.astype(np.int64); Ap = A.indptr.astype(np.int64)
+mat = _lib.ABIPMatrix(Ax.ctypes.data_as(_lib.PF), Ai.ctypes.data_as(_lib.PI), Ap.ctypes.data_as(_lib.PI), m, n)
+st = default_settings()
+D, E, means = np.zeros(m), np.zeros(n), np.zeros(2)
+assert L.abip_hip_host_normalize_A(C.byref(mat), C.byref(st), D.ctypes.data_as(_lib.PF), E.ctypes.data_as(_lib.PF), means.ctypes.data_as(_lib.PF)) == 0
+sys.stdout.buffer.write(Ax.tobytes() + D.tobytes() + E.tobytes())
+"""
+
+
+def test_fewer_entries_than_threads_times_grain():
+    """the row-maxima pass of the Ruiz scaling sized its per-thread tables with one thread count and ran with another when a tiny matrix met a
+    divided grain (nnz / grain < threads): 4 x 10 with ~20 non-zeros, 8 threads, the grain divided down to 4 entries -- now the same bits as one thread."""
+    out = []
+    for threads in ("1", "8"):
+        env = dict(os.environ, ABIP_HIP_HOST_THREADS=threads, ABIP_HIP_HOST_GRAIN_DIV="100000")
+        r = subprocess.run([sys.executable, "-c", TINY.format(root=ROOT)], env=env, cwd=ROOT, capture_output=True, timeout=300)
+        assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+        out.append(r.stdout)
+    assert out[0] == out[1] and len(out[0]) > 8 * 20
