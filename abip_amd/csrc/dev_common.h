@@ -95,6 +95,14 @@ struct Ctl {
   double pp_cur;   // sharded PCG: ||p||^2 of the current direction, by the recurrence ||z + beta p||^2 = z'z + 2 beta z'p + beta^2 ||p||^2
   long xcd_cg_total; // one-XCD persistent launch (dev_xcd.h): PCG iterations of all the ADMM iterations it ran
   XcdOut xo;         // ... and, when the launch spans outer iterations, the loop state it stopped in
+  // the Barzilai-Borwein search of the launch path with its decisions on the device (solver.hip: adaptive_search_stream; adaptive.c:87-251)
+  double bb_prev;    // beta_prev of the search in flight
+  double bb_beta;    // beta as the last look-ahead left it (w->beta when the search ends)
+  int bb_act;        // what lp_bb_beta decided last: 0 stop, 1 go on with v_prev rebuilt for the new penalty, 2 go on as is
+  int bb_it;         // look-aheads completed
+  int bb_stage;      // inside a look-ahead: 0 before the first step, 1 the first step is done, 2 the second
+  int bb_cg[2];      // PCG iterations of the last first / second solve
+  long bb_cg_total;  // ... and of all solves of this search
 };
 
 // Device-side launch timing (bench.py's roofline leg, inside the timed region: no hipEvent records, no second pass).  A kernel handed a

@@ -736,9 +736,17 @@ __global__ __launch_bounds__(BS) void k_clip_v(double *v, Dims d) {
 // Barzilai-Borwein look-ahead (adaptive.c:101-178)
 // ---------------------------------------------------------------------------------------------
 // one ADMM step on scratch vectors: (ut, u_prev, v_prev) -> (u, v) with penalty beta_prev
+// ctl != null (the streamed search, solver.hip: adaptive_search_stream): the penalty is mu / ctl->bb_prev (the device keeps beta_prev), the step runs only behind a
+// solve that has converged -- else it raises halt = 2 ("stalled": the host adds PCG iterations and enqueues the rest again) -- and leaves `which` in bb_stage.
 __global__ __launch_bounds__(BS) void k_adapt_step(const double *ut_in, double *ut_tail_fix, const double *__restrict__ up,
                                                    const double *__restrict__ vp, double *__restrict__ u, double *__restrict__ v,
-                                                   double alpha, double mu_over_beta, Dims d, const double *part, int nb, const double *gs) {
+                                                   double alpha, double mu_over_beta, Dims d, const double *part, int nb, const double *gs,
+                                                   Ctl *ctl, double mu, int which) {
+  if (ctl) {
+    ABIP_GATE_HALT(ctl);
+    if (!ctl->cg_done) { if (blockIdx.x == 0 && threadIdx.x == 0) ctl->halt = 2; return; }
+    mu_over_beta = mu / ctl->bb_prev;
+  }
   __shared__ double sm[WAVES];
   double dh[1];
   const int rs[1] = {S_DH};
@@ -755,6 +763,7 @@ __global__ __launch_bounds__(BS) void k_adapt_step(const double *ut_in, double *
     u[q] = un;
     v[q] = vp[q] + (un - alpha * utq - (1 - alpha) * up[q]);
   }
+  if (ctl && blockIdx.x == 0 && threadIdx.x == 0) { ctl->bb_stage = which; ctl->bb_cg[which - 1] = ctl->cg_it; ctl->bb_cg_total += ctl->cg_it; }
 }
 // the five inner products of the difference vectors, formed on the fly (adaptive.c:154-174)
 __global__ __launch_bounds__(BS) void k_adapt_dots(const double *__restrict__ u, const double *__restrict__ v, const double *__restrict__ un,
@@ -777,6 +786,59 @@ __global__ __launch_bounds__(BS) void k_adapt_dots(const double *__restrict__ u,
 // v_prev[x,tau] = (mu/beta)/u_prev  (adaptive.c:238-241); y block copied by the caller
 __global__ __launch_bounds__(BS) void k_adapt_vprev(double *vp, const double *up, double mu_over_beta, Dims d) {
   for (int j = blockIdx.x * BS + threadIdx.x; j <= d.n; j += gridDim.x * BS) vp[d.MP + j] = mu_over_beta / up[d.MP + j];
+}
+
+// The decision of one look-ahead on the device (adaptive.c:170-247; lp_scalars.h: lp_bb_beta -- the host's arithmetic, contraction off): the five sums, the spectral
+// step, beta_prev for the next look-ahead; halt = 4 once the search is over (stop, or the look-back is used up).  The control block is mirrored in every case (a
+// stalled look-ahead reaches this kernel with halt = 2: the host reads that from the mirror).
+__global__ __launch_bounds__(1024) void k_adapt_decide(const double *part, int nb, Ctl *ctl, double eps_cor, double eps_pen, int lookback, Ctl *mirror) {
+  const int halt0 = ctl->halt;
+  __syncthreads();
+  if (!halt0) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int PER = MAXNB / 64;
+    if (wave < 5) { // (d_finalize's fold: one wavefront per slot, lane order)
+      const int slot = S_A0 + wave;
+      double t[PER];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) { const int i = lane + u * 64; t[u] = (i < nb) ? part[slot * MAXNB + i] : 0.0; }
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) acc += t[u];
+      acc = wave_sum(acc);
+      if (lane == 0) ctl->out[slot] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double *o = ctl->out;
+      double beta = 0.0;
+      const int act = lp_bb_beta(o[S_A0], o[S_A1], o[S_A2], o[S_A3], o[S_A4], eps_cor, eps_pen, ctl->bb_prev, beta);
+      ctl->bb_act = act; ctl->bb_beta = beta;
+      if (act == 1) ctl->bb_prev = beta;
+      ctl->bb_it = ctl->bb_it + 1; ctl->bb_stage = 0;
+      if (act == 0 || ctl->bb_it >= lookback) ctl->halt = 4;
+    }
+  }
+  __syncthreads();
+  if (mirror) {
+    const double *src = reinterpret_cast<const double *>(ctl);
+    double *dst = reinterpret_cast<double *>(mirror);
+    for (int q = threadIdx.x; q < (int)(sizeof(Ctl) / sizeof(double)); q += blockDim.x) dst[q] = src[q];
+  }
+}
+// (u_prev, v_prev) for the next look-ahead as the last decision wants them (adaptive.c:230-247): u_prev = u; v_prev = v, its (x, tau) part rebuilt as
+// (mu / beta_prev) / u_prev when the penalty changed
+__global__ __launch_bounds__(BS) void k_adapt_next(double *__restrict__ up, double *__restrict__ vp, const double *__restrict__ u, const double *__restrict__ v, double mu, Dims d, const Ctl *ctl) {
+  ABIP_GATE_HALT(ctl);
+  const int act = ctl->bb_act;
+  const double mob = mu / ctl->bb_prev;
+  const int len = d.MP + d.n + 1;
+  for (int i = blockIdx.x * BS + threadIdx.x; i < len; i += gridDim.x * BS) {
+    if (i >= d.m && i < d.MP) continue; // padding
+    const double ui = u[i];
+    up[i] = ui;
+    vp[i] = (act == 1 && i >= d.MP) ? mob / ui : v[i];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -228,7 +228,7 @@ struct ABIP_WORK {
   // Valid from a plain iteration of the launch path (one GPU, PCG, no restart, no half update) until something else writes u_y.
   DBuf<double> aty; bool aty_valid = false, aty_on = true;
   // streamed iterations of the launch path (admm_stream_pcg): two pinned mirrors of the control block, written by k_finalize_stream, and the events behind them
-  Ctl *hmir[2] = {nullptr, nullptr}; hipEvent_t mir_ev[2] = {nullptr, nullptr}; bool stream_on = true;
+  Ctl *hmir[2] = {nullptr, nullptr}; hipEvent_t mir_ev[2] = {nullptr, nullptr}; bool stream_on = true, bb_stream_on = true;
   long stream_stalls = 0, stream_iters = 0;
   DBuf<double> a_up, a_vp, a_ut, a_u, a_v, a_utn, a_un, a_vn; // adaptive.c:13-32 (the three delta vectors are never stored)
   DBuf<double> part;
@@ -881,7 +881,10 @@ int admm_stream_pcg(W *w, long nmax, long *ran, double *metric_out, int *why) {
     if (enqueue_q_and_finalize(w, avg_stats, false, true, nullptr, keep ? (const double *)w->aty.p : (const double *)nullptr, &fs)) return -1;
     return hipEventRecord(w->mir_ev[q & 1], w->stream) == hipSuccess ? 0 : -1;
   };
-  int chunk = next_chunk(w);
+  // PCG iterations enqueued blind.  From one ADMM iteration to the next the count hardly moves (C4, 400 steps: unchanged 378 times, +1 four times, jumps only behind
+  // an outer iteration: profiles/r05e_c4_cg_counts.txt), a launch past convergence costs ~2 us x 3 kernels, a stall ~0.2 ms once: enqueue exactly the last count.
+  auto blind = [&]() { return std::max(2, std::min((int)w->m_glob, w->last_cg_its)); };
+  int chunk = blind();
   auto enqueue_iter = [&](long q, bool have) -> int {
     launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, w->ut.p, (const double *)w->h.p, st->rho_y, w->g_th, d,
            w->part.p, w->NB, ctl, (const double *)w->gs, have ? (const double *)w->aty.p : (const double *)nullptr, have ? (double2 *)w->cg_pair.p : (double2 *)nullptr);
@@ -910,7 +913,7 @@ int admm_stream_pcg(W *w, long nmax, long *ran, double *metric_out, int *why) {
     memcpy(w->hctl, &hm, sizeof(Ctl));
     if (w->hctl->it_count != w->it_seen + 1) { fprintf(stderr, "abip_hip: streamed iteration %ld: the device reports %d completed iterations, expected %d\n", (long)(k0 + done), w->hctl->it_count, w->it_seen + 1); return -1; }
     w->last_cg_its = w->hctl->cg_it; w->tot_cg_its += w->hctl->cg_it; w->prof.cg_iters += w->hctl->cg_it;
-    chunk = next_chunk(w);
+    chunk = blind();
     w->tot_solves++; w->prof.kkt_solves++; w->prof.admm_iters++; ++w->stream_iters;
     take_verdict(w, metric_out);
     ++done;
@@ -1388,7 +1391,84 @@ int lin_projection(W *w, double *ut, const double *u, const double *v, abip_int 
          (const double *)w->gs, (const double *)nullptr, (double2 *)nullptr);
   return kkt_solve_sync(w, ut, u, iter) < 0 ? -1 : 0; // S_DH is left for k_adapt_step
 }
+// The search with its decisions on the device (PCG back-end, one GPU, LPs beyond the caches -- the C4 path): round 4 read the control block
+// back after every look-ahead solve (is the PCG through?) and after every look-ahead (lp_bb_beta on the host) -- ~80 round trips of ~25 us in the driver's
+// 20-step window.  Here a look-ahead is ONE unit of launches -- both projections, both steps, the five inner products, k_adapt_decide (lp_bb_beta from
+// lp_scalars.h, beta_prev kept in the control block), k_adapt_next -- and unit L + 1 is enqueued before the host has seen the verdict of unit L, as
+// admm_stream_pcg does with iterations: a solve whose PCG needs more iterations than were enqueued stalls the unit (halt 2; bb_stage says which solve), the end
+// of the search is halt 4.  Same kernels and arithmetic as adaptive_search below: the same bits.
+int adaptive_search_stream(W *w, abip_int iter) {
+  const Dims d = dims(w);
+  ABIPSettings *st = w->stgs;
+  const size_t bytes = sizeof(double) * (size_t)w->LV;
+  const int lookback = (int)st->adaptive_lookback;
+  if (lookback <= 0) { w->beta = 0.0; return 0; } // adaptive.c:90: the loop does not run
+  HIP_OK(hipMemcpyAsync(w->a_up.p, w->u.p, bytes, hipMemcpyDeviceToDevice, w->stream));
+  HIP_OK(hipMemcpyAsync(w->a_vp.p, w->v.p, bytes, hipMemcpyDeviceToDevice, w->stream));
+  { // bb_prev = 1, the counters zero (one small copy: the fields sit side by side at the end of the control block)
+    static_assert(offsetof(Ctl, bb_cg_total) + sizeof(long) - offsetof(Ctl, bb_prev) == 48, "layout of the search's fields");
+    struct { double prev, beta; int act, it, stage, cg0, cg1, pad; long tot; } init = {1.0, 0.0, 0, 0, 0, 0, 0, 0, 0L};
+    static_assert(sizeof(init) == 48, "layout of the search's fields");
+    HIP_OK(hipMemcpyAsync(&w->ctl.p->bb_prev, &init, sizeof(init), hipMemcpyHostToDevice, w->stream));
+    HIP_OK(hipStreamSynchronize(w->stream)); // (the source is on this stack frame)
+  }
+  int chunk[2] = {next_chunk(w), next_chunk(w)};
+  auto projection = [&](double *ut, const double *u, const double *v) -> int { // abip.c:552-559 on scratch vectors, the PCG's first `chunk` iterations
+    launch(w, ABIP_HIP_K_VEC, k_dot_wg, w->NB, BS, u, v, (const double *)w->g.p, st->rho_y, d, w->part.p, w->xwt);
+    launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, u, v, ut, (const double *)w->h.p, st->rho_y, w->g_th, d, w->part.p, w->NB, (const Ctl *)w->ctl.p,
+           (const double *)w->gs, (const double *)nullptr, (double2 *)nullptr);
+    return enqueue_cg_begin(w, ut, u, iter);
+  };
+  // a unit from one of its entry points: 0 = the top, 1 = behind the first solve's PCG chunk, 2 = behind the second solve's
+  auto unit = [&](long L, int from) -> int {
+    if (from == 0) { if (projection(w->a_ut.p, w->a_up.p, w->a_vp.p) || enqueue_cg_chunk(w, w->a_ut.p, chunk[0])) return -1; }
+    if (from <= 1) {
+      if (enqueue_cg_post(w, w->a_ut.p)) return -1;
+      launch(w, ABIP_HIP_K_VEC, k_adapt_step, w->NB, BS, (const double *)w->a_ut.p, w->a_ut.p, (const double *)w->a_up.p, (const double *)w->a_vp.p,
+             w->a_u.p, w->a_v.p, st->alpha, 0.0, d, (const double *)w->part.p, w->NB, (const double *)w->gs, w->ctl.p, w->mu, 1);
+      if (projection(w->a_utn.p, w->a_u.p, w->a_v.p) || enqueue_cg_chunk(w, w->a_utn.p, chunk[1])) return -1;
+    }
+    if (enqueue_cg_post(w, w->a_utn.p)) return -1;
+    launch(w, ABIP_HIP_K_VEC, k_adapt_step, w->NB, BS, (const double *)w->a_utn.p, w->a_utn.p, (const double *)w->a_u.p, (const double *)w->a_v.p,
+           w->a_un.p, w->a_vn.p, st->alpha, 0.0, d, (const double *)w->part.p, w->NB, (const double *)w->gs, w->ctl.p, w->mu, 2);
+    launch(w, ABIP_HIP_K_VEC, k_adapt_dots, w->NB, BS, (const double *)w->a_u.p, (const double *)w->a_v.p, (const double *)w->a_un.p,
+           (const double *)w->a_vn.p, (const double *)w->a_vp.p, st->alpha, d, w->part.p, w->xwt);
+    launch(w, ABIP_HIP_K_VEC, k_adapt_decide, 1, 1024, (const double *)w->part.p, w->NB, w->ctl.p, st->eps_cor, st->eps_pen, lookback, w->hmir[L & 1]);
+    if (hipEventRecord(w->mir_ev[L & 1], w->stream) != hipSuccess) return -1;
+    launch(w, ABIP_HIP_K_VEC, k_adapt_next, w->NB, BS, w->a_up.p, w->a_vp.p, (const double *)w->a_u.p, (const double *)w->a_v.p, w->mu, d, (const Ctl *)w->ctl.p);
+    return 0;
+  };
+  long enq = 0, done = 0;
+  const Ctl *hm = nullptr;
+  for (;;) {
+    while (enq < lookback && enq - done < 2) { if (unit(enq, 0)) return -1; ++enq; }
+    const int sl = (int)(done & 1);
+    if (hipEventSynchronize(w->mir_ev[sl]) != hipSuccess) return -1;
+    hm = w->hmir[sl];
+    if (hm->halt == 2) { // a solve of unit `done` stalled; whatever was enqueued behind it ran as no-ops
+      ++w->stream_stalls;
+      const int which = hm->bb_stage == 0 ? 0 : 1;
+      HIP_OK(hipMemsetAsync(&w->ctl.p->halt, 0, sizeof(int), w->stream));
+      chunk[which] = std::max(4, chunk[which]);
+      if (enqueue_cg_chunk(w, which == 0 ? w->a_ut.p : w->a_utn.p, chunk[which]) || unit(done, which + 1)) return -1;
+      enq = done + 1;
+      continue;
+    }
+    ++done;
+    for (int q = 0; q < 2; ++q) chunk[q] = std::max(2, std::min((int)w->m_glob, hm->bb_cg[q] + std::max(2, hm->bb_cg[q] >> 3))); // (next_chunk's rule, per solve of the pair)
+    if (hm->halt == 4) break; // the search is over (adaptive.c:221-229, or the look-back used up)
+    if (hm->halt != 0 || hm->bb_it != (int)done) { fprintf(stderr, "abip_hip: streamed search: unexpected state (halt %d, look-ahead %d of %ld)\n", hm->halt, hm->bb_it, done); return -1; }
+  }
+  w->beta = hm->bb_beta;
+  w->tot_solves += 2 * done; w->prof.kkt_solves += 2 * done;
+  w->tot_cg_its += hm->bb_cg_total; w->prof.cg_iters += hm->bb_cg_total;
+  w->last_cg_its = hm->bb_cg[1];
+  memcpy(w->hctl, hm, sizeof(Ctl));
+  w->wg_valid = false;
+  return clear_halt(w);
+}
 int adaptive_search(W *w, abip_int iter) {
+  if (stream_ok(w) && w->bb_stream_on) return adaptive_search_stream(w, iter);
   const Dims d = dims(w);
   const size_t bytes = sizeof(double) * (size_t)w->LV;
   ABIPSettings *st = w->stgs;
@@ -1398,10 +1478,10 @@ int adaptive_search(W *w, abip_int iter) {
   for (abip_int it = 0; it < st->adaptive_lookback; ++it) {
     if (lin_projection(w, w->a_ut.p, w->a_up.p, w->a_vp.p, iter)) return -1;
     launch(w, ABIP_HIP_K_VEC, k_adapt_step, w->NB, BS, (const double *)w->a_ut.p, w->a_ut.p, (const double *)w->a_up.p, (const double *)w->a_vp.p,
-           w->a_u.p, w->a_v.p, st->alpha, w->mu / beta_prev, d, (const double *)w->part.p, w->NB, (const double *)w->gs);
+           w->a_u.p, w->a_v.p, st->alpha, w->mu / beta_prev, d, (const double *)w->part.p, w->NB, (const double *)w->gs, (Ctl *)nullptr, 0.0, 0);
     if (lin_projection(w, w->a_utn.p, w->a_u.p, w->a_v.p, iter)) return -1;
     launch(w, ABIP_HIP_K_VEC, k_adapt_step, w->NB, BS, (const double *)w->a_utn.p, w->a_utn.p, (const double *)w->a_u.p, (const double *)w->a_v.p,
-           w->a_un.p, w->a_vn.p, st->alpha, w->mu / beta_prev, d, (const double *)w->part.p, w->NB, (const double *)w->gs);
+           w->a_un.p, w->a_vn.p, st->alpha, w->mu / beta_prev, d, (const double *)w->part.p, w->NB, (const double *)w->gs, (Ctl *)nullptr, 0.0, 0);
     launch(w, ABIP_HIP_K_VEC, k_adapt_dots, w->NB, BS, (const double *)w->a_u.p, (const double *)w->a_v.p, (const double *)w->a_un.p,
            (const double *)w->a_vn.p, (const double *)w->a_vp.p, st->alpha, d, w->part.p, w->xwt);
     if (w->dist) { enqueue_fold(w, {S_A0, S_A1, S_A2, S_A3, S_A4}); if (allreduce_scalars(w)) return -1; }
@@ -1845,6 +1925,7 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
     { const char *e = getenv("ABIP_HIP_ATY"); w->aty_on = !(e && atoi(e) == 0); } // ABIP_HIP_ATY=0: every product formed where the reference forms it (A / B, tests)
     if (!w->dist && w->aty_on && w->aty.alloc(n)) return fail("init_lin_sys_work failure");
     { const char *e = getenv("ABIP_HIP_STREAM"); w->stream_on = !(e && atoi(e) == 0); } // ABIP_HIP_STREAM=0: one control read per iteration, as in round 4
+    { const char *e = getenv("ABIP_HIP_STREAM_BB"); w->bb_stream_on = !(e && atoi(e) == 0); } // ABIP_HIP_STREAM_BB=0: the Barzilai-Borwein search driven by the host, as in round 4
     if (!w->dist && w->stream_on) {
       for (int q = 0; q < 2; ++q) {
         if (hipHostMalloc((void **)&w->hmir[q], sizeof(Ctl), hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&w->mir_ev[q], hipEventDisableTiming) != hipSuccess)

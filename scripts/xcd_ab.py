@@ -14,4 +14,4 @@ for rep in range(3):
         S.begin(); S.step(warm); S.sync()
         t0 = time.perf_counter(); fin, done = S.step(steps); S.sync(); dt = time.perf_counter() - t0
         best = max(best, done / dt)
-print(name, os.environ.get("ABIP_HIP_LIBRARY", "default"), "best of 3: %.0f it/s" % best, flush=True)
+os.write(bench._REAL_STDOUT, ("%s %s best of 3: %.0f it/s\n" % (name, os.environ.get("ABIP_HIP_LIBRARY", "default"), best)).encode())   # (importing bench points the C-level stdout at stderr)

@@ -32,9 +32,9 @@ def test_one_rank_sharded_over_rccl():
     assert r["n_gpus"] == 1 and r["scaling"] == "strong" and r["rccl_ranks"] == 1 and r["transport"] == "rccl"
     assert r["rank_rows"] == [[0, r["extra"]["m"]]] and r["value"] > 0
     assert r["roofline"]["launches"] > 0 and 0 < r["roofline"]["frac"] < 1
-    assert r["dist_cg"] == "rows" and r["extra"]["collectives"]["ms_in_allreduce_per_step"] >= 0     # hipEvents around each ncclAllReduce (one rank: next to nothing)
+    assert r["dist_cg"] == "cols" and r["extra"]["collectives"]["ms_in_allreduce_per_step"] >= 0     # hipEvents around each ncclAllReduce (one rank: next to nothing)
     assert r["extra"]["collectives"]["collectives_per_step"] > 1 and r["extra"]["collectives"]["bytes_per_step"] > 0
-    assert r["extra"]["dist_cols"]["collectives"]["bytes_per_step"] > 0
+    assert r["extra"]["dist_rows"]["collectives"]["bytes_per_step"] > 0
 
 
 def test_two_ranks_started_by_bench_itself():
@@ -45,9 +45,9 @@ def test_two_ranks_started_by_bench_itself():
     rows = r["rank_rows"]
     assert rows[0][0] == 0 and rows[0][1] == rows[1][0] and rows[1][1] == r["extra"]["m"] and rows[0][1] > 0
     assert r["steps"] == 6 and r["value"] > 0
-    # one invocation measures both forms of the sharded solve: the headline is the row form, the column form sits beside it
-    assert r["dist_cg"] == "rows" and r["extra"]["dist_cols"]["value"] > 0
-    for c in (r["extra"]["collectives"], r["extra"]["dist_cols"]["collectives"]):
+    # one invocation measures both forms of the sharded solve: the headline is the library default (columns: m < n), the row form sits beside it
+    assert r["dist_cg"] == "cols" and r["extra"]["dist_rows"]["value"] > 0
+    for c in (r["extra"]["collectives"], r["extra"]["dist_rows"]["collectives"]):
         assert c["collectives_per_step"] > 1 and c["bytes_per_step"] > 0 and c["ms_in_allreduce_per_step"] >= 0
 
 
