@@ -103,6 +103,8 @@ struct Ctl {
   int bb_stage;      // inside a look-ahead: 0 before the first step, 1 the first step is done, 2 the second
   int bb_cg[2];      // PCG iterations of the last first / second solve
   long bb_cg_total;  // ... and of all solves of this search
+  int bb_skip;       // 1: the look-ahead in flight starts from the previous one's second step (its first solve would repeat that solve bit for bit: k_adapt_next)
+  int bb_pad;
 };
 
 // Device-side launch timing (bench.py's roofline leg, inside the timed region: no hipEvent records, no second pass).  A kernel handed a

@@ -791,7 +791,7 @@ __global__ __launch_bounds__(BS) void k_adapt_vprev(double *vp, const double *up
 // The decision of one look-ahead on the device (adaptive.c:170-247; lp_scalars.h: lp_bb_beta -- the host's arithmetic, contraction off): the five sums, the spectral
 // step, beta_prev for the next look-ahead; halt = 4 once the search is over (stop, or the look-back is used up).  The control block is mirrored in every case (a
 // stalled look-ahead reaches this kernel with halt = 2: the host reads that from the mirror).
-__global__ __launch_bounds__(1024) void k_adapt_decide(const double *part, int nb, Ctl *ctl, double eps_cor, double eps_pen, int lookback, Ctl *mirror) {
+__global__ __launch_bounds__(1024) void k_adapt_decide(const double *part, int nb, Ctl *ctl, double eps_cor, double eps_pen, int lookback, Ctl *mirror, int skip_ok) {
   const int halt0 = ctl->halt;
   __syncthreads();
   if (!halt0) {
@@ -815,8 +815,9 @@ __global__ __launch_bounds__(1024) void k_adapt_decide(const double *part, int n
       const int act = lp_bb_beta(o[S_A0], o[S_A1], o[S_A2], o[S_A3], o[S_A4], eps_cor, eps_pen, ctl->bb_prev, beta);
       ctl->bb_act = act; ctl->bb_beta = beta;
       if (act == 1) ctl->bb_prev = beta;
-      ctl->bb_it = ctl->bb_it + 1; ctl->bb_stage = 0;
+      ctl->bb_it = ctl->bb_it + 1; ctl->bb_stage = 0; ctl->bb_skip = 0;
       if (act == 0 || ctl->bb_it >= lookback) ctl->halt = 4;
+      else if (act == 2 && skip_ok) { ctl->bb_skip = 1; ctl->halt = 5; } // the next look-ahead's first half is this one's second: see k_adapt_next
     }
   }
   __syncthreads();
@@ -826,18 +827,37 @@ __global__ __launch_bounds__(1024) void k_adapt_decide(const double *part, int n
     for (int q = threadIdx.x; q < (int)(sizeof(Ctl) / sizeof(double)); q += blockDim.x) dst[q] = src[q];
   }
 }
+// Behind the first step of a look-ahead: if that first half was skipped (halt 5: its results were moved over from the previous look-ahead, k_adapt_next) the
+// second half may run -- halt is lowered here, by a launch of its own, so that no kernel both reads and writes it -- and the skipped solve is counted as the
+// reference counts it (it solves again and takes the same number of PCG iterations).
+__global__ void k_adapt_resume(Ctl *ctl) {
+  if (ctl->halt == 5) { ctl->halt = 0; ctl->bb_stage = 1; ctl->bb_cg[0] = ctl->bb_cg[1]; ctl->bb_cg_total += ctl->bb_cg[1]; }
+}
 // (u_prev, v_prev) for the next look-ahead as the last decision wants them (adaptive.c:230-247): u_prev = u; v_prev = v, its (x, tau) part rebuilt as
-// (mu / beta_prev) / u_prev when the penalty changed
-__global__ __launch_bounds__(BS) void k_adapt_next(double *__restrict__ up, double *__restrict__ vp, const double *__restrict__ u, const double *__restrict__ v, double mu, Dims d, const Ctl *ctl) {
-  ABIP_GATE_HALT(ctl);
+// (mu / beta_prev) / u_prev when the penalty changed.
+// When it did NOT change (act 2: beta = beta_prev, by far the most frequent outcome -- profiles/r05h_c4_bb_trace.txt), the next look-ahead's first half is this
+// one's second half over again: the same right-hand side from (u, v), the same warm start u, the same tolerance -- the reference runs that solve a second time
+// and gets the same bits.  Here its results are moved instead -- u_t <- u_t,next, u <- u_next, v[x, tau] <- v_next[x, tau] (the y block of v is never written:
+// adaptive.c:118-121): k_adapt_decide has raised bb_skip with halt = 5, every gated kernel of the next unit's first half falls through, and k_adapt_resume
+// behind them lowers halt again.
+__global__ __launch_bounds__(BS) void k_adapt_next(double *__restrict__ up, double *__restrict__ vp, double *__restrict__ u, double *__restrict__ v,
+                                                   double *__restrict__ ut, const double *__restrict__ utn, const double *__restrict__ un, const double *__restrict__ vn,
+                                                   double mu, Dims d, const Ctl *ctl) {
+  if (ctl->halt && ctl->halt != 5) return;
   const int act = ctl->bb_act;
   const double mob = mu / ctl->bb_prev;
+  const bool skip = ctl->bb_skip != 0;
   const int len = d.MP + d.n + 1;
   for (int i = blockIdx.x * BS + threadIdx.x; i < len; i += gridDim.x * BS) {
     if (i >= d.m && i < d.MP) continue; // padding
-    const double ui = u[i];
+    const double ui = u[i], vi = v[i];
     up[i] = ui;
-    vp[i] = (act == 1 && i >= d.MP) ? mob / ui : v[i];
+    vp[i] = (act == 1 && i >= d.MP) ? mob / ui : vi;
+    if (skip) {
+      ut[i] = utn[i];
+      u[i] = un[i];
+      if (i >= d.MP) v[i] = vn[i];
+    }
   }
 }
 

@@ -71,6 +71,7 @@ struct XcdOuter {
   int phase;            // entry point: 0 = iteration (k, j) of the inner loop, 1 = the outer end of abip.c:2217 (Ctl::out holds the iterate's sums)
   int avg_crit;         // stgs->avg_criterion at entry
   int adaptive, lookback, hybrid_mu;
+  int bb_reuse;         // 1: a look-ahead whose penalty did not change hands its second step to the next one (ABIP_HIP_BB_REUSE=0: every look-ahead solves twice, as the reference does)
   long i, fre_old;
   double mu, beta, sigma, gamma, dyn_sigma;
   long max_ipm, inner_stopper, restart_thresh, restart_fre;
@@ -1466,11 +1467,9 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
           x_bbdots(al, uo, vo, un, vn, x_at(xo.a_vp, MP + j2), d5);
         }
       }
-      {
-        double un, vn;
-        x_bbstep(al, mob, utq_t, bu_t, bv_t, un, vn);
-        if (rank == 0 && t == 0) x_bbdots(al, bu_t, bv_t, un, vn, bvp_t, d5);
-      }
+      double bun_t, bvn_t; // the tau entry of (u_next, v_next)
+      x_bbstep(al, mob, utq_t, bu_t, bv_t, bun_t, bvn_t);
+      if (rank == 0 && t == 0) x_bbdots(al, bu_t, bv_t, bun_t, bvn_t, bvp_t, d5);
       open(12);
       x_publish<5, SA>(d5, red, psc, sc_off, tag);
       double D5[5];
@@ -1501,6 +1500,24 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
           }
         }
         csw(CS_BBPREV, bb_prev); csw(CS_BUPT, bu_t); csw(CS_BVPT, (act == 1) ? mob2 / bu_t : bv_t); csw(CS_BBIT, (double)(bb_it + 1));
+        if (act == 2 && xo.bb_reuse) {
+          // The penalty did not change (beta = beta_prev: by far the most frequent outcome).  The next look-ahead's first step would start from (u_prev, v_prev) = (u, v)
+          // with the same beta_prev, the same warm start and the same tolerance: it is this look-ahead's second step over again -- the reference runs that solve a
+          // second time and gets the same bits.  Its results are moved instead: u <- u_next, v[x, tau] <- v_next[x, tau] (the y block of v is never written,
+          // adaptive.c:118-121), and the loop goes on at the second step.  The skipped solve is counted as the reference counts it.
+#pragma unroll
+          for (int q = 0; q < RM; ++q) { const unsigned i = m0 + tb + q * XTB; if (i < m1) x_at(xo.a_u, i) = x_at(xo.a_un, i); }
+#pragma unroll
+          for (int q = 0; q < RN; ++q) {
+            const unsigned j2 = n0 + tb + q * XTB;
+            if (j2 < n1) { x_at(xo.a_u, MP + j2) = x_at(xo.a_un, MP + j2); x_at(xo.a_v, MP + j2) = x_at(xo.a_vn, MP + j2); }
+          }
+          csw(CS_BUT, bun_t); csw(CS_BVT, bvn_t);
+          cg_total += last_cg;
+          mode = XM_BB2; need_pre = true;
+          XQ_ADD(2, xq_t)
+          continue;
+        }
         mode = XM_BB1; need_pre = true;
         XQ_ADD(2, xq_t)
         continue;

@@ -229,7 +229,7 @@ struct ABIP_WORK {
   DBuf<double> aty; bool aty_valid = false, aty_on = true;
   // streamed iterations of the launch path (admm_stream_pcg): two pinned mirrors of the control block, written by k_finalize_stream, and the events behind them
   Ctl *hmir[2] = {nullptr, nullptr}; hipEvent_t mir_ev[2] = {nullptr, nullptr}; bool stream_on = true, bb_stream_on = true;
-  long stream_stalls = 0, stream_iters = 0;
+  long stream_stalls = 0, stream_iters = 0; int cg_steady = 0; // (iterations since the PCG count last changed)
   DBuf<double> a_up, a_vp, a_ut, a_u, a_v, a_utn, a_un, a_vn; // adaptive.c:13-32 (the three delta vectors are never stored)
   DBuf<double> part;
   DBuf<Ctl> ctl;
@@ -883,7 +883,8 @@ int admm_stream_pcg(W *w, long nmax, long *ran, double *metric_out, int *why) {
   };
   // PCG iterations enqueued blind.  From one ADMM iteration to the next the count hardly moves (C4, 400 steps: unchanged 378 times, +1 four times, jumps only behind
   // an outer iteration: profiles/r05e_c4_cg_counts.txt), a launch past convergence costs ~2 us x 3 kernels, a stall ~0.2 ms once: enqueue exactly the last count.
-  auto blind = [&]() { return std::max(2, std::min((int)w->m_glob, w->last_cg_its)); };
+  // ... unless it moved within the last eight iterations (the first iterations of an inner loop: 11, 11, 12, 12, 12, 13, ...): then one more.
+  auto blind = [&]() { return std::max(2, std::min((int)w->m_glob, w->last_cg_its + (w->cg_steady < 8 ? 1 : 0))); };
   int chunk = blind();
   auto enqueue_iter = [&](long q, bool have) -> int {
     launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, w->ut.p, (const double *)w->h.p, st->rho_y, w->g_th, d,
@@ -912,6 +913,7 @@ int admm_stream_pcg(W *w, long nmax, long *ran, double *metric_out, int *why) {
     }
     memcpy(w->hctl, &hm, sizeof(Ctl));
     if (w->hctl->it_count != w->it_seen + 1) { fprintf(stderr, "abip_hip: streamed iteration %ld: the device reports %d completed iterations, expected %d\n", (long)(k0 + done), w->hctl->it_count, w->it_seen + 1); return -1; }
+    w->cg_steady = (w->hctl->cg_it == w->last_cg_its) ? w->cg_steady + 1 : 0;
     w->last_cg_its = w->hctl->cg_it; w->tot_cg_its += w->hctl->cg_it; w->prof.cg_iters += w->hctl->cg_it;
     chunk = blind();
     w->tot_solves++; w->prof.kkt_solves++; w->prof.admm_iters++; ++w->stream_iters;
@@ -1269,6 +1271,7 @@ int xcd_run(W *w, int phase, long max_steps, long *ran, int *reason) {
   const double left_ms = std::max(1.0, (st->max_time - ((double)clock() - w->cpu0) / CLOCKS_PER_SEC) * 1e3);
   o.slice_ticks = (unsigned long long)(std::min(slice_ms, left_ms) * x.ticks_per_ms);
   o.eps_cor = st->eps_cor; o.eps_pen = st->eps_pen; o.hybrid_thresh = st->hybrid_thresh; o.dyn_sigma_second = st->dynamic_sigma_second;
+  { const char *e = getenv("ABIP_HIP_BB_REUSE"); o.bb_reuse = (e && atoi(e) == 0) ? 0 : 1; }
   { // update_barrier_dynamic_2 (abip.c:982-992) applied 1, 2, ... times to the current mu: pow() stays on the host
     double mu = w->mu;
     for (int q = 0; q < XcdPlan::MU_TAB; ++q) { mu *= std::min(st->dynamic_x * mu, std::pow(mu, st->dynamic_sigma)); x.hmu_tab[q] = mu; }
@@ -1406,13 +1409,15 @@ int adaptive_search_stream(W *w, abip_int iter) {
   HIP_OK(hipMemcpyAsync(w->a_up.p, w->u.p, bytes, hipMemcpyDeviceToDevice, w->stream));
   HIP_OK(hipMemcpyAsync(w->a_vp.p, w->v.p, bytes, hipMemcpyDeviceToDevice, w->stream));
   { // bb_prev = 1, the counters zero (one small copy: the fields sit side by side at the end of the control block)
-    static_assert(offsetof(Ctl, bb_cg_total) + sizeof(long) - offsetof(Ctl, bb_prev) == 48, "layout of the search's fields");
-    struct { double prev, beta; int act, it, stage, cg0, cg1, pad; long tot; } init = {1.0, 0.0, 0, 0, 0, 0, 0, 0, 0L};
-    static_assert(sizeof(init) == 48, "layout of the search's fields");
+    static_assert(offsetof(Ctl, bb_pad) + sizeof(int) - offsetof(Ctl, bb_prev) == 56, "layout of the search's fields");
+    struct { double prev, beta; int act, it, stage, cg0, cg1, pad; long tot; int skip, pad2; } init = {1.0, 0.0, 0, 0, 0, 0, 0, 0, 0L, 0, 0};
+    static_assert(sizeof(init) == 56, "layout of the search's fields");
     HIP_OK(hipMemcpyAsync(&w->ctl.p->bb_prev, &init, sizeof(init), hipMemcpyHostToDevice, w->stream));
     HIP_OK(hipStreamSynchronize(w->stream)); // (the source is on this stack frame)
   }
   int chunk[2] = {next_chunk(w), next_chunk(w)};
+  static const bool bb_trace = getenv("ABIP_HIP_BB_TRACE") != nullptr; // developer: the PCG counts of every look-ahead pair on stderr
+  const bool bb_reuse = !(getenv("ABIP_HIP_BB_REUSE") && atoi(getenv("ABIP_HIP_BB_REUSE")) == 0); // 0: every look-ahead solves twice, as the reference does (A / B, tests)
   auto projection = [&](double *ut, const double *u, const double *v) -> int { // abip.c:552-559 on scratch vectors, the PCG's first `chunk` iterations
     launch(w, ABIP_HIP_K_VEC, k_dot_wg, w->NB, BS, u, v, (const double *)w->g.p, st->rho_y, d, w->part.p, w->xwt);
     launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, u, v, ut, (const double *)w->h.p, st->rho_y, w->g_th, d, w->part.p, w->NB, (const Ctl *)w->ctl.p,
@@ -1426,6 +1431,7 @@ int adaptive_search_stream(W *w, abip_int iter) {
       if (enqueue_cg_post(w, w->a_ut.p)) return -1;
       launch(w, ABIP_HIP_K_VEC, k_adapt_step, w->NB, BS, (const double *)w->a_ut.p, w->a_ut.p, (const double *)w->a_up.p, (const double *)w->a_vp.p,
              w->a_u.p, w->a_v.p, st->alpha, 0.0, d, (const double *)w->part.p, w->NB, (const double *)w->gs, w->ctl.p, w->mu, 1);
+      if (bb_reuse) launch(w, ABIP_HIP_K_VEC, k_adapt_resume, 1, 1, w->ctl.p);
       if (projection(w->a_utn.p, w->a_u.p, w->a_v.p) || enqueue_cg_chunk(w, w->a_utn.p, chunk[1])) return -1;
     }
     if (enqueue_cg_post(w, w->a_utn.p)) return -1;
@@ -1433,9 +1439,10 @@ int adaptive_search_stream(W *w, abip_int iter) {
            w->a_un.p, w->a_vn.p, st->alpha, 0.0, d, (const double *)w->part.p, w->NB, (const double *)w->gs, w->ctl.p, w->mu, 2);
     launch(w, ABIP_HIP_K_VEC, k_adapt_dots, w->NB, BS, (const double *)w->a_u.p, (const double *)w->a_v.p, (const double *)w->a_un.p,
            (const double *)w->a_vn.p, (const double *)w->a_vp.p, st->alpha, d, w->part.p, w->xwt);
-    launch(w, ABIP_HIP_K_VEC, k_adapt_decide, 1, 1024, (const double *)w->part.p, w->NB, w->ctl.p, st->eps_cor, st->eps_pen, lookback, w->hmir[L & 1]);
+    launch(w, ABIP_HIP_K_VEC, k_adapt_decide, 1, 1024, (const double *)w->part.p, w->NB, w->ctl.p, st->eps_cor, st->eps_pen, lookback, w->hmir[L & 1], bb_reuse ? 1 : 0);
     if (hipEventRecord(w->mir_ev[L & 1], w->stream) != hipSuccess) return -1;
-    launch(w, ABIP_HIP_K_VEC, k_adapt_next, w->NB, BS, w->a_up.p, w->a_vp.p, (const double *)w->a_u.p, (const double *)w->a_v.p, w->mu, d, (const Ctl *)w->ctl.p);
+    launch(w, ABIP_HIP_K_VEC, k_adapt_next, w->NB, BS, w->a_up.p, w->a_vp.p, w->a_u.p, w->a_v.p, w->a_ut.p, (const double *)w->a_utn.p, (const double *)w->a_un.p, (const double *)w->a_vn.p,
+           w->mu, d, (const Ctl *)w->ctl.p);
     return 0;
   };
   long enq = 0, done = 0;
@@ -1455,9 +1462,12 @@ int adaptive_search_stream(W *w, abip_int iter) {
       continue;
     }
     ++done;
-    for (int q = 0; q < 2; ++q) chunk[q] = std::max(2, std::min((int)w->m_glob, hm->bb_cg[q] + std::max(2, hm->bb_cg[q] >> 3))); // (next_chunk's rule, per solve of the pair)
+    if (bb_trace) fprintf(stderr, "[bb] k %ld look-ahead %ld: PCG %d + %d (enqueued %d + %d) act %d beta %.6g\n", (long)iter, done, hm->bb_cg[0], hm->bb_cg[1], chunk[0], chunk[1], hm->bb_act, hm->bb_beta);
+    // (blind counts of the pair, two units behind the verdict they come from: the counts jump by 2 - 3 when the penalty changes -- profiles/r05h_c4_bb_trace.txt --
+    //  a launch past convergence costs ~6 us per PCG iteration, a stalled unit ~0.4 ms)
+    for (int q = 0; q < 2; ++q) chunk[q] = std::max(2, std::min((int)w->m_glob, hm->bb_cg[q] + std::max(3, hm->bb_cg[q] >> 2)));
     if (hm->halt == 4) break; // the search is over (adaptive.c:221-229, or the look-back used up)
-    if (hm->halt != 0 || hm->bb_it != (int)done) { fprintf(stderr, "abip_hip: streamed search: unexpected state (halt %d, look-ahead %d of %ld)\n", hm->halt, hm->bb_it, done); return -1; }
+    if ((hm->halt != 0 && hm->halt != 5) || hm->bb_it != (int)done) { fprintf(stderr, "abip_hip: streamed search: unexpected state (halt %d, look-ahead %d of %ld)\n", hm->halt, hm->bb_it, done); return -1; }
   }
   w->beta = hm->bb_beta;
   w->tot_solves += 2 * done; w->prof.kkt_solves += 2 * done;

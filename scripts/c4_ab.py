@@ -1,5 +1,6 @@
 """A / B of the launch path on C4 (BASELINE configs[3]) under environment switches: ABIP_HIP_ATY (the back-substitution's A'u_y kept for the stopping test and the next
-solve's set-up), ABIP_HIP_STREAM (iterations streamed: the host one verdict behind the device), ABIP_HIP_STREAM_BB (the Barzilai-Borwein search streamed too, its decisions on the device).  Prints the driver's window (20 steps after 5), a 200-step window and,
+solve's set-up), ABIP_HIP_STREAM (iterations streamed: the host one verdict behind the device), ABIP_HIP_STREAM_BB (the Barzilai-Borwein search streamed too, its decisions on the device),
+ABIP_HIP_BB_REUSE (a look-ahead whose penalty did not change hands its second step to the next one instead of solving the same system again).  Prints the driver's window (20 steps after 5), a 200-step window and,
 with --solve, the whole solve to eps 1e-6; checks that every variant leaves the same iterate.
 
     python scripts/c4_ab.py [--solve] [--out FILE]"""
@@ -14,7 +15,8 @@ def emit(*a):
 
 A, b, c = problems.lp_random_sparse()
 VARIANTS = [("round 4 form", {"ABIP_HIP_ATY": "0", "ABIP_HIP_STREAM": "0", "ABIP_HIP_STREAM_BB": "0"}), ("A'u_y kept", {"ABIP_HIP_ATY": "1", "ABIP_HIP_STREAM": "0", "ABIP_HIP_STREAM_BB": "0"}),
-            ("+ streamed", {"ABIP_HIP_ATY": "1", "ABIP_HIP_STREAM": "1", "ABIP_HIP_STREAM_BB": "0"}), ("+ search (default)", {"ABIP_HIP_ATY": "1", "ABIP_HIP_STREAM": "1", "ABIP_HIP_STREAM_BB": "1"})]
+            ("+ streamed", {"ABIP_HIP_ATY": "1", "ABIP_HIP_STREAM": "1", "ABIP_HIP_STREAM_BB": "0"}), ("+ search", {"ABIP_HIP_ATY": "1", "ABIP_HIP_STREAM": "1", "ABIP_HIP_STREAM_BB": "1", "ABIP_HIP_BB_REUSE": "0"}),
+            ("+ reuse (default)", {"ABIP_HIP_ATY": "1", "ABIP_HIP_STREAM": "1", "ABIP_HIP_STREAM_BB": "1", "ABIP_HIP_BB_REUSE": "1"})]
 if "--quick" in sys.argv:
     VARIANTS = VARIANTS[2:]
 ref = None
