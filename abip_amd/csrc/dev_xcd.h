@@ -96,6 +96,7 @@ struct XcdArgs {
   int G, m, n, MP;
   UpdArgs upd;                          // u, v, ut, sums, g, b, c, alpha, mu/beta, rho, half_update (dom / avg_stats are set per iteration)
   const double *h, *wD, *wE;
+  const double *hAh;                    // h_y + A h_x (m): the y-side weights of u_t'h (see the back-substitution)
   const double *Mjac;                   // PCG: Jacobi preconditioner (m)
   const double *Minv; long ldM;         // direct: inv(rho I + A A'), dense row-major
   int minv_lds_rows;                    // direct: how many of a workgroup's rows of it fit its LDS (the first ones; the others stream from the L2)
@@ -831,8 +832,9 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     bool have_rhs = false;
     int leave = 0;
     double hy[RM], hx[RN]; // h of the owned elements: constant, read by three phases of every trip
+    double hy2[RM];        // h_y + (A h_x) of the owned rows
 #pragma unroll
-    for (int q = 0; q < RM; ++q) { const unsigned i = m0 + t + q * XTB; hy[q] = i < m1 ? x_at(a.h, i) : 0.0; }
+    for (int q = 0; q < RM; ++q) { const unsigned i = m0 + t + q * XTB; hy[q] = i < m1 ? x_at(a.h, i) : 0.0; hy2[q] = i < m1 ? x_at(a.hAh, i) : 0.0; }
 #pragma unroll
     for (int q = 0; q < RN; ++q) { const unsigned j2 = n0 + t + q * XTB; hx[q] = j2 < n1 ? x_at(a.h, MP + j2) : 0.0; }
     for (;;) {
@@ -1093,6 +1095,9 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       XP_LAP(3)
     }
     // ---- back-substitution x = A'y - rhs_x (indirect.c:419-420) and u_t'h (abip.c:560) ----
+    // u_t'h = y'h_y + (A'y - rhs_x)'h_x = y'(h_y + A h_x) - rhs_x'h_x: with A h_x formed once per solve (XcdArgs::hAh) every term is known BEFORE this exchange,
+    // so the sum rides on it -- its granule is the flag -- and the scalar-only exchange round 4 ran behind the gather (one rendez-vous of a direct iteration's
+    // five, ~1.2 us of c2's 15.2) is gone.  The sum is regrouped, like every sum of this kernel; the reference adds u_t[i] h[i] in index order.
     double dh[1] = {0.0};
     open(6);
 #pragma unroll
@@ -1102,28 +1107,27 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         x_putd<SA>(pm0, i * 8u, y[q]);
         if (solo) x_at(a.srhs, i) = y[q];
         else if (mode == XM_MAIN) x_at(up.ut, i) = y[q];
-        dh[0] += y[q] * hy[q];
+        dh[0] += y[q] * hy2[q];
       }
     }
+#pragma unroll
+    for (int q = 0; q < RN; ++q) dh[0] -= rhs_x[q] * hx[q]; // (zero beyond the owned columns)
     {
-      x_flag<SA>(psc, sc_off, tag);
-      x_wait<CROSS>(w, G);
-      if (__builtin_expect(w.dead, 0)) return;
-      double tx[NZ], vt[NZ], tq[RN];
+      x_publish<1, SA>(dh, red, psc, sc_off, tag);
+      double tx[NZ];
       x_mat<NZ>(gT, nt, tx);
+      x_collect<1, CROSS>(w, G, tot, dhS);
+      if (__builtin_expect(w.dead, 0)) return;
+      double vt[NZ], tq[RN];
       x_gather<NZ>(pm0, ti, vt);
       x_rows<NZ, RN>(prod, flip, tx, vt, nt, st, et, tq);
 #pragma unroll
       for (int q = 0; q < RN; ++q) {
         const unsigned j2 = n0 + tb + q * XTB;
         zx[q] = 0.0;
-        if (j2 < n1) { zx[q] = tq[q] - rhs_x[q]; dh[0] += zx[q] * hx[q]; }
+        if (j2 < n1) zx[q] = tq[q] - rhs_x[q];
       }
     }
-    open(7);
-    x_publish<1, SA>(dh, red, psc, sc_off, tag);
-    x_collect<1, CROSS>(w, G, tot, dhS);
-    if (__builtin_expect(w.dead, 0)) return;
     if (!PCG) { XP_LAP(4) }
     if (__builtin_expect(solo || mode != XM_MAIN, 0)) break; // (not an ADMM iteration: see below the loop)
     // ---- element-wise update (k_admm_update): barrier prox, dual update, running sums, averages, statistics ----

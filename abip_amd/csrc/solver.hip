@@ -227,6 +227,7 @@ struct ABIP_WORK {
   // (abip.c:731-734), so the stopping test's A'u_y and the next solve's warm-start product are that vector -- one product per iteration instead of three.
   // Valid from a plain iteration of the launch path (one GPU, PCG, no restart, no half update) until something else writes u_y.
   DBuf<double> aty; bool aty_valid = false, aty_on = true;
+  DBuf<double> hAh; // persistent launch: h_y + A h_x (m): u_t'h = y'(h_y + A h_x) - rhs_x'h_x is known BEFORE the back-substitution's exchange and rides on it (dev_xcd.h)
   // streamed iterations of the launch path (admm_stream_pcg): two pinned mirrors of the control block, written by k_finalize_stream, and the events behind them
   Ctl *hmir[2] = {nullptr, nullptr}; hipEvent_t mir_ev[2] = {nullptr, nullptr}; bool stream_on = true, bb_stream_on = true;
   long stream_stalls = 0, stream_iters = 0; int cg_steady = 0; // (iterations since the PCG count last changed)
@@ -884,7 +885,9 @@ int admm_stream_pcg(W *w, long nmax, long *ran, double *metric_out, int *why) {
   // PCG iterations enqueued blind.  From one ADMM iteration to the next the count hardly moves (C4, 400 steps: unchanged 378 times, +1 four times, jumps only behind
   // an outer iteration: profiles/r05e_c4_cg_counts.txt), a launch past convergence costs ~2 us x 3 kernels, a stall ~0.2 ms once: enqueue exactly the last count.
   // ... unless it moved within the last eight iterations (the first iterations of an inner loop: 11, 11, 12, 12, 12, 13, ...): then one more.
-  auto blind = [&]() { return std::max(2, std::min((int)w->m_glob, w->last_cg_its + (w->cg_steady < 8 ? 1 : 0))); };
+  const char *fb = getenv("ABIP_HIP_STREAM_BLIND"); // tests: a fixed (too small) count, so that iterations stall and are resumed
+  const int forced = fb ? std::max(1, atoi(fb)) : 0;
+  auto blind = [&]() { return forced ? forced : std::max(2, std::min((int)w->m_glob, w->last_cg_its + (w->cg_steady < 8 ? 1 : 0))); };
   int chunk = blind();
   auto enqueue_iter = [&](long q, bool have) -> int {
     launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, (const double *)w->u.p, (const double *)w->v.p, w->ut.p, (const double *)w->h.p, st->rho_y, w->g_th, d,
@@ -906,7 +909,7 @@ int admm_stream_pcg(W *w, long nmax, long *ran, double *metric_out, int *why) {
     if (hm.halt == 2) { // stalled: the PCG needs more iterations than were enqueued.  Resume it; what was enqueued behind ran as no-ops.
       ++w->stream_stalls;
       HIP_OK(hipMemsetAsync(&w->ctl.p->halt, 0, sizeof(int), w->stream));
-      chunk = std::max(4, chunk);
+      chunk = forced ? forced : std::max(4, chunk);
       if (enqueue_cg_chunk(w, w->ut.p, chunk) || tail(done)) return -1;
       enq = done + 1;
       continue;
@@ -1085,6 +1088,8 @@ void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
     if (getenv("ABIP_HIP_XCD_VERBOSE")) printf("[xcd] dense inverse of rho I + A A' (%d x %d): residual %.2e\n", m, m, res);
     if (!(res <= 1e-9)) { x.release(); return; }
   }
+  // h_y + A h_x (see abip_hip_solve_begin): zero like h itself until a solve begins (the unit-level abip_hip_kkt_solve may run before that)
+  if (w->hAh.alloc(w->m) || hipMemsetAsync(w->hAh.p, 0, sizeof(double) * w->m, w->stream) != hipSuccess) { (void)hipGetLastError(); x.release(); return; }
   x.tag = 0; x.launches = 0; x.tickets_used = 0;
   x.on = true;
   { const char *e = getenv("ABIP_HIP_XCD_OUTER"); x.outer = !(e && atoi(e) == 0); }
@@ -1119,7 +1124,7 @@ void xcd_fill(W *w, XcdArgs &a) {
   a.mb = x.mb.p; a.nb = x.nb.p;
   a.G = x.G; a.m = (int)w->m; a.n = (int)w->n; a.MP = w->MP;
   a.upd = upd_args(w, true, false, w->j);
-  a.h = w->h.p; a.wD = st->normalize ? w->wD.p : nullptr; a.wE = st->normalize ? w->wE.p : nullptr;
+  a.h = w->h.p; a.hAh = w->hAh.p; a.wD = st->normalize ? w->wD.p : nullptr; a.wE = st->normalize ? w->wE.p : nullptr;
   a.Mjac = pcg ? w->cg_M.p : nullptr; a.Minv = x.Minv.p; a.ldM = x.ldM; a.minv_lds_rows = x.minv_lds_rows;
   a.g_th = w->g_th;
   a.xn0 = x.xn0.p; a.xn1 = x.xn1.p; a.xm0 = x.xm0.p; a.xm1 = x.xm1.p; a.sc = x.sc.p; a.n_pad = x.n_pad; a.m_pad = x.m_pad;
@@ -1415,7 +1420,9 @@ int adaptive_search_stream(W *w, abip_int iter) {
     HIP_OK(hipMemcpyAsync(&w->ctl.p->bb_prev, &init, sizeof(init), hipMemcpyHostToDevice, w->stream));
     HIP_OK(hipStreamSynchronize(w->stream)); // (the source is on this stack frame)
   }
-  int chunk[2] = {next_chunk(w), next_chunk(w)};
+  const char *fb = getenv("ABIP_HIP_STREAM_BLIND"); // tests: a fixed (too small) count, so that look-aheads stall and are resumed
+  const int bb_forced = fb ? std::max(1, atoi(fb)) : 0;
+  int chunk[2] = {bb_forced ? bb_forced : next_chunk(w), bb_forced ? bb_forced : next_chunk(w)};
   static const bool bb_trace = getenv("ABIP_HIP_BB_TRACE") != nullptr; // developer: the PCG counts of every look-ahead pair on stderr
   const bool bb_reuse = !(getenv("ABIP_HIP_BB_REUSE") && atoi(getenv("ABIP_HIP_BB_REUSE")) == 0); // 0: every look-ahead solves twice, as the reference does (A / B, tests)
   auto projection = [&](double *ut, const double *u, const double *v) -> int { // abip.c:552-559 on scratch vectors, the PCG's first `chunk` iterations
@@ -1456,7 +1463,7 @@ int adaptive_search_stream(W *w, abip_int iter) {
       ++w->stream_stalls;
       const int which = hm->bb_stage == 0 ? 0 : 1;
       HIP_OK(hipMemsetAsync(&w->ctl.p->halt, 0, sizeof(int), w->stream));
-      chunk[which] = std::max(4, chunk[which]);
+      chunk[which] = bb_forced ? bb_forced : std::max(4, chunk[which]);
       if (enqueue_cg_chunk(w, which == 0 ? w->a_ut.p : w->a_utn.p, chunk[which]) || unit(done, which + 1)) return -1;
       enq = done + 1;
       continue;
@@ -1465,7 +1472,7 @@ int adaptive_search_stream(W *w, abip_int iter) {
     if (bb_trace) fprintf(stderr, "[bb] k %ld look-ahead %ld: PCG %d + %d (enqueued %d + %d) act %d beta %.6g\n", (long)iter, done, hm->bb_cg[0], hm->bb_cg[1], chunk[0], chunk[1], hm->bb_act, hm->bb_beta);
     // (blind counts of the pair, two units behind the verdict they come from: the counts jump by 2 - 3 when the penalty changes -- profiles/r05h_c4_bb_trace.txt --
     //  a launch past convergence costs ~6 us per PCG iteration, a stalled unit ~0.4 ms)
-    for (int q = 0; q < 2; ++q) chunk[q] = std::max(2, std::min((int)w->m_glob, hm->bb_cg[q] + std::max(3, hm->bb_cg[q] >> 2)));
+    for (int q = 0; q < 2; ++q) chunk[q] = bb_forced ? bb_forced : std::max(2, std::min((int)w->m_glob, hm->bb_cg[q] + std::max(3, hm->bb_cg[q] >> 2)));
     if (hm->halt == 4) break; // the search is over (adaptive.c:221-229, or the look-back used up)
     if ((hm->halt != 0 && hm->halt != 5) || hm->bb_it != (int)done) { fprintf(stderr, "abip_hip: streamed search: unexpected state (halt %d, look-ahead %d of %ld)\n", hm->halt, hm->bb_it, done); return -1; }
   }
@@ -1733,7 +1740,7 @@ void free_work(W *w) {
   { DBuf<double> *cb[] = {&w->cc_b, &w->cc_y, &w->cc_r, &w->cc_z, &w->cc_p, &w->cc_Gp, &w->cc_M, &w->cc_tmp, &w->cc_d, &w->cc_buf}; for (auto *b : cb) b->release(); }
   DBuf<double> *bufs[] = {&w->u, &w->v, &w->ut, &w->u_avg, &w->v_avg, &w->u_sum, &w->v_sum, &w->u_avgc, &w->v_avgc, &w->h, &w->g, &w->b, &w->c,
                           &w->wD, &w->wE, &w->cg_p, &w->cg_r, &w->cg_Gp, &w->cg_z, &w->cg_M, &w->cg_tmp, &w->cg_pair, &w->a_up, &w->a_vp, &w->a_ut, &w->a_u,
-                          &w->a_v, &w->a_utn, &w->a_un, &w->a_vn, &w->part, &w->aty};
+                          &w->a_v, &w->a_utn, &w->a_un, &w->a_vn, &w->part, &w->aty, &w->hAh};
   for (auto *b : bufs) b->release();
   w->ctl.release(); w->ldl.release(); w->T.release(); w->xcd.release();
   if (w->hctl) (void)hipHostFree(w->hctl);
@@ -2060,6 +2067,10 @@ abip_int abip_hip_solve_begin(ABIPWork *w, const ABIPData *d, const ABIPSolution
     std::vector<double> hy(m);
     for (abip_int i = 0; i < m; ++i) hy[i] = -hb[r0 + i];
     if (upload_lvec(w, w->h, hy.data(), hc.data(), 0.0) || upload_lvec(w, w->g, hy.data(), hc.data(), 0.0)) return ABIP_FAILED;
+    if (w->xcd.on) { // h_y + A h_x for the persistent launch (before its first launch: the set-up solve below)
+      HIP_OK(hipMemcpyAsync(w->hAh.p, w->h.p, sizeof(double) * m, hipMemcpyDeviceToDevice, w->stream));
+      launch(w, ABIP_HIP_K_SPMV_A, PICK(k_spmv_acc, w->dA), w->NB, BS, w->dA.view(), (const double *)(w->h.p + w->MP), w->hAh.p);
+    }
     launch(w, ABIP_HIP_K_VEC, k_norm_y, w->NB, BS, (const double *)w->g.p, dims(w), w->part.p);
     if (kkt_solve_sync(w, w->g.p, nullptr, -1) < 0) return ABIP_FAILED;
     launch(w, ABIP_HIP_K_VEC, k_neg_x, w->NB, BS, w->g.p, dims(w));
