@@ -1315,8 +1315,8 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     open(9);
     if (!PCG) {
       // Direct back-end: the NEXT iteration's right-hand side rides on this exchange -- everything it needs (S_WG, the tau entries, the new iterate) is
-      // known since the previous one, its x block goes out with the sums of the stopping test, and the next trip starts at its first product: five
-      // rendez-vous per iteration instead of six.  If the exit test below ends the inner loop the entries are simply not used.  (The PCG back-end's first
+      // known since the previous one, its x block goes out with the sums of the stopping test, and the next trip starts at its first product: one
+      // rendez-vous less per iteration (four, with u_t'h on the back-substitution's exchange).  If the exit test below ends the inner loop the entries are simply not used.  (The PCG back-end's first
       // exchange also carries |rhs_y|^2 for its tolerance -- a thirteenth sum on the iterations that test the averaged iterate; it keeps the exchange.)
       const double ts_n = S13[9] + S13[10];
       const double cf_n = (S13[0] - ts_n * a.g_th) / (a.g_th + 1.0);

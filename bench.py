@@ -317,9 +317,9 @@ def run_conic(workload, linsys, no_cpu, rank, world, dist, torch):
                                 f"(+ {oi['setup_time'] / 1e3:.1f} s set-up), oracle/abip_qcp_oracle.c, single thread, gcc -O2")
     # "eps 1e-3 ... and 1e-6": the same problem once more at the tight tolerance (one GPU)
     tt6 = None
-    if rank == 0 and world == 1 and not ml and dist is None:
+    if rank == 0 and world == 1 and dist is None:
         stg6 = dict(stg, eps=1e-6)
-        _, i6 = qcp.abip_qcp(data, K, stg6)
+        _, i6 = qcp.abip_ml(dict(X=X, y=yv, **{"lambda": lam}), stg6) if ml else qcp.abip_qcp(data, K, stg6)
         torch.cuda.synchronize()
         tt6 = dict(seconds=i6["runtime"], setup_s=i6["setup_time"], solve_s=i6["solve_time"], status=i6["status"], admm_iter=int(i6["admm_iter"]), ipm_iter=i6["ipm_iter"],
                    res_pri=i6["res_pri"], res_dual=i6["res_dual"], rel_gap=i6["gap"], value=int(i6["admm_iter"]) / max(i6["solve_time"], 1e-12), unit="ADMM iterations/s", eps=1e-6)
@@ -430,7 +430,7 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         # exchanges counted by the kernel itself (every rendez-vous of the window's launches, the look-ahead solves of the Barzilai-Borwein search included:
         # since round 4 the search runs inside the launch, so its time is inside `ms` as well)
         xd = {k: S.scalar(k) - xstat0[k] for k in xstat0}
-        exch = xd["xcd_exchanges"] / its if xd["xcd_exchanges"] > 0 else ((2 * cg_step + 7) if linsys == "indirect" else 6.0)
+        exch = xd["xcd_exchanges"] / its if xd["xcd_exchanges"] > 0 else ((2 * cg_step + 6) if linsys == "indirect" else 4.0)
         # HBM bytes per launch from the committed counter passes (per inner iteration there, FETCH_SIZE / WRITE_SIZE summed over the kernel's dispatches)
         tpi = pmc_traffic(name).get("k_lp_xcd", {}).get("traffic_bytes_per_iteration") if pmc and world == 1 else None
         roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=(tpi * its / nl) if tpi else None,

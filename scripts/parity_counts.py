@@ -19,6 +19,7 @@ bad = 0
 for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "lp_*.npz"))):
     name = os.path.basename(f)[:-4]
     if ONLY and ONLY not in name: continue
+    if name in ("lp_c4_prefix", "lp_pds_like_full"): continue   # the BASELINE-size fixtures carry no LP (tests/test_gpu_baseline_size.py rebuilds it and holds the device to them)
     z, A, b, c = load(name)
     kw = TINY_VARIANTS.get(name.replace("lp_tiny_", ""), {}) if name.startswith("lp_tiny_") else {}
     for tag in sorted(k[:-5] for k in z.keys() if k.endswith("_info")):
