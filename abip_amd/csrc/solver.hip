@@ -1402,9 +1402,9 @@ int lin_projection(W *w, double *ut, const double *u, const double *v, abip_int 
 // The search with its decisions on the device (PCG back-end, one GPU, LPs beyond the caches -- the C4 path): round 4 read the control block
 // back after every look-ahead solve (is the PCG through?) and after every look-ahead (lp_bb_beta on the host) -- ~80 round trips of ~25 us in the driver's
 // 20-step window.  Here a look-ahead is ONE unit of launches -- both projections, both steps, the five inner products, k_adapt_decide (lp_bb_beta from
-// lp_scalars.h, beta_prev kept in the control block), k_adapt_next -- and unit L + 1 is enqueued before the host has seen the verdict of unit L, as
-// admm_stream_pcg does with iterations: a solve whose PCG needs more iterations than were enqueued stalls the unit (halt 2; bb_stage says which solve), the end
-// of the search is halt 4.  Same kernels and arithmetic as adaptive_search below: the same bits.
+// lp_scalars.h, beta_prev kept in the control block), k_adapt_next -- with ONE control read per look-ahead: a solve whose PCG needs more iterations than were
+// enqueued stalls the unit (halt 2; bb_stage says which solve), a look-ahead that hands its second step on is halt 5, the end of the search halt 4.  Same
+// kernels and arithmetic as adaptive_search below: the same bits.
 int adaptive_search_stream(W *w, abip_int iter) {
   const Dims d = dims(w);
   ABIPSettings *st = w->stgs;
@@ -1431,50 +1431,56 @@ int adaptive_search_stream(W *w, abip_int iter) {
            (const double *)w->gs, (const double *)nullptr, (double2 *)nullptr);
     return enqueue_cg_begin(w, ut, u, iter);
   };
-  // a unit from one of its entry points: 0 = the top, 1 = behind the first solve's PCG chunk, 2 = behind the second solve's
-  auto unit = [&](long L, int from) -> int {
+  // a unit from one of its entry points: 0 = the top, 1 = behind the first solve's PCG chunk, 2 = behind the second solve's, 3 = the second half alone (the
+  // first one was handed over by the previous look-ahead: k_adapt_resume lowers halt 5 and counts the solve that is not repeated)
+  auto unit = [&](int from) -> int {
     if (from == 0) { if (projection(w->a_ut.p, w->a_up.p, w->a_vp.p) || enqueue_cg_chunk(w, w->a_ut.p, chunk[0])) return -1; }
     if (from <= 1) {
       if (enqueue_cg_post(w, w->a_ut.p)) return -1;
       launch(w, ABIP_HIP_K_VEC, k_adapt_step, w->NB, BS, (const double *)w->a_ut.p, w->a_ut.p, (const double *)w->a_up.p, (const double *)w->a_vp.p,
              w->a_u.p, w->a_v.p, st->alpha, 0.0, d, (const double *)w->part.p, w->NB, (const double *)w->gs, w->ctl.p, w->mu, 1);
-      if (bb_reuse) launch(w, ABIP_HIP_K_VEC, k_adapt_resume, 1, 1, w->ctl.p);
-      if (projection(w->a_utn.p, w->a_u.p, w->a_v.p) || enqueue_cg_chunk(w, w->a_utn.p, chunk[1])) return -1;
     }
+    if (from == 3) launch(w, ABIP_HIP_K_VEC, k_adapt_resume, 1, 1, w->ctl.p);
+    if (from <= 1 || from == 3) { if (projection(w->a_utn.p, w->a_u.p, w->a_v.p) || enqueue_cg_chunk(w, w->a_utn.p, chunk[1])) return -1; }
     if (enqueue_cg_post(w, w->a_utn.p)) return -1;
     launch(w, ABIP_HIP_K_VEC, k_adapt_step, w->NB, BS, (const double *)w->a_utn.p, w->a_utn.p, (const double *)w->a_u.p, (const double *)w->a_v.p,
            w->a_un.p, w->a_vn.p, st->alpha, 0.0, d, (const double *)w->part.p, w->NB, (const double *)w->gs, w->ctl.p, w->mu, 2);
     launch(w, ABIP_HIP_K_VEC, k_adapt_dots, w->NB, BS, (const double *)w->a_u.p, (const double *)w->a_v.p, (const double *)w->a_un.p,
            (const double *)w->a_vn.p, (const double *)w->a_vp.p, st->alpha, d, w->part.p, w->xwt);
-    launch(w, ABIP_HIP_K_VEC, k_adapt_decide, 1, 1024, (const double *)w->part.p, w->NB, w->ctl.p, st->eps_cor, st->eps_pen, lookback, w->hmir[L & 1], bb_reuse ? 1 : 0);
-    if (hipEventRecord(w->mir_ev[L & 1], w->stream) != hipSuccess) return -1;
+    launch(w, ABIP_HIP_K_VEC, k_adapt_decide, 1, 1024, (const double *)w->part.p, w->NB, w->ctl.p, st->eps_cor, st->eps_pen, lookback, w->hmir[0], bb_reuse ? 1 : 0);
+    if (hipEventRecord(w->mir_ev[0], w->stream) != hipSuccess) return -1;
     launch(w, ABIP_HIP_K_VEC, k_adapt_next, w->NB, BS, w->a_up.p, w->a_vp.p, w->a_u.p, w->a_v.p, w->a_ut.p, (const double *)w->a_utn.p, (const double *)w->a_un.p, (const double *)w->a_vn.p,
            w->mu, d, (const Ctl *)w->ctl.p);
     return 0;
   };
-  long enq = 0, done = 0;
-  const Ctl *hm = nullptr;
+  // One unit in flight: the host reads a look-ahead's verdict before it enqueues the next one, because the verdict decides the next unit's SHAPE -- handed a
+  // second step (four look-aheads of five) it has no first half at all.  (Round 5 first enqueued units two deep, whole: the ~45 launches of a first half that
+  // then fell through cost ~0.1 ms, four times the ~25 us the device now idles while the verdict travels.)
+  long done = 0;
+  const Ctl *hm = w->hmir[0];
+  int from = 0;
   for (;;) {
-    while (enq < lookback && enq - done < 2) { if (unit(enq, 0)) return -1; ++enq; }
-    const int sl = (int)(done & 1);
-    if (hipEventSynchronize(w->mir_ev[sl]) != hipSuccess) return -1;
-    hm = w->hmir[sl];
-    if (hm->halt == 2) { // a solve of unit `done` stalled; whatever was enqueued behind it ran as no-ops
+    if (unit(from)) return -1;
+    for (;;) {
+      if (hipEventSynchronize(w->mir_ev[0]) != hipSuccess) return -1;
+      if (hm->halt != 2) break;
+      // a solve of this unit stalled: more PCG iterations, then the rest of the unit
       ++w->stream_stalls;
       const int which = hm->bb_stage == 0 ? 0 : 1;
       HIP_OK(hipMemsetAsync(&w->ctl.p->halt, 0, sizeof(int), w->stream));
       chunk[which] = bb_forced ? bb_forced : std::max(4, chunk[which]);
-      if (enqueue_cg_chunk(w, which == 0 ? w->a_ut.p : w->a_utn.p, chunk[which]) || unit(done, which + 1)) return -1;
-      enq = done + 1;
-      continue;
+      if (enqueue_cg_chunk(w, which == 0 ? w->a_ut.p : w->a_utn.p, chunk[which]) || unit(which + 1)) return -1;
     }
     ++done;
-    if (bb_trace) fprintf(stderr, "[bb] k %ld look-ahead %ld: PCG %d + %d (enqueued %d + %d) act %d beta %.6g\n", (long)iter, done, hm->bb_cg[0], hm->bb_cg[1], chunk[0], chunk[1], hm->bb_act, hm->bb_beta);
-    // (blind counts of the pair, two units behind the verdict they come from: the counts jump by 2 - 3 when the penalty changes -- profiles/r05h_c4_bb_trace.txt --
-    //  a launch past convergence costs ~6 us per PCG iteration, a stalled unit ~0.4 ms)
-    for (int q = 0; q < 2; ++q) chunk[q] = bb_forced ? bb_forced : std::max(2, std::min((int)w->m_glob, hm->bb_cg[q] + std::max(3, hm->bb_cg[q] >> 2)));
+    if (bb_trace) fprintf(stderr, "[bb] k %ld look-ahead %ld: PCG %d + %d (enqueued %d + %d) act %d beta %.6g%s\n", (long)iter, done, hm->bb_cg[0], hm->bb_cg[1], chunk[0], chunk[1], hm->bb_act, hm->bb_beta, from == 3 ? "  (first half handed over)" : "");
     if (hm->halt == 4) break; // the search is over (adaptive.c:221-229, or the look-back used up)
     if ((hm->halt != 0 && hm->halt != 5) || hm->bb_it != (int)done) { fprintf(stderr, "abip_hip: streamed search: unexpected state (halt %d, look-ahead %d of %ld)\n", hm->halt, hm->bb_it, done); return -1; }
+    from = hm->halt == 5 ? 3 : 0;
+    // blind PCG counts of the next pair (profiles/r05h_c4_bb_trace.txt): behind an unchanged penalty the second solve takes the previous second solve's count or one
+    // less; behind a changed one both take more.  A launch past convergence costs ~6 us per PCG iteration, a stalled unit a round trip + the launches behind it.
+    // The first change of a search (beta_prev 1 -> ~3) nearly doubles the counts; a later one adds a fifth to a quarter.
+    const int base = hm->bb_cg[1], margin = (hm->bb_act != 1) ? 1 : (done == 1 ? (3 * base) / 4 + 2 : std::max(3, (base + 3) / 4 + 1));
+    for (int q = 0; q < 2; ++q) chunk[q] = bb_forced ? bb_forced : std::max(2, std::min((int)w->m_glob, base + margin));
   }
   w->beta = hm->bb_beta;
   w->tot_solves += 2 * done; w->prof.kkt_solves += 2 * done;
