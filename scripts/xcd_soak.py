@@ -21,8 +21,8 @@ def soak(name, reps, env=None):
         assert h == first, (name, env, r, h, first)
     for k in (env or {}):
         os.environ.pop(k, None)
-    print("ok  %-3s %-22s %3d solves, workgroups %3d, %6d iterations each, identical bits; solve time min %.3f median %.3f max %.3f s" % (
-        name, str(env or ""), reps, g, first[0], min(times), sorted(times)[len(times) // 2], max(times)), flush=True)
+    os.write(bench._REAL_STDOUT, ("ok  %-3s %-22s %3d solves, workgroups %3d, %6d iterations each, identical bits; solve time min %.3f median %.3f max %.3f s\n" % (
+        name, str(env or ""), reps, g, first[0], min(times), sorted(times)[len(times) // 2], max(times))).encode())   # (importing bench points the C-level stdout at stderr)
 
 n2 = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 n3 = int(sys.argv[2]) if len(sys.argv) > 2 else 6
