@@ -102,6 +102,7 @@ struct XcdArgs {
   int minv_lds_rows;                    // direct: how many of a workgroup's rows of it fit its LDS (the first ones; the others stream from the L2)
   double g_th;
   double *xn0, *xn1, *xm0, *xm1;        // exchange areas: 2 parities x (n_pad | m_pad) doubles
+  double *xnv;                          // direct: the new v_x beside the new u_x (2 parities x n_pad): every rank forms the next right-hand side's x entries it gathers itself
   u32x4 *sc;                            // 2 parities x XG x XKS granules: the partial sums = the flags
   int n_pad, m_pad;
   unsigned tag0;
@@ -527,6 +528,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   int flip = 0;
   XWait w; w.xstat = a.xstat; w.dead = false; w.site = 0; w.rank = rank; w.ldead = mnb + 15; // (x_block_min uses the first XWAVES of the 16)
   xrsrc pn0, pn1, pm0, pm1, psc; // the exchange areas of the parity in use
+  xrsrc pnv;                     // (direct) v_x of the update's exchange
   const unsigned sc_off = (unsigned)rank * XKS * 16u;
   auto open = [&](int site) { // next exchange: tag and the areas of its parity
     tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(tag + 1u)); // (uniform by construction; the loops' give-up exits hide that from the compiler)
@@ -535,6 +537,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     pn0 = x_rsrc(a.xn0 + par * a.n_pad, 8u * (unsigned)a.n_pad); pn1 = x_rsrc(a.xn1 + par * a.n_pad, 8u * (unsigned)a.n_pad);
     pm0 = x_rsrc(a.xm0 + par * a.m_pad, 8u * (unsigned)a.m_pad); pm1 = x_rsrc(a.xm1 + par * a.m_pad, 8u * (unsigned)a.m_pad);
     psc = x_rsrc(a.sc + par * (size_t)(XG * XKS), 16u * XG * XKS);
+    if (!PCG) pnv = x_rsrc(a.xnv + par * a.n_pad, 8u * (unsigned)a.n_pad);
     w.n0 = pn0; w.n1 = pn1; w.m0 = pm0; w.m1 = pm1; w.sc = psc;
     if (t == 0) { a.xstat[8 + 2 * rank] = (int)tag; a.xstat[9 + 2 * rank] = site; } // (post-mortem: where every rank was when a wait gave up)
   };
@@ -830,7 +833,11 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       }
     };
     bool have_rhs = false;
+    bool have_w = false; // (direct) w of this trip went out with the previous iteration's stopping-test sums: the trip starts at the all-gather
     int leave = 0;
+    double hA[NZ];       // (direct) h_x at the columns this thread's non-zeros of A gather: constant
+#pragma unroll
+    for (int u = 0; u < NZ; ++u) hA[u] = (!PCG && u < na) ? x_at(a.h + MP, ai[u] >> 3) : 0.0;
     double hy[RM], hx[RN]; // h of the owned elements: constant, read by three phases of every trip
     double hy2[RM];        // h_y + (A h_x) of the owned rows
 #pragma unroll
@@ -847,7 +854,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     const double coef = (wg - tsum * a.g_th) / (a.g_th + 1.0);
     if (!PCG) { XP_START }
     double bn[1] = {0.0}, bnS[1] = {0.0};
-    if (!have_rhs) {
+    if (!have_rhs && !have_w) {
       open(2);
       build_rhs(tb, tsum, coef, bn);
       x_publish<1, SA>(bn, red, psc, sc_off, tag);
@@ -982,20 +989,23 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       for (int q = 0; q < RM; ++q) y[q] = cx[q];
     } else {
       // ---- direct: w = rhs_y + A rhs_x; y = inv(rho I + A A') w; (x follows below) ----
-      double sA[RM];
-      {
-        double ax[NZ], va[NZ];
-        x_mat<NZ>(gA, na, ax);
-        x_gather<NZ>(pn0, ai, va);
-        x_rows<NZ, RM>(prod, flip, ax, va, na, sa, ea, sA);
-      }
-      XP_LAP(0)
-      open(5);
+      if (!have_w) { // (the first trip of a loop, a look-ahead step, the solve-only mode: later trips find w out already -- see the end of the trip)
+        double sA[RM];
+        {
+          double ax[NZ], va[NZ];
+          x_mat<NZ>(gA, na, ax);
+          x_gather<NZ>(pn0, ai, va);
+          x_rows<NZ, RM>(prod, flip, ax, va, na, sa, ea, sA);
+        }
+        XP_LAP(0)
+        open(5);
 #pragma unroll
-      for (int q = 0; q < RM; ++q) { const unsigned i = m0 + tb + q * XTB; if (i < m1) x_putd<SA>(pm0, i * 8u, rhs_y[q] + sA[q]); }
-      x_flag<SA>(psc, sc_off, tag);
-      x_wait<CROSS>(w, G);
-      if (__builtin_expect(w.dead, 0)) return;
+        for (int q = 0; q < RM; ++q) { const unsigned i = m0 + tb + q * XTB; if (i < m1) x_putd<SA>(pm0, i * 8u, rhs_y[q] + sA[q]); }
+        x_flag<SA>(psc, sc_off, tag);
+        x_wait<CROSS>(w, G);
+        if (__builtin_expect(w.dead, 0)) return;
+      }
+      have_w = false;
       XP_LAP(1)
       for (unsigned i0 = t; i0 < (unsigned)a.m; i0 += 4 * XTB) { // every workgroup needs the whole w (four loads in flight)
         double tv[4];
@@ -1206,6 +1216,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         x_at(up.u_avgc, qq) = ua; x_at(up.v_avgc, qq) = vac;
         nux[q] = un; nvx[q] = vn; vacx[q] = vac;
         x_putd<SA>(pn0, j2 * 8u, un);
+        if (!PCG) x_putd<SA>(pnv, j2 * 8u, vn);
         if (avg_stats) x_putd<SA>(pn1, j2 * 8u, ua);
       }
     }
@@ -1246,6 +1257,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     // ---- stopping-test products (k_q_both): A u_x and A'u_y, residual sums; A'u_y is also the next solve's warm-start product ----
     // One round trip for everything the phase reads from the L2: rank 0's tau granules (there since its flags are), the matrix values and the gathered entries
     // of both products; b, c, the scale factors, v and the averaged v of the owned elements come from the update in registers.
+    double axk[NZ], uxg[NZ], vxg[NZ]; // (direct) A's values, the gathered new u_x and v_x: the next right-hand side's x entries are formed from them below
     {
       u32x4 tg[4];
 #pragma unroll
@@ -1253,8 +1265,11 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       double ax[NZ], va[NZ], tx[NZ], vt[NZ];
       x_mat<NZ>(gA, na, ax);
       x_gather<NZ>(pn0, ai, va);
+      if (!PCG) x_gather<NZ>(pnv, ai, vxg);
       x_mat<NZ>(gT, nt, tx);
       x_gather<NZ>(pm0, ti, vt);
+#pragma unroll
+      for (int u = 0; u < NZ; ++u) { axk[u] = ax[u]; uxg[u] = va[u]; if (PCG) vxg[u] = 0.0; }
       double pri[RM];
       x_rows<NZ, RM>(prod, flip, ax, va, na, sa, ea, pri);
       x_rows<NZ, RN>(prod, flip, tx, vt, nt, st, et, aty);
@@ -1312,12 +1327,13 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       }
     }
     if (!PCG) { XP_LAP(5) }
-    open(9);
+    double Q[12];
     if (!PCG) {
-      // Direct back-end: the NEXT iteration's right-hand side rides on this exchange -- everything it needs (S_WG, the tau entries, the new iterate) is
-      // known since the previous one, its x block goes out with the sums of the stopping test, and the next trip starts at its first product: one
-      // rendez-vous less per iteration (four, with u_t'h on the back-substitution's exchange).  If the exit test below ends the inner loop the entries are simply not used.  (The PCG back-end's first
-      // exchange also carries |rhs_y|^2 for its tolerance -- a thirteenth sum on the iterations that test the averaged iterate; it keeps the exchange.)
+      // Direct back-end: the NEXT iteration's w = rhs_y + A rhs_x rides on this exchange with the sums of the stopping test.  Everything the next right-hand side
+      // needs (S_WG, the tau entries, the new iterate) is known since the update's exchange; its y entries are the owner's, and the x entries a row of A gathers
+      // are formed by the gathering thread itself from the new (u_x, v_x) it gathered for the stopping test (v_x went out beside u_x) and from h at those columns --
+      // k_rhs's expressions on the same numbers, the same bits as the owner's.  So the exchange that handed rhs_x round in round 4 is gone: three rendez-vous per
+      // iteration (w + stopping-test sums, y + u_t'h, the update).  If the exit test below ends the inner loop, w is simply not used.
       const double ts_n = S13[9] + S13[10];
       const double cf_n = (S13[0] - ts_n * a.g_th) / (a.g_th + 1.0);
       // (build_rhs with the iterate and h in registers: the same expressions, no loads)
@@ -1341,12 +1357,22 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
           r += -ts_n * hx[q];
           r += -cf_n * hx[q];
           rhs_x[q] = -r;
-          x_putd<SA>(pn0, j2 * 8u, -r);
         }
       }
-      have_rhs = true;
-    }
-    double Q[12];
+      double rxg[NZ], sA[RM];
+#pragma unroll
+      for (int u = 0; u < NZ; ++u) {
+        double r = uxg[u] + vxg[u];
+        r += -ts_n * hA[u];
+        r += -cf_n * hA[u];
+        rxg[u] = -r;
+      }
+      x_rows<NZ, RM>(prod, flip, axk, rxg, na, sa, ea, sA);
+      open(5);
+#pragma unroll
+      for (int q = 0; q < RM; ++q) { const unsigned i = m0 + tb + q * XTB; if (i < m1) x_putd<SA>(pm0, i * 8u, rhs_y[q] + sA[q]); }
+      have_w = true;
+    } else open(9);
     if (avg_stats) {
       x_publish<12, SA>(q6, red, psc, sc_off, tag);
       x_collect<12, CROSS>(w, G, tot, Q);

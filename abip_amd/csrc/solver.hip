@@ -167,7 +167,7 @@ struct XcdPlan {
   unsigned tickets_used = 0; // tickets drawn by the launches so far (G per launch)
   abip::hostutil::DBuf<int> mb, nb, xstat;
   abip::hostutil::DBuf<unsigned> tickets;
-  abip::hostutil::DBuf<double> xn0, xn1, xm0, xm1;
+  abip::hostutil::DBuf<double> xn0, xn1, xm0, xm1, xnv; // (xnv: direct variant, the new v_x beside the new u_x)
   abip::hostutil::DBuf<abip::u32x4> sc;
   abip::hostutil::DBuf<double> tolf, Minv;
   double *htolf = nullptr; int *hstat = nullptr; // pinned
@@ -190,7 +190,7 @@ struct XcdPlan {
   long giveups = 0;
   int desert_at = -1; // fault injection (libabip_hip_hooks.so): the launch number whose last rank leaves at once
   void release() {
-    mb.release(); nb.release(); xstat.release(); tickets.release(); xn0.release(); xn1.release(); xm0.release(); xm1.release(); sc.release(); tolf.release(); Minv.release();
+    mb.release(); nb.release(); xstat.release(); tickets.release(); xn0.release(); xn1.release(); xm0.release(); xm1.release(); xnv.release(); sc.release(); tolf.release(); Minv.release();
     mu_tab.release(); xlog.release(); snap.release();
     if (htolf) (void)hipHostFree(htolf);
     if (hstat) (void)hipHostFree(hstat);
@@ -1053,9 +1053,11 @@ void xcd_setup(W *w, const host::HostCsr &hA, const host::HostCsr &hAt) {
   const std::vector<unsigned> zero1(1, 0u);
   bool bad = x.mb.upload(mb, w->stream) || x.nb.upload(nb, w->stream) || x.xstat.upload(zero2, w->stream) || x.tickets.upload(zero1, w->stream) ||
              x.xn0.alloc(2 * (size_t)x.n_pad) || x.xn1.alloc(2 * (size_t)x.n_pad) || x.xm0.alloc(2 * (size_t)x.m_pad) || x.xm1.alloc(2 * (size_t)x.m_pad) ||
+             (!pcg && x.xnv.alloc(2 * (size_t)x.n_pad)) ||
              x.sc.alloc(2 * (size_t)XG * XKS) || x.tolf.alloc(x.max_batch) || x.mu_tab.alloc(XcdPlan::MU_TAB) || x.xlog.alloc((size_t)XcdPlan::LOG_CAP * XLOG_W) ||
              x.snap.alloc(9 * (size_t)w->LV);
   x.snap_len = (size_t)w->LV;
+  if (!bad && !pcg) bad = hipMemsetAsync(x.xnv.p, 0, sizeof(double) * 2 * x.n_pad, w->stream) != hipSuccess;
   if (!bad) bad = hipMemsetAsync(x.xn0.p, 0, sizeof(double) * 2 * x.n_pad, w->stream) != hipSuccess || hipMemsetAsync(x.xn1.p, 0, sizeof(double) * 2 * x.n_pad, w->stream) != hipSuccess ||
                   hipMemsetAsync(x.xm0.p, 0, sizeof(double) * 2 * x.m_pad, w->stream) != hipSuccess || hipMemsetAsync(x.xm1.p, 0, sizeof(double) * 2 * x.m_pad, w->stream) != hipSuccess ||
                   hipMemsetAsync(x.sc.p, 0, sizeof(u32x4) * 2 * XG * XKS, w->stream) != hipSuccess;
@@ -1127,7 +1129,7 @@ void xcd_fill(W *w, XcdArgs &a) {
   a.h = w->h.p; a.hAh = w->hAh.p; a.wD = st->normalize ? w->wD.p : nullptr; a.wE = st->normalize ? w->wE.p : nullptr;
   a.Mjac = pcg ? w->cg_M.p : nullptr; a.Minv = x.Minv.p; a.ldM = x.ldM; a.minv_lds_rows = x.minv_lds_rows;
   a.g_th = w->g_th;
-  a.xn0 = x.xn0.p; a.xn1 = x.xn1.p; a.xm0 = x.xm0.p; a.xm1 = x.xm1.p; a.sc = x.sc.p; a.n_pad = x.n_pad; a.m_pad = x.m_pad;
+  a.xn0 = x.xn0.p; a.xn1 = x.xn1.p; a.xm0 = x.xm0.p; a.xm1 = x.xm1.p; a.xnv = x.xnv.p; a.sc = x.sc.p; a.n_pad = x.n_pad; a.m_pad = x.m_pad;
   a.nxcd = x.nxcd;
   a.ctl = w->ctl.p; a.xstat = x.xstat.p;
   a.j0 = (long)w->j;

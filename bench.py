@@ -430,7 +430,7 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         # exchanges counted by the kernel itself (every rendez-vous of the window's launches, the look-ahead solves of the Barzilai-Borwein search included:
         # since round 4 the search runs inside the launch, so its time is inside `ms` as well)
         xd = {k: S.scalar(k) - xstat0[k] for k in xstat0}
-        exch = xd["xcd_exchanges"] / its if xd["xcd_exchanges"] > 0 else ((2 * cg_step + 6) if linsys == "indirect" else 4.0)
+        exch = xd["xcd_exchanges"] / its if xd["xcd_exchanges"] > 0 else ((2 * cg_step + 6) if linsys == "indirect" else 3.0)
         # HBM bytes per launch from the committed counter passes (per inner iteration there, FETCH_SIZE / WRITE_SIZE summed over the kernel's dispatches)
         tpi = pmc_traffic(name).get("k_lp_xcd", {}).get("traffic_bytes_per_iteration") if pmc and world == 1 else None
         roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=(tpi * its / nl) if tpi else None,
