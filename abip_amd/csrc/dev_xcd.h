@@ -227,7 +227,10 @@ __device__ __forceinline__ void x_collect(XWait &w, int G, double *tot, double (
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int kk = 0; kk < K; kk += XWAVES) {
-  const int wave = kk + (int)(threadIdx.x >> 6); // (the scalar this wavefront looks after in this pass)
+  // The scalar this wavefront looks after in this pass.  On one XCD the LAST wavefronts poll: the first ones own the workgroup's elements and may have stores in
+  // flight, behind which a poll's load would wait (c2: +1.7 %).  Across XCDs the first ones do, as ever: there a poll is 2 x 64 loads past the L2 per round, and
+  // waiting behind the own written-through stores is the cheapest way not to ask before anything can have arrived (the last wavefronts polling at once: c3 -4 %).
+  const int wave = kk + (WIDE ? (int)(threadIdx.x >> 6) : XWAVES - 1 - (int)(threadIdx.x >> 6));
   if (wave < K) {
     u32x4 g[XQ];
 #pragma unroll
@@ -1146,6 +1149,11 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     // form: nine of them per element, which the compiler must keep in order because the arrays may alias) is a chain of that many L2 round trips.
     Stat sst = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double tau4[4] = {0.0, 0.0, 0.0, 0.0};
+    double uay[RM], uax[RN], utq_t = 0.0; // the averaged u of the owned elements, the tau entry of u_t: kept for the stores behind the flags
+#pragma unroll
+    for (int q = 0; q < RM; ++q) uay[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < RN; ++q) uax[q] = 0.0;
     open(8);
     XLd Ly[RM], Lx[RN], Lt;
     // What the phases behind the update need of the owned elements rides in registers from here: the scale factors with this batch of loads, the new
@@ -1191,11 +1199,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         if (!up.half_update) { vn = Ly[q].v; un = uti - vn; }
         else { double vh = Ly[q].v + 0.5 * (Ly[q].u - uti); un = uti - vh; vn = vh + (un - uti); }
         const double ua = xs_y2(up, Ly[q], un, vn, sst);
-        x_at(up.u, i) = un; x_at(up.v, i) = vn;
-        x_at(up.u_avg, i) = Ly[q].ua + un; x_at(up.v_avg, i) = Ly[q].va + vn;
-        x_at(up.u_sum, i) = Ly[q].us + un; x_at(up.v_sum, i) = Ly[q].vs + vn;
-        x_at(up.u_avgc, i) = ua; x_at(up.v_avgc, i) = (Ly[q].vs + vn) / up.dom;
-        nuy[q] = un; nvy[q] = vn;
+        nuy[q] = un; nvy[q] = vn; uay[q] = ua;
         x_putd<SA>(pm0, i * 8u, un);
         if (avg_stats) x_putd<SA>(pm1, i * 8u, ua);
       }
@@ -1208,13 +1212,8 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         double un, vn;
         x_prox(up, Lx[q].u, Lx[q].v, zx[q], un, vn);
         const double ua = xs_x2(up, Lx[q], false, un, vn, sst);
-        x_at(up.ut, qq) = zx[q];
-        x_at(up.u, qq) = un; x_at(up.v, qq) = vn;
-        x_at(up.u_avg, qq) = Lx[q].ua + un; x_at(up.v_avg, qq) = Lx[q].va + vn;
-        x_at(up.u_sum, qq) = Lx[q].us + un; x_at(up.v_sum, qq) = Lx[q].vs + vn;
         const double vac = (Lx[q].vs + vn) / up.dom;
-        x_at(up.u_avgc, qq) = ua; x_at(up.v_avgc, qq) = vac;
-        nux[q] = un; nvx[q] = vn; vacx[q] = vac;
+        nux[q] = un; nvx[q] = vn; vacx[q] = vac; uax[q] = ua;
         x_putd<SA>(pn0, j2 * 8u, un);
         if (!PCG) x_putd<SA>(pnv, j2 * 8u, vn);
         if (avg_stats) x_putd<SA>(pn1, j2 * 8u, ua);
@@ -1225,11 +1224,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       double un, vn;
       x_prox(up, Lt.u, Lt.v, utq, un, vn);
       const double ua = xs_x2(up, Lt, true, un, vn, sst), va = (Lt.vs + vn) / up.dom;
-      x_at(up.ut, tail) = utq;
-      x_at(up.u, tail) = un; x_at(up.v, tail) = vn;
-      x_at(up.u_avg, tail) = Lt.ua + un; x_at(up.v_avg, tail) = Lt.va + vn;
-      x_at(up.u_sum, tail) = Lt.us + un; x_at(up.v_sum, tail) = Lt.vs + vn;
-      x_at(up.u_avgc, tail) = ua; x_at(up.v_avgc, tail) = va;
+      utq_t = utq;
       tau4[0] = un; tau4[1] = vn; tau4[2] = ua; tau4[3] = va;
       // the tau / kappa entries are nobody's sum: they travel as granules of rank 0 behind the sums' (slots 12..15), acknowledged before its flags go out
 #pragma unroll
@@ -1237,17 +1232,57 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     }
     // (an exchange costs per scalar it carries -- a wavefront sum in every wavefront, a polling wavefront: the averaged iterate's four sums go
     //  out only on the iterations that test it, one in ten)
+    // The state's own stores -- eight arrays per element, nobody else's business -- go out BEHIND this rank's flags: in front of them (round 4) the flags waited for
+    // their acknowledgements too (one in-order counter), for nothing.  The polling wavefronts are the workgroup's last ones, which own no elements.
+    // (One XCD only: c2 +1.7 %.  Across XCDs the first wavefronts poll -- see x_collect -- and would wait behind these stores: there the round-4 order stays.)
+    auto store_state = [&]() {
+#pragma unroll
+      for (int q = 0; q < RM; ++q) {
+        const unsigned i = m0 + tb + q * XTB;
+        if (i < m1) {
+          const double un = nuy[q], vn = nvy[q];
+          x_at(up.u, i) = un; x_at(up.v, i) = vn;
+          x_at(up.u_avg, i) = Ly[q].ua + un; x_at(up.v_avg, i) = Ly[q].va + vn;
+          x_at(up.u_sum, i) = Ly[q].us + un; x_at(up.v_sum, i) = Ly[q].vs + vn;
+          x_at(up.u_avgc, i) = uay[q]; x_at(up.v_avgc, i) = (Ly[q].vs + vn) / up.dom;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < RN; ++q) {
+        const unsigned j2 = n0 + tb + q * XTB;
+        if (j2 < n1) {
+          const unsigned qq = MP + j2;
+          const double un = nux[q], vn = nvx[q];
+          x_at(up.ut, qq) = zx[q];
+          x_at(up.u, qq) = un; x_at(up.v, qq) = vn;
+          x_at(up.u_avg, qq) = Lx[q].ua + un; x_at(up.v_avg, qq) = Lx[q].va + vn;
+          x_at(up.u_sum, qq) = Lx[q].us + un; x_at(up.v_sum, qq) = Lx[q].vs + vn;
+          x_at(up.u_avgc, qq) = uax[q]; x_at(up.v_avgc, qq) = vacx[q];
+        }
+      }
+      if (rank == 0 && t == 0) {
+        x_at(up.ut, tail) = utq_t;
+        x_at(up.u, tail) = tau4[0]; x_at(up.v, tail) = tau4[1];
+        x_at(up.u_avg, tail) = Lt.ua + tau4[0]; x_at(up.v_avg, tail) = Lt.va + tau4[1];
+        x_at(up.u_sum, tail) = Lt.us + tau4[0]; x_at(up.v_sum, tail) = Lt.vs + tau4[1];
+        x_at(up.u_avgc, tail) = tau4[2]; x_at(up.v_avgc, tail) = tau4[3];
+      }
+    };
     double q6[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     double S13[13];
     if (avg_stats) {
       double s9[9] = {sst.wg, sst.nu, sst.nv, sst.cx, sst.by, sst.nua, sst.nva, sst.cxa, sst.bya}, S9[9];
+      if (CROSS) store_state();
       x_publish<9, SA>(s9, red, psc, sc_off, tag);
+      if (!CROSS) store_state();
       x_collect<9, CROSS>(w, G, tot, S9);
 #pragma unroll
       for (int q = 0; q < 9; ++q) S13[q] = S9[q];
     } else {
       double s5[5] = {sst.wg, sst.nu, sst.nv, sst.cx, sst.by}, S5[5];
+      if (CROSS) store_state();
       x_publish<5, SA>(s5, red, psc, sc_off, tag);
+      if (!CROSS) store_state();
       x_collect<5, CROSS>(w, G, tot, S5);
 #pragma unroll
       for (int q = 0; q < 5; ++q) S13[q] = S5[q];
