@@ -1125,8 +1125,47 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     }
 #pragma unroll
     for (int q = 0; q < RN; ++q) dh[0] -= rhs_x[q] * hx[q]; // (zero beyond the owned columns)
+    // (one XCD) The update's loads -- the old (u, v), the running sums, g, b / c, the scale factors of the owned elements: nothing the solve changes -- go out HERE,
+    // behind this rank's flags: their round trip to the L2 overlaps with the wait for the other ranks and with the gather.  (Tried before the polling moved to the
+    // wavefronts that own no elements: the polls then waited behind these loads, a loss.  Across XCDs the first wavefronts still poll: there the loads stay put.)
+    const bool upd_next = (mode == XM_MAIN) && !solo;
+    double wsy[RM], wsx[RN];
+    x_publish<1, SA>(dh, red, psc, sc_off, tag);
+    XLd Ly[RM], Lx[RN], Lt;
+    // What the phases behind the update need of the owned elements rides in registers from here: the scale factors with this batch of loads, the new
+    // (u, v) and the averaged v as they are computed -- the stopping test and the next right-hand side then start without a round trip to the L2 of their own
+    // (the arrays are written all the same: everything outside this loop reads them there).
+#pragma unroll
+    for (int q = 0; q < RM; ++q) {
+      const unsigned i = m0 + tb + q * XTB;
+      Ly[q] = XLd{0, 0, 0, 0, 0, 0, 0, 0};
+      wsy[q] = 1.0;
+      if (upd_next && i < m1) {
+        Ly[q].v = x_at(up.v, i); if (up.half_update) Ly[q].u = x_at(up.u, i);
+        Ly[q].ua = x_at(up.u_avg, i); Ly[q].va = x_at(up.v_avg, i); Ly[q].us = x_at(up.u_sum, i); Ly[q].vs = x_at(up.v_sum, i);
+        Ly[q].g = x_at(up.g, i); Ly[q].bc = x_at(up.b, i);
+        if (a.wD) wsy[q] = x_at(a.wD, i);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RN; ++q) {
+      const unsigned j2 = n0 + tb + q * XTB;
+      Lx[q] = XLd{0, 0, 0, 0, 0, 0, 0, 0};
+      wsx[q] = 1.0;
+      if (upd_next && j2 < n1) {
+        const unsigned qq = MP + j2;
+        Lx[q].u = x_at(up.u, qq); Lx[q].v = x_at(up.v, qq);
+        Lx[q].ua = x_at(up.u_avg, qq); Lx[q].va = x_at(up.v_avg, qq); Lx[q].us = x_at(up.u_sum, qq); Lx[q].vs = x_at(up.v_sum, qq);
+        Lx[q].g = x_at(up.g, qq); Lx[q].bc = x_at(up.c, j2);
+        if (a.wE) wsx[q] = x_at(a.wE, j2);
+      }
+    }
+    Lt = XLd{0, 0, 0, 0, 0, 0, 0, 0};
+    if (upd_next && rank == 0 && t == 0) {
+      Lt.u = x_at(up.u, tail); Lt.v = x_at(up.v, tail);
+      Lt.ua = x_at(up.u_avg, tail); Lt.va = x_at(up.v_avg, tail); Lt.us = x_at(up.u_sum, tail); Lt.vs = x_at(up.v_sum, tail);
+    }
     {
-      x_publish<1, SA>(dh, red, psc, sc_off, tag);
       double tx[NZ];
       x_mat<NZ>(gT, nt, tx);
       x_collect<1, CROSS>(w, G, tot, dhS);
@@ -1155,41 +1194,12 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
 #pragma unroll
     for (int q = 0; q < RN; ++q) uax[q] = 0.0;
     open(8);
-    XLd Ly[RM], Lx[RN], Lt;
-    // What the phases behind the update need of the owned elements rides in registers from here: the scale factors with this batch of loads, the new
-    // (u, v) and the averaged v as they are computed -- the stopping test and the next right-hand side then start without a round trip to the L2 of their own
-    // (the arrays are written all the same: everything outside this loop reads them there).
-    double wsy[RM], wsx[RN], nuy[RM], nvy[RM], nux[RN], nvx[RN], vacx[RN];
+    // (the old values of the owned elements -- Ly, Lx, Lt, the scale factors -- were requested behind the back-substitution's flags: see there)
+    double nuy[RM], nvy[RM], nux[RN], nvx[RN], vacx[RN];
 #pragma unroll
-    for (int q = 0; q < RM; ++q) {
-      const unsigned i = m0 + tb + q * XTB;
-      Ly[q] = XLd{0, 0, 0, 0, 0, 0, 0, 0};
-      wsy[q] = 1.0; nuy[q] = 0.0; nvy[q] = 0.0;
-      if (i < m1) {
-        Ly[q].v = x_at(up.v, i); if (up.half_update) Ly[q].u = x_at(up.u, i);
-        Ly[q].ua = x_at(up.u_avg, i); Ly[q].va = x_at(up.v_avg, i); Ly[q].us = x_at(up.u_sum, i); Ly[q].vs = x_at(up.v_sum, i);
-        Ly[q].g = x_at(up.g, i); Ly[q].bc = x_at(up.b, i);
-        if (a.wD) wsy[q] = x_at(a.wD, i);
-      }
-    }
+    for (int q = 0; q < RM; ++q) { nuy[q] = 0.0; nvy[q] = 0.0; }
 #pragma unroll
-    for (int q = 0; q < RN; ++q) {
-      const unsigned j2 = n0 + tb + q * XTB;
-      Lx[q] = XLd{0, 0, 0, 0, 0, 0, 0, 0};
-      wsx[q] = 1.0; nux[q] = 0.0; nvx[q] = 0.0; vacx[q] = 0.0;
-      if (j2 < n1) {
-        const unsigned qq = MP + j2;
-        Lx[q].u = x_at(up.u, qq); Lx[q].v = x_at(up.v, qq);
-        Lx[q].ua = x_at(up.u_avg, qq); Lx[q].va = x_at(up.v_avg, qq); Lx[q].us = x_at(up.u_sum, qq); Lx[q].vs = x_at(up.v_sum, qq);
-        Lx[q].g = x_at(up.g, qq); Lx[q].bc = x_at(up.c, j2);
-        if (a.wE) wsx[q] = x_at(a.wE, j2);
-      }
-    }
-    Lt = XLd{0, 0, 0, 0, 0, 0, 0, 0};
-    if (rank == 0 && t == 0) {
-      Lt.u = x_at(up.u, tail); Lt.v = x_at(up.v, tail);
-      Lt.ua = x_at(up.u_avg, tail); Lt.va = x_at(up.v_avg, tail); Lt.us = x_at(up.u_sum, tail); Lt.vs = x_at(up.v_sum, tail);
-    }
+    for (int q = 0; q < RN; ++q) { nux[q] = 0.0; nvx[q] = 0.0; vacx[q] = 0.0; }
 #pragma unroll
     for (int q = 0; q < RM; ++q) {
       const unsigned i = m0 + tb + q * XTB;
