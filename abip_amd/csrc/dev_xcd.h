@@ -155,10 +155,19 @@ __device__ __forceinline__ double x_uni(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 // wavefront sum on the DPP network (no LDS round trips: __shfl_down is a ds_bpermute per step); fixed order; the total lands in lane 63
+// (No "old" value for the lanes a step does not write: with every row written and bound_ctrl set the compiler drops it, and the two row_bcast steps leave the rows
+// they skip undefined -- nothing that reaches lane 63 reads them.  Handing 0 in as the old value cost two v_mov per step: 250 of the 1 450 instructions of a PCG
+// iteration of the persistent launch.)
 template <int CTRL, int ROWS>
 __device__ __forceinline__ double x_dpp(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xf, false);
+  int lo, hi;
+  if (ROWS == 0xf) {
+    lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  } else {
+    lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, ROWS, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, ROWS, 0xf, false);
+  }
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double x_wave_sum63(double v) {
@@ -168,6 +177,16 @@ __device__ __forceinline__ double x_wave_sum63(double v) {
   v += x_dpp<0x128, 0xf>(v); // row_ror:8   -> every lane holds its row's sum
   v += x_dpp<0x142, 0xa>(v); // row_bcast:15 into rows 1, 3
   v += x_dpp<0x143, 0xc>(v); // row_bcast:31 into rows 2, 3
+  return v;
+}
+
+// the sum of the first XWAVES (<= 16) lanes' values: the additions x_wave_sum63 makes of them when every other lane holds 0 (its further steps add zeros), without
+// those steps; the total lands in each of the first XWAVES lanes (the mirrors pair lane i with lane 7 - i / 15 - i: no direction of rotation to get wrong)
+__device__ __forceinline__ double x_sum_first_lanes(double v) {
+  v += x_dpp<0xB1, 0xf>(v);                   // quad_perm [1,0,3,2]
+  v += x_dpp<0x4E, 0xf>(v);                   // quad_perm [2,3,0,1]
+  if (XWAVES > 4) v += x_dpp<0x141, 0xf>(v);  // row_half_mirror
+  if (XWAVES > 8) v += x_dpp<0x140, 0xf>(v);  // row_mirror
   return v;
 }
 
@@ -217,8 +236,8 @@ __device__ __forceinline__ void x_publish(double (&v)[K], double *red, xrsrc sc,
   for (int kk = 0; kk < K; kk += XWAVES) { // wavefront k adds the XWAVES partials of scalar k (and k + XWAVES) and raises the flag
     const int k = kk + wave;
     if (k < K) {
-      const double s = x_wave_sum63(lane < XWAVES ? red[k * XWAVES + lane] : 0.0);
-      if (lane == 63) x_putg<SA>(sc, sc_off + (unsigned)k * 16u, s, tag);
+      const double s = x_sum_first_lanes(lane < XWAVES ? red[k * XWAVES + lane] : 0.0);
+      if (lane == 0) x_putg<SA>(sc, sc_off + (unsigned)k * 16u, s, tag);
     }
   }
 }
@@ -1218,7 +1237,6 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     for (int q = 0; q < RN; ++q) {
       const unsigned j2 = n0 + tb + q * XTB;
       if (j2 < n1) {
-        const unsigned qq = MP + j2;
         double un, vn;
         x_prox(up, Lx[q].u, Lx[q].v, zx[q], un, vn);
         const double ua = xs_x2(up, Lx[q], false, un, vn, sst);
