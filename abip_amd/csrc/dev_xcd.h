@@ -150,6 +150,9 @@ __device__ __forceinline__ double x_val(const u32x4 &g) { return __hiloint2doubl
 template <class T> __device__ __forceinline__ T &x_at(T *base, unsigned i) { return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (size_t)(unsigned)(i * (unsigned)sizeof(T))); }
 template <class T> __device__ __forceinline__ const T &x_at(const T *base, unsigned i) { return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)(unsigned)(i * (unsigned)sizeof(T))); }
 
+// the wavefront's index in its workgroup as the scalar it is (threadIdx.x >> 6 alone is a vector value to the compiler: every test on it an exec-mask dance,
+// every address formed from it a vector register for the whole launch)
+__device__ __forceinline__ int x_wave() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 // the same value in every lane, told to the compiler (scalar registers, uniform branches)
 __device__ __forceinline__ double x_uni(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
@@ -223,7 +226,7 @@ __device__ __forceinline__ bool x_spin(XWait &w, int &spins, unsigned found, int
 template <int K, int SA>
 __device__ __forceinline__ void x_publish(double (&v)[K], double *red, xrsrc sc, unsigned sc_off /* byte offset of this rank's granules */, unsigned tag) {
   static_assert(K >= 1 && K <= 12, "at most 12 sums per exchange (granule slots 12..15 carry the tau entries)");
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = x_wave();
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] = x_wave_sum63(v[k]); // (while the stores travel)
   if (lane == 63) {
@@ -249,7 +252,7 @@ __device__ __forceinline__ void x_collect(XWait &w, int G, double *tot, double (
   // The scalar this wavefront looks after in this pass.  On one XCD the LAST wavefronts poll: the first ones own the workgroup's elements and may have stores in
   // flight, behind which a poll's load would wait (c2: +1.7 %).  Across XCDs the first ones do, as ever: there a poll is 2 x 64 loads past the L2 per round, and
   // waiting behind the own written-through stores is the cheapest way not to ask before anything can have arrived (the last wavefronts polling at once: c3 -4 %).
-  const int wave = kk + (WIDE ? (int)(threadIdx.x >> 6) : XWAVES - 1 - (int)(threadIdx.x >> 6));
+  const int wave = kk + (WIDE ? x_wave() : XWAVES - 1 - x_wave());
   if (wave < K) {
     u32x4 g[XQ];
 #pragma unroll
@@ -460,7 +463,7 @@ __device__ __forceinline__ double x_block_min(double v, double *mnb /* XWAVES do
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
   __syncthreads(); // (the previous call's readers are through)
-  if ((threadIdx.x & 63) == 0) mnb[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0) mnb[x_wave()] = v;
   __syncthreads();
   double m = mnb[0];
 #pragma unroll
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   double *mrow = wv + a.m_pad + RM * XTB;
   __shared__ int s_rank;
   const unsigned t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
+  const int lane = t & 63, wave = x_wave();
   if (t == 0) {
     int r = -1;
     if (x_xcc_id() < (unsigned)a.nxcd) {
