@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: HBM-traffic counter passes (FETCH_SIZE and WRITE_SIZE in SEPARATE runs, kernel-trace only -- MI355X_MICROARCH.md, HBM / rocprofv3) over
-# short slices of C4 (LP PCG), C5 direct, C5 PCG and the LASSO protocol.   usage: scripts/r05_pmc.sh [tag]  ->  gpurun_out/<tag>/<case>_<counter>/
+# short slices of C4 (LP PCG), C5 direct, C5 PCG and the LASSO protocol.   usage: [CASES="c2 c3"] scripts/r05_pmc.sh [tag]  ->  gpurun_out/<tag>/<case>_<counter>/
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r05_pmc}
@@ -10,6 +10,7 @@ export TMPDIR=/tmp
 cd /tmp
 run() { # name, counter, program args...
   local name=$1 ctr=$2; shift 2
+  case " ${CASES:-c4 c5_direct c5_pcg lasso_pcg c2 c3} " in *" $name "*) ;; *) return 0 ;; esac
   timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d "$OUT/${name}_$ctr" --output-format csv -- python3 "$@" > "$OUT/${name}_$ctr.log" 2>&1
   echo "$name $ctr: rc $?" >> "$OUT/summary.txt"
 }

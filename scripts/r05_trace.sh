@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: rocprofv3 kernel traces of the bench windows the round-5 records are quoted on (LP: c4 / c2 / c3; conic: c5 direct, c5 PCG, the LASSO protocol), the
 # per-kernel medians, the step breakdown of the C4 window, and the durations file bench.py reads (trace / stamp ratio + a hash of the kernel sources it was taken on).
-#   usage: scripts/r05_trace.sh [tag]  ->  gpurun_out/<tag>/{c4,c2,c3,c5_direct,c5_pcg,lasso}_kernel_stats.csv, *_kernel_medians.txt, trace_durations.json, the bench lines printed under the profiler
+#   usage: [WLS="c2 c3"] scripts/r05_trace.sh [tag]  ->  gpurun_out/<tag>/{c4,c2,c3,c5_direct,c5_pcg,lasso}_kernel_stats.csv, *_kernel_medians.txt, trace_durations.json, the bench lines printed under the profiler
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r05_trace}
@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-for wl in c4 c2 c3 c5_direct c5_pcg lasso; do
+for wl in ${WLS:-c4 c2 c3 c5_direct c5_pcg lasso}; do
   case $wl in
     c4) args="--workload c4 --steps 20 --warmup 5" ;;      # the driver's window
     c2|c3) args="--workload $wl" ;;                        # the windows their records on the default line are quoted on
