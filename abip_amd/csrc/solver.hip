@@ -227,6 +227,7 @@ struct ABIP_WORK {
   // (abip.c:731-734), so the stopping test's A'u_y and the next solve's warm-start product are that vector -- one product per iteration instead of three.
   // Valid from a plain iteration of the launch path (one GPU, PCG, no restart, no half update) until something else writes u_y.
   DBuf<double> aty; bool aty_valid = false, aty_on = true;
+  DBuf<double> aty_bb; // the same for the look-ahead solves of the streamed Barzilai-Borwein search (its own buffer: `aty` stays good for the iteration behind the search)
   DBuf<double> hAh; // persistent launch: h_y + A h_x (m): u_t'h = y'(h_y + A h_x) - rhs_x'h_x is known BEFORE the back-substitution's exchange and rides on it (dev_xcd.h)
   // streamed iterations of the launch path (admm_stream_pcg): two pinned mirrors of the control block, written by k_finalize_stream, and the events behind them
   Ctl *hmir[2] = {nullptr, nullptr}; hipEvent_t mir_ev[2] = {nullptr, nullptr}; bool stream_on = true, bb_stream_on = true;
@@ -1427,24 +1428,31 @@ int adaptive_search_stream(W *w, abip_int iter) {
   int chunk[2] = {bb_forced ? bb_forced : next_chunk(w), bb_forced ? bb_forced : next_chunk(w)};
   static const bool bb_trace = getenv("ABIP_HIP_BB_TRACE") != nullptr; // developer: the PCG counts of every look-ahead pair on stderr
   const bool bb_reuse = !(getenv("ABIP_HIP_BB_REUSE") && atoi(getenv("ABIP_HIP_BB_REUSE")) == 0); // 0: every look-ahead solves twice, as the reference does (A / B, tests)
-  auto projection = [&](double *ut, const double *u, const double *v) -> int { // abip.c:552-559 on scratch vectors, the PCG's first `chunk` iterations
+  // A look-ahead solve's warm start is the y block of the step before it, and with v_y = 0 that block is the previous solve's y as it stands (adaptive.c:101-104:
+  // u_y = u_t,y - 0): its A'y is at hand from that solve's back-substitution, exactly as between iterations (k_post_At keeps it: W::aty_bb), and k_rhs writes
+  // the set-up's gather pairs from it -- no k_cg_init_At launch.  The search's very first solve starts from u itself: there the iteration's own `aty` serves.
+  const bool keep = w->aty_on && w->vy_zero && !st->half_update && w->aty_bb.p;
+  const bool first_have = keep && w->aty_valid;
+  auto projection = [&](double *ut, const double *u, const double *v, const double *aty) -> int { // abip.c:552-559 on scratch vectors, the PCG's first `chunk` iterations
     launch(w, ABIP_HIP_K_VEC, k_dot_wg, w->NB, BS, u, v, (const double *)w->g.p, st->rho_y, d, w->part.p, w->xwt);
     launch(w, ABIP_HIP_K_VEC, k_rhs, w->NB, BS, u, v, ut, (const double *)w->h.p, st->rho_y, w->g_th, d, w->part.p, w->NB, (const Ctl *)w->ctl.p,
-           (const double *)w->gs, (const double *)nullptr, (double2 *)nullptr);
-    return enqueue_cg_begin(w, ut, u, iter);
+           (const double *)w->gs, aty, aty ? (double2 *)w->cg_pair.p : (double2 *)nullptr);
+    return enqueue_cg_begin(w, ut, u, iter, aty != nullptr);
   };
+  double *const kbb = keep ? w->aty_bb.p : nullptr;
+  long done = 0;
   // a unit from one of its entry points: 0 = the top, 1 = behind the first solve's PCG chunk, 2 = behind the second solve's, 3 = the second half alone (the
   // first one was handed over by the previous look-ahead: k_adapt_resume lowers halt 5 and counts the solve that is not repeated)
   auto unit = [&](int from) -> int {
-    if (from == 0) { if (projection(w->a_ut.p, w->a_up.p, w->a_vp.p) || enqueue_cg_chunk(w, w->a_ut.p, chunk[0])) return -1; }
+    if (from == 0) { if (projection(w->a_ut.p, w->a_up.p, w->a_vp.p, (done == 0 && first_have) ? (const double *)w->aty.p : nullptr) || enqueue_cg_chunk(w, w->a_ut.p, chunk[0])) return -1; }
     if (from <= 1) {
-      if (enqueue_cg_post(w, w->a_ut.p)) return -1;
+      if (enqueue_cg_post(w, w->a_ut.p, kbb)) return -1;
       launch(w, ABIP_HIP_K_VEC, k_adapt_step, w->NB, BS, (const double *)w->a_ut.p, w->a_ut.p, (const double *)w->a_up.p, (const double *)w->a_vp.p,
              w->a_u.p, w->a_v.p, st->alpha, 0.0, d, (const double *)w->part.p, w->NB, (const double *)w->gs, w->ctl.p, w->mu, 1);
     }
     if (from == 3) launch(w, ABIP_HIP_K_VEC, k_adapt_resume, 1, 1, w->ctl.p);
-    if (from <= 1 || from == 3) { if (projection(w->a_utn.p, w->a_u.p, w->a_v.p) || enqueue_cg_chunk(w, w->a_utn.p, chunk[1])) return -1; }
-    if (enqueue_cg_post(w, w->a_utn.p)) return -1;
+    if (from <= 1 || from == 3) { if (projection(w->a_utn.p, w->a_u.p, w->a_v.p, kbb) || enqueue_cg_chunk(w, w->a_utn.p, chunk[1])) return -1; }
+    if (enqueue_cg_post(w, w->a_utn.p, kbb)) return -1;
     launch(w, ABIP_HIP_K_VEC, k_adapt_step, w->NB, BS, (const double *)w->a_utn.p, w->a_utn.p, (const double *)w->a_u.p, (const double *)w->a_v.p,
            w->a_un.p, w->a_vn.p, st->alpha, 0.0, d, (const double *)w->part.p, w->NB, (const double *)w->gs, w->ctl.p, w->mu, 2);
     launch(w, ABIP_HIP_K_VEC, k_adapt_dots, w->NB, BS, (const double *)w->a_u.p, (const double *)w->a_v.p, (const double *)w->a_un.p,
@@ -1458,7 +1466,6 @@ int adaptive_search_stream(W *w, abip_int iter) {
   // One unit in flight: the host reads a look-ahead's verdict before it enqueues the next one, because the verdict decides the next unit's SHAPE -- handed a
   // second step (four look-aheads of five) it has no first half at all.  (Round 5 first enqueued units two deep, whole: the ~45 launches of a first half that
   // then fell through cost ~0.1 ms, four times the ~25 us the device now idles while the verdict travels.)
-  long done = 0;
   const Ctl *hm = w->hmir[0];
   int from = 0;
   for (;;) {
@@ -1748,7 +1755,7 @@ void free_work(W *w) {
   { DBuf<double> *cb[] = {&w->cc_b, &w->cc_y, &w->cc_r, &w->cc_z, &w->cc_p, &w->cc_Gp, &w->cc_M, &w->cc_tmp, &w->cc_d, &w->cc_buf}; for (auto *b : cb) b->release(); }
   DBuf<double> *bufs[] = {&w->u, &w->v, &w->ut, &w->u_avg, &w->v_avg, &w->u_sum, &w->v_sum, &w->u_avgc, &w->v_avgc, &w->h, &w->g, &w->b, &w->c,
                           &w->wD, &w->wE, &w->cg_p, &w->cg_r, &w->cg_Gp, &w->cg_z, &w->cg_M, &w->cg_tmp, &w->cg_pair, &w->a_up, &w->a_vp, &w->a_ut, &w->a_u,
-                          &w->a_v, &w->a_utn, &w->a_un, &w->a_vn, &w->part, &w->aty, &w->hAh};
+                          &w->a_v, &w->a_utn, &w->a_un, &w->a_vn, &w->part, &w->aty, &w->aty_bb, &w->hAh};
   for (auto *b : bufs) b->release();
   w->ctl.release(); w->ldl.release(); w->T.release(); w->xcd.release();
   if (w->hctl) (void)hipHostFree(w->hctl);
@@ -1948,7 +1955,7 @@ ABIPWork *abip_init(const ABIPData *d, ABIPInfo *info) { // abip.c:2341-2388 + i
     if (w->cg_M.upload(Minv, w->stream) || w->cg_p.alloc(m) || w->cg_r.alloc(m) || w->cg_Gp.alloc(m) || w->cg_z.alloc(m) || w->cg_tmp.alloc(n) || w->cg_pair.alloc(2 * (size_t)n))
       return fail("init_lin_sys_work failure");
     { const char *e = getenv("ABIP_HIP_ATY"); w->aty_on = !(e && atoi(e) == 0); } // ABIP_HIP_ATY=0: every product formed where the reference forms it (A / B, tests)
-    if (!w->dist && w->aty_on && w->aty.alloc(n)) return fail("init_lin_sys_work failure");
+    if (!w->dist && w->aty_on && (w->aty.alloc(n) || w->aty_bb.alloc(n))) return fail("init_lin_sys_work failure");
     { const char *e = getenv("ABIP_HIP_STREAM"); w->stream_on = !(e && atoi(e) == 0); } // ABIP_HIP_STREAM=0: one control read per iteration, as in round 4
     { const char *e = getenv("ABIP_HIP_STREAM_BB"); w->bb_stream_on = !(e && atoi(e) == 0); } // ABIP_HIP_STREAM_BB=0: the Barzilai-Borwein search driven by the host, as in round 4
     if (!w->dist && w->stream_on) {
