@@ -50,6 +50,17 @@ constexpr int XSTAT_N = 1024;       // ints of the status / post-mortem record
 #define XCD_SLEEP 2
 #endif
 constexpr int XSLEEP = XCD_SLEEP;   // s_sleep between two polling rounds of a wavefront (units of 64 clocks)
+#ifndef XCD_POLL_DELAY
+#define XCD_POLL_DELAY 22
+#endif
+#ifndef XCD_POLL_DELAY1
+#define XCD_POLL_DELAY1 0
+#endif
+// s_sleep units before a collect's first polling round.  Across XCDs every polling round is 2 x 128 requests per workgroup to the memory side, where the exchange's own
+// written-through stores and gathers queue too, and nothing can have arrived for the first ~1.5 us: the rounds that cannot succeed only stand in the way
+// (c3: 0 -> 1 870, 12 -> 1 947, 20-24 -> 1 975-2 000, 28 -> 1 935, 32 -> 1 900, 40 -> 1 800 it/s; two rounds in flight half a round trip apart: 1 700 --
+// profiles/r05zq_*, r05zr_*, r05zs_*)
+constexpr int XPOLL_DELAY = XCD_POLL_DELAY, XPOLL_DELAY1 = XCD_POLL_DELAY1;
 constexpr int XSPIN = 1 << 17;     // polling rounds before a wavefront gives up (a round is ~1 us: about a tenth of a second, then the launch path takes over)
 constexpr int XCD_LDS_MIN = 84 * 1024; // more than half a CU's LDS: one workgroup per CU
 static_assert(XTB % 64 == 0 && XWAVES >= 4 && XWAVES <= 16, "wavefront k handles the sums k, k + XWAVES, ... of an exchange (at most 12 sums; the granule slots 12..15 carry the tau entries)");
@@ -258,6 +269,7 @@ __device__ __forceinline__ void x_collect(XWait &w, int G, double *tot, double (
 #pragma unroll
     for (int q = 0; q < XQ; ++q) { g[q].x = 0; g[q].y = w.tag; g[q].z = 0; g[q].w = w.tag; }
     int spins = 0;
+    if (WIDE ? XPOLL_DELAY > 0 : XPOLL_DELAY1 > 0) __builtin_amdgcn_s_sleep(WIDE ? XPOLL_DELAY : XPOLL_DELAY1);
     for (;;) {
       asm volatile("" ::: "memory"); // (the loads are issued anew every round)
       // all the loads of a round first, the tags afterwards: a test behind each load (`ok = ok && ...`) makes the compiler wait for it before the next one goes
