@@ -45,6 +45,10 @@ constexpr int XWAVES = XTB / 64;
 constexpr int XG = 256;            // most workgroups taking part: the CUs of one XCD (32), or of 2, 4, 8 XCDs
 constexpr int XQ = XG / 64;        // flags a polling lane looks after
 constexpr int XKS = 16;            // granule slots per workgroup per exchange: sums 0..11 (wavefront k handles sum k), slots 12..15 the tau entries
+// Slot k of rank r is granule k * XG + r: the granules a polling wavefront reads (slot k of every rank) are contiguous -- four lanes to a 64-byte request, 32
+// requests per round of 128 ranks.  (Until round 5 rank r's slots sat side by side, r * XKS + k: one request per lane, and across XCDs the polls were a third of
+// the exchange's traffic at the memory side.)
+constexpr unsigned XSLOT = 16u * XG; // bytes from a rank's slot k to its slot k + 1
 constexpr int XSTAT_N = 1024;       // ints of the status / post-mortem record
 #ifndef XCD_SLEEP
 #define XCD_SLEEP 2
@@ -235,7 +239,7 @@ __device__ __forceinline__ bool x_spin(XWait &w, int &spins, unsigned found, int
 // (3) x_collect<K>: wavefront k polls scalar k of every rank, adds them in rank order; barrier: from here on every rank's entries are there;
 // (4) x_gather: the entries this thread's non-zeros name.
 template <int K, int SA>
-__device__ __forceinline__ void x_publish(double (&v)[K], double *red, xrsrc sc, unsigned sc_off /* byte offset of this rank's granules */, unsigned tag) {
+__device__ __forceinline__ void x_publish(double (&v)[K], double *red, xrsrc sc, unsigned sc_off /* byte offset of this rank's granule of slot 0 */, unsigned tag) {
   static_assert(K >= 1 && K <= 12, "at most 12 sums per exchange (granule slots 12..15 carry the tau entries)");
   const int lane = threadIdx.x & 63, wave = x_wave();
 #pragma unroll
@@ -251,7 +255,7 @@ __device__ __forceinline__ void x_publish(double (&v)[K], double *red, xrsrc sc,
     const int k = kk + wave;
     if (k < K) {
       const double s = x_sum_first_lanes(lane < XWAVES ? red[k * XWAVES + lane] : 0.0);
-      if (lane == 0) x_putg<SA>(sc, sc_off + (unsigned)k * 16u, s, tag);
+      if (lane == 0) x_putg<SA>(sc, sc_off + (unsigned)k * XSLOT, s, tag);
     }
   }
 }
@@ -276,12 +280,12 @@ __device__ __forceinline__ void x_collect(XWait &w, int G, double *tot, double (
       // out -- four memory round trips per polling round on 256 workgroups instead of one
       bool ok = true;
       if (!WIDE) { // one XCD's worth of ranks: one load per round
-        if (lane < G) g[0] = x_ldg(w.sc, (unsigned)(lane * XKS + wave) * 16u);
+        if (lane < G) g[0] = x_ldg(w.sc, (unsigned)wave * XSLOT + (unsigned)lane * 16u);
         ok = x_ok(g[0], w.tag);
       } else {
 #pragma unroll
         for (int q = 0; q < XQ; ++q)
-          if (q * 64 < G && q * 64 + lane < G) g[q] = x_ldg(w.sc, (unsigned)((q * 64 + lane) * XKS + wave) * 16u);
+          if (q * 64 < G && q * 64 + lane < G) g[q] = x_ldg(w.sc, (unsigned)wave * XSLOT + (unsigned)(q * 64 + lane) * 16u);
 #pragma unroll
         for (int q = 0; q < XQ; ++q) ok = ok & x_ok(g[q], w.tag); // (slots past G keep the tag they were initialised with)
       }
@@ -325,12 +329,12 @@ __device__ __forceinline__ void x_wait(XWait &w, int G) {
       for (int q = 0; q < XQ; ++q) { g[q].x = 0; g[q].y = w.tag; g[q].z = 0; g[q].w = w.tag; }
       bool ok = true;
       if (!WIDE) {
-        if (lane < G) g[0] = x_ldg(w.sc, (unsigned)(lane * XKS) * 16u);
+        if (lane < G) g[0] = x_ldg(w.sc, (unsigned)lane * 16u);
         ok = x_ok(g[0], w.tag);
       } else {
 #pragma unroll
         for (int q = 0; q < XQ; ++q) // (all the loads of a round first: see x_collect)
-          if (q * 64 < G && q * 64 + lane < G) g[q] = x_ldg(w.sc, (unsigned)((q * 64 + lane) * XKS) * 16u);
+          if (q * 64 < G && q * 64 + lane < G) g[q] = x_ldg(w.sc, (unsigned)(q * 64 + lane) * 16u);
 #pragma unroll
         for (int q = 0; q < XQ; ++q) ok = ok & x_ok(g[q], w.tag);
       }
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   XWait w; w.xstat = a.xstat; w.dead = false; w.site = 0; w.rank = rank; w.ldead = mnb + 15; // (x_block_min uses the first XWAVES of the 16)
   xrsrc pn0, pn1, pm0, pm1, psc; // the exchange areas of the parity in use
   xrsrc pnv;                     // (direct) v_x of the update's exchange
-  const unsigned sc_off = (unsigned)rank * XKS * 16u;
+  const unsigned sc_off = (unsigned)rank * 16u; // this rank's granule of slot 0 (slot k: + k * XSLOT)
   auto open = [&](int site) { // next exchange: tag and the areas of its parity
     tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(tag + 1u)); // (uniform by construction; the loops' give-up exits hide that from the compiler)
     const size_t par = tag & 1u;
@@ -658,13 +662,13 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         p2[0] = ((unsigned long long)wall_clock64() - t_launch > xo.slice_ticks) ? 1.0 : 0.0;
       }
       mn = x_block_min(mn, mnb);
-      if (t == 0) x_putg<SA>(psc, sc_off + 12u * 16u, mn, tag); // (acknowledged before this rank's flags go out)
+      if (t == 0) x_putg<SA>(psc, sc_off + 12u * XSLOT, mn, tag); // (acknowledged before this rank's flags go out)
       x_publish<2, SA>(p2, red, psc, sc_off, tag);
       double P2[2];
       x_collect<2, CROSS>(w, G, tot, P2);
       if (__builtin_expect(w.dead, 0)) return;
       double gmin = 1e+10;
-      if ((int)t < G) gmin = x_val(x_ldg(psc, (t * XKS + 12u) * 16u));
+      if ((int)t < G) gmin = x_val(x_ldg(psc, 12u * XSLOT + t * 16u));
       gmin = x_block_min(gmin, mnb);
       if (P2[0] > 0.0 || log_n >= xo.log_cap) { csw(CS_REASON, (double)XR_SLICE); break; } // (nothing of this outer end has been applied: the next launch enters here again.
                                                                                           //  A full log -- LOQO rule on a tiny LP: no mu-table limit -- ends the launch the same way: the host prints its rows)
@@ -1271,7 +1275,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       tau4[0] = un; tau4[1] = vn; tau4[2] = ua; tau4[3] = va;
       // the tau / kappa entries are nobody's sum: they travel as granules of rank 0 behind the sums' (slots 12..15), acknowledged before its flags go out
 #pragma unroll
-      for (int q = 0; q < 4; ++q) x_putg<SA>(psc, sc_off + (unsigned)(12 + q) * 16u, tau4[q], tag);
+      for (int q = 0; q < 4; ++q) x_putg<SA>(psc, sc_off + (unsigned)(12 + q) * XSLOT, tau4[q], tag);
     }
     // (an exchange costs per scalar it carries -- a wavefront sum in every wavefront, a polling wavefront: the averaged iterate's four sums go
     //  out only on the iterations that test it, one in ten)
@@ -1339,7 +1343,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     {
       u32x4 tg[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) tg[q] = x_ldg(psc, (unsigned)(12 + q) * 16u);
+      for (int q = 0; q < 4; ++q) tg[q] = x_ldg(psc, (unsigned)(12 + q) * XSLOT); // (rank 0's)
       double ax[NZ], va[NZ], tx[NZ], vt[NZ];
       x_mat<NZ>(gA, na, ax);
       x_gather<NZ>(pn0, ai, va);
