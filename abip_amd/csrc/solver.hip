@@ -987,9 +987,13 @@ bool xcd_plan(XcdPlan &x, const host::HostCsr &hA, const host::HostCsr &hAt, boo
   // direct: inv(rho I + A A') is kept dense -- 8 m^2 bytes read per iteration.  Staircase LPs, persistent launch against launch path: m = 2000: 25.3 k / 12.2 k it/s,
   // 3000: 19.7 k / 11.5 k, 4000: 15.3 k / 10.8 k; the curves meet somewhere beyond (ABIP_HIP_XCD_MMAX moves the limit)
   { const char *e = getenv("ABIP_HIP_XCD_MMAX"); if (!pcg && m > (e ? atol(e) : 4096L)) return false; }
-  // How many XCDs.  A second (fourth) XCD halves (quarters) a slice -- the gathers and row sums of an exchange -- and costs ~0.5 us per exchange for
-  // stores written through to where the other XCDs' loads find them.  PCG back-end, c3 (136 k non-zeros), 32 / 64 / 128 / 256 workgroups:
-  // 3.24 / 2.89 / 2.58 / 3.04 us per exchange -> aim at ~1000 non-zeros per slice, at most 4 XCDs (ABIP_HIP_XCD_G forces 32 .. 256, either back-end).
+  // How many XCDs.  More XCDs shrink a slice -- the gathers and row sums of an exchange -- and cost ~0.5 us per exchange for stores written through to where the
+  // other XCDs' loads find them, plus polls that go to the memory side.  PCG back-end, window rates with 32 / 64 / 128 / 256 workgroups on the last kernels of
+  // round 5 (scripts/xcd_g_sweep.py, profiles/r05zzb_*, r05zzc_*): 40.6 k non-zeros 4 177 / 3 557 / 3 479 / 3 154 it/s; 56 k 9 763 / 9 143 / 10 566 / 10 328;
+  // 97.8 k 2 267 / 2 583 / 2 977 / 2 877; c3 (136 k) - / 2 100 / 2 512 / 2 557 (whole solve 5.31 / 4.49 / 4.29 s); 140 k - / 6 204 / 7 556 / 8 638;
+  // 260 k - / - / 4 649 / 4 967; 321 k - / - / 1 904 / 2 196; 500 k - / - / - / 3 358 (the launch path on the last three: 3 050, 859, 2 076)
+  // -> one XCD up to 48 k non-zeros, four up to 120 k, eight beyond, as far as a variant fits (~8e5; two never win; ABIP_HIP_XCD_G forces 32 .. 256, either back-end).  Until the polls were
+  // tamed (slot-major granules, the first round delayed) eight XCDs lost to four on c3 and the launch stopped at four.
   x.G = 32;
   {
     const char *e = getenv("ABIP_HIP_XCD_G");
@@ -997,7 +1001,7 @@ bool xcd_plan(XcdPlan &x, const host::HostCsr &hA, const host::HostCsr &hAt, boo
     if (ge == 32 || ge == 64 || ge == 128 || ge == 256) x.G = ge;
     else if (pcg) {
       const long nnz = hA.ptr[hA.nrows];
-      while (x.G < 128 && nnz > 1536L * x.G) x.G *= 2;
+      x.G = nnz <= 48000L ? 32 : nnz <= 120000L ? 128 : 256;
     } else if (m >= 1280) x.G = 128; // direct: the rows of the dense inverse dominate from there (staircase LPs, 32 / 64 / 128 workgroups: m = 816: 48.3 / 37.2 / 33.1 k it/s,
                                      // m = 1400: 29.1 / 28.8 / 30.9 k, m = 2000: 21.0 / 23.5 / 25.3 k)
   }
@@ -1009,7 +1013,8 @@ bool xcd_plan(XcdPlan &x, const host::HostCsr &hA, const host::HostCsr &hAt, boo
   for (const XcdVariant &v : kXcdVariants)
     if (std::max(*nzA, *nzT) <= (long)v.nz * XTB && *rA <= v.rm * XTB && *rT <= v.rn * XTB) { pick = &v; break; }
   if (!pick) return false;
-  if (pcg && x.G >= 128 && pick->nz > 4 && !getenv("ABIP_HIP_XCD_G")) return false; // ~5e5 non-zeros: the launch path has caught up (rand 20000 x 50000 x 16: 1513 against 1549 it/s)
+  // (whatever fits a variant stays here: 5.0e5 non-zeros, 6 per thread on 256 workgroups, 3 352 it/s against the launch path's 2 018; 7.4e5, 8 per thread, 2 405 against 1 639 --
+  // until round 5 more than 4 per thread went to the launch path, which had caught up with the four-XCD launch there)
   x.NZ = pick->nz; x.RM = pick->rm; x.RN = pick->rn;
   x.kern = pcg ? (x.G > 32 ? pick->pcg2 : pick->pcg) : (x.G > 32 ? pick->direct2 : pick->direct);
   x.n_pad = (int)((n + 63) / 64 * 64); x.m_pad = (int)((m + 63) / 64 * 64);

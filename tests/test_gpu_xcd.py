@@ -92,12 +92,12 @@ def test_one_xcd_launch_run_to_run_identical(gpu, monkeypatch):
 
 
 def test_problems_that_do_not_fit_stay_on_the_launch_path(gpu, monkeypatch):
-    """The persistent launch takes an LP only when its slices fit the registers / LDS of the workgroups of at most 4 XCDs with at most 4 non-zeros per
-    thread (beyond ~5e5 non-zeros the launch path has caught up) and, for the direct back-end, when the dense inverse of the m x m Schur complement
+    """The persistent launch takes an LP only when its slices fit the registers / LDS of the workgroups of the 8 XCDs with at most 8 non-zeros per
+    thread (~8e5 non-zeros; beyond, the launch path) and, for the direct back-end, when the dense inverse of the m x m Schur complement
     is affordable (m <= 4096): otherwise abip_init leaves the launch path in charge, silently.  (The plan itself: tests/test_xcd_plan_cpu.py.)"""
     from abip_amd import problems
     monkeypatch.setenv("ABIP_HIP_XCD", "1")
-    A, b, c = problems.lp_random_sparse(m=20000, n=50000, per_col=16, seed=3)      # 5e5 non-zeros: 6 per thread on 128 workgroups
+    A, b, c = problems.lp_random_sparse(m=20000, n=50000, per_col=32, seed=3)      # 9.8e5 non-zeros: more than 8 per thread on 256 workgroups
     with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-3, max_admm_iters=20) as S:
         assert S.scalar("xcd") == 0.0
         S.solve()
@@ -112,6 +112,27 @@ def test_problems_that_do_not_fit_stay_on_the_launch_path(gpu, monkeypatch):
 
 
 # (BASELINE configs[1] / configs[2] at full size on both paths: tests/test_gpu_baseline_size.py and the lp_staircase fixture tests -- against the reference.)
+
+
+def test_the_largest_class_the_launch_takes_agrees_with_the_launch_path(gpu, monkeypatch):
+    """5e5 non-zeros: six per thread on the 256 workgroups of all eight XCDs (until round 5 the launch path's).  No reference run at this size fits the suite; the
+    launch path is the pinned one (fixtures, C3 / C4 at BASELINE size): same outer and inner counts, (x, y, s) to 1e-6."""
+    from abip_amd import problems
+    A, b, c = problems.lp_random_sparse(m=20000, n=50000, per_col=16, seed=3)[:3]
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ABIP_HIP_XCD", mode)
+        with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-4) as S:
+            assert S.scalar("xcd") == float(mode)
+            if mode == "1":
+                assert S.scalar("xcd_g") == 256.0
+            info = S.solve()
+            out[mode] = (info, S.x.copy(), S.y.copy(), S.s.copy())
+    a, l = out["1"], out["0"]
+    assert a[0]["status_val"] == l[0]["status_val"] == 1
+    assert (a[0]["ipm_iter"], a[0]["admm_iter"]) == (l[0]["ipm_iter"], l[0]["admm_iter"]), (a[0]["ipm_iter"], a[0]["admm_iter"], l[0]["ipm_iter"], l[0]["admm_iter"])
+    for k in (1, 2, 3):
+        assert rel(a[k], l[k]) < 1e-6
 
 
 @pytest.mark.parametrize("G", [64, 128, 256])

@@ -55,13 +55,23 @@ def test_netlib_class_surrogates_run_on_one_xcd(linsys, monkeypatch):
         assert 1 <= p["minv_rows"] <= int(np.diff(p["mb"]).max())
 
 
-def test_pds_class_surrogate_spreads_over_four_xcds(monkeypatch):
+def test_pds_class_surrogate_spreads_over_all_xcds(monkeypatch):
     monkeypatch.delenv("ABIP_HIP_XCD_G", raising=False)
     A = problems.lp_multicommodity(nodes=1200, arcs=4400, commodities=10)[0]      # the C3 surrogate: 136 k non-zeros
     p = plan(A, "indirect")
-    assert p["ok"] and p["G"] == 128 and p["xcds"] == 4 and p["NZ"] == 4           # (1065 non-zeros per slice, 512 threads)
+    assert p["ok"] and p["G"] == 256 and p["xcds"] == 8 and p["NZ"] == 2           # (533 non-zeros per slice, 512 threads; round 4 stopped at four XCDs)
     check_slices(A, p)
     assert not plan(A, "direct")["ok"]                   # m = 16 390: no dense inverse of the Schur complement
+
+
+def test_pcg_workgroup_count_follows_the_non_zero_count(monkeypatch):
+    """One XCD up to 48 k non-zeros, four up to 120 k, eight beyond (scripts/xcd_g_sweep.py: two never win)."""
+    monkeypatch.delenv("ABIP_HIP_XCD_G", raising=False)
+    for kw, G in ((dict(nodes=240, arcs=1100, commodities=12), 32), (dict(nodes=400, arcs=2000, commodities=16), 128), (dict(nodes=900, arcs=4400, commodities=24), 256)):
+        A = problems.lp_multicommodity(**kw)[0]
+        p = plan(A, "indirect")
+        assert p["ok"] and p["G"] == G, (kw, p["G"], p["NZ"])
+        check_slices(A, p)
 
 
 @pytest.mark.parametrize("G", [32, 64, 128, 256])
@@ -89,7 +99,11 @@ def test_direct_back_end_spreads_out_when_the_dense_inverse_dominates(monkeypatc
 
 def test_what_does_not_fit_is_left_to_the_launch_path(monkeypatch):
     monkeypatch.delenv("ABIP_HIP_XCD_G", raising=False)
-    A = problems.lp_random_sparse(m=20000, n=50000, per_col=16, seed=3)[0]       # 5e5 non-zeros: the launch path has caught up
+    A = problems.lp_random_sparse(m=20000, n=50000, per_col=16, seed=3)[0]       # 5e5 non-zeros: six per thread on 256 workgroups (round 4 left this one to the launch path)
+    p = plan(A, "indirect")
+    assert p["ok"] and p["G"] == 256 and p["NZ"] == 6
+    check_slices(A, p)
+    A = problems.lp_random_sparse(m=20000, n=50000, per_col=32, seed=3)[0]       # 9.8e5: no variant holds a slice -- the launch path's
     assert not plan(A, "indirect")["ok"]
     A = problems.lp_random_sparse(m=4500, n=9000, per_col=4, seed=4)[0]
     assert not plan(A, "direct")["ok"] and plan(A, "indirect")["ok"]             # direct: m > 4096
