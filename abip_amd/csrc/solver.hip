@@ -1002,8 +1002,9 @@ bool xcd_plan(XcdPlan &x, const host::HostCsr &hA, const host::HostCsr &hAt, boo
     else if (pcg) {
       const long nnz = hA.ptr[hA.nrows];
       x.G = nnz <= 48000L ? 32 : nnz <= 120000L ? 128 : 256;
-    } else if (m >= 1280) x.G = 128; // direct: the rows of the dense inverse dominate from there (staircase LPs, 32 / 64 / 128 workgroups: m = 816: 48.3 / 37.2 / 33.1 k it/s,
-                                     // m = 1400: 29.1 / 28.8 / 30.9 k, m = 2000: 21.0 / 23.5 / 25.3 k)
+    } else x.G = m <= 1024 ? 32 : m <= 1500 ? 128 : 256; // direct: the rows of the dense inverse dominate beyond m = 1024 (there the dense product changes form too). Staircase LPs,
+                                                         // 32 / 128 / 256 workgroups on the last kernels of round 5 (profiles/r05zzf_*): m = 816: 92.4 / 74.5 / 70.6 k it/s, 1000: 77.6 / 71.1 / 67.6,
+                                                         // 1200: 50.6 / 67.3 / 66.6, 1400: - / 66.4 / 66.2, 1600: 31.3 / 62.1 / 65.8, 2000: - / 51.1 / 63.7, 3000: - / 32.7 / 45.5, 4000: - / 22.1 / 33.1
   }
   x.nxcd = x.G / 32;
   xcd_best_slices(hA, x.G, mb, nzA, rA, lA, pcg ? 0.0 : (double)m);

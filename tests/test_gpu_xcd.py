@@ -158,19 +158,24 @@ def test_launch_spread_over_several_xcds_matches_the_reference(gpu, name, linsys
     assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
 
 
-@pytest.mark.parametrize("m", [63, 65, 129, 1000, 1024, 1025, 1100, 1300])
+@pytest.mark.parametrize("m", [63, 65, 129, 1000, 1024, 1025, 1100, 1300, 1600])
 def test_direct_variant_row_counts_around_its_paddings(gpu, m, monkeypatch):
     """The dense product of the direct variant reads its rows without a guard per element: out to 64 x 16 columns on small systems (m_pad <= 1024: the pad
     behind the last LDS row is zero, the lanes' entries of w are zero beyond m), four columns per lane at a time on larger ones (LDS rows) or eight (rows
     streamed from the L2), w zero-padded to m_pad.  Row counts one short of, on, and one past a multiple of 64, the last small size (1024), the first sizes of
-    the larger form on one XCD (1025, 1100) and on four (1300): the persistent launch agrees with the launch path as on the fixtures."""
+    the larger form on one XCD (1025, 1100: forced -- the planner gives them four), on four (1300) and on eight (1600): the persistent launch agrees with the launch
+    path as on the fixtures."""
     from abip_amd import problems
     A, b, c = problems.lp_random_sparse(m=m, n=int(2.3 * m) + 7, per_col=4, seed=1000 + m)[:3]
     out = {}
+    if m in (1025, 1100):
+        monkeypatch.setenv("ABIP_HIP_XCD_G", "32")
     for mode in ("1", "0"):
         monkeypatch.setenv("ABIP_HIP_XCD", mode)
         with gpu.Solver(A, b, c, linsys="direct", verbose=0, eps=1e-8) as S:
             assert S.scalar("xcd") == float(mode)
+            if mode == "1":
+                assert S.scalar("xcd_g") == (32.0 if m <= 1100 else 128.0 if m <= 1500 else 256.0)
             info = S.solve()
             out[mode] = (info, S.x.copy(), S.y.copy(), S.s.copy())
     a, l = out["1"], out["0"]

@@ -92,9 +92,13 @@ def test_direct_back_end_spreads_out_when_the_dense_inverse_dominates(monkeypatc
     small = problems.lp_staircase()[0]                                            # m = 816
     big = problems.lp_staircase(stages=20, rows_per=100, cols_per=230)[0]         # m = 2000
     p, q = plan(small, "direct"), plan(big, "direct")
-    assert p["ok"] and p["G"] == 32 and q["ok"] and q["G"] == 128 and q["xcds"] == 4
+    assert p["ok"] and p["G"] == 32 and q["ok"] and q["G"] == 256 and q["xcds"] == 8
     check_slices(big, q)
     assert q["minv_rows"] >= 1
+    mid = problems.lp_staircase(stages=12, rows_per=100, cols_per=230)[0]         # m = 1200: the larger form of the dense product, four XCDs
+    r = plan(mid, "direct")
+    assert r["ok"] and r["G"] == 128 and r["xcds"] == 4
+    check_slices(mid, r)
 
 
 def test_what_does_not_fit_is_left_to_the_launch_path(monkeypatch):
