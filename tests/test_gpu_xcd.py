@@ -114,11 +114,12 @@ def test_problems_that_do_not_fit_stay_on_the_launch_path(gpu, monkeypatch):
 # (BASELINE configs[1] / configs[2] at full size on both paths: tests/test_gpu_baseline_size.py and the lp_staircase fixture tests -- against the reference.)
 
 
-def test_the_largest_class_the_launch_takes_agrees_with_the_launch_path(gpu, monkeypatch):
-    """5e5 non-zeros: six per thread on the 256 workgroups of all eight XCDs (until round 5 the launch path's).  No reference run at this size fits the suite; the
-    launch path is the pinned one (fixtures, C3 / C4 at BASELINE size): same outer and inner counts, (x, y, s) to 1e-6."""
+@pytest.mark.parametrize("per_col", [16, 24])
+def test_the_largest_class_the_launch_takes_agrees_with_the_launch_path(gpu, per_col, monkeypatch):
+    """5e5 / 7.4e5 non-zeros: six / eight per thread on the 256 workgroups of all eight XCDs (until round 5 the launch path's).  No reference run at this size fits the
+    suite; the launch path is the pinned one (fixtures, C3 / C4 at BASELINE size): same outer and inner counts, (x, y, s) to 1e-6."""
     from abip_amd import problems
-    A, b, c = problems.lp_random_sparse(m=20000, n=50000, per_col=16, seed=3)[:3]
+    A, b, c = problems.lp_random_sparse(m=20000, n=50000, per_col=per_col, seed=3)[:3]
     out = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("ABIP_HIP_XCD", mode)
