@@ -984,9 +984,10 @@ void xcd_best_slices(const host::HostCsr &M, int G, std::vector<int> &bounds, lo
 bool xcd_plan(XcdPlan &x, const host::HostCsr &hA, const host::HostCsr &hAt, bool pcg, std::vector<int> &mb, std::vector<int> &nb, long *nzA, long *nzT, int *rA, int *rT,
               int *lA, int *lT) {
   const long m = hA.nrows, n = hAt.nrows;
-  // direct: inv(rho I + A A') is kept dense -- 8 m^2 bytes read per iteration.  Staircase LPs, persistent launch against launch path: m = 2000: 25.3 k / 12.2 k it/s,
-  // 3000: 19.7 k / 11.5 k, 4000: 15.3 k / 10.8 k; the curves meet somewhere beyond (ABIP_HIP_XCD_MMAX moves the limit)
-  { const char *e = getenv("ABIP_HIP_XCD_MMAX"); if (!pcg && m > (e ? atol(e) : 4096L)) return false; }
+  // direct: inv(rho I + A A') is kept dense -- 8 m^2 bytes read per iteration, m^3 flops of set-up.  Staircase LPs on eight XCDs against the launch path
+  // (profiles/r05zzk_*): m = 4000: 24.8 k / 6.7 k it/s, solve to 1e-6 with the set-up 0.34 / 0.45 s; 5000: 18.0 k / 6.4 k, 0.60 / 0.85 s; 6000: 13.6 k / 6.1 k,
+  // 0.84 / 0.99 s; 8000: 7.7 k / 4.4 k, 1.59 / 1.53 s -- the set-up eats the lead there (ABIP_HIP_XCD_MMAX moves the limit; 4096 until the launch went to eight XCDs)
+  { const char *e = getenv("ABIP_HIP_XCD_MMAX"); if (!pcg && m > (e ? atol(e) : 6144L)) return false; }
   // How many XCDs.  More XCDs shrink a slice -- the gathers and row sums of an exchange -- and cost ~0.5 us per exchange for stores written through to where the
   // other XCDs' loads find them, plus polls that go to the memory side.  PCG back-end, window rates with 32 / 64 / 128 / 256 workgroups on the last kernels of
   // round 5 (scripts/xcd_g_sweep.py, profiles/r05zzb_*, r05zzc_*): 40.6 k non-zeros 4 177 / 3 557 / 3 479 / 3 154 it/s; 56 k 9 763 / 9 143 / 10 566 / 10 328;

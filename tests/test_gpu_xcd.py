@@ -94,14 +94,14 @@ def test_one_xcd_launch_run_to_run_identical(gpu, monkeypatch):
 def test_problems_that_do_not_fit_stay_on_the_launch_path(gpu, monkeypatch):
     """The persistent launch takes an LP only when its slices fit the registers / LDS of the workgroups of the 8 XCDs with at most 8 non-zeros per
     thread (~8e5 non-zeros; beyond, the launch path) and, for the direct back-end, when the dense inverse of the m x m Schur complement
-    is affordable (m <= 4096): otherwise abip_init leaves the launch path in charge, silently.  (The plan itself: tests/test_xcd_plan_cpu.py.)"""
+    is affordable (m <= 6144): otherwise abip_init leaves the launch path in charge, silently.  (The plan itself: tests/test_xcd_plan_cpu.py.)"""
     from abip_amd import problems
     monkeypatch.setenv("ABIP_HIP_XCD", "1")
     A, b, c = problems.lp_random_sparse(m=20000, n=50000, per_col=32, seed=3)      # 9.8e5 non-zeros: more than 8 per thread on 256 workgroups
     with gpu.Solver(A, b, c, linsys="indirect", verbose=0, eps=1e-3, max_admm_iters=20) as S:
         assert S.scalar("xcd") == 0.0
         S.solve()
-    A, b, c = problems.lp_random_sparse(m=4500, n=9000, per_col=4, seed=4)         # direct: m > 4096
+    A, b, c = problems.lp_random_sparse(m=6500, n=13000, per_col=4, seed=4)        # direct: m > 6144
     with gpu.Solver(A, b, c, linsys="direct", verbose=0, eps=1e-3, max_admm_iters=20) as S:
         assert S.scalar("xcd") == 0.0
         S.solve()
@@ -157,6 +157,24 @@ def test_launch_spread_over_several_xcds_matches_the_reference(gpu, name, linsys
             info = S.solve()
             runs.append((info["admm_iter"], S.x.copy(), S.y.copy()))
     assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+
+
+def test_direct_variant_beyond_m_4096_agrees_with_the_launch_path(gpu, monkeypatch):
+    """m = 5000 (round 4's limit was 4096): rows of the dense inverse streamed from the L2 / HBM on eight XCDs; same counts as the launch path, (x, y, s) to 1e-6."""
+    from abip_amd import problems
+    A, b, c = problems.lp_staircase(stages=50, rows_per=100, cols_per=230)[:3]
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ABIP_HIP_XCD", mode)
+        with gpu.Solver(A, b, c, linsys="direct", verbose=0, eps=1e-6) as S:
+            assert S.scalar("xcd") == float(mode)
+            info = S.solve()
+            out[mode] = (info, S.x.copy(), S.y.copy(), S.s.copy())
+    a, l = out["1"], out["0"]
+    assert a[0]["status_val"] == l[0]["status_val"] == 1
+    assert (a[0]["ipm_iter"], a[0]["admm_iter"]) == (l[0]["ipm_iter"], l[0]["admm_iter"]), (a[0]["ipm_iter"], a[0]["admm_iter"], l[0]["ipm_iter"], l[0]["admm_iter"])
+    for k in (1, 2, 3):
+        assert rel(a[k], l[k]) < 1e-6
 
 
 @pytest.mark.parametrize("m", [63, 65, 129, 1000, 1024, 1025, 1100, 1300, 1600])

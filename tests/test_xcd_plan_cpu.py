@@ -109,8 +109,8 @@ def test_what_does_not_fit_is_left_to_the_launch_path(monkeypatch):
     check_slices(A, p)
     A = problems.lp_random_sparse(m=20000, n=50000, per_col=32, seed=3)[0]       # 9.8e5: no variant holds a slice -- the launch path's
     assert not plan(A, "indirect")["ok"]
-    A = problems.lp_random_sparse(m=4500, n=9000, per_col=4, seed=4)[0]
-    assert not plan(A, "direct")["ok"] and plan(A, "indirect")["ok"]             # direct: m > 4096
+    A = problems.lp_random_sparse(m=6500, n=13000, per_col=4, seed=4)[0]
+    assert not plan(A, "direct")["ok"] and plan(A, "indirect")["ok"]             # direct: m > 6144
     rng = np.random.default_rng(0)
     D = sp.hstack([sp.csc_matrix(np.ones((1, 700))), sp.csc_matrix((1, 300))])  # one row of 700 entries: longer than a thread adds up
     A = sp.vstack([D, sp.random(60, 1000, density=0.01, random_state=rng, format="csc")]).tocsc()
