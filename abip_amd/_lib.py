@@ -58,7 +58,7 @@ class AbipHipProfile(C.Structure):
     _fields_ = [("ms", C.c_double * 8), ("launches", C.c_long * 8), ("noop_ms", C.c_double), ("noop_launches", C.c_long),
                 ("admm_iters", C.c_long), ("cg_iters", C.c_long), ("kkt_solves", C.c_long),
                 ("stamp_ms", C.c_double * 8), ("stamp_launches", C.c_long * 8), ("stamp_noop_launches", C.c_long),
-                ("allreduce_ms", C.c_double), ("allreduce_calls", C.c_long), ("allreduce_bytes", C.c_double)]
+                ("allreduce_ms", C.c_double), ("allreduce_calls", C.c_long), ("allreduce_bytes", C.c_double), ("cg_iters_skipped", C.c_long)]
 
 
 # every symbol include/abip.h and include/abip_hip.h declare

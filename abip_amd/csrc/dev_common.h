@@ -74,6 +74,7 @@ struct XcdOut {
   long ran;         // ADMM iterations of this launch
   long solves;      // KKT solves of this launch (iterations + look-ahead solves of the search)
   long cg_total;    // PCG iterations of all of them
+  long cg_skipped;  // ... of which counted as the reference counts them but not executed (look-ahead solves handed over, XcdOuter::bb_reuse)
   double mu, beta, dyn_sigma;
 };
 
@@ -104,7 +105,7 @@ struct Ctl {
   int bb_cg[2];      // PCG iterations of the last first / second solve
   long bb_cg_total;  // ... and of all solves of this search
   int bb_skip;       // 1: the look-ahead in flight starts from the previous one's second step (its first solve would repeat that solve bit for bit: k_adapt_next)
-  int bb_pad;
+  int bb_cg_skipped; // PCG iterations of bb_cg_total that were counted, not executed: the solves a look-ahead took over from its predecessor (k_adapt_resume)
 };
 
 // Device-side launch timing (bench.py's roofline leg, inside the timed region: no hipEvent records, no second pass).  A kernel handed a

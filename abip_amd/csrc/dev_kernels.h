@@ -831,7 +831,7 @@ __global__ __launch_bounds__(1024) void k_adapt_decide(const double *part, int n
 // second half may run -- halt is lowered here, by a launch of its own, so that no kernel both reads and writes it -- and the skipped solve is counted as the
 // reference counts it (it solves again and takes the same number of PCG iterations).
 __global__ void k_adapt_resume(Ctl *ctl) {
-  if (ctl->halt == 5) { ctl->halt = 0; ctl->bb_stage = 1; ctl->bb_cg[0] = ctl->bb_cg[1]; ctl->bb_cg_total += ctl->bb_cg[1]; }
+  if (ctl->halt == 5) { ctl->halt = 0; ctl->bb_stage = 1; ctl->bb_cg[0] = ctl->bb_cg[1]; ctl->bb_cg_total += ctl->bb_cg[1]; ctl->bb_cg_skipped += ctl->bb_cg[1]; }
 }
 // (u_prev, v_prev) for the next look-ahead as the last decision wants them (adaptive.c:230-247): u_prev = u; v_prev = v, its (x, tau) part rebuilt as
 // (mu / beta_prev) / u_prev when the penalty changed.

@@ -100,7 +100,7 @@ struct XcdOuter {
 constexpr int XLOG_W = 12; // i, k, mu, res_pri, res_dual, rel_gap, c'x / tau-free, b'y, tau, kap, ticks since launch, spare
 enum { XM_MAIN = 0, XM_BB1 = 1, XM_BB2 = 2 };                  // whose projection is running: the ADMM iteration's, the first / second look-ahead step's
 enum { XS_PROJECT = 0, XS_OUTER_END = 1, XS_OUTER_BEGIN = 2 }; // what the launch does next
-enum { CS_MU = 0, CS_BETA, CS_DYNS, CS_OI, CS_FRE, CS_BBPREV, CS_BUPT, CS_BVPT, CS_BUT, CS_BVT, CS_RUT, CS_RVT, CS_ODONE, CS_DYN2, CS_LOGN, CS_BBTOT, CS_BBIT, CS_AV, CS_PHASE, CS_REASON, CS_T0 }; // cs[]: see the kernel
+enum { CS_MU = 0, CS_BETA, CS_DYNS, CS_OI, CS_FRE, CS_BBPREV, CS_BUPT, CS_BVPT, CS_BUT, CS_BVT, CS_RUT, CS_RVT, CS_ODONE, CS_DYN2, CS_LOGN, CS_BBTOT, CS_BBIT, CS_AV, CS_PHASE, CS_REASON, CS_T0, CS_CGSKIP }; // cs[]: see the kernel
 enum { XR_BATCH = 0 /* one batch of iterations, the exit test or the batch's end */, XR_STEPS = 1, XR_RESTART = 2, XR_FINAL = 3 /* the final check holds */,
        XR_HOST_OUTER = 4 /* this outer end is the host's */, XR_SLICE = 5, XR_MAXIPM = 6 };
 
@@ -534,6 +534,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     cs[CS_BBPREV] = 1.0; cs[CS_BUPT] = 0.0; cs[CS_BVPT] = 0.0; cs[CS_BUT] = 0.0; cs[CS_BVT] = 0.0; cs[CS_RUT] = 0.0; cs[CS_RVT] = 0.0;
     cs[CS_ODONE] = 0.0; cs[CS_DYN2] = 0.0; cs[CS_LOGN] = 0.0; cs[CS_BBTOT] = 0.0; cs[CS_BBIT] = 0.0; cs[CS_AV] = 0.0; cs[CS_PHASE] = 0.0; cs[CS_REASON] = (double)XR_BATCH;
     cs[CS_T0] = __longlong_as_double(wall_clock64());
+    cs[CS_CGSKIP] = 0.0;
   }
   __syncthreads();
   const int rank = __builtin_amdgcn_readfirstlane(s_rank); // (uniform, and the compiler may know it: everything derived from it lives in scalar registers)
@@ -1626,6 +1627,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
           }
           csw(CS_BUT, bun_t); csw(CS_BVT, bvn_t);
           cg_total += last_cg;
+          csw(CS_CGSKIP, csr(CS_CGSKIP) + (double)last_cg);
           mode = XM_BB2; need_pre = true;
           XQ_ADD(2, xq_t)
           continue;
@@ -1665,7 +1667,7 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       XcdOut &o = c->xo;
       o.phase = (int)cs[CS_PHASE]; o.reason = (int)cs[CS_REASON]; o.final_check = final_check; o.avg_crit = avg_crit; o.stats_valid = stats_valid ? 1 : 0; o.avg_stats = avg_stats_last;
       o.outer_done = (int)cs[CS_ODONE]; o.log_n = (int)cs[CS_LOGN]; o.last_cg = last_cg; o.bb_lookaheads = (int)cs[CS_BBTOT];
-      o.i = (long)cs[CS_OI]; o.j = jj; o.k = a.fc.k0 + ran; o.ran = ran; o.solves = (long)ran + 2 * (long)cs[CS_BBTOT]; o.cg_total = cg_total;
+      o.i = (long)cs[CS_OI]; o.j = jj; o.k = a.fc.k0 + ran; o.ran = ran; o.solves = (long)ran + 2 * (long)cs[CS_BBTOT]; o.cg_total = cg_total; o.cg_skipped = (long)cs[CS_CGSKIP];
       o.mu = cs[CS_MU]; o.beta = cs[CS_BETA]; o.dyn_sigma = cs[CS_DYNS];
     }
     a.xstat[1] = (int)(tag - a.tag0);

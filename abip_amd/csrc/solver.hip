@@ -70,6 +70,7 @@ struct PeerHost { // dev_peer.h: the hand-rolled exchange over peer-mapped mailb
   long cap = 0;
   bool fused = true;      // the product kernels of the sharded PCG push their rows themselves (ABIP_HIP_PEER_FUSED=0: every all-reduce is the stand-alone kernel)
   bool fine = false;      // the mailbox is fine-grained device memory (else plain device memory: see dev_peer.h "Coherence")
+  bool cross_device = false; // some peer's mailbox lives on another device (a real node; false when the ranks share one GPU)
 };
 struct DistCtx {
   int kind = 0; // 0 none, 1 RCCL, 2 host callback (tests), 3 peer-mapped mailboxes (dev_peer.h)
@@ -256,7 +257,7 @@ struct ABIP_WORK {
   int last_cg_its = 6;
   double factor_resid = 0; // set-up guard of the direct back-end: ||K z - rhs|| / ||rhs|| of one known right-hand side
   int cg_enq = 0; // CG iterations enqueued so far for the solve in flight
-  long tot_cg_its = 0, tot_solves = 0;
+  long tot_cg_its = 0, tot_solves = 0, tot_cg_skipped = 0; // (skipped: counted in tot_cg_its as the reference counts them, not executed -- look-ahead solves handed over)
   // solution staged on the host by finish_solution()
   std::vector<double> sol_x, sol_y, sol_s;
   ABIPInfo last_info;
@@ -1327,7 +1328,7 @@ int xcd_run(W *w, int phase, long max_steps, long *ran, int *reason) {
   w->wg_valid = false;
   w->r.last_admm_iter = -1;
   w->tot_solves += r.solves; w->prof.kkt_solves += r.solves; w->prof.admm_iters += r.ran;
-  if (w->linsys == ABIP_HIP_LINSYS_INDIRECT) { w->last_cg_its = r.last_cg; w->tot_cg_its += r.cg_total; w->prof.cg_iters += r.cg_total; }
+  if (w->linsys == ABIP_HIP_LINSYS_INDIRECT) { w->last_cg_its = r.last_cg; w->tot_cg_its += r.cg_total; w->prof.cg_iters += r.cg_total; w->tot_cg_skipped += r.cg_skipped; w->prof.cg_iters_skipped += r.cg_skipped; }
   x.outer_done += r.outer_done; x.lookaheads += r.bb_lookaheads;
   w->phase = r.phase == 0 ? PH_INNER : (r.phase == 1 ? PH_OUTER_END : PH_OUTER_BEGIN);
   return 0;
@@ -1424,7 +1425,7 @@ int adaptive_search_stream(W *w, abip_int iter) {
   HIP_OK(hipMemcpyAsync(w->a_up.p, w->u.p, bytes, hipMemcpyDeviceToDevice, w->stream));
   HIP_OK(hipMemcpyAsync(w->a_vp.p, w->v.p, bytes, hipMemcpyDeviceToDevice, w->stream));
   { // bb_prev = 1, the counters zero (one small copy: the fields sit side by side at the end of the control block)
-    static_assert(offsetof(Ctl, bb_pad) + sizeof(int) - offsetof(Ctl, bb_prev) == 56, "layout of the search's fields");
+    static_assert(offsetof(Ctl, bb_cg_skipped) + sizeof(int) - offsetof(Ctl, bb_prev) == 56, "layout of the search's fields");
     struct { double prev, beta; int act, it, stage, cg0, cg1, pad; long tot; int skip, pad2; } init = {1.0, 0.0, 0, 0, 0, 0, 0, 0, 0L, 0, 0};
     static_assert(sizeof(init) == 56, "layout of the search's fields");
     HIP_OK(hipMemcpyAsync(&w->ctl.p->bb_prev, &init, sizeof(init), hipMemcpyHostToDevice, w->stream));
@@ -1501,6 +1502,7 @@ int adaptive_search_stream(W *w, abip_int iter) {
   w->beta = hm->bb_beta;
   w->tot_solves += 2 * done; w->prof.kkt_solves += 2 * done;
   w->tot_cg_its += hm->bb_cg_total; w->prof.cg_iters += hm->bb_cg_total;
+  w->tot_cg_skipped += hm->bb_cg_skipped; w->prof.cg_iters_skipped += hm->bb_cg_skipped;
   w->last_cg_its = hm->bb_cg[1];
   memcpy(w->hctl, hm, sizeof(Ctl));
   w->wg_valid = false;
@@ -2104,7 +2106,7 @@ abip_int abip_hip_solve_begin(ABIPWork *w, const ABIPData *d, const ABIPSolution
     w->g_th = w->hctl->out[S_T0];
   }
   w->i = 0; w->j = 0; w->k = 0; w->phase = PH_OUTER_BEGIN; w->wg_valid = false; w->stats_valid = false; w->have_solution = false; w->aty_valid = false;
-  w->tot_cg_its = 0; w->tot_solves = 0; w->last_cg_its = 6;
+  w->tot_cg_its = 0; w->tot_solves = 0; w->tot_cg_skipped = 0; w->last_cg_its = 6;
   if (st->verbose) print_header(w);
   return 0;
 }
@@ -2471,7 +2473,7 @@ abip_float abip_hip_get_scalar(ABIPWork *w, const char *name) {
   if (!w || !name) return NAN;
 #define RET(nm, val) if (!strcmp(name, nm)) return (abip_float)(val);
   RET("mu", w->mu) RET("beta", w->beta) RET("sigma", w->sigma) RET("gamma", w->gamma) RET("g_th", w->g_th)
-  RET("sc_b", w->sc_b) RET("sc_c", w->sc_c) RET("nm_b", w->nm_b) RET("nm_c", w->nm_c) RET("tot_cg_its", w->tot_cg_its)
+  RET("sc_b", w->sc_b) RET("sc_c", w->sc_c) RET("nm_b", w->nm_b) RET("nm_c", w->nm_c) RET("tot_cg_its", w->tot_cg_its) RET("tot_cg_skipped", w->tot_cg_skipped)
   RET("lnnz", w->ldl.lnnz) RET("levels_fwd", w->ldl.F.nlev) RET("levels_bwd", w->ldl.B.nlev) RET("tail", w->ldl.T) RET("admm_iter", w->k) RET("ipm_iter", w->i)
   RET("sell_At", w->dAt.nslices) RET("sell_A", w->dA.nslices) RET("nb", w->NB) RET("dist_cols", w->cg_cols ? 1 : 0) RET("small_solve", w->ldl.small ? 1 : 0) RET("factor_resid", w->factor_resid)
   RET("xcd", w->xcd.on ? 1 : 0) RET("xcd_nz", w->xcd.NZ) RET("xcd_g", w->xcd.on ? w->xcd.G : 0) RET("xcd_batches", w->xcd.batches) RET("xcd_exchanges", w->xcd.exchanges)
@@ -2679,6 +2681,32 @@ int abip_hip_dist_init_peer(int rank, int world, const void *handles /* world x 
     if (hipIpcOpenMemHandle(&p.mapped[r], h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
       fprintf(stderr, "abip_hip: rank %d cannot map the mailbox of rank %d (%s)\n", rank, r, hipGetErrorString(hipGetLastError()));
       return -2;
+    }
+  }
+  // Coherence: peers on OTHER devices will write into this rank's mailbox while its kernels poll and read it.  HIP promises that to work for
+  // fine-grained memory only; a mailbox that had to fall back to plain (coarse-grained) device memory may serve stale lines to its owner whatever the scope of
+  // the loads.  Ranks that share one device (the one-GPU dry runs) go through the same L2 and are fine.  So: a coarse-grained mailbox with a peer on another
+  // device is REFUSED (-4; the caller keeps RCCL) unless ABIP_HIP_PEER_COARSE_OK=1 says the experiment is wanted.
+  {
+    int mydev = -1;
+    (void)hipGetDevice(&mydev);
+    bool cross = false;
+    for (int r = 0; r < world; ++r) {
+      if (r == rank) continue;
+      hipPointerAttribute_t at;
+      if (hipPointerGetAttributes(&at, p.mapped[r]) == hipSuccess) { if (at.device != mydev) cross = true; }
+      else (void)hipGetLastError();
+    }
+#ifdef ABIP_HIP_TEST_HOOKS
+    if (getenv("ABIP_HIP_PEER_PRETEND_CROSS")) cross = true; // one-GPU boxes: behave as if the peers sat on other devices
+#endif
+    p.cross_device = cross;
+    const char *ok = getenv("ABIP_HIP_PEER_COARSE_OK");
+    if (cross && !p.fine && !(ok && atoi(ok) != 0)) {
+      fprintf(stderr, "abip_hip: rank %d: the mailbox could not be allocated as fine-grained memory and a peer sits on another device: the peer-mapped transport is "
+                      "refused (no coherence guarantee); use the RCCL transport (ABIP_HIP_PEER_COARSE_OK=1 overrides)\n", rank);
+      for (int r = 0; r < world; ++r) if (p.mapped[r] && p.mapped[r] != p.mine) { (void)hipIpcCloseMemHandle(p.mapped[r]); p.mapped[r] = nullptr; }
+      return -4;
     }
   }
   p.ctx.rank = rank; p.ctx.world = world; p.ctx.cap = p.cap; p.ctx.sync = p.sync;

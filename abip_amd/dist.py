@@ -86,8 +86,13 @@ def init_peer(rank: int, world: int, m: int, n: int, allgather) -> None:
         raise RuntimeError("the handle exchange did not return one 64-byte handle per rank")
     allh = C.create_string_buffer(b"".join(handles), 64 * world)
     rc = L.abip_hip_dist_init_peer(rank, world, allh)
-    if rc != 0:
-        raise RuntimeError(f"abip_hip_dist_init_peer failed ({rc})")
+    # every rank must come to the same conclusion: one that refuses (-4: a coarse-grained mailbox with a peer on another device, no coherence guarantee) while
+    # the others go on would leave them waiting in the first exchange
+    rcs = [int.from_bytes(b[:4], "little", signed=True) for b in allgather(int(rc).to_bytes(4, "little", signed=True) + bytes(60))]
+    if any(r != 0 for r in rcs):
+        L.abip_hip_dist_finalize()
+        raise RuntimeError(f"abip_hip_dist_init_peer failed on rank(s) {[q for q, r in enumerate(rcs) if r != 0]} (codes {rcs}); "
+                           "-4 = the mailbox is not fine-grained and a peer sits on another device: use the RCCL transport (dist.init_torch)")
 
 
 def init_peer_torch(m: int, n: int, process_group=None) -> None:
@@ -100,6 +105,26 @@ def init_peer_torch(m: int, n: int, process_group=None) -> None:
         return box
 
     init_peer(rank, world, m, n, gather)
+
+
+def ordered_sum_allreduce(process_group=None):
+    """A host-staged all-reduce for dist.init_callback that adds the ranks' contributions IN RANK ORDER ((r0 + r1) + r2 + ...): the order the peer-mapped
+    transport uses (dev_peer.h), so a run over this callback is bit-identical to a run over the mailboxes at any world size (gloo's own ring all-reduce
+    associates three or more terms in another order)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(process_group)
+
+    def allreduce(arr: np.ndarray) -> None:
+        mine = torch.from_numpy(arr)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=process_group)
+        acc = parts[0].clone()
+        for q in range(1, world):
+            acc += parts[q]
+        arr[:] = acc.numpy()
+
+    return allreduce
 
 
 def comm_count() -> int:

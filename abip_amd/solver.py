@@ -173,7 +173,8 @@ class Solver:
                     stamp_ms={k: p.stamp_ms[i] for i, k in enumerate(K_CLASSES)},
                     stamp_launches={k: p.stamp_launches[i] for i, k in enumerate(K_CLASSES)},
                     stamp_noop_launches=p.stamp_noop_launches,
-                    allreduce_ms=p.allreduce_ms, allreduce_calls=p.allreduce_calls, allreduce_bytes=p.allreduce_bytes)
+                    allreduce_ms=p.allreduce_ms, allreduce_calls=p.allreduce_calls, allreduce_bytes=p.allreduce_bytes,
+                    cg_iters_skipped=p.cg_iters_skipped)
 
     def close(self) -> None:
         if getattr(self, "w", None):

@@ -362,7 +362,15 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
     nnz = A.nnz
     sharded = sharded and linsys == "indirect"
 
-    S = Solver(A, b, c, linsys=linsys, eps=1e-6, verbose=0)
+    if dist is not None:
+        dist.barrier()
+    t_setup = time.perf_counter()
+    S = Solver(A, b, c, linsys=linsys, eps=1e-6, verbose=0)      # abip_init: every rank scales the whole A on its host cores, then uploads its share
+    t_setup = time.perf_counter() - t_setup
+    if dist is not None:
+        ts = torch.tensor([t_setup], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        t_setup = float(ts.item())
     xcd = S.scalar("xcd") == 1.0       # cache-resident LP: the inner loop runs as the persistent launch on 1, 2 or 4 XCDs (abip_amd/csrc/dev_xcd.h)
     xg = int(S.scalar("xcd_g")) if xcd else 0
     S.begin()
@@ -416,13 +424,14 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
 
     roof = None
     l = m + n + 1
-    cg_step = prof["cg_iters"] / max(prof["admm_iters"], 1)
+    cg_step = prof["cg_iters"] / max(prof["admm_iters"], 1)      # as the reference counts them (a look-ahead solve the device does not repeat is booked with its count)
+    cg_exec = (prof["cg_iters"] - prof.get("cg_iters_skipped", 0)) / max(prof["admm_iters"], 1)   # what the device executed
     if xcd:
         # SURVEY.md 8(d), per inner iteration: PCG  cg (2 B_spmv + vectors) + 4 B_spmv + vectors;  direct  B_solve of this back-end = the dense
         # inverse of rho I + A A' (8 m^2) + the two products around it, + 2 B_spmv of the stopping test + vectors
         b_cg = b_spmv(n, m, nnz) + b_spmv(m, n, nnz) + 8 * (21 * m + n)
         b_vec = 8 * (37 * l + 8 * m + 19 * n)
-        b_iter = (cg_step * b_cg + 4 * b_spmv(m, n, nnz) + b_vec) if linsys == "indirect" else (8 * m * m + 4 * b_spmv(m, n, nnz) + b_vec)
+        b_iter = (cg_exec * b_cg + 4 * b_spmv(m, n, nnz) + b_vec) if linsys == "indirect" else (8 * m * m + 4 * b_spmv(m, n, nnz) + b_vec)   # executed PCG iterations only
         nl = max(prof["launches"]["xcd"], 1)
         its = max(prof["admm_iters"], 1)
         ms = prof["ms"]["xcd"]
@@ -504,13 +513,17 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         coll = dict(collectives_per_step=prof["allreduce_calls"] / its_, bytes_per_step=prof["allreduce_bytes"] / its_,
                     ms_in_allreduce_per_step=prof["allreduce_ms"] / its_, share_of_step=prof["allreduce_ms"] / its_ / max(1e3 * elapsed / max(steps_eff, 1), 1e-12),
                     timing="hipEvents around every ncclAllReduce on the solver's stream (rank 0's view)")
-    extra = dict(collectives=coll, cg_iters_per_step=cg_step, events_pass=events_pass, m=m, n=n, nnz=int(nnz), rows=[int(row0), int(row1)], persistent_launch=bool(xcd), persistent_launch_workgroups=xg)
+    extra = dict(collectives=coll, cg_iters_per_step=cg_step, cg_iters_executed_per_step=cg_exec, events_pass=events_pass, m=m, n=n, nnz=int(nnz), rows=[int(row0), int(row1)], persistent_launch=bool(xcd), persistent_launch_workgroups=xg,
+                 setup_wall_s=t_setup)   # abip_init, max over the ranks (N ranks on one node run N host passes over A side by side)
     if linsys == "indirect":
         cg = extra["cg_iters_per_step"]
         b_cg = b_spmv(n, m, nnz) + b_spmv(m, n, nnz) + 8 * (21 * m + n)
         b_vec = 8 * (37 * l + 8 * m + 19 * n)
         b_iter = cg * b_cg + 4 * b_spmv(m, n, nnz) + b_vec            # SURVEY.md 8(d) "Indirect"
-        extra["effective_GBs_whole_iteration"] = b_iter * (steps_eff / elapsed) / 1e9
+        extra["effective_GBs_whole_iteration"] = b_iter * (steps_eff / elapsed) / 1e9      # prices the reference-equivalent PCG count (bytes of skipped solves never moved)
+        extra["effective_GBs_executed"] = (extra["cg_iters_executed_per_step"] * b_cg + 4 * b_spmv(m, n, nnz) + b_vec) * (steps_eff / elapsed) / 1e9
+        extra["cg_iters_note"] = ("cg_iters_per_step counts PCG iterations as the reference does (it repeats a look-ahead solve whose penalty did not change, adaptive.c:233-247); "
+                                  "cg_iters_executed_per_step leaves out the solves the device took over bit for bit instead of repeating them")
     S.close()
 
     tt = None
@@ -522,7 +535,8 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         tt = dict(seconds=time.perf_counter() - t1, setup_s=info["setup_time"] / 1e3, solve_s=info["solve_time"] / 1e3,
                   status=info["status"], admm_iter=info["admm_iter"], ipm_iter=info["ipm_iter"],
                   res_pri=info["res_pri"], res_dual=info["res_dual"], rel_gap=info["rel_gap"],
-                  cg_iters_per_step=S2.scalar("tot_cg_its") / max(info["admm_iter"], 1) if linsys == "indirect" else None)
+                  cg_iters_per_step=S2.scalar("tot_cg_its") / max(info["admm_iter"], 1) if linsys == "indirect" else None,
+                  cg_iters_executed_per_step=(S2.scalar("tot_cg_its") - S2.scalar("tot_cg_skipped")) / max(info["admm_iter"], 1) if linsys == "indirect" else None)
         if S2.scalar("xcd") == 1.0:   # how many launches the whole solve took, and how much of the outer loop ran inside them (dev_xcd.h XcdOuter)
             tt.update(launches=int(S2.scalar("xcd_launches")), outer_iterations_inside_the_launches=int(S2.scalar("xcd_outer_done")),
                       lookahead_steps_inside_the_launches=int(S2.scalar("xcd_lookaheads")), launches_abandoned=int(S2.scalar("xcd_giveups")))
@@ -623,7 +637,7 @@ def main():
             os.environ["ABIP_HIP_DIST_CG"] = "cols" if form0 == "rows" else "rows"
             r2 = run_lp(args.workload, steps, warmup, args, rank, world, dist, torch, sharded, linsys_override=args.linsys, to_tol=False, cpu=False)
             rec["extra"]["dist_" + os.environ["ABIP_HIP_DIST_CG"]] = {k: r2[k] for k in ("value", "ms_per_step", "roofline") if k in r2} | dict(collectives=r2["extra"]["collectives"],
-                                                                                                                      cg_iters_per_step=r2["extra"]["cg_iters_per_step"])
+                                                                                                                      cg_iters_per_step=r2["extra"]["cg_iters_per_step"], cg_iters_executed_per_step=r2["extra"]["cg_iters_executed_per_step"])
             os.environ["ABIP_HIP_DIST_CG"] = form0
         if dist is not None:
             rows = [None] * world

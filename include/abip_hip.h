@@ -151,6 +151,8 @@ typedef struct {
   double allreduce_ms;
   long allreduce_calls;
   double allreduce_bytes;
+  long cg_iters_skipped;             /* of cg_iters: counted as the reference counts them, NOT executed -- a look-ahead of the Barzilai-Borwein search whose penalty did not
+                                      * change hands its second solve to the next look-ahead, whose first solve would repeat it bit for bit (adaptive.c:233-247) */
 } AbipHipProfile;
 /* mask = bitmask of classes to bracket with events (0 disables).  Timing a class adds two event
  * records per launch of that class only. */

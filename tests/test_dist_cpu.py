@@ -66,14 +66,14 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 4])
 def test_sharded_pcg_equals_unsharded(world):
     import torch.multiprocessing as mp
     sys.path.insert(0, ROOT)
     from abip_amd import problems
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29871
+    port = 29871 + world
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -169,7 +169,7 @@ def _worker_cols(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_column_form_of_the_sharded_pcg_equals_unsharded(world):
     import torch.multiprocessing as mp
     sys.path.insert(0, ROOT)
@@ -194,3 +194,38 @@ def test_column_form_of_the_sharded_pcg_equals_unsharded(world):
     y1, x1, its1, _ = pcg_kkt(A, rhs[:m], rhs[m:], 1e-3, 1e-10, lambda arr: None, m)     # the row form's model on one "rank"
     assert its == its1 and ncoll == its + 3          # one exchange of m doubles per PCG iteration + gather of b_y, A b_x, the back-substitution
     assert np.linalg.norm(y - y1) / np.linalg.norm(y1) < 1e-9 and np.linalg.norm(x - x1) / np.linalg.norm(x1) < 1e-9
+
+
+# ---- the rank-ordered host-staged sum (abip_amd.dist.ordered_sum_allreduce): the order of the peer-mapped transport (dev_peer.h), any world size ----
+def _worker_ordered(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from abip_amd import dist as adist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ar = adist.ordered_sum_allreduce()
+    v = np.random.default_rng(100 + rank).standard_normal(1001) * 10.0 ** np.random.default_rng(200 + rank).integers(-8, 8, 1001)
+    ar(v)
+    q.put((rank, v))
+    dist.destroy_process_group()
+
+
+def test_ordered_sum_allreduce_adds_in_rank_order():
+    """((r0 + r1) + r2) + ... on every rank, bit for bit: what lets the GPU tests hold the peer-mapped transport to the host-staged one with 4 and 8 ranks."""
+    import torch.multiprocessing as mp
+    world = 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_ordered, args=(r, world, 29899, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    parts = [np.random.default_rng(100 + r).standard_normal(1001) * 10.0 ** np.random.default_rng(200 + r).integers(-8, 8, 1001) for r in range(world)]
+    want = parts[0].copy()
+    for r in range(1, world):
+        want += parts[r]
+    for r in range(world):
+        assert np.array_equal(got[r], want), r
