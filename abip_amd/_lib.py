@@ -61,6 +61,19 @@ class AbipHipProfile(C.Structure):
                 ("allreduce_ms", C.c_double), ("allreduce_calls", C.c_long), ("allreduce_bytes", C.c_double), ("cg_iters_skipped", C.c_long)]
 
 
+def kernel_sources_sha256() -> str:
+    """Hash of everything the launch path's kernels are built from: dev_kernels.h and every header it includes, plus solver.hip (launch geometry and arguments).
+    Ties a committed trace / stamp ratio (scripts/trace_medians.py -> profiles/*_trace_durations.json) to the kernels it was measured on: bench.py does not apply a
+    ratio taken on other sources.  One helper for bench.py and scripts/trace_medians.py."""
+    import hashlib
+    import os
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha256()
+    for f in ("dev_common.h", "dev_kernels.h", "dev_peer.h", "lp_scalars.h", "solver.hip"):
+        h.update(open(os.path.join(src, f), "rb").read())
+    return h.hexdigest()
+
+
 # every symbol include/abip.h and include/abip_hip.h declare
 EXPORTS = (
     "abip_init", "abip_solve", "abip_finish", "abip_main", "abip_version", "abip_set_default_settings",

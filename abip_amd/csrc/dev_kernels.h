@@ -537,7 +537,10 @@ __global__ __launch_bounds__(BS, (SELLA || SELLT) ? 6 : 8) void k_q_both(Csr A, 
 }
 
 // the same launch when A'u_y is at hand (k_post_At's `aty`): workgroups [0, nbA) take A u_x as before, the rest walk the n dual residuals element-wise --
-// d_q_At's row epilogue on the stored product: the same per-element numbers, summed by a different set of workgroups
+// d_q_At's row epilogue on the stored product: the same per-element numbers, but DEALT TO THE WORKGROUPS DIFFERENTLY (a strided walk here, row blocks there), so the
+// three folded sums S_QD, S_RD, S_NATY agree with ABIP_HIP_ATY=0 to rounding, not bit for bit.  The iterate does not depend on them; the exit test and
+// the final check do, so at an exact tie the two settings could stop an iteration apart -- none of the fixtures has such a tie (the tests hold both to the same
+// counts), and each setting by itself is deterministic.
 template <bool SELLA>
 __global__ __launch_bounds__(BS, SELLA ? 6 : 8) void k_q_A_aty(Csr A, const double *__restrict__ aty, const double *__restrict__ uu, const double *__restrict__ vv, const double *__restrict__ b,
                                                 const double *__restrict__ c, const double *__restrict__ wD, const double *__restrict__ wE, Dims d,

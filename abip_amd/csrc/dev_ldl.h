@@ -26,6 +26,7 @@
 
 #include "dev_host_util.h"
 #include "dev_sptrsv.h"
+#include "dev_tail.h"
 #include "host_setup.h"
 
 namespace abip {
@@ -383,85 +384,7 @@ static __global__ __launch_bounds__(BS) void k_tail_mv(const double *__restrict_
   }
 }
 
-// ---- the tail as ONE symmetric mat-vec --------------------------------------------------------------------------------------------
-// x2 = W' D2^-1 W w = M w with M = inv(S) formed once at set-up (k_dgemm_mfma, lower triangle stored).  Every stored entry serves two outputs
-// (M[r][c] w[c] into row r, M[r][c] w[r] into row c), so a solve streams the triangle ONCE -- T^2 / 2 doubles instead of the T^2 of the two
-// triangular mat-vecs (C5, T = 10 048: 404 MB instead of 808 MB per KKT solve).  Tiles of 64 rows x 512 columns; a tile leaves 64 row sums and
-// 512 column sums in two partial tables which k_tail_sym_fin adds up in a fixed order (no atomics: deterministic).
-constexpr int SYR = 64, SYC = 512;
-static __global__ __launch_bounds__(256) void k_tail_sym(const double *__restrict__ M, int ld, const int2 *__restrict__ tiles, const double *__restrict__ w,
-                                                         double *__restrict__ rowpart, double *__restrict__ colpart, int T, const Ctl *ctl) {
-  if (ctl->halt) return;
-  __shared__ double cs[4][SYC];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int rb = tiles[blockIdx.x].x, cc = tiles[blockIdx.x].y;
-  const int c0 = cc * SYC, r0 = rb * SYR + wave * 16;
-  const bool inside = c0 + SYC <= rb * SYR; // the whole tile lies strictly below the diagonal: no masks
-  double2 wc[4], ca[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = c0 + 128 * k + 2 * lane;
-    wc[k] = c + 1 < T ? *reinterpret_cast<const double2 *>(w + c) : make_double2(c < T ? w[c] : 0.0, 0.0);
-    ca[k] = make_double2(0.0, 0.0);
-  }
-#pragma unroll 2
-  for (int i = 0; i < 16; ++i) {
-    const int r = r0 + i;
-    const double wr = w[r];
-    const double2 *row2 = reinterpret_cast<const double2 *>(M + (long)r * ld + c0);
-    double acc = 0.0;
-    if (inside) {
-      double2 m[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) m[k] = row2[64 * k + lane];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { acc += m[k].x * wc[k].x; acc += m[k].y * wc[k].y; ca[k].x += m[k].x * wr; ca[k].y += m[k].y * wr; }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int c = c0 + 128 * k + 2 * lane;
-        if (c <= r) { // the pair (c, c + 1) starts inside the row (rows are 512-byte aligned and ld >= T: the load itself is always in bounds)
-          const double2 m = row2[64 * k + lane];
-          acc += m.x * wc[k].x;
-          if (c < r) ca[k].x += m.x * wr;
-          if (c + 1 <= r) { acc += m.y * wc[k].y; if (c + 1 < r) ca[k].y += m.y * wr; }
-        }
-      }
-    }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (lane == 0) rowpart[(long)cc * T + r] = acc;
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { cs[wave][128 * k + 2 * lane] = ca[k].x; cs[wave][128 * k + 2 * lane + 1] = ca[k].y; }
-  __syncthreads();
-  for (int c = tid; c < SYC; c += 256)
-    if (c0 + c < T) colpart[(long)rb * T + c0 + c] = (cs[0][c] + cs[1][c]) + (cs[2][c] + cs[3][c]);
-}
-// x2[i] = sum over the column chunks of row i's block of rowpart + sum over the row blocks at or below i's of colpart; (xh, Dh, nh) as in k_tail_mv.
-// One 1024-thread workgroup per 64 outputs: 16 groups of lanes share the up to T / 64 column partials of an output and are added in a fixed order.
-static __global__ __launch_bounds__(1024) void k_tail_sym_fin(const double *__restrict__ rowpart, const double *__restrict__ colpart, int T, double *__restrict__ x2, const Ctl *ctl,
-                                                              double *__restrict__ xh, const double *__restrict__ Dh, int nh) {
-  if (ctl->halt) return;
-  __shared__ double ps[16][64];
-  const int tid = threadIdx.x, l = tid & 63, g = tid >> 6;
-  for (int j = blockIdx.x * 1024 + tid; j < nh; j += gridDim.x * 1024) xh[j] /= Dh[j];
-  const int nt = T / SYR;
-  for (int rb = blockIdx.x; rb < nt; rb += gridDim.x) {
-    const int i = rb * SYR + l, ncc = (rb * SYR + SYR + SYC - 1) / SYC;
-    double b = 0.0;
-    for (int cc = g; cc < ncc; cc += 16) b += rowpart[(long)cc * T + i];
-    for (int q = rb + g; q < nt; q += 16) b += colpart[(long)q * T + i];
-    ps[g][l] = b;
-    __syncthreads();
-    if (g == 0) {
-      double t = 0.0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) t += ps[k][l];
-      x2[i] = t;
-    }
-    __syncthreads();
-  }
-}
+// (the tail as ONE symmetric mat-vec: dev_tail.h)
 
 // ---- small systems: the sparse part of the solve in ONE 1024-thread workgroup ---------------------------------------------------
 // A level costs one workgroup barrier plus the latency of whatever it loads after the barrier.  Only the gathers x[idx] depend
@@ -620,8 +543,9 @@ struct DevLdl {
   DBuf<int> Pmap, flag;
   DBuf<double> D, xw, W, Wt, tmp;
   DBuf<double> Msym, rowpart, colpart; // the tail as one symmetric mat-vec (k_tail_sym): M = W' D2^-1 W, W and W' released
-  DBuf<int2> sym_tiles;
-  int n_sym_tiles = 0;
+  SymPlan sym;       // how the triangle is dealt to the wavefronts (dev_tail.h)
+  SymArgs sym_args;
+  int n_sym_tiles = 0; // > 0: the symmetric form is in use (= workgroups of k_tail_sym)
   bool small = false, xl = false; // one-workgroup sparse part; x in LDS
   int N = 0, t0 = 0, T = 0;
   long lnnz = 0;
@@ -765,16 +689,16 @@ struct DevLdl {
     const char *se = getenv("ABIP_HIP_TAIL_SYM");
     const bool want_sym = use_mfma && (se ? atoi(se) != 0 : T >= 2048);
     if (want_sym) {
-      std::vector<int2> tl;
-      for (int rb = nt - 1; rb >= 0; --rb) // long rows first
-        for (int cc = 0; cc * SYC < rb * SYR + SYR; ++cc) tl.push_back(make_int2(rb, cc));
-      const int ncc_max = (T + SYC - 1) / SYC;
-      if (Msym.alloc((size_t)T * T) || rowpart.alloc((size_t)ncc_max * T) || colpart.alloc((size_t)nt * T) || sym_tiles.upload(tl, s)) {
-        Msym.release(); rowpart.release(); colpart.release(); sym_tiles.release(); (void)hipGetLastError(); // no room: the two mat-vecs stay
+      // wavefronts of the stream: eight per CU (two workgroups of four; ABIP_HIP_TAIL_WAVES names another number)
+      const char *we = getenv("ABIP_HIP_TAIL_WAVES");
+      const bool planned = sym.make(T, we && atoi(we) > 0 ? atoi(we) : 2048);
+      if (planned) { sym_args.T = sym.T; sym_args.ncc = sym.ncc; sym_args.nw = sym.nw; sym_args.nwv = sym.nwv; memcpy(sym_args.pre, sym.pre, sizeof(sym.pre)); }
+      if (!planned || Msym.alloc((size_t)T * T) || rowpart.alloc((size_t)sym.ncc * T) || colpart.alloc((size_t)sym.slots * SYC)) {
+        Msym.release(); rowpart.release(); colpart.release(); (void)hipGetLastError(); // no room: the two mat-vecs stay
       } else {
         hipLaunchKernelGGL(k_dgemm_mfma, dim3(nt, nt), dim3(256), 0, s, Msym.p, (long)T, (const double *)Wt.p, (long)T, (const double *)W.p, (long)T, T, 1.0, 2, 0, (const double *)Dt);
         if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) return -1;
-        n_sym_tiles = (int)tl.size();
+        n_sym_tiles = sym.nwv / 4;
         // before W and W' go: M v against W' D2^-1 W v on one pseudo-random v.  The explicit inverse of S must not cost the solve more than the set-up guard
         // allows (1e-8); if it does, the two mat-vecs stay.
         bool keep = false;
@@ -787,8 +711,8 @@ struct DevLdl {
             const int grid = std::max(1, std::min(MAXNB, (T + BS / 64 - 1) / (BS / 64)));
             hipLaunchKernelGGL(k_tail_mv, dim3(grid), dim3(BS), 0, s, (const double *)W.p, T, T, 0, (const double *)dv.p, tmp.p, (const double *)Dt, (const Ctl *)zc, (double *)nullptr, (const double *)nullptr, 0);
             hipLaunchKernelGGL(k_tail_mv, dim3(grid), dim3(BS), 0, s, (const double *)Wt.p, T, T, 1, (const double *)tmp.p, da.p, (const double *)nullptr, (const Ctl *)zc, (double *)nullptr, (const double *)nullptr, 0);
-            hipLaunchKernelGGL(k_tail_sym, dim3(n_sym_tiles), dim3(256), 0, s, (const double *)Msym.p, T, (const int2 *)sym_tiles.p, (const double *)dv.p, rowpart.p, colpart.p, T, (const Ctl *)zc);
-            hipLaunchKernelGGL(k_tail_sym_fin, dim3(nt), dim3(1024), 0, s, (const double *)rowpart.p, (const double *)colpart.p, T, db.p, (const Ctl *)zc, (double *)nullptr, (const double *)nullptr, 0);
+            hipLaunchKernelGGL((k_tail_sym<4, 2>), dim3(n_sym_tiles), dim3(256), 0, s, (const double *)Msym.p, T, (const double *)dv.p, rowpart.p, colpart.p, sym_args, (const Ctl *)zc);
+            hipLaunchKernelGGL(k_tail_sym_fin, dim3(nt), dim3(1024), 0, s, (const double *)rowpart.p, (const double *)colpart.p, sym_args, db.p, (const Ctl *)zc, (double *)nullptr, (const double *)nullptr, 0);
             if (hipMemcpyAsync(ha.data(), da.p, sizeof(double) * T, hipMemcpyDeviceToHost, s) == hipSuccess && hipMemcpyAsync(hb.data(), db.p, sizeof(double) * T, hipMemcpyDeviceToHost, s) == hipSuccess &&
                 hipStreamSynchronize(s) == hipSuccess) {
               double num = 0.0, den = 0.0;
@@ -806,7 +730,7 @@ struct DevLdl {
           if (zc) (void)hipFree(zc);
         }
         if (keep) { W.release(); Wt.release(); tmp.release(); }
-        else { n_sym_tiles = 0; Msym.release(); rowpart.release(); colpart.release(); sym_tiles.release(); }
+        else { n_sym_tiles = 0; Msym.release(); rowpart.release(); colpart.release(); }
       }
       lap("M = W' D2^-1 W (the tail as one symmetric mat-vec)");
     }
@@ -819,8 +743,8 @@ struct DevLdl {
     auto tail = [&](bool scale_head) {
       if (T == 0) return;
       if (n_sym_tiles > 0) {
-        launch(k_tail_sym, n_sym_tiles, 256, (size_t)0, (const double *)Msym.p, T, (const int2 *)sym_tiles.p, (const double *)(xw.p + t0), rowpart.p, colpart.p, T, ctl);
-        launch(k_tail_sym_fin, std::max(T / SYR, std::min(256, scale_head ? (t0 + 1023) / 1024 : 1)), 1024, (size_t)0, (const double *)rowpart.p, (const double *)colpart.p, T, xw.p + t0, ctl,
+        launch(k_tail_sym<4, 2>, n_sym_tiles, 256, (size_t)0, (const double *)Msym.p, T, (const double *)(xw.p + t0), rowpart.p, colpart.p, sym_args, ctl);
+        launch(k_tail_sym_fin, std::max(T / 64, std::min(256, scale_head ? (t0 + 1023) / 1024 : 1)), 1024, (size_t)0, (const double *)rowpart.p, (const double *)colpart.p, sym_args, xw.p + t0, ctl,
                xw.p, (const double *)D.p, scale_head ? t0 : 0);
         return;
       }
@@ -849,7 +773,13 @@ struct DevLdl {
     launch(k_perm_in, gN, BS, (size_t)0, (const int *)Pmap.p, (const double *)rhs, xw.p, N, ctl);
     auto run = [&](const DevTri &Tr) {
       for (const Segment &sg : Tr.segs) {
-        if (sg.wide) launch(k_tri_wide, std::max(1, std::min(NB, sg.nrb)), BS, (size_t)0, Tr.view(), (const int4 *)Tr.rbd.p + sg.rb0, sg.nrb, xw.p, ctl);
+        if (sg.wide && sg.lpr > 0) {
+          const int rpb = BS / sg.lpr, grid = std::max(1, std::min(8192, (sg.b - sg.a + rpb - 1) / rpb));
+          if (sg.lpr == 64) launch(k_tri_rows<64>, grid, BS, (size_t)0, Tr.view(), sg.a, sg.b, xw.p, ctl);
+          else if (sg.lpr == 32) launch(k_tri_rows<32>, grid, BS, (size_t)0, Tr.view(), sg.a, sg.b, xw.p, ctl);
+          else if (sg.lpr == 16) launch(k_tri_rows<16>, grid, BS, (size_t)0, Tr.view(), sg.a, sg.b, xw.p, ctl);
+          else launch(k_tri_rows<8>, grid, BS, (size_t)0, Tr.view(), sg.a, sg.b, xw.p, ctl);
+        } else if (sg.wide) launch(k_tri_wide, std::max(1, std::min(NB, sg.nrb)), BS, (size_t)0, Tr.view(), (const int4 *)Tr.rbd.p + sg.rb0, sg.nrb, xw.p, ctl);
         else launch(k_tri_thin, 1, TBS, (size_t)0, Tr.view(), xw.p, sg.l0, sg.l1, ctl);
       }
     };
@@ -862,7 +792,7 @@ struct DevLdl {
 
   void release() {
     F.release(); B.release(); Pmap.release(); flag.release(); D.release(); xw.release(); W.release(); Wt.release(); tmp.release();
-    Msym.release(); rowpart.release(); colpart.release(); sym_tiles.release(); n_sym_tiles = 0;
+    Msym.release(); rowpart.release(); colpart.release(); n_sym_tiles = 0;
   }
 };
 

@@ -353,9 +353,13 @@ int enqueue_stamp_readback(W *w, size_t *lo, size_t *hi) { // D2H of the records
   return 0;
 }
 void harvest_stamps(W *w, size_t lo, size_t hi) {
+  // developer: ABIP_HIP_STAMP_DUMP=<file> appends every stamped launch in enqueue order -- class, begin tick, end tick (0 0: it returned at a gate) -- so that the
+  // idle time BETWEEN two launches can be read off outside the profiler (scripts/stamp_gaps.py)
+  static FILE *dump = getenv("ABIP_HIP_STAMP_DUMP") ? fopen(getenv("ABIP_HIP_STAMP_DUMP"), "a") : nullptr;
   for (size_t a = lo; a < hi; ++a) {
     const size_t slot = a % W::ST_RING;
     const Stamp &r = w->hstamps[slot];
+    if (dump) fprintf(dump, "%d %llu %llu\n", (int)w->st_cls[slot], r.t1 ? (unsigned long long)~r.t0_inv : 0ull, (unsigned long long)r.t1);
     if (r.t1 == 0) { w->prof.stamp_noop_launches++; continue; } // returned at a gate (enqueued past PCG convergence)
     const unsigned long long t0 = ~r.t0_inv;
     if (r.t1 <= t0) continue;
@@ -403,6 +407,10 @@ int allreduce_dev(W *w, double *buf, size_t count) {
 // The peer-mapped transport (dev_peer.h) lets a producer kernel push its result straight into the reducing ranks' mailboxes: peer_push_begin hands the kernel
 // what it needs (and takes the epoch of this exchange); peer_finish enqueues steps 2 + 3 behind it under the producer's gate `mode`.  pp.on == 0: any other
 // transport -- the producer stores locally and the caller runs the collective as before.
+// INVARIANT of a fused exchange: the producer pushes the rows [0, n) (columns form: [0, m_glob)) and the scalar slots its fold list names, nothing else.
+// The padding T[n, n_pad) and the gs slots outside the list keep whatever earlier exchanges with other counts left in the inboxes: after the reduce they are
+// UNDEFINED (with RCCL or the stand-alone all-reduce they are sums of zeros).  Nothing reads them: k_dist_cg_step / k_dist_post / k_dist_q stop at n and take
+// only the slots folded for them; a new consumer of T beyond n, or of an unfolded slot, must not run behind a fused exchange.
 PeerPush peer_push_begin(W *w, size_t count) {
   PeerPush pp{};
   pp.on = 0;

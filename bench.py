@@ -121,12 +121,10 @@ def b_spmv(R, C, nnz):
 
 
 def kernel_sources_sha256() -> str:
-    """Hash of the sources of the launch path's kernels: ties a committed trace / stamp ratio (scripts/trace_medians.py) to the kernels it was measured on."""
-    import hashlib
-    h = hashlib.sha256()
-    for f in ("dev_common.h", "dev_kernels.h"):
-        h.update(open(os.path.join(ROOT, "abip_amd", "csrc", f), "rb").read())
-    return h.hexdigest()
+    """Hash of the sources of the launch path's kernels (abip_amd/_lib.py: dev_kernels.h, every header it includes, solver.hip): ties a committed trace / stamp
+    ratio (scripts/trace_medians.py) to the kernels it was measured on."""
+    from abip_amd import _lib
+    return _lib.kernel_sources_sha256()
 
 
 def host_cores() -> int:
@@ -268,8 +266,8 @@ def run_conic(workload, linsys, no_cpu, rank, world, dist, torch):
     avg_ms = f["solve_ms_total"] / max(f["solves_timed"], 1)
     # what THIS back-end streams per solve: the dense tail (one symmetric mat-vec: the lower triangle of inv(S) once + its two partial tables, written and read;
     # or inv(L22) and its transpose), the head's level streams forward and backward (12 bytes per non-zero each), the permuted vectors
-    ncc, ntile = (T + 511) // 512, T // 64
-    tail_bytes = (4 * T * (T + 1) + 2 * 8 * (ncc + ntile) * T) if tail_sym(T) else 8 * T * (T + 1)
+    ncc, nwv = (T + 511) // 512, int(os.environ.get("ABIP_HIP_TAIL_WAVES", "2048"))     # dev_tail.h: column chunks, wavefronts of the stream
+    tail_bytes = (4 * T * (T + 1) + 2 * 8 * (ncc * T + (nwv + ncc) * 512)) if tail_sym(T) else 8 * T * (T + 1)
     streamed = tail_bytes + 2 * 12 * f["head_nnz"] + 2 * 20 * N
     ach = streamed / (avg_ms * 1e-3) / 1e9
     tr = pmc_traffic("c5_direct") if not ml else {}
@@ -338,9 +336,24 @@ def run_conic(workload, linsys, no_cpu, rank, world, dist, torch):
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_note": cpu_why, "time_to_tol_eps_1e-6": tt6,
             "time_to_tol": dict(seconds=info["runtime"], setup_s=info["setup_time"], solve_s=info["solve_time"], status=info["status"], admm_iter=steps,
                                 ipm_iter=info["ipm_iter"], res_pri=info["res_pri"], res_dual=info["res_dual"], rel_gap=info["gap"]),
-            "extra": {"nnz": nnz_op, "nonzero_coefficients": int(np.sum(np.abs(beta) > 1e-6)), "pobj": info["pobj"], "cpu_reduced_instance": cpu_small},
+            "extra": {"nnz": nnz_op, "nonzero_coefficients": int(np.sum(np.abs(beta) > 1e-6)), "pobj": info["pobj"], "cpu_reduced_instance": cpu_small,
+                      "cpu_solve_reference": cpu_solve_reference(avg_ms) if (not ml and not pcg) else None},
         })
     return None
+
+
+def cpu_solve_reference(device_solve_ms):
+    """The kernel-level CPU leg of the conic direct back-end: the reference's own QDLDL_solve on the C5 KKT system, measured ONCE by scripts/qdldl_cpu_leg.py
+    (the one-off QDLDL_factor takes minutes) and committed -- a recorded figure with its date and box, NOT a same-run baseline (that key stays null)."""
+    f = os.path.join(ROOT, "profiles", "r06_c5_cpu_qdldl_solve.json")
+    try:
+        r = json.load(open(f))
+    except Exception:  # noqa: BLE001
+        return None
+    return dict(solve_ms=1e3 * r["solve_s_each"], solves_per_s=r["solves_per_s"], factor_s=r["factor_s"], nnz_L=r["nnz_L"], threads=r["threads"], host_cores=r["host_cores"],
+                box=r["box"], date=r["date"], source="profiles/r06_c5_cpu_qdldl_solve.json (scripts/qdldl_cpu_leg.py: QDLDL_solve, src/external/qdldl/src/qdldl.c:236-281, oracle/_ref/libqdldl_ref.so)",
+                device_solve_ms_this_run=device_solve_ms, ratio=1e3 * r["solve_s_each"] / max(device_solve_ms, 1e-12),
+                note="recorded once on the development container's CPU, not on this run's host: never a cpu_baseline")
 
 
 # ---------------------------------------------------------------------------------------------------------

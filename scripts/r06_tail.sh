@@ -1,0 +1,53 @@
+#!/bin/bash
+# Round 6, VERDICT r5 item 4 (dense-tail stream kernels) and item 2 (C4 gaps outside the profiler): probes and A/B runs.  Output: gpurun_out/r06_tail/
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/r06_tail
+mkdir -p "$OUT"
+cd "$ROOT"
+what=${1:-all}
+if [ "$what" = all ] || [ "$what" = probe ]; then
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-result -o tools/tail_sym_probe tools/tail_sym_probe.hip 2> "$OUT/probe_build.err"
+  timeout 300 tools/tail_sym_probe 10048 30 > "$OUT/tail_sym_probe_T10048.txt" 2>&1
+  timeout 300 tools/tail_sym_probe 8960 30 > "$OUT/tail_sym_probe_T8960.txt" 2>&1
+  timeout 300 tools/tail_sym_probe 2048 30 > "$OUT/tail_sym_probe_T2048.txt" 2>&1
+  cat "$OUT/tail_sym_probe_T10048.txt"
+fi
+c5() {  # tag env...
+  local tag=$1; shift
+  env "$@" timeout 900 python bench.py --workload c5 --linsys direct --no-cpu > "$OUT/c5_$tag.json" 2> "$OUT/c5_$tag.err"
+  python3 - "$OUT/c5_$tag.json" "$tag" <<'PY'
+import json, sys
+ln = [l for l in open(sys.argv[1]) if l.startswith("{")]
+if not ln: print(sys.argv[2], "NO LINE"); sys.exit(0)
+r = json.loads(ln[-1]); ro = r["roofline"]
+print(f"c5 direct [{sys.argv[2]}]: {r['value']:.0f} it/s, {r['steps']} its, solve {ro['avg_launch_us']:.1f} us, frac {ro['frac']:.3f}, status {r['time_to_tol']['status']}, pobj {r['extra']['pobj']:.12g}, setup {r['time_to_tol']['setup_s']:.2f} s")
+PY
+}
+if [ "$what" = all ] || [ "$what" = c5 ]; then
+  c5 default ABIP_X=0
+  c5 tri_stream ABIP_HIP_TRI_ROWS=0
+  c5 waves1024 ABIP_HIP_TAIL_WAVES=1024
+  c5 waves4096 ABIP_HIP_TAIL_WAVES=4096
+  c5 tri32 ABIP_HIP_TRI_ROWS=32
+  c5 tri16 ABIP_HIP_TRI_ROWS=16
+fi
+if [ "$what" = all ] || [ "$what" = tests ]; then
+  timeout 1500 python -m pytest tests/test_gpu_qdldl_pin.py tests/test_gpu_qcp.py tests/test_gpu_baseline_size.py -x -q -m gpu --durations=15 > "$OUT/pytest_tail.txt" 2>&1; tail -25 "$OUT/pytest_tail.txt"
+  timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "direct or tail or ldl" > "$OUT/pytest_parity_direct.txt" 2>&1; tail -5 "$OUT/pytest_parity_direct.txt"
+fi
+if [ "$what" = all ] || [ "$what" = gaps ]; then
+  rm -f /tmp/st.txt
+  ABIP_HIP_STAMP_DUMP=/tmp/st.txt timeout 900 python bench.py --workload c4 --steps 20 --warmup 5 --no-cpu --no-extra --no-to-tol > "$OUT/c4_gaps_bench.json" 2> "$OUT/c4_gaps_bench.err"
+  python3 scripts/stamp_gaps.py /tmp/st.txt > "$OUT/c4_stamp_gaps_steps20.txt" 2>&1
+  cp /tmp/st.txt "$OUT/c4_stamps_raw_steps20.txt"
+  rm -f /tmp/st.txt
+  ABIP_HIP_STAMP_DUMP=/tmp/st.txt timeout 900 python bench.py --workload c4 --steps 200 --warmup 20 --no-cpu --no-extra --no-to-tol > "$OUT/c4_gaps_bench200.json" 2>> "$OUT/c4_gaps_bench.err"
+  python3 scripts/stamp_gaps.py /tmp/st.txt > "$OUT/c4_stamp_gaps_steps200.txt" 2>&1
+  cat "$OUT/c4_stamp_gaps_steps20.txt" "$OUT/c4_stamp_gaps_steps200.txt"
+  python3 -c "
+import json
+for f in ('c4_gaps_bench.json','c4_gaps_bench200.json'):
+    r=json.loads([l for l in open('$OUT/'+f) if l.startswith('{')][-1]); print(f, r['value'], r['ms_per_step'], r['extra']['cg_iters_per_step'], r['extra']['cg_iters_executed_per_step'])
+"
+fi

@@ -44,12 +44,10 @@ def main():
                 out[base] = dict(median_working_us=statistics.median(w), mean_working_us=statistics.mean(w), n_working=len(w), launches=len(v), stamp_avg_us_same_run=stamp[base])
         out["source"] = "kernel trace of: " + cmd
         # which kernels this ratio was measured on: bench.py ignores the file (and says so) when the sources have changed since
-        import hashlib, os
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        h = hashlib.sha256()
-        for f in ("dev_common.h", "dev_kernels.h"):
-            h.update(open(os.path.join(root, "abip_amd", "csrc", f), "rb").read())
-        out["kernel_sources_sha256"] = h.hexdigest()
+        import os, sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from abip_amd import _lib
+        out["kernel_sources_sha256"] = _lib.kernel_sources_sha256()   # (one helper with bench.py: dev_kernels.h, every header it includes, solver.hip)
         out["note"] = ("kernel-trace duration (dispatch to drain) of the launches that did work, and the device-side stamp figure bench.py measured in the SAME profiled run: "
                        "the stamps (first sampled workgroup begin .. last sampled workgroup end) leave out dispatch and drain")
         json.dump(out, open(jout, "w"), indent=1)

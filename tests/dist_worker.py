@@ -5,7 +5,8 @@
 MODE = gloo-callback : every rank uses cuda:0 and the host-staged collective over gloo (runs on a 1-GPU box)
 MODE = gloo-ordered  : the same with the contributions added in rank order (abip_amd.dist.ordered_sum_allreduce): the peer transport's order
 MODE = peer          : every rank uses cuda:0 and the hand-rolled exchange over peer-mapped mailboxes (abip_amd/csrc/dev_peer.h; IPC handles over gloo)
-MODE = peer+ordered  : the solve twice in the same processes, over the mailboxes and over the ordered host-staged sums (result of the second under "second")
+MODE = peer+ordered  : the solve twice in the same processes, over the mailboxes and over the ordered host-staged sums (result of the second under "second");
+                       single+peer+ordered: in front of them rank 0 solves the LP on its own, unsharded (under "single")
 MODE = rccl          : one GPU per rank, RCCL communicator bootstrapped over torch.distributed
 Rank 0 prints a JSON line with the result."""
 import json
@@ -96,9 +97,17 @@ def main():
         adist.finalize()
         return out
 
-    if mode == "peer+ordered":   # both transports in the same processes (eight ranks take a while to start): the second result rides under "second"
+    if mode in ("peer+ordered", "single+peer+ordered"):   # both transports in the same processes (eight ranks take a while to start): the second result rides under "second"
+        single = None
+        if mode.startswith("single") and rank == 0:   # ... and in front of them the plain one-GPU solve, by rank 0 on its own (the others wait at the barrier)
+            with Solver(A, b, c, linsys="indirect", verbose=0, eps=eps) as S1:
+                i1 = S1.solve()
+                single = dict(status=i1["status"], admm_iter=i1["admm_iter"], ipm_iter=i1["ipm_iter"], pobj=i1["pobj"], cg=S1.scalar("tot_cg_its"), x=S1.x.tolist(), y=S1.y.tolist(), s=S1.s.tolist())
+        dist.barrier()
         out = run("peer")
         out["second"] = run("gloo-ordered")
+        out["single"] = single
+        out["shape"] = [int(A.shape[0]), int(A.shape[1])]
     else:
         out = run(mode)
     if rank == 0:

@@ -51,22 +51,6 @@ def test_two_ranks_started_by_bench_itself():
         assert c["collectives_per_step"] > 1 and c["bytes_per_step"] > 0 and c["ms_in_allreduce_per_step"] >= 0
 
 
-@pytest.mark.parametrize("transport", ["gloo-callback", "peer"])
-def test_eight_ranks_started_by_bench_itself(transport):
-    """bench.py --gpus 8 as the driver will start it on an eight-GPU node, here with every rank on cuda:0 (a functional dry run, the line says so): the
-    8-way partitioner, spawn_ranks with eight children, both forms of the sharded PCG on one line, the collectives counted."""
-    p, lines = _run(["--gpus", "8"] + QUICK, {"ABIP_BENCH_TRANSPORT": transport})
-    assert p.returncode == 0 and len(lines) == 1, p.stderr[-3000:]
-    r = json.loads(lines[0])
-    assert r["n_gpus"] == 8 and r["scaling"] == "strong" and r["rccl_ranks"] == 8 and "NOT a scaling number" in r["transport"]
-    rows = r["rank_rows"]
-    assert len(rows) == 8 and rows[0][0] == 0 and rows[-1][1] == r["extra"]["m"] and all(rows[q][1] == rows[q + 1][0] and rows[q][1] > rows[q][0] for q in range(7))
-    assert r["steps"] == 6 and r["value"] > 0 and r["dist_cg"] == "cols" and r["extra"]["dist_rows"]["value"] > 0
-    assert abs(r["extra"]["cg_iters_per_step"] - r["extra"]["dist_rows"]["cg_iters_per_step"]) <= 0.02 * r["extra"]["cg_iters_per_step"] + 1   # the same trajectory (the forms add in different orders: a PCG count may move by one)
-    for c in (r["extra"]["collectives"], r["extra"]["dist_rows"]["collectives"]):
-        assert c["collectives_per_step"] > 1 and c["bytes_per_step"] > 0
-
-
 def test_two_ranks_over_rccl_refused_on_one_gpu():
     import torch
     if torch.cuda.device_count() >= 2:

@@ -182,38 +182,6 @@ def test_peer_mapped_exchange_is_a_drop_in_for_the_collective(gpu, world, name, 
             assert rel(np.array(a[k]), np.array(b[k])) < 10 * eps, k
 
 
-# ---- four and eight ranks (the metric is quoted at 1 / 2 / 4 / 8 GPUs; nothing above three ranks had ever run) ----
-@pytest.mark.parametrize("world,name,eps,form", [(8, "lp_random_sparse_small", 1e-3, "rows"), (8, "gen:odd:7", 1e-4, "cols"),
-                                                 (4, "gen:odd:7", 1e-4, "rows"), (4, "lp_random_sparse_small", 1e-3, "cols")])
-def test_four_and_eight_ranks_on_one_gpu(gpu, world, name, eps, form):
-    """4 and 8 processes on the one GPU, both forms of the sharded PCG, two transports in the same processes: the peer-mapped mailboxes (PEER_MAX = 8 ranks,
-    dev_peer.h) and the host-staged callback adding in rank order.  'gen:odd' has odd m and n, no multiples of 8 * 32: the exchange's chunks (peer_chunk,
-    rounded to 32) do not tile the vectors and the last ranks' chunks are short.  Asserted: every rank holds the same bits, the two transports agree BIT
-    for bit, the row blocks tile [0, m), and the counts are the single-GPU solve's (= the reference's where a fixture exists)."""
-    out = _run_worker(world, "peer+ordered", name, eps, {"ABIP_HIP_DIST_CG": form})
-    a, b = out, out["second"]
-    if name.startswith("gen:"):
-        import dist_worker
-        A, bb, c = dist_worker.gen_problem(name)
-        ref, rx, ry, rs, rcg = _single(gpu, A, bb, c, eps)
-        want = (ref["ipm_iter"], ref["admm_iter"])
-    else:
-        z, A, bb, c = load(name)
-        g = info_of(z, f"indirect_{eps:g}")
-        want = (g["ipm_iter"], g["admm_iter"])
-        rx, ry, rs = (z[f"indirect_{eps:g}_{k}"] for k in "xys")
-    for r in (a, b):
-        assert r["consistent"] and r["status"] == "Solved" and r["cols"] == (1.0 if form == "cols" else 0.0)
-        assert (r["ipm_iter"], r["admm_iter"]) == want, (r["transport"], r["ipm_iter"], r["admm_iter"], want)
-        rows = r["rank_rows"]
-        assert len(rows) == world and rows[0][0] == 0 and rows[-1][1] == A.shape[0] and all(rows[q][1] == rows[q + 1][0] and rows[q][1] > rows[q][0] for q in range(world - 1))
-    assert a["cg"] == b["cg"] and a["pobj"] == b["pobj"]
-    for k in "xys":
-        assert np.array_equal(np.array(a[k]), np.array(b[k])), k          # the two transports: the same bits
-    for got, ref_ in ((a["x"], rx), (a["y"], ry), (a["s"], rs)):
-        assert rel(np.array(got), np.asarray(ref_)) < 10 * eps
-
-
 def test_coarse_mailbox_with_peers_on_other_devices_is_refused(gpu):
     """when the mailbox cannot be fine-grained memory (here: ABIP_HIP_PEER_FINE=0) and a peer sits on another device (pretended through the hooks
     library on this one-GPU box), remote writes into memory a local kernel polls have no coherence guarantee: abip_hip_dist_init_peer refuses (-4), every rank

@@ -390,7 +390,9 @@ def test_sliced_ell_layout(gpu, oracle_built, monkeypatch):
 def test_streamed_launch_path_is_the_stepwise_one(gpu, name, eps, monkeypatch):
     """The launch path of the PCG back-end (the C4 path) enqueues iteration j + 1 before it has read the verdict of iteration j, keeps A'u_y across an iteration,
     streams the Barzilai-Borwein search with its decisions on the device and hands a look-ahead's second step to the next one when the penalty did not change
-    (solver.hip: admm_stream_pcg, adaptive_search_stream).  None of that may change a bit: every combination of the switches -- and a blind PCG count forced so
+    (solver.hip: admm_stream_pcg, adaptive_search_stream).  None of that may change a bit of the ITERATE (with ABIP_HIP_ATY the dual residual sums of the stopping
+    test are dealt to the workgroups differently -- equal to rounding, dev_kernels.h k_q_A_aty -- which could only show as a count that differs at an exact tie:
+    the counts are asserted equal here): every combination of the switches -- and a blind PCG count forced so
     small that every iteration and every look-ahead stalls and is resumed (ABIP_HIP_STREAM_BLIND=2) -- ends on the iterate, the counts and the PCG total of
     round 4's form (one control read per iteration, every product where the reference forms it), and on the reference's fixture."""
     monkeypatch.setenv("ABIP_HIP_XCD", "0")
