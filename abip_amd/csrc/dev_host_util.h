@@ -82,8 +82,7 @@ struct DevCsr {
   void release() { ptr.release(); idx.release(); rbd.release(); val.release(); sval.release(); sidx.release(); slen.release(); soff.release(); nslices = 0; }
 };
 
-struct Segment { bool wide; int l0, l1; int rb0 = 0, nrb = 0; int a = 0, b = 0, lpr = 0; }; // wide: one level streamed over the grid, row blocks [rb0, rb0+nrb); positions [a, b);
-                                                                                           // lpr > 0: lanes per row of the row-parallel kernel (k_tri_rows), 0: the CSR-stream kernel
+struct Segment { bool wide; int l0, l1; int rb0 = 0, nrb = 0; }; // wide: one level streamed over the grid, row blocks [rb0, rb0+nrb)
 
 struct DevTri {
   DBuf<int> ptr, idx, lev_ptr, lev_rows, lev_g, rbd;
@@ -120,13 +119,6 @@ struct DevTri {
           r = e;
         }
         sg.nrb = (int)d4.size() / 4 - sg.rb0;
-        sg.a = a; sg.b = b;
-        { // lanes per row by the level's mean row length (ABIP_HIP_TRI_ROWS=0: always the CSR-stream kernel; very short rows pack better there)
-          const char *te = getenv("ABIP_HIP_TRI_ROWS");
-          const double mean = (double)(h.ptr[b] - h.ptr[a]) / std::max(1, b - a);
-          sg.lpr = (te && atoi(te) == 0) ? 0 : (mean >= 192 ? 64 : mean >= 96 ? 32 : mean >= 24 ? 16 : mean >= 12 ? 8 : 0);
-          if (te && atoi(te) > 1) sg.lpr = atoi(te); // (developer: a fixed group size -- 8, 16, 32, 64)
-        }
         segs.push_back(sg);
         ++l;
       } else {

@@ -544,7 +544,6 @@ struct DevLdl {
   DBuf<double> D, xw, W, Wt, tmp;
   DBuf<double> Msym, rowpart, colpart; // the tail as one symmetric mat-vec (k_tail_sym): M = W' D2^-1 W, W and W' released
   SymPlan sym;       // how the triangle is dealt to the wavefronts (dev_tail.h)
-  SymArgs sym_args;
   int n_sym_tiles = 0; // > 0: the symmetric form is in use (= workgroups of k_tail_sym)
   bool small = false, xl = false; // one-workgroup sparse part; x in LDS
   int N = 0, t0 = 0, T = 0;
@@ -692,7 +691,6 @@ struct DevLdl {
       // wavefronts of the stream: eight per CU (two workgroups of four; ABIP_HIP_TAIL_WAVES names another number)
       const char *we = getenv("ABIP_HIP_TAIL_WAVES");
       const bool planned = sym.make(T, we && atoi(we) > 0 ? atoi(we) : 2048);
-      if (planned) { sym_args.T = sym.T; sym_args.ncc = sym.ncc; sym_args.nw = sym.nw; sym_args.nwv = sym.nwv; memcpy(sym_args.pre, sym.pre, sizeof(sym.pre)); }
       if (!planned || Msym.alloc((size_t)T * T) || rowpart.alloc((size_t)sym.ncc * T) || colpart.alloc((size_t)sym.slots * SYC)) {
         Msym.release(); rowpart.release(); colpart.release(); (void)hipGetLastError(); // no room: the two mat-vecs stay
       } else {
@@ -711,8 +709,8 @@ struct DevLdl {
             const int grid = std::max(1, std::min(MAXNB, (T + BS / 64 - 1) / (BS / 64)));
             hipLaunchKernelGGL(k_tail_mv, dim3(grid), dim3(BS), 0, s, (const double *)W.p, T, T, 0, (const double *)dv.p, tmp.p, (const double *)Dt, (const Ctl *)zc, (double *)nullptr, (const double *)nullptr, 0);
             hipLaunchKernelGGL(k_tail_mv, dim3(grid), dim3(BS), 0, s, (const double *)Wt.p, T, T, 1, (const double *)tmp.p, da.p, (const double *)nullptr, (const Ctl *)zc, (double *)nullptr, (const double *)nullptr, 0);
-            hipLaunchKernelGGL((k_tail_sym<4, 2>), dim3(n_sym_tiles), dim3(256), 0, s, (const double *)Msym.p, T, (const double *)dv.p, rowpart.p, colpart.p, sym_args, (const Ctl *)zc);
-            hipLaunchKernelGGL(k_tail_sym_fin, dim3(nt), dim3(1024), 0, s, (const double *)rowpart.p, (const double *)colpart.p, sym_args, db.p, (const Ctl *)zc, (double *)nullptr, (const double *)nullptr, 0);
+            hipLaunchKernelGGL((k_tail_sym<2>), dim3(n_sym_tiles), dim3(256), 0, s, (const double *)Msym.p, T, (const double *)dv.p, rowpart.p, colpart.p, sym.args(), (const Ctl *)zc);
+            hipLaunchKernelGGL(k_tail_sym_fin, dim3(nt), dim3(1024), 0, s, (const double *)rowpart.p, (const double *)colpart.p, sym.args(), db.p, (const Ctl *)zc, (double *)nullptr, (const double *)nullptr, 0);
             if (hipMemcpyAsync(ha.data(), da.p, sizeof(double) * T, hipMemcpyDeviceToHost, s) == hipSuccess && hipMemcpyAsync(hb.data(), db.p, sizeof(double) * T, hipMemcpyDeviceToHost, s) == hipSuccess &&
                 hipStreamSynchronize(s) == hipSuccess) {
               double num = 0.0, den = 0.0;
@@ -743,8 +741,8 @@ struct DevLdl {
     auto tail = [&](bool scale_head) {
       if (T == 0) return;
       if (n_sym_tiles > 0) {
-        launch(k_tail_sym<4, 2>, n_sym_tiles, 256, (size_t)0, (const double *)Msym.p, T, (const double *)(xw.p + t0), rowpart.p, colpart.p, sym_args, ctl);
-        launch(k_tail_sym_fin, std::max(T / 64, std::min(256, scale_head ? (t0 + 1023) / 1024 : 1)), 1024, (size_t)0, (const double *)rowpart.p, (const double *)colpart.p, sym_args, xw.p + t0, ctl,
+        launch(k_tail_sym<2>, n_sym_tiles, 256, (size_t)0, (const double *)Msym.p, T, (const double *)(xw.p + t0), rowpart.p, colpart.p, sym.args(), ctl);
+        launch(k_tail_sym_fin, std::max(T / 64, std::min(256, scale_head ? (t0 + 1023) / 1024 : 1)), 1024, (size_t)0, (const double *)rowpart.p, (const double *)colpart.p, sym.args(), xw.p + t0, ctl,
                xw.p, (const double *)D.p, scale_head ? t0 : 0);
         return;
       }
@@ -773,13 +771,7 @@ struct DevLdl {
     launch(k_perm_in, gN, BS, (size_t)0, (const int *)Pmap.p, (const double *)rhs, xw.p, N, ctl);
     auto run = [&](const DevTri &Tr) {
       for (const Segment &sg : Tr.segs) {
-        if (sg.wide && sg.lpr > 0) {
-          const int rpb = BS / sg.lpr, grid = std::max(1, std::min(8192, (sg.b - sg.a + rpb - 1) / rpb));
-          if (sg.lpr == 64) launch(k_tri_rows<64>, grid, BS, (size_t)0, Tr.view(), sg.a, sg.b, xw.p, ctl);
-          else if (sg.lpr == 32) launch(k_tri_rows<32>, grid, BS, (size_t)0, Tr.view(), sg.a, sg.b, xw.p, ctl);
-          else if (sg.lpr == 16) launch(k_tri_rows<16>, grid, BS, (size_t)0, Tr.view(), sg.a, sg.b, xw.p, ctl);
-          else launch(k_tri_rows<8>, grid, BS, (size_t)0, Tr.view(), sg.a, sg.b, xw.p, ctl);
-        } else if (sg.wide) launch(k_tri_wide, std::max(1, std::min(NB, sg.nrb)), BS, (size_t)0, Tr.view(), (const int4 *)Tr.rbd.p + sg.rb0, sg.nrb, xw.p, ctl);
+        if (sg.wide) launch(k_tri_wide, std::max(1, std::min(NB, sg.nrb)), BS, (size_t)0, Tr.view(), (const int4 *)Tr.rbd.p + sg.rb0, sg.nrb, xw.p, ctl);
         else launch(k_tri_thin, 1, TBS, (size_t)0, Tr.view(), xw.p, sg.l0, sg.l1, ctl);
       }
     };

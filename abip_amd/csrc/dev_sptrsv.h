@@ -63,30 +63,4 @@ static __global__ __launch_bounds__(BS) void k_tri_wide(Tri T, const int4 *__res
   spmv_stream<1>(M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
                  [&](int pos, double(&acc)[1]) { const int row = T.lev_rows[pos]; x[row] -= acc[0]; });
 }
-// The same wide level with LPR lanes per ROW instead of a workgroup per block of non-zeros (round 6): where the rows are long (the tail rows of L: C5's L21 holds
-// ~450 entries per row) or of even length (its transpose: ~45 per row) a group of lanes walks its row alone -- values and indices coalesced, four entries per
-// lane requested before the first is used, a cross-lane sum over the group, one store -- with no LDS staging, no row-block descriptor chain and no workgroup
-// barrier: the CSR-stream kernel above spends two barriers and a descriptor round trip per 1024 non-zeros, which is most of its time on a level that is over
-// in ~30 us.  Row sums are formed in a fixed order (lane q takes entries q, q + LPR, ... into four accumulators, then the butterfly): deterministic.
-template <int LPR>
-static __global__ __launch_bounds__(BS) void k_tri_rows(Tri T, int a, int b, double *x, const Ctl *ctl) {
-  if (ctl->halt) return;
-  constexpr int RPB = BS / LPR;
-  const int q = threadIdx.x % LPR, g = threadIdx.x / LPR;
-  for (int r = a + (int)blockIdx.x * RPB + g; r < b; r += (int)gridDim.x * RPB) {
-    const int s = T.ptr[r], e = T.ptr[r + 1];
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int k = s + q;
-    for (; k + 3 * LPR < e; k += 4 * LPR) {
-      const double v0 = T.val[k], v1 = T.val[k + LPR], v2 = T.val[k + 2 * LPR], v3 = T.val[k + 3 * LPR];
-      const int c0 = T.idx[k], c1 = T.idx[k + LPR], c2 = T.idx[k + 2 * LPR], c3 = T.idx[k + 3 * LPR];
-      a0 += v0 * x[c0]; a1 += v1 * x[c1]; a2 += v2 * x[c2]; a3 += v3 * x[c3];
-    }
-    for (; k < e; k += LPR) a0 += T.val[k] * x[T.idx[k]];
-    double acc = (a0 + a1) + (a2 + a3);
-#pragma unroll
-    for (int off = LPR >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (q == 0) { const int row = T.lev_rows[r]; x[row] -= acc; }
-  }
-}
 } // namespace abip

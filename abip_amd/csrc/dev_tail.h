@@ -28,24 +28,35 @@
 namespace abip {
 
 constexpr int SYC = 512; // columns of a chunk
-constexpr int SYR = 16;  // rows of a wave-tile
-constexpr int SYG = SYC / SYR; // row groups per chunk width: chunk cc's first row group is SYG * cc
+constexpr int SYR = 16;  // rows whose sums are reduced together (a wave-tile)
+constexpr int SYU = 4;   // rows of a unit: what a wavefront requests together, and the grain of the partition
 
-struct SymPlan {    // host side: how the triangle is dealt to the wavefronts (T % 64 == 0)
-  int T = 0, ncc = 0, ng = 0, nw = 0, nwv = 0, slots = 0;
-  int pre[64 + 1]; // wave-tiles in front of chunk cc (ncc <= 64: T <= 32 768)
+struct SymArgs { int T, ncc, nu, nwv; int pre[64 + 1]; int qlo[64], qhi[64]; };
+struct SymPlan : SymArgs {    // host side: how the triangle is dealt to the wavefronts (T % 64 == 0)
+  int slots = 0;
+  static long first_unit(long q, long nu, long nwv) { return q * nu / nwv; }
   bool make(int T_, int waves_wanted) {
-    T = T_; ng = T / SYR; ncc = (T + SYC - 1) / SYC;
+    T = T_; ncc = (T + SYC - 1) / SYC;
     if (T <= 0 || T % SYR || ncc > 64) return false;
     pre[0] = 0;
-    for (int cc = 0; cc < ncc; ++cc) pre[cc + 1] = pre[cc] + (ng - SYG * cc);
-    nw = pre[ncc];
-    nwv = std::max(4, std::min(waves_wanted, nw) / 4 * 4);
+    for (int cc = 0; cc < ncc; ++cc) pre[cc + 1] = pre[cc] + (T - SYC * cc) / SYU; // units of chunk cc: its rows [512 cc, T), four at a time
+    nu = pre[ncc];
+    nwv = std::max(4, std::min(waves_wanted, nu) / 4 * 4);
     slots = nwv + ncc;
+    // the wavefronts whose range meets chunk cc (a contiguous run: the ranges are in list order)
+    int q = 0;
+    for (int cc = 0; cc < ncc; ++cc) {
+      while (q + 1 < nwv && first_unit(q + 1, nu, nwv) <= pre[cc]) ++q;
+      qlo[cc] = q;
+      int e = q;
+      while (e + 1 < nwv && first_unit(e + 1, nu, nwv) < pre[cc + 1]) ++e;
+      qhi[cc] = e;
+    }
+    for (int cc = ncc; cc < 64; ++cc) { qlo[cc] = 0; qhi[cc] = -1; }
     return true;
   }
+  const SymArgs &args() const { return *this; }
 };
-struct SymArgs { int T, ncc, nw, nwv; int pre[64 + 1]; };
 
 // 16 per-lane partial sums of 16 rows -> the rows' totals: afterwards every lane holds the total of row (lane >> 2) in a[0].
 __device__ __forceinline__ void sym_reduce16(double (&a)[SYR], int lane) {
@@ -62,23 +73,20 @@ __device__ __forceinline__ void sym_reduce16(double (&a)[SYR], int lane) {
   a[0] += __shfl_xor(a[0], 1, 64);
 }
 
-// U consecutive rows of a chunk as a wavefront holds them: 4 U loads of 16 bytes per lane, and w at those rows (wave-uniform: scalar loads)
-template <int U>
-struct SymRows { double2 m[U][4]; double wr[U]; };
-template <int U>
-__device__ __forceinline__ void sym_load(SymRows<U> &b, const double *__restrict__ M, int ld, const double *__restrict__ w, int r, int c0, int lane) {
+// SYU consecutive rows of a chunk as a wavefront holds them: 16 loads of 16 bytes per lane, and w at those rows (wave-uniform: scalar loads)
+struct SymRows { double2 m[SYU][4]; double wr[SYU]; };
+__device__ __forceinline__ void sym_load(SymRows &b, const double *__restrict__ M, int ld, const double *__restrict__ w, int r, int c0, int lane) {
 #pragma unroll
-  for (int i = 0; i < U; ++i) {
+  for (int i = 0; i < SYU; ++i) {
     const double2 *row2 = reinterpret_cast<const double2 *>(M + (long)(r + i) * ld + c0);
     b.wr[i] = w[r + i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) b.m[i][k] = row2[64 * k + lane];
   }
 }
-template <int U>
-__device__ __forceinline__ void sym_fma(const SymRows<U> &b, double *acc /* U row sums */, double2 (&ca)[4], const double2 (&wc)[4]) {
+__device__ __forceinline__ void sym_fma(const SymRows &b, double *acc /* SYU row sums */, double2 (&ca)[4], const double2 (&wc)[4]) {
 #pragma unroll
-  for (int i = 0; i < U; ++i) {
+  for (int i = 0; i < SYU; ++i) {
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s += b.m[i][k].x * wc[k].x; s += b.m[i][k].y * wc[k].y; ca[k].x += b.m[i][k].x * b.wr[i]; ca[k].y += b.m[i][k].y * b.wr[i]; }
@@ -88,50 +96,53 @@ __device__ __forceinline__ void sym_fma(const SymRows<U> &b, double *acc /* U ro
 #pragma unroll
   for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(ca[k].x), "+v"(ca[k].y));
 }
-// a wave-tile the diagonal runs through (the first 32 of a chunk): entry (r, c) counts for row r when c <= r and for column c when c < r; what lies right of the
+// nr <= 16 rows the diagonal runs through (the first 512 of a chunk): entry (r, c) counts for row r when c <= r and for column c when c < r; what lies right of the
 // diagonal is never used (the loads stay inside the row: a lane whose columns lie beyond it reads the row's last pair instead and drops it)
-__device__ __forceinline__ void sym_tile_diag(const double *__restrict__ M, int ld, const double *__restrict__ w, int r0, int c0, int lane, double (&acc)[SYR], double2 (&ca)[4],
+__device__ __forceinline__ void sym_tile_diag(const double *__restrict__ M, int ld, const double *__restrict__ w, int r0, int nr, int c0, int lane, double (&acc)[SYR], double2 (&ca)[4],
                                               const double2 (&wc)[4]) {
-#pragma unroll 4
+#pragma unroll
   for (int i = 0; i < SYR; ++i) {
-    const int r = r0 + i;
-    const double2 *row2 = reinterpret_cast<const double2 *>(M + (long)r * ld + c0);
-    const double wr = w[r];
-    const int last = (r - c0) >> 1; // the pair that holds the diagonal entry (c0 <= r)
-    double2 m[4];
+    acc[i] = 0.0;
+    if (i < nr) {
+      const int r = r0 + i;
+      const double2 *row2 = reinterpret_cast<const double2 *>(M + (long)r * ld + c0);
+      const double wr = w[r];
+      const int last = (r - c0) >> 1; // the pair that holds the diagonal entry (c0 <= r)
+      double2 m[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) m[k] = row2[min(64 * k + lane, last)];
-    double s = 0.0;
+      for (int k = 0; k < 4; ++k) m[k] = row2[min(64 * k + lane, last)];
+      double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = c0 + 128 * k + 2 * lane;
-      const double mxr = (c <= r) ? m[k].x : 0.0, myr = (c + 1 <= r) ? m[k].y : 0.0, mxc = (c < r) ? m[k].x : 0.0, myc = (c + 1 < r) ? m[k].y : 0.0;
-      s += mxr * wc[k].x; s += myr * wc[k].y; ca[k].x += mxc * wr; ca[k].y += myc * wr;
+      for (int k = 0; k < 4; ++k) {
+        const int c = c0 + 128 * k + 2 * lane;
+        const double mxr = (c <= r) ? m[k].x : 0.0, myr = (c + 1 <= r) ? m[k].y : 0.0, mxc = (c < r) ? m[k].x : 0.0, myc = (c + 1 < r) ? m[k].y : 0.0;
+        s += mxr * wc[k].x; s += myr * wc[k].y; ca[k].x += mxc * wr; ca[k].y += myc * wr;
+      }
+      acc[i] = s;
     }
-    acc[i] = s;
   }
 }
 
-// U rows are requested while the U before them are consumed (two register buffers; the scheduler is told not to move anything across the phases: left alone it
+// Four rows are requested while the four before them are consumed (two register buffers; the scheduler is told not to move anything across the phases: left alone it
 // hoists all 64 loads of a wave-tile and spills); MINW wavefronts per SIMD bound the registers.  The request runs ahead across wave-tiles: the cross-lane
 // reduction of a tile's 16 row sums overlaps the next tile's first loads.
-template <int U, int MINW>
+template <int MINW>
 static __global__ __launch_bounds__(256, MINW) void k_tail_sym(const double *__restrict__ M, int ld, const double *__restrict__ w, double *__restrict__ rowpart,
                                                                 double *__restrict__ colpart, const SymArgs sa, const Ctl *ctl) {
-  static_assert(SYR % (2 * U) == 0, "an even number of row groups per wave-tile");
   if (ctl->halt) return;
   const int lane = threadIdx.x & 63, T = sa.T;
   const int q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))); // this wavefront's number: a scalar
   if (q >= sa.nwv) return;
-  int t = (int)((long)q * sa.nw / sa.nwv);
-  const int t1 = (int)((long)(q + 1) * sa.nw / sa.nwv);
-  if (t >= t1) return;
+  int u = (int)((long)q * sa.nu / sa.nwv);
+  const int u1 = (int)((long)(q + 1) * sa.nu / sa.nwv);
+  if (u >= u1) return;
   int cc = 0;
-  while (sa.pre[cc + 1] <= t) ++cc;
-  while (t < t1) {
+  while (sa.pre[cc + 1] <= u) ++cc;
+  while (u < u1) {
     const int c0 = cc * SYC, pre_cc = sa.pre[cc];
-    const int tend = min(t1, sa.pre[cc + 1]);
-    int r0 = (SYG * cc + (t - pre_cc)) * SYR;
+    const int uend = min(u1, sa.pre[cc + 1]);
+    int r = c0 + SYU * (u - pre_cc);
+    const int rend = c0 + SYU * (uend - pre_cc);
     double2 wc[4], ca[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -139,62 +150,71 @@ static __global__ __launch_bounds__(256, MINW) void k_tail_sym(const double *__r
       wc[k] = c + 1 < T ? *reinterpret_cast<const double2 *>(w + c) : make_double2(c < T ? w[c] : 0.0, 0.0);
       ca[k] = make_double2(0.0, 0.0);
     }
-    for (; t < tend && r0 < c0 + SYC; ++t, r0 += SYR) { // the chunk's top: the diagonal runs through these tiles
+    const int rd = min(rend, c0 + SYC);
+    while (r < rd) { // the chunk's top: the diagonal runs through these rows
+      const int nr = min(SYR, rd - r);
       double acc[SYR];
-      sym_tile_diag(M, ld, w, r0, c0, lane, acc, ca, wc);
+      sym_tile_diag(M, ld, w, r, nr, c0, lane, acc, ca, wc);
       sym_reduce16(acc, lane);
-      if ((lane & 3) == 0) rowpart[(long)cc * T + r0 + (lane >> 2)] = acc[0];
+      if ((lane & 3) == 0 && (lane >> 2) < nr) rowpart[(long)cc * T + r + (lane >> 2)] = acc[0];
+      r += nr;
     }
-    if (t < tend) { // strictly below the diagonal: the stream
-      SymRows<U> bufA, bufB;
-      sym_load<U>(bufA, M, ld, w, r0, c0, lane);
-      for (; t < tend; ++t, r0 += SYR) {
+    if (r < rend) { // strictly below the diagonal: the stream
+      SymRows bufA, bufB;
+      sym_load(bufA, M, ld, w, r, c0, lane);
+      while (r < rend) {
+        const int nr = min(SYR, rend - r); // a multiple of four; 16 unless this is the range's last tile
+        const bool more = r + SYR < rend;
         double acc[SYR];
-        const bool more = t + 1 < tend;
 #pragma unroll
-        for (int g = 0; g < SYR / U; g += 2) {
-          sym_load<U>(bufB, M, ld, w, r0 + (g + 1) * U, c0, lane);
+        for (int i = 0; i < SYR; ++i) acc[i] = 0.0;
+#pragma unroll
+        for (int g = 0; g < SYR / SYU; g += 2) {
+          // (a request is never conditional -- behind the range's end it asks for the tile's own first rows once more and nobody uses them: a conditional request
+          // would make the compiler keep the buffers in scratch memory)
+          sym_load(bufB, M, ld, w, (g + 1) * SYU < nr ? r + (g + 1) * SYU : r, c0, lane);
           __builtin_amdgcn_sched_barrier(0);
-          sym_fma<U>(bufA, acc + g * U, ca, wc);
+          if (g * SYU < nr) sym_fma(bufA, acc + g * SYU, ca, wc);
           __builtin_amdgcn_sched_barrier(0);
-          // (the last group of a tile requests the next tile's first rows; behind the segment's last tile it requests that tile's own first rows once more and nobody
-          // uses them: a conditional request would make the compiler keep the buffers in scratch memory)
-          sym_load<U>(bufA, M, ld, w, (g + 2 < SYR / U || more) ? r0 + (g + 2) * U : r0, c0, lane);
+          sym_load(bufA, M, ld, w, (g + 2) * SYU < nr ? r + (g + 2) * SYU : ((g + 2) * SYU == SYR && more ? r + SYR : r), c0, lane); // (the last group of a tile requests the next tile's first rows)
           __builtin_amdgcn_sched_barrier(0);
-          sym_fma<U>(bufB, acc + (g + 1) * U, ca, wc);
+          if ((g + 1) * SYU < nr) sym_fma(bufB, acc + (g + 1) * SYU, ca, wc);
           __builtin_amdgcn_sched_barrier(0);
         }
         sym_reduce16(acc, lane);
-        if ((lane & 3) == 0) rowpart[(long)cc * T + r0 + (lane >> 2)] = acc[0];
+        if ((lane & 3) == 0 && (lane >> 2) < nr) rowpart[(long)cc * T + r + (lane >> 2)] = acc[0];
+        r += nr;
       }
     }
     double2 *cp = reinterpret_cast<double2 *>(colpart + (long)(q + cc) * SYC);
 #pragma unroll
     for (int k = 0; k < 4; ++k) cp[64 * k + lane] = ca[k];
+    u = uend;
     ++cc;
   }
 }
 
-// x2[i] = sum over the chunks cc <= i / 512 of rowpart[cc][i] + sum over the wavefronts that walked through i's chunk of their column partials; then (xh, Dh, nh):
-// optionally xh[j] /= Dh[j] for j < nh -- the head's D^-1 of the segmented path rides on this launch.  One 1024-thread workgroup per 64 outputs: sixteen groups of
-// lanes share the partials of an output and are added in a fixed order.
+// x2[i] = sum over the chunks cc <= i / 512 of rowpart[cc][i] + sum over the wavefronts that walked through i's chunk (qlo .. qhi: the host's table) of their column
+// partials; then (xh, Dh, nh): optionally xh[j] /= Dh[j] for j < nh -- the head's D^-1 of the segmented path rides on this launch.  One 1024-thread workgroup per 64
+// outputs: sixteen groups of lanes share the partials of an output and are added in a fixed order.
 static __global__ __launch_bounds__(1024) void k_tail_sym_fin(const double *__restrict__ rowpart, const double *__restrict__ colpart, const SymArgs sa, double *__restrict__ x2,
-                                                             const Ctl *ctl, double *__restrict__ xh, const double *__restrict__ Dh, int nh) {
+                                                              const Ctl *ctl, double *__restrict__ xh, const double *__restrict__ Dh, int nh) {
   if (ctl->halt) return;
   __shared__ double ps[16][64];
   const int tid = threadIdx.x, l = tid & 63, g = tid >> 6, T = sa.T;
   for (int j = blockIdx.x * 1024 + tid; j < nh; j += gridDim.x * 1024) xh[j] /= Dh[j];
   for (int ib = blockIdx.x; ib * 64 < T; ib += gridDim.x) {
     const int i = ib * 64 + l, cc = (ib * 64) / SYC;
-    // wavefronts whose range meets chunk cc: q Nw / NWV < pre[cc + 1] and (q + 1) Nw / NWV > pre[cc]
-    const long a = sa.pre[cc], b = sa.pre[cc + 1];
-    int qlo = (int)(a * sa.nwv / sa.nw), qhi = (int)((b * sa.nwv + sa.nw - 1) / sa.nw); // candidates [qlo - 1, qhi]: the exact test below decides
+    const int qlo = sa.qlo[cc], qhi = sa.qhi[cc];
     double s = 0.0;
     for (int c2 = g; c2 <= cc; c2 += 16) s += rowpart[(long)c2 * T + i];
-    for (int q = max(qlo - 1, 0) + g; q <= min(qhi, sa.nwv - 1); q += 16) {
-      const long s0 = (long)q * sa.nw / sa.nwv, s1 = (long)(q + 1) * sa.nw / sa.nwv;
-      if (s0 < b && s1 > a && s0 < s1) s += colpart[(long)(q + cc) * SYC + (i - cc * SYC)];
+    const double *cp = colpart + (long)cc * SYC + (i - cc * SYC);
+    int qq = qlo + g;
+    for (; qq + 48 <= qhi; qq += 64) { // four partials in flight
+      const double v0 = cp[(long)qq * SYC], v1 = cp[(long)(qq + 16) * SYC], v2 = cp[(long)(qq + 32) * SYC], v3 = cp[(long)(qq + 48) * SYC];
+      s += v0; s += v1; s += v2; s += v3;
     }
+    for (; qq <= qhi; qq += 16) s += cp[(long)qq * SYC];
     ps[g][l] = s;
     __syncthreads();
     if (g == 0) {

@@ -26,11 +26,9 @@ PY
 }
 if [ "$what" = all ] || [ "$what" = c5 ]; then
   c5 default ABIP_X=0
-  c5 tri_stream ABIP_HIP_TRI_ROWS=0
   c5 waves1024 ABIP_HIP_TAIL_WAVES=1024
   c5 waves4096 ABIP_HIP_TAIL_WAVES=4096
-  c5 tri32 ABIP_HIP_TRI_ROWS=32
-  c5 tri16 ABIP_HIP_TRI_ROWS=16
+  c5 two_matvecs ABIP_HIP_TAIL_SYM=0
 fi
 if [ "$what" = all ] || [ "$what" = tests ]; then
   timeout 1500 python -m pytest tests/test_gpu_qdldl_pin.py tests/test_gpu_qcp.py tests/test_gpu_baseline_size.py -x -q -m gpu --durations=15 > "$OUT/pytest_tail.txt" 2>&1; tail -25 "$OUT/pytest_tail.txt"

@@ -29,16 +29,16 @@ __global__ void k_naive(const double *M, long ld, int T, const double *w, double
   for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) x[i] = sm[0];
 }
-template <int UNR, int MINW>
+template <int MINW>
 void run(const char *name, const double *M, int T, const double *w, double *rowpart, double *colpart, double *x, const Ctl *ctl, int waves, const std::vector<double> &ref, int reps) {
   SymPlan pl;
   if (!pl.make(T, waves)) { printf("%s: no plan\n", name); return; }
-  SymArgs sa; sa.T = pl.T; sa.ncc = pl.ncc; sa.nw = pl.nw; sa.nwv = pl.nwv; memcpy(sa.pre, pl.pre, sizeof(pl.pre));
+  const SymArgs sa = pl.args();
   hipEvent_t a, b; OK(hipEventCreate(&a)); OK(hipEventCreate(&b));
   float best = 1e30f, tot = 0.f, fin = 0.f;
   for (int it = 0; it < reps + 2; ++it) {
     OK(hipEventRecord(a));
-    hipLaunchKernelGGL((k_tail_sym<UNR, MINW>), dim3(pl.nwv / 4), dim3(256), 0, 0, M, T, w, rowpart, colpart, sa, ctl);
+    hipLaunchKernelGGL((k_tail_sym<MINW>), dim3(pl.nwv / 4), dim3(256), 0, 0, M, T, w, rowpart, colpart, sa, ctl);
     OK(hipEventRecord(b));
     OK(hipEventSynchronize(b));
     float ms; OK(hipEventElapsedTime(&ms, a, b));
@@ -54,7 +54,7 @@ void run(const char *name, const double *M, int T, const double *w, double *rowp
   double num = 0, den = 0;
   for (int i = 0; i < T; ++i) { num += (hx[i] - ref[i]) * (hx[i] - ref[i]); den += ref[i] * ref[i]; }
   const double bytes = 4.0 * T * (T + 1.0);
-  printf("%-22s waves %5d (wave-tiles %d): avg %7.2f us  best %7.2f us  = %6.0f GB/s avg / %6.0f best (%.3f of 8 TB/s);  fin %5.2f us;  rel err %.2e\n", name, pl.nwv, pl.nw, 1e3 * tot / reps,
+  printf("%-22s waves %5d (units %d): avg %7.2f us  best %7.2f us  = %6.0f GB/s avg / %6.0f best (%.3f of 8 TB/s);  fin %5.2f us;  rel err %.2e\n", name, pl.nwv, pl.nu, 1e3 * tot / reps,
          1e3 * best, bytes / (tot / reps * 1e-3) / 1e9, bytes / (best * 1e-3) / 1e9, bytes / (tot / reps * 1e-3) / 1e9 / 8000.0, 1e3 * fin / reps, std::sqrt(num / den));
   fflush(stdout);
 }
@@ -73,11 +73,8 @@ int main(int argc, char **argv) {
   OK(hipMemcpy(ref.data(), xr, sizeof(double) * T, hipMemcpyDeviceToHost));
   printf("T = %d: lower triangle %.1f MB\n", T, 4.0 * T * (T + 1.0) / 1e6);
   for (int waves : {1024, 2048, 4096, 8192}) {
-    run<2, 2>("rows 2+2, 2 waves/SIMD", M, T, w, rowpart, colpart, x, ctl, waves, ref, reps);
-    run<2, 3>("rows 2+2, 3 waves/SIMD", M, T, w, rowpart, colpart, x, ctl, waves, ref, reps);
-    run<4, 2>("rows 4+4, 2 waves/SIMD", M, T, w, rowpart, colpart, x, ctl, waves, ref, reps);
-    run<4, 1>("rows 4+4, 1 wave/SIMD", M, T, w, rowpart, colpart, x, ctl, waves, ref, reps);
-    run<8, 1>("rows 8+8, 1 wave/SIMD", M, T, w, rowpart, colpart, x, ctl, waves, ref, reps);
+    run<2>("2 waves/SIMD", M, T, w, rowpart, colpart, x, ctl, waves, ref, reps);
+    run<1>("1 wave/SIMD", M, T, w, rowpart, colpart, x, ctl, waves, ref, reps);
   }
   return 0;
 }
