@@ -49,3 +49,11 @@ for f in ('c4_gaps_bench.json','c4_gaps_bench200.json'):
     r=json.loads([l for l in open('$OUT/'+f) if l.startswith('{')][-1]); print(f, r['value'], r['ms_per_step'], r['extra']['cg_iters_per_step'], r['extra']['cg_iters_executed_per_step'])
 "
 fi
+if [ "$what" = kernarg ]; then   # where the kernel arguments live: does the ~4.8 us launch boundary move?
+  for v in 0 1; do
+    rm -f /tmp/st.txt
+    HIP_FORCE_DEV_KERNARG=$v ABIP_HIP_STAMP_DUMP=/tmp/st.txt timeout 900 python bench.py --workload c4 --steps 20 --warmup 5 --no-cpu --no-extra --no-to-tol > "$OUT/c4_kernarg$v.json" 2> "$OUT/c4_kernarg$v.err"
+    echo "HIP_FORCE_DEV_KERNARG=$v: $(python3 -c "import json; r=json.loads([l for l in open('$OUT/c4_kernarg$v.json') if l.startswith('{')][-1]); print(round(r['value'],1), 'it/s', round(r['ms_per_step'],3), 'ms/step')")"
+    python3 scripts/stamp_gaps.py /tmp/st.txt | grep -A1 "one boundary\|two boundaries" | cut -c1-200
+  done
+fi
