@@ -75,15 +75,19 @@ __device__ __forceinline__ void sym_reduce16(double (&a)[SYR], int lane) {
 
 // SYU consecutive rows of a chunk as a wavefront holds them: 16 loads of 16 bytes per lane, and w at those rows (wave-uniform: scalar loads)
 struct SymRows { double2 m[SYU][4]; double wr[SYU]; };
+// (a lane whose columns lie beyond the diagonal entry of a row reads the row's last pair instead: rows are 512-byte aligned, c0 <= r, and the loads stay inside the
+// row; below the chunk's first 512 rows the clamp never bites)
 __device__ __forceinline__ void sym_load(SymRows &b, const double *__restrict__ M, int ld, const double *__restrict__ w, int r, int c0, int lane) {
 #pragma unroll
   for (int i = 0; i < SYU; ++i) {
     const double2 *row2 = reinterpret_cast<const double2 *>(M + (long)(r + i) * ld + c0);
+    const int last = (r + i - c0) >> 1; // the pair that holds the diagonal entry
     b.wr[i] = w[r + i];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) b.m[i][k] = row2[64 * k + lane];
+    for (int k = 0; k < 4; ++k) b.m[i][k] = row2[min(64 * k + lane, last)];
   }
 }
+// rows strictly below the diagonal of the chunk (r >= c0 + 512): every entry counts for its row and for its column
 __device__ __forceinline__ void sym_fma(const SymRows &b, double *acc /* SYU row sums */, double2 (&ca)[4], const double2 (&wc)[4]) {
 #pragma unroll
   for (int i = 0; i < SYU; ++i) {
@@ -96,36 +100,67 @@ __device__ __forceinline__ void sym_fma(const SymRows &b, double *acc /* SYU row
 #pragma unroll
   for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(ca[k].x), "+v"(ca[k].y));
 }
-// nr <= 16 rows the diagonal runs through (the first 512 of a chunk): entry (r, c) counts for row r when c <= r and for column c when c < r; what lies right of the
-// diagonal is never used (the loads stay inside the row: a lane whose columns lie beyond it reads the row's last pair instead and drops it)
-__device__ __forceinline__ void sym_tile_diag(const double *__restrict__ M, int ld, const double *__restrict__ w, int r0, int nr, int c0, int lane, double (&acc)[SYR], double2 (&ca)[4],
-                                              const double2 (&wc)[4]) {
+// rows the diagonal runs through (the first 512 of a chunk): entry (r, c) counts for row r when c <= r and for column c when c < r; what lies right of the diagonal
+// was never read
+__device__ __forceinline__ void sym_fma_diag(const SymRows &b, double *acc, double2 (&ca)[4], const double2 (&wc)[4], int r, int c0, int lane) {
 #pragma unroll
-  for (int i = 0; i < SYR; ++i) {
-    acc[i] = 0.0;
-    if (i < nr) {
-      const int r = r0 + i;
-      const double2 *row2 = reinterpret_cast<const double2 *>(M + (long)r * ld + c0);
-      const double wr = w[r];
-      const int last = (r - c0) >> 1; // the pair that holds the diagonal entry (c0 <= r)
-      double2 m[4];
+  for (int i = 0; i < SYU; ++i) {
+    const int rr = r + i;
+    double s = 0.0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) m[k] = row2[min(64 * k + lane, last)];
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int c = c0 + 128 * k + 2 * lane;
-        const double mxr = (c <= r) ? m[k].x : 0.0, myr = (c + 1 <= r) ? m[k].y : 0.0, mxc = (c < r) ? m[k].x : 0.0, myc = (c + 1 < r) ? m[k].y : 0.0;
-        s += mxr * wc[k].x; s += myr * wc[k].y; ca[k].x += mxc * wr; ca[k].y += myc * wr;
-      }
-      acc[i] = s;
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + 128 * k + 2 * lane;
+      const double2 m = b.m[i][k];
+      const double mxr = (c <= rr) ? m.x : 0.0, myr = (c + 1 <= rr) ? m.y : 0.0, mxc = (c < rr) ? m.x : 0.0, myc = (c + 1 < rr) ? m.y : 0.0;
+      s += mxr * wc[k].x; s += myr * wc[k].y; ca[k].x += mxc * b.wr[i]; ca[k].y += myc * b.wr[i];
     }
+    acc[i] = s;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(ca[k].x), "+v"(ca[k].y));
+}
+
+// Rows [r, rend) of chunk cc (multiples of four), all of them above (DIAG) or all of them below the chunk's 512th row.  Four rows are requested while the four before
+// them are consumed (two register buffers; the scheduler is told not to move anything across the phases: left alone it hoists all 64 loads of a wave-tile and
+// spills).  The request runs ahead across wave-tiles: the cross-lane reduction of a tile's 16 row sums overlaps the next tile's first loads.
+template <bool DIAG>
+__device__ __forceinline__ void sym_stream(const double *__restrict__ M, int ld, const double *__restrict__ w, double *__restrict__ rowpart, int T, int cc, int r, int rend, int lane,
+                                           double2 (&ca)[4], const double2 (&wc)[4]) {
+  const int c0 = cc * SYC;
+  SymRows bufA, bufB;
+  sym_load(bufA, M, ld, w, r, c0, lane);
+  while (r < rend) {
+    const int nr = min(SYR, rend - r); // a multiple of four; 16 unless this is the range's last tile
+    const bool more = r + SYR < rend;
+    double acc[SYR];
+#pragma unroll
+    for (int i = 0; i < SYR; ++i) acc[i] = 0.0;
+#pragma unroll
+    for (int g = 0; g < SYR / SYU; g += 2) {
+      // (a request is never conditional -- behind the range's end it asks for the tile's own first rows once more and nobody uses them: a conditional request
+      // would make the compiler keep the buffers in scratch memory)
+      sym_load(bufB, M, ld, w, (g + 1) * SYU < nr ? r + (g + 1) * SYU : r, c0, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g * SYU < nr) {
+        if (DIAG) sym_fma_diag(bufA, acc + g * SYU, ca, wc, r + g * SYU, c0, lane);
+        else sym_fma(bufA, acc + g * SYU, ca, wc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      sym_load(bufA, M, ld, w, (g + 2) * SYU < nr ? r + (g + 2) * SYU : ((g + 2) * SYU == SYR && more ? r + SYR : r), c0, lane); // (the last group of a tile requests the next tile's first rows)
+      __builtin_amdgcn_sched_barrier(0);
+      if ((g + 1) * SYU < nr) {
+        if (DIAG) sym_fma_diag(bufB, acc + (g + 1) * SYU, ca, wc, r + (g + 1) * SYU, c0, lane);
+        else sym_fma(bufB, acc + (g + 1) * SYU, ca, wc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    sym_reduce16(acc, lane);
+    if ((lane & 3) == 0 && (lane >> 2) < nr) rowpart[(long)cc * T + r + (lane >> 2)] = acc[0];
+    r += nr;
   }
 }
 
-// Four rows are requested while the four before them are consumed (two register buffers; the scheduler is told not to move anything across the phases: left alone it
-// hoists all 64 loads of a wave-tile and spills); MINW wavefronts per SIMD bound the registers.  The request runs ahead across wave-tiles: the cross-lane
-// reduction of a tile's 16 row sums overlaps the next tile's first loads.
+// MINW wavefronts per SIMD bound the registers.
 template <int MINW>
 static __global__ __launch_bounds__(256, MINW) void k_tail_sym(const double *__restrict__ M, int ld, const double *__restrict__ w, double *__restrict__ rowpart,
                                                                 double *__restrict__ colpart, const SymArgs sa, const Ctl *ctl) {
@@ -141,8 +176,7 @@ static __global__ __launch_bounds__(256, MINW) void k_tail_sym(const double *__r
   while (u < u1) {
     const int c0 = cc * SYC, pre_cc = sa.pre[cc];
     const int uend = min(u1, sa.pre[cc + 1]);
-    int r = c0 + SYU * (u - pre_cc);
-    const int rend = c0 + SYU * (uend - pre_cc);
+    const int r = c0 + SYU * (u - pre_cc), rend = c0 + SYU * (uend - pre_cc);
     double2 wc[4], ca[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -150,42 +184,9 @@ static __global__ __launch_bounds__(256, MINW) void k_tail_sym(const double *__r
       wc[k] = c + 1 < T ? *reinterpret_cast<const double2 *>(w + c) : make_double2(c < T ? w[c] : 0.0, 0.0);
       ca[k] = make_double2(0.0, 0.0);
     }
-    const int rd = min(rend, c0 + SYC);
-    while (r < rd) { // the chunk's top: the diagonal runs through these rows
-      const int nr = min(SYR, rd - r);
-      double acc[SYR];
-      sym_tile_diag(M, ld, w, r, nr, c0, lane, acc, ca, wc);
-      sym_reduce16(acc, lane);
-      if ((lane & 3) == 0 && (lane >> 2) < nr) rowpart[(long)cc * T + r + (lane >> 2)] = acc[0];
-      r += nr;
-    }
-    if (r < rend) { // strictly below the diagonal: the stream
-      SymRows bufA, bufB;
-      sym_load(bufA, M, ld, w, r, c0, lane);
-      while (r < rend) {
-        const int nr = min(SYR, rend - r); // a multiple of four; 16 unless this is the range's last tile
-        const bool more = r + SYR < rend;
-        double acc[SYR];
-#pragma unroll
-        for (int i = 0; i < SYR; ++i) acc[i] = 0.0;
-#pragma unroll
-        for (int g = 0; g < SYR / SYU; g += 2) {
-          // (a request is never conditional -- behind the range's end it asks for the tile's own first rows once more and nobody uses them: a conditional request
-          // would make the compiler keep the buffers in scratch memory)
-          sym_load(bufB, M, ld, w, (g + 1) * SYU < nr ? r + (g + 1) * SYU : r, c0, lane);
-          __builtin_amdgcn_sched_barrier(0);
-          if (g * SYU < nr) sym_fma(bufA, acc + g * SYU, ca, wc);
-          __builtin_amdgcn_sched_barrier(0);
-          sym_load(bufA, M, ld, w, (g + 2) * SYU < nr ? r + (g + 2) * SYU : ((g + 2) * SYU == SYR && more ? r + SYR : r), c0, lane); // (the last group of a tile requests the next tile's first rows)
-          __builtin_amdgcn_sched_barrier(0);
-          if ((g + 1) * SYU < nr) sym_fma(bufB, acc + (g + 1) * SYU, ca, wc);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        sym_reduce16(acc, lane);
-        if ((lane & 3) == 0 && (lane >> 2) < nr) rowpart[(long)cc * T + r + (lane >> 2)] = acc[0];
-        r += nr;
-      }
-    }
+    const int rdiag = c0 + SYC; // rows below it lie strictly under the diagonal: no masks
+    if (r < rdiag) sym_stream<true>(M, ld, w, rowpart, T, cc, r, min(rend, rdiag), lane, ca, wc); // the chunk's top: the diagonal runs through these rows
+    if (rend > rdiag) sym_stream<false>(M, ld, w, rowpart, T, cc, max(r, rdiag), rend, lane, ca, wc);
     double2 *cp = reinterpret_cast<double2 *>(colpart + (long)(q + cc) * SYC);
 #pragma unroll
     for (int k = 0; k < 4; ++k) cp[64 * k + lane] = ca[k];
