@@ -82,7 +82,7 @@ struct DevCsr {
   void release() { ptr.release(); idx.release(); rbd.release(); val.release(); sval.release(); sidx.release(); slen.release(); soff.release(); nslices = 0; }
 };
 
-struct Segment { bool wide; int l0, l1; int rb0 = 0, nrb = 0; }; // wide: one level streamed over the grid, row blocks [rb0, rb0+nrb)
+struct Segment { bool wide; int l0, l1; int rb0 = 0, nrb = 0; int a = 0, b = 0; double mean_len = 0.0; }; // wide: one level streamed over the grid, row blocks [rb0, rb0+nrb); positions [a, b), mean entries per row
 
 struct DevTri {
   DBuf<int> ptr, idx, lev_ptr, lev_rows, lev_g, rbd;
@@ -119,6 +119,7 @@ struct DevTri {
           r = e;
         }
         sg.nrb = (int)d4.size() / 4 - sg.rb0;
+        sg.a = a; sg.b = b; sg.mean_len = (double)(h.ptr[b] - h.ptr[a]) / std::max(1, b - a);
         segs.push_back(sg);
         ++l;
       } else {

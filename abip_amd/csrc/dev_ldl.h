@@ -546,6 +546,7 @@ struct DevLdl {
   SymPlan sym;       // how the triangle is dealt to the wavefronts (dev_tail.h)
   int n_sym_tiles = 0; // > 0: the symmetric form is in use (= workgroups of k_tail_sym)
   bool small = false, xl = false; // one-workgroup sparse part; x in LDS
+  int bwd_lds = 0, n_cu = 0;      // backward wide levels with the tail's solution in LDS (dev_sptrsv.h k_tri_wide_lds): 0 off, else the LDS bytes; one workgroup per CU
   int N = 0, t0 = 0, T = 0;
   long lnnz = 0;
 
@@ -578,6 +579,25 @@ struct DevLdl {
     xl = small && N <= XL_MAX;
     if (xl && !allow_lds<NoFuse>()) xl = false;
     lap("upload of the sparse head (forward / backward forms)");
+    // backward wide levels: the tail's solution x2 resident in LDS where it fits and the levels are large enough to be bound by their gathers (ABIP_HIP_TRI_LDS=0 / 1 forces)
+    bwd_lds = 0;
+    if (!small && T > 0 && T <= 16384) {
+      const char *e = getenv("ABIP_HIP_TRI_LDS");
+      long wide_nnz = 0;
+      for (const Segment &sg : B.segs) if (sg.wide) wide_nnz += (long)(sg.mean_len * (sg.b - sg.a));
+      int dev = 0, cus = 0;
+      (void)hipGetDevice(&dev);
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+      n_cu = cus;
+      if (cus > 0 && (e ? atoi(e) != 0 : wide_nnz >= 1000000)) {
+        const int bytes = (int)(sizeof(double) * (size_t)T);
+        bool ok = true;
+        if (bytes > 48 * 1024)
+          ok = hipFuncSetAttribute((const void *)k_tri_wide_lds<16>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute((const void *)k_tri_wide_lds<64>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+        if (ok) bwd_lds = bytes; else (void)hipGetLastError();
+      }
+    }
     return 0;
   }
   int setup_tail(const host::LdlHost &H, hipStream_t s, bool tms) {
@@ -769,16 +789,19 @@ struct DevLdl {
     }
     const int gN = std::max(1, std::min(NB, (N + BS - 1) / BS));
     launch(k_perm_in, gN, BS, (size_t)0, (const int *)Pmap.p, (const double *)rhs, xw.p, N, ctl);
-    auto run = [&](const DevTri &Tr) {
+    auto run = [&](const DevTri &Tr, bool backward) {
       for (const Segment &sg : Tr.segs) {
-        if (sg.wide) launch(k_tri_wide, std::max(1, std::min(NB, sg.nrb)), BS, (size_t)0, Tr.view(), (const int4 *)Tr.rbd.p + sg.rb0, sg.nrb, xw.p, ctl);
+        if (sg.wide && backward && bwd_lds > 0) {
+          if (sg.mean_len <= 96.0) launch(k_tri_wide_lds<16>, n_cu, 1024, (size_t)bwd_lds, Tr.view(), sg.a, sg.b, xw.p, t0, T, ctl);
+          else launch(k_tri_wide_lds<64>, n_cu, 1024, (size_t)bwd_lds, Tr.view(), sg.a, sg.b, xw.p, t0, T, ctl);
+        } else if (sg.wide) launch(k_tri_wide, std::max(1, std::min(NB, sg.nrb)), BS, (size_t)0, Tr.view(), (const int4 *)Tr.rbd.p + sg.rb0, sg.nrb, xw.p, ctl);
         else launch(k_tri_thin, 1, TBS, (size_t)0, Tr.view(), xw.p, sg.l0, sg.l1, ctl);
       }
     };
-    run(F);
+    run(F, false);
     tail(true);
     if (T == 0) launch(k_dscale, gN, BS, (size_t)0, xw.p, (const double *)D.p, t0, ctl);
-    run(B);
+    run(B, true);
     launch(k_perm_out, gN, BS, (size_t)0, (const int *)Pmap.p, rhs, (const double *)xw.p, N, ctl);
   }
 

@@ -63,4 +63,49 @@ static __global__ __launch_bounds__(BS) void k_tri_wide(Tri T, const int4 *__res
   spmv_stream<1>(M, lds, lptr, sm, [&](int c, double a, double(&pr)[1]) { pr[0] = a * x[c]; },
                  [&](int pos, double(&acc)[1]) { const int row = T.lev_rows[pos]; x[row] -= acc[0]; });
 }
+// A wide level of the BACKWARD sweep with the dense tail's part of x RESIDENT IN LDS (round 6; the design of qcp_pcg.h kq_pcg_Aty_lds, which runs the same-shaped product
+// A'y in 20 us where the CSR-stream kernel takes 30).  The rows of such a level are head columns of L; what they gather is mostly x2 -- the solution on the last T
+// pivots (C5: all of it: L11 = I, every entry of a head column lies in L21) -- and T doubles fit the LDS of a CU up to T = 16 384.  With x2 in LDS those gathers never
+// leave the CU: k_tri_wide runs at the rate at which a CU keeps L2 gathers in flight (one request per non-zero: DESIGN section 4), this kernel at the rate of the
+// stream of L's entries.  One 1024-thread workgroup per CU; G lanes per row (16 for short rows, 64 for long ones), four loads in flight per lane for each of two rows,
+// the next pair's extents requested before the current pair is reduced.  An entry outside the tail window (an earlier head level) is gathered from global memory.
+// A row's products add up lane-strided, then by a G-lane butterfly: a fixed order.
+template <int G>
+static __global__ __launch_bounds__(1024) void k_tri_wide_lds(Tri T, int a, int b, double *x, int t0, int tl, const Ctl *ctl) {
+  extern __shared__ double gl[];
+  if (ctl->halt) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < tl; i += 1024) gl[i] = x[t0 + i];
+  __syncthreads();
+  constexpr int GPW = 64 / G;
+  const int gidx = ((int)blockIdx.x * 16 + wave) * GPW + lane / G, gl_ = lane % G, TG = (int)gridDim.x * 16 * GPW;
+  auto extent = [&](int r, int &s, int &e) { s = 0; e = 0; if (r < b) { s = T.ptr[r]; e = T.ptr[r + 1]; } };
+  auto gat = [&](int c) { const int k = c - t0; return (k >= 0 && k < tl) ? gl[k] : x[c]; };
+  auto finish = [&](int r, double acc) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, G);
+    if (gl_ == 0 && r < b) { const int row = T.lev_rows[r]; x[row] -= acc; }
+  };
+  int r = a + gidx, sa, ea, sb, eb;
+  extent(r, sa, ea); extent(r + TG, sb, eb);
+  while (r < b) {
+    int na, ma, nb2, mb;
+    extent(r + 2 * TG, na, ma); extent(r + 3 * TG, nb2, mb);
+    double acca = 0.0, accb = 0.0;
+    for (int qa = sa + gl_, qb = sb + gl_; qa < ea || qb < eb; qa += 4 * G, qb += 4 * G) {
+      double va[4], vb[4]; int ca[4], cb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q1 = qa + k * G, q2 = qb + k * G;
+        const bool o1 = q1 < ea, o2 = q2 < eb;
+        va[k] = o1 ? T.val[q1] : 0.0; ca[k] = o1 ? T.idx[q1] : t0;
+        vb[k] = o2 ? T.val[q2] : 0.0; cb[k] = o2 ? T.idx[q2] : t0;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { acca += va[k] * gat(ca[k]); accb += vb[k] * gat(cb[k]); }
+    }
+    finish(r, acca); finish(r + TG, accb);
+    r += 2 * TG; sa = na; ea = ma; sb = nb2; eb = mb;
+  }
+}
 } // namespace abip

@@ -192,7 +192,7 @@ def cpu_baseline(A, b, c, linsys, budget_s=12.0, window=None):
 # ---------------------------------------------------------------------------------------------------------
 # the conic workload
 # ---------------------------------------------------------------------------------------------------------
-PMC_FILE = next((f for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r04_pmc_traffic.json")
+PMC_FILE = next((f for f in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r04_pmc_traffic.json")
 
 
 def pmc_traffic(case):
@@ -271,14 +271,15 @@ def run_conic(workload, linsys, no_cpu, rank, world, dist, torch):
     streamed = tail_bytes + 2 * 12 * f["head_nnz"] + 2 * 20 * N
     ach = streamed / (avg_ms * 1e-3) / 1e9
     tr = pmc_traffic("c5_direct") if not ml else {}
-    traffic = (tr["k_tail_sym"]["traffic_bytes"] + tr.get("k_tail_sym_fin", {}).get("traffic_bytes", 0) + 2 * tr.get("k_tri_wide", {}).get("traffic_bytes", 0)) if "k_tail_sym" in tr else None
+    tw = tr.get("k_tri_wide", {}).get("traffic_bytes", 0)
+    traffic = (tr["k_tail_sym"]["traffic_bytes"] + tr.get("k_tail_sym_fin", {}).get("traffic_bytes", 0) + tw + tr.get("k_tri_wide_lds", {}).get("traffic_bytes", tw)) if "k_tail_sym" in tr else None
     roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic,
-                traffic_source="profiles/" + PMC_FILE + ": k_tail_sym + k_tail_sym_fin + 2 k_tri_wide per solve (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
+                traffic_source="profiles/" + PMC_FILE + ": k_tail_sym + k_tail_sym_fin + k_tri_wide + k_tri_wide_lds per solve (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
                 effective_frac=bytes_solve / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 explanation="achieved / frac count the bytes this back-end streams per KKT solve; effective_frac prices the same time against SURVEY 8(d)'s B_solve_direct "
                             "(the two triangular sweeps of the reference's algorithm): the symmetric tail halves the bytes, so the effective figure can exceed the real one",
                 kernel="KKT solve of the conic projection: k_perm_in, k_tri_wide (L21 stream), the dense tail (T >= 2048: k_tail_sym + k_tail_sym_fin, the lower triangle of "
-                       "inv(S) streamed once; else k_tail_mv x2 on inv(L22), inv(L22)'), k_tri_wide, k_perm_out",
+                       "inv(S) streamed once, dev_tail.h; else k_tail_mv x2 on inv(L22), inv(L22)'), k_tri_wide_lds (L21' with the tail's solution in LDS; k_tri_wide where it does not fit), k_perm_out",
                 avg_launch_us=avg_ms * 1e3, launches=f["solves_timed"], algorithmic_bytes_per_launch=streamed, reference_algorithm_bytes_per_solve=bytes_solve, lnnz=lnnz, dense_tail=T,
                 streamed_bytes_per_solve=streamed, levels=f["levels"])
     if pcg:   # one solve = prep + (warm set-up pair) + avg_cg_iters x (A'z, A tn, update) + back-substitution: 2 + 2 + 2 cg + 1 products of the matrix
@@ -481,7 +482,7 @@ def run_lp(name, steps, warmup, args, rank, world, dist, torch, sharded, linsys_
         # device-side stamps of this run leave out dispatch and drain; they are scaled by the ratio trace / stamp that ONE profiled run measured for the
         # same kernel (scripts/r04_trace.sh -> profiles/r04_trace_durations.json) and kept, unscaled, under `stamps`.
         ratio, tsrc2, tr, stale = 1.0, None, None, None
-        for trf in ("r05_trace_durations.json", "r04w_trace_durations.json"):
+        for trf in ("r06_trace_durations.json", "r05_trace_durations.json", "r04w_trace_durations.json"):
             path = os.path.join(ROOT, "profiles", trf)
             if name == "c4" and world == 1 and os.path.exists(path):
                 blob = json.load(open(path))

@@ -4,7 +4,7 @@ traffic_bytes = 2 x FETCH + WRITE (gfx950 tallies a 128-byte read request as 64 
 import csv, glob, json, os, statistics, sys
 
 out = sys.argv[1]
-want = ("k_tail_sym", "k_tail_sym_fin", "k_tri_wide", "k_tail_mv", "kq_pcg_Gp", "kq_pcg_Aty_lds", "kq_pcg_Aty", "kq_pcg_update", "k_cg_init_A", "k_cg_init_At",
+want = ("k_tail_sym", "k_tail_sym_fin", "k_tri_wide", "k_tri_wide_lds", "k_tail_mv", "kq_pcg_Gp", "kq_pcg_Aty_lds", "kq_pcg_Aty", "kq_pcg_update", "k_cg_init_A", "k_cg_init_At",
         "k_cg_spmv_A", "k_cg_spmv_At", "k_post_At", "k_q_both", "kq_rhs", "kq_ut_prox", "kq_cones", "kq_inner_both", "kq_resid", "kq_resid_lasso")
 res = {}
 for case in ("c4", "c5_direct", "c5_pcg", "lasso_pcg"):

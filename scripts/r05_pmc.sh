@@ -22,5 +22,5 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   run c2 $ctr "$ROOT/scripts/pmc_lp.py" c2 600
   run c3 $ctr "$ROOT/scripts/pmc_lp.py" c3 60
 done
-python3 "$ROOT/scripts/pmc_summarize.py" "$OUT" > "$OUT/r05_pmc_traffic.json" 2>> "$OUT/summary.txt"
+python3 "$ROOT/scripts/pmc_summarize.py" "$OUT" > "$OUT/pmc_traffic.json" 2>> "$OUT/summary.txt"   # (copied to profiles/rNN_pmc_traffic.json)
 cat "$OUT/summary.txt"

@@ -26,9 +26,18 @@ PY
 }
 if [ "$what" = all ] || [ "$what" = c5 ]; then
   c5 default ABIP_X=0
+  c5 tri_lds_off ABIP_HIP_TRI_LDS=0
   c5 waves1024 ABIP_HIP_TAIL_WAVES=1024
-  c5 waves4096 ABIP_HIP_TAIL_WAVES=4096
+  c5 waves1536 ABIP_HIP_TAIL_WAVES=1536
   c5 two_matvecs ABIP_HIP_TAIL_SYM=0
+  for v in 1 0; do
+    ABIP_HIP_TRI_LDS=$v timeout 900 python bench.py --workload c3 --linsys direct --no-cpu --no-extra > "$OUT/c3_direct_trilds$v.json" 2> "$OUT/c3_direct_trilds$v.err"
+    python3 -c "
+import json
+r=json.loads([l for l in open('$OUT/c3_direct_trilds$v.json') if l.startswith('{')][-1]); tt=r['time_to_tol']
+print('c3 --linsys direct [ABIP_HIP_TRI_LDS=$v]:', round(r['value'],1), 'it/s; whole solve', tt['status'], tt['ipm_iter'], tt['admm_iter'], round(tt['solve_s'],3), 's; solve', round(r['roofline']['avg_launch_us'],1), 'us, tail', r['roofline']['dense_tail'])
+"
+  done
 fi
 if [ "$what" = all ] || [ "$what" = tests ]; then
   timeout 1500 python -m pytest tests/test_gpu_qdldl_pin.py tests/test_gpu_qcp.py tests/test_gpu_baseline_size.py -x -q -m gpu --durations=15 > "$OUT/pytest_tail.txt" 2>&1; tail -25 "$OUT/pytest_tail.txt"

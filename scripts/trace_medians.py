@@ -44,7 +44,7 @@ def main():
                 out[base] = dict(median_working_us=statistics.median(w), mean_working_us=statistics.mean(w), n_working=len(w), launches=len(v), stamp_avg_us_same_run=stamp[base])
         out["source"] = "kernel trace of: " + cmd
         # which kernels this ratio was measured on: bench.py ignores the file (and says so) when the sources have changed since
-        import os, sys
+        import os
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from abip_amd import _lib
         out["kernel_sources_sha256"] = _lib.kernel_sources_sha256()   # (one helper with bench.py: dev_kernels.h, every header it includes, solver.hip)
