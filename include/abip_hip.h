@@ -83,7 +83,10 @@ int abip_hip_dist_init_callback(int rank, int world, abip_hip_allreduce_fn fn, v
  * summed in ONE place in rank order -- deterministic, the same bits on every rank -- one kernel launch per collective, no library in between; what SURVEY 8(e)
  * prices for xGMI).  Every rank: abip_hip_dist_peer_prepare (allocates its mailbox for vectors of up to cap_doubles -- abip_hip_dist_peer_capacity(m, n) is
  * enough for an LP -- and returns the 64-byte IPC handle); the host program gathers the handles of all ranks in rank order; every rank:
- * abip_hip_dist_init_peer.  At most 8 ranks (one node).  Selected by the host program; RCCL stays the default of bench.py until hardware says otherwise. */
+ * abip_hip_dist_init_peer.  At most 8 ranks (one node).  Selected by the host program; RCCL stays the default of bench.py until hardware says otherwise.
+ * abip_hip_dist_init_peer returns -4 (and the transport is not set up: use RCCL) when this rank's mailbox could not be allocated as fine-grained memory and a
+ * peer sits on another device -- remote writes into coarse-grained memory a local kernel polls have no coherence guarantee; EVERY rank must learn of one rank's
+ * refusal before any of them solves (abip_amd/dist.py: init_peer gathers the return codes).  ABIP_HIP_PEER_COARSE_OK=1 overrides. */
 long abip_hip_dist_peer_capacity(long m, long n);
 int abip_hip_dist_peer_prepare(long cap_doubles, void *handle_out64);
 int abip_hip_dist_init_peer(int rank, int world, const void *handles64_by_rank);
