@@ -39,7 +39,8 @@ namespace abip {
 constexpr int PEER_MAX = 8;            // ranks of one node
 constexpr int PEER_HEAD = 2 * PEER_MAX * 8; // doubles in front of the inbox: 2 x PEER_MAX flags, 64 bytes apart
 constexpr int PEER_PAD = 32 * PEER_MAX;     // slack of the inbox / gather areas for the rounding of a chunk
-constexpr unsigned long long XP_WAIT_TICKS = 300000000ull; // ticks of wall_clock64 (100 MHz) before a wait gives up: 3 s
+constexpr unsigned long long XP_WAIT_TICKS = 300000000ull; // ticks of wall_clock64 (100 MHz) before a wait gives up: 3 s (PeerCtx::wait_ticks; ABIP_HIP_PEER_WAIT_MS names another limit --
+                                                           // several ranks sharing ONE device take turns on it, and a rank whose peer is not scheduled for a while must not fail the dry run)
 
 struct PeerCtx {
   int rank, world;
@@ -47,6 +48,7 @@ struct PeerCtx {
   double *mail[PEER_MAX];            // every rank's mailbox as mapped here (mail[rank] = this rank's own allocation)
   unsigned *sync;                    // this rank's own: [0] workgroups through the push, [1] through the reduction (reset by the last one)
   int *status;                       // host-mapped: != 0 after a wait gave up (1 + the rank it waited for)
+  unsigned long long wait_ticks;     // how long a wait may see no progress (XP_WAIT_TICKS unless ABIP_HIP_PEER_WAIT_MS says otherwise)
 };
 inline long peer_mailbox_doubles(long cap) { return PEER_HEAD + 2 * (cap + PEER_PAD); }
 __host__ __device__ inline long peer_chunk(long count, int W) { return ((count + W - 1) / W + 31) / 32 * 32; } // (the same on every rank: derived from count and W only)
@@ -68,7 +70,7 @@ __device__ __forceinline__ bool peer_wait(const PeerCtx &c, int which, int from,
     unsigned spins = 0;
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(peer_flag(c, c.rank, which, from), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-      if ((++spins & 255u) == 0 && (__hip_atomic_load(c.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || (unsigned long long)wall_clock64() - t0 > XP_WAIT_TICKS)) {
+      if ((++spins & 255u) == 0 && (__hip_atomic_load(c.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || (unsigned long long)wall_clock64() - t0 > c.wait_ticks)) {
         int expect = 0; // the first culprit stays on record
         (void)__hip_atomic_compare_exchange_strong(c.status, &expect, 1 + from, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         ok = 0;

@@ -2722,6 +2722,8 @@ int abip_hip_dist_init_peer(int rank, int world, const void *handles /* world x 
   int *dstatus = nullptr;
   if (hipHostGetDevicePointer((void **)&dstatus, p.hstatus, 0) != hipSuccess) return -3;
   p.ctx.status = dstatus;
+  p.ctx.wait_ticks = abip::XP_WAIT_TICKS;
+  if (const char *e = getenv("ABIP_HIP_PEER_WAIT_MS")) { const long ms = atol(e); if (ms > 0) p.ctx.wait_ticks = (unsigned long long)ms * 100000ull; }
   p.epoch = 0;
   g_dist.kind = 3; g_dist.rank = rank; g_dist.world = world;
   return 0;

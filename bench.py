@@ -611,6 +611,8 @@ def main():
     # rccl: one GPU per rank.  peer (the hand-rolled exchange over IPC-mapped mailboxes, dev_peer.h): one GPU per rank where the node has them, else every rank on
     # cuda:0 (a functional dry run).  gloo-callback: every rank on cuda:0, host-staged sums.
     peer_one_gpu = transport == "peer" and torch.cuda.device_count() < world
+    if peer_one_gpu:
+        os.environ.setdefault("ABIP_HIP_PEER_WAIT_MS", "60000")   # the ranks take turns on the one device: a wait inside a kernel may see its peer off it for a while
     torch.cuda.set_device(local_rank if (transport == "rccl" or (transport == "peer" and not peer_one_gpu)) else 0)
     dist = None
     if world > 1 or force_shard:

@@ -38,7 +38,7 @@ def _run_jobs(world, jobs, timeout=900):
     """One launch of `world` ranks running every job of the list in the same processes (tests/dist_worker.py JOBS): the ranks take ~15 s to start."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "JOBS", json.dumps(jobs)]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ABIP_HIP_PEER_WAIT_MS="60000")   # (eight ranks take turns on one device: a peer may be off it for a while)
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
     assert p.returncode == 0 and lines, p.stdout[-2000:] + p.stderr[-3000:]

@@ -114,7 +114,7 @@ def runs(gpu):
         if world not in cache:
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                    "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), "JOBS", json.dumps(JOBS[world])]
-            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ABIP_HIP_PEER_WAIT_MS="60000")   # (the ranks share one device: a peer may be off it for a while)
             env.pop("ABIP_HIP_DIST_CG", None)
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
             lines = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
