@@ -41,7 +41,7 @@ struct SymPlan : SymArgs {    // host side: how the triangle is dealt to the wav
     pre[0] = 0;
     for (int cc = 0; cc < ncc; ++cc) pre[cc + 1] = pre[cc] + (T - SYC * cc) / SYU; // units of chunk cc: its rows [512 cc, T), four at a time
     nu = pre[ncc];
-    nwv = std::max(4, std::min(waves_wanted, nu) / 4 * 4);
+    nwv = std::max(4, std::min(waves_wanted, std::max(nu / 4, 4)) / 4 * 4); // (at least four units = one 16-row tile per wavefront: small tails take fewer, longer walks)
     slots = nwv + ncc;
     // the wavefronts whose range meets chunk cc (a contiguous run: the ranges are in list order)
     int q = 0;
