@@ -84,7 +84,7 @@ EXPORTS = (
     "abip_hip_dist_get_unique_id", "abip_hip_dist_init_rccl", "abip_hip_dist_init_callback", "abip_hip_dist_finalize",
     "abip_hip_dist_peer_capacity", "abip_hip_dist_peer_prepare", "abip_hip_dist_init_peer",
     "abip_hip_dist_partition", "abip_hip_dist_rows", "abip_hip_host_factor_solve", "abip_hip_host_normalize_A",
-    "abip_hip_dist_comm_count", "abip_hip_profile_enable_stamps", "abip_hip_set_copy_a_matrix", "abip_hip_get_copy_a_matrix", "abip_hip_ldl_solve", "abip_hip_xcd_plan", "abip_hip_csc_to_csr",
+    "abip_hip_dist_comm_count", "abip_hip_profile_enable_stamps", "abip_hip_set_copy_a_matrix", "abip_hip_get_copy_a_matrix", "abip_hip_ldl_solve", "abip_hip_xcd_plan", "abip_hip_tail_plan", "abip_hip_csc_to_csr",
     "abip_qcp", "abip_qcp_set_default_settings", "abip_hip_qcp_last_stats", "abip_hip_qcp_phase_times", "abip_hip_qcp_cone_prox", "abip_hip_qcp_dist_partition", "abip_hip_qcp_host_probe",
 )
 

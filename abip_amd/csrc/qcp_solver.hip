@@ -959,4 +959,16 @@ qcp_int abip_qcp(const QCPData *d, QCPSolution *sol, QCPInfo *info, QCPCone *K) 
   return info->status_val;
 }
 
+// Pure host code: how the dense tail's triangle is dealt to the wavefronts of its stream (dev_tail.h SymPlan).  out4 = {column chunks, units of four rows, wavefronts,
+// column-partial slots}; pre (chunks + 1), qlo / qhi (chunks) as the kernels get them.  For tests/test_tail_plan_cpu.py.  Returns 0, -1 where there is no plan.
+__attribute__((visibility("default"))) int abip_hip_tail_plan(int T, int waves, int *out4, int *pre, int *qlo, int *qhi) { // (declared in abip_hip.h, which this file does not include: the export is marked here)
+  if (!out4) return -1;
+  abip::SymPlan p;
+  if (!p.make(T, waves)) return -1;
+  out4[0] = p.ncc; out4[1] = p.nu; out4[2] = p.nwv; out4[3] = p.slots;
+  if (pre) std::copy(p.pre, p.pre + p.ncc + 1, pre);
+  if (qlo) std::copy(p.qlo, p.qlo + p.ncc, qlo);
+  if (qhi) std::copy(p.qhi, p.qhi + p.ncc, qhi);
+  return 0;
+}
 } // extern "C"

@@ -116,6 +116,10 @@ void abip_hip_dist_rows(ABIPWork *w, abip_int *row0, abip_int *row1);
  * NULL) receive the row boundaries of the workgroups' slices of A / A'.  ABIP_HIP_XCD_G in the environment forces the workgroup count as it does in
  * abip_init.  Returns 0, < 0 on invalid arguments. */
 int abip_hip_xcd_plan(abip_int m, abip_int n, const abip_int *Ap, const abip_int *Ai, int linsys, double *out8, int *mb, int *nb);
+/* Pure host code: the plan of the dense tail's stream (abip_amd/csrc/dev_tail.h) for a tail of T pivots (T % 64 == 0) and `waves` wavefronts wanted: out4 = {column
+ * chunks of 512, units of four rows, wavefronts used, slots of the column-partial table}; pre (chunks + 1: units in front of a chunk), qlo / qhi (chunks: the
+ * wavefronts whose ranges meet a chunk) may be NULL (room for 65 / 64 / 64 ints).  Returns 0, -1 where no plan exists (T not a multiple of 16, T > 32 768). */
+int abip_hip_tail_plan(int T, int waves, int *out4, int *pre, int *qlo, int *qhi);
 /* Unit-level access to the direct back-end's LDL' as the LP and the conic path use it: K symmetric quasi-definite, given by its UPPER triangle in CSC
  * form (32-bit indices); rhs (N) <- K^-1 rhs.  on_device 0: everything on the host (no GPU needed); 1: sparse head on the host, dense tail factored and
  * the solve applied on the device.  tail: -1 automatic, 0 none, T forced.  stats4 (may be NULL) = {T, nnz(L), forward levels, backward levels}.
