@@ -25,10 +25,12 @@ print(f"c5 direct [{sys.argv[2]}]: {r['value']:.0f} it/s, {r['steps']} its, solv
 PY
 }
 if [ "$what" = all ] || [ "$what" = c5 ]; then
-  c5 default ABIP_X=0
+  for rep in 1 2 3; do
+    c5 waves2048_$rep ABIP_HIP_TAIL_WAVES=2048
+    c5 waves1024_$rep ABIP_HIP_TAIL_WAVES=1024
+    c5 waves1280_$rep ABIP_HIP_TAIL_WAVES=1280
+  done
   c5 tri_lds_off ABIP_HIP_TRI_LDS=0
-  c5 waves1024 ABIP_HIP_TAIL_WAVES=1024
-  c5 waves1536 ABIP_HIP_TAIL_WAVES=1536
   c5 two_matvecs ABIP_HIP_TAIL_SYM=0
   for v in 1 0; do
     ABIP_HIP_TRI_LDS=$v timeout 900 python bench.py --workload c3 --linsys direct --no-cpu --no-extra > "$OUT/c3_direct_trilds$v.json" 2> "$OUT/c3_direct_trilds$v.err"
