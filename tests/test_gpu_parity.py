@@ -326,19 +326,25 @@ def test_tail_residual_guard_falls_back(gpu, monkeypatch):
         """, {"ABIP_HIP_TAIL_RESID_FAIL": "1"})                # ... the tests' variant takes it
 
 
-def test_direct_solve_wide_head_with_tail(gpu):
-    """A factor whose head levels are wider than one workgroup (segmented path) and whose tail is several thousand pivots."""
+def test_direct_solve_wide_head_with_tail(gpu, monkeypatch):
+    """A factor whose head levels are wider than one workgroup (segmented path) and whose tail is several thousand pivots; the backward wide levels through the
+    CSR-stream kernel (ABIP_HIP_TRI_LDS=0) and with the tail's solution resident in LDS (=1: dev_sptrsv.h k_tri_wide_lds, by itself only from 1e6 non-zeros in those
+    levels on): the same solution to 1e-12."""
     from abip_amd import problems
     A, b, c = problems.lp_random_sparse(m=2000, n=10000, per_col=4)[:3]
     A = sp.csc_matrix(A); A.sort_indices()
-    rng = np.random.default_rng(8)
-    with gpu.Solver(A, b, c, linsys="direct", verbose=0) as S:
-        assert S.scalar("tail") >= 1024 and S.scalar("small_solve") == 0
-        Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
-        K = kkt_matrix(Asc, 1e-3)
-        rhs = rng.standard_normal(S.m + S.n)
-        sol, its = S.kkt_solve(rhs, None, -1)
-        assert rel(K @ sol, rhs) < 1e-10
+    rhs = np.random.default_rng(8).standard_normal(A.shape[0] + A.shape[1])
+    sols = {}
+    for lds in ("0", "1"):
+        monkeypatch.setenv("ABIP_HIP_TRI_LDS", lds)
+        with gpu.Solver(A, b, c, linsys="direct", verbose=0) as S:
+            assert S.scalar("tail") >= 1024 and S.scalar("small_solve") == 0
+            Asc = sp.csc_matrix((S.vector("Ax"), A.indices, A.indptr), shape=A.shape)
+            K = kkt_matrix(Asc, 1e-3)
+            sol, its = S.kkt_solve(rhs, None, -1)
+            assert rel(K @ sol, rhs) < 1e-10, lds
+            sols[lds] = sol
+    assert rel(sols["1"], sols["0"]) < 1e-12
 
 
 def test_spmv_long_rows_and_ragged_blocks(gpu):
