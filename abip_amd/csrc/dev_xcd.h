@@ -554,6 +554,13 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     if (kt0 + (int)k < kt1) { ti[u] = 8u * (unsigned)x_at(a.Ti, kt0 + k); nt = u + 1; }
   }
   const double *gA = a.Ax + ka0, *gT = a.Tx + kt0; // the slices' values
+#ifdef XCD_HALO_PROBE // developer build (make exp EXPNAME=haloprobe EXPDEF=-DXCD_HALO_PROBE): what a halo form of the PCG would ADD to the first exchange's gather phase --
+  // two more slices of the same size gathered from the m-space and summed by rows (a rank would form A'p for every column its rows touch: ~3x its own slice on c3)
+  unsigned ti2[NZ], ti3[NZ];
+#pragma unroll
+  for (int u = 0; u < NZ; ++u) { ti2[u] = 8u * ((ti[u] / 8u + 37u) % (unsigned)a.m); ti3[u] = 8u * ((ti[u] / 8u + (unsigned)a.m / 2u + 5u) % (unsigned)a.m); }
+  double hp_sink = 0.0;
+#endif
   int sa[RM], ea[RM], st[RN], et[RN];
 #pragma unroll
   for (int q = 0; q < RM; ++q) { const unsigned i = m0 + t + q * XTB; sa[q] = 0; ea[q] = 0; if (i < m1) { sa[q] = x_at(a.Ap, i) - ka0; ea[q] = x_at(a.Ap, i + 1) - ka0; } }
@@ -965,8 +972,19 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         {
           double vt[NZ];
           x_gather<NZ>(pm0, ti, vt);
+#ifdef XCD_HALO_PROBE
+          double v2[NZ], v3[NZ], d2[RN], d3[RN];
+          x_gather<NZ>(pm0, ti2, v2); // (all three gathers in flight together, as a halo form would issue them)
+          x_gather<NZ>(pm0, ti3, v3);
+#endif
           XP_LAP(3)
           x_rows<NZ, RN>(prod, flip, tx, vt, nt, st, et, tq);
+#ifdef XCD_HALO_PROBE
+          x_rows<NZ, RN>(prod, flip, tx, v2, nt, st, et, d2);
+          x_rows<NZ, RN>(prod, flip, tx, v3, nt, st, et, d3);
+#pragma unroll
+          for (int q = 0; q < RN; ++q) hp_sink += d2[q] + d3[q];
+#endif
         }
         XP_LAP(4)
         const double cbeta = (cgit == 0) ? 0.0 : rzS[1] / zr_prev;
@@ -1672,6 +1690,9 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     }
     a.xstat[1] = (int)(tag - a.tag0);
   }
+#ifdef XCD_HALO_PROBE
+  if (hp_sink == 123.456789) a.xstat[1] = -1; // (keeps the probe's sums alive)
+#endif
   XP_DUMP
 }
 
