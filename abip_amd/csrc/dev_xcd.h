@@ -636,6 +636,23 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   double wg = 0.0, u_tau = 0.0, v_tau = 0.0;
 #pragma unroll
   for (int q = 0; q < RN; ++q) aty[q] = 0.0;
+#ifdef XCD_RSUM // developer build (make exp EXPNAME=rsum EXPDEF=-DXCD_RSUM): the restart sums and the running sums of the owned elements live in registers for
+  // the whole launch instead of four read-modify-write streams per element and iteration; the arrays are written once, when the launch ends
+  double Rua_y[RM], Rva_y[RM], Rus_y[RM], Rvs_y[RM], Rua_x[RN], Rva_x[RN], Rus_x[RN], Rvs_x[RN], Rtl[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < RM; ++q) {
+    const unsigned i = m0 + t + q * XTB;
+    Rua_y[q] = 0.0; Rva_y[q] = 0.0; Rus_y[q] = 0.0; Rvs_y[q] = 0.0;
+    if (i < m1 && !solo) { Rua_y[q] = x_at(up.u_avg, i); Rva_y[q] = x_at(up.v_avg, i); Rus_y[q] = x_at(up.u_sum, i); Rvs_y[q] = x_at(up.v_sum, i); }
+  }
+#pragma unroll
+  for (int q = 0; q < RN; ++q) {
+    const unsigned j2 = n0 + t + q * XTB;
+    Rua_x[q] = 0.0; Rva_x[q] = 0.0; Rus_x[q] = 0.0; Rvs_x[q] = 0.0;
+    if (j2 < n1 && !solo) { const unsigned qq = MP + j2; Rua_x[q] = x_at(up.u_avg, qq); Rva_x[q] = x_at(up.v_avg, qq); Rus_x[q] = x_at(up.u_sum, qq); Rvs_x[q] = x_at(up.v_sum, qq); }
+  }
+  if (rank == 0 && t == 0 && !solo) { Rtl[0] = x_at(up.u_avg, tail); Rtl[1] = x_at(up.v_avg, tail); Rtl[2] = x_at(up.u_sum, tail); Rtl[3] = x_at(up.v_sum, tail); }
+#endif
 
   for (;;) {
     // (an index the optimiser cannot see through: otherwise it hoists the element addresses of an iteration out of this loop and spills them)
@@ -781,6 +798,13 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         x_at(up.u_avg, tail) = 0.0; x_at(up.v_avg, tail) = 0.0; x_at(up.u_sum, tail) = 0.0; x_at(up.v_sum, tail) = 0.0;
         if (av) { x_at(up.u, tail) = r_ut; x_at(up.v, tail) = r_vt; }
       }
+#ifdef XCD_RSUM
+#pragma unroll
+      for (int q = 0; q < RM; ++q) { Rua_y[q] = 0.0; Rva_y[q] = 0.0; Rus_y[q] = 0.0; Rvs_y[q] = 0.0; }
+#pragma unroll
+      for (int q = 0; q < RN; ++q) { Rua_x[q] = 0.0; Rva_x[q] = 0.0; Rus_x[q] = 0.0; Rvs_x[q] = 0.0; }
+      Rtl[0] = 0.0; Rtl[1] = 0.0; Rtl[2] = 0.0; Rtl[3] = 0.0;
+#endif
       jj = 0;
       up.mu_over_beta = x_uni(mu / beta);
       thr = x_uni(xo.gamma * mu);
@@ -1199,7 +1223,11 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       wsy[q] = 1.0;
       if (upd_next && i < m1) {
         Ly[q].v = x_at(up.v, i); if (up.half_update) Ly[q].u = x_at(up.u, i);
+#ifdef XCD_RSUM
+        Ly[q].ua = Rua_y[q]; Ly[q].va = Rva_y[q]; Ly[q].us = Rus_y[q]; Ly[q].vs = Rvs_y[q];
+#else
         Ly[q].ua = x_at(up.u_avg, i); Ly[q].va = x_at(up.v_avg, i); Ly[q].us = x_at(up.u_sum, i); Ly[q].vs = x_at(up.v_sum, i);
+#endif
         Ly[q].g = x_at(up.g, i); Ly[q].bc = x_at(up.b, i);
         if (a.wD) wsy[q] = x_at(a.wD, i);
       }
@@ -1212,7 +1240,11 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
       if (upd_next && j2 < n1) {
         const unsigned qq = MP + j2;
         Lx[q].u = x_at(up.u, qq); Lx[q].v = x_at(up.v, qq);
+#ifdef XCD_RSUM
+        Lx[q].ua = Rua_x[q]; Lx[q].va = Rva_x[q]; Lx[q].us = Rus_x[q]; Lx[q].vs = Rvs_x[q];
+#else
         Lx[q].ua = x_at(up.u_avg, qq); Lx[q].va = x_at(up.v_avg, qq); Lx[q].us = x_at(up.u_sum, qq); Lx[q].vs = x_at(up.v_sum, qq);
+#endif
         Lx[q].g = x_at(up.g, qq); Lx[q].bc = x_at(up.c, j2);
         if (a.wE) wsx[q] = x_at(a.wE, j2);
       }
@@ -1220,7 +1252,11 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
     Lt = XLd{0, 0, 0, 0, 0, 0, 0, 0};
     if (upd_next && rank == 0 && t == 0) {
       Lt.u = x_at(up.u, tail); Lt.v = x_at(up.v, tail);
+#ifdef XCD_RSUM
+      Lt.ua = Rtl[0]; Lt.va = Rtl[1]; Lt.us = Rtl[2]; Lt.vs = Rtl[3];
+#else
       Lt.ua = x_at(up.u_avg, tail); Lt.va = x_at(up.v_avg, tail); Lt.us = x_at(up.u_sum, tail); Lt.vs = x_at(up.v_sum, tail);
+#endif
     }
     {
       double tx[NZ];
@@ -1308,8 +1344,12 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
         if (i < m1) {
           const double un = nuy[q], vn = nvy[q];
           x_at(up.u, i) = un; x_at(up.v, i) = vn;
+#ifdef XCD_RSUM
+          Rua_y[q] = Ly[q].ua + un; Rva_y[q] = Ly[q].va + vn; Rus_y[q] = Ly[q].us + un; Rvs_y[q] = Ly[q].vs + vn;
+#else
           x_at(up.u_avg, i) = Ly[q].ua + un; x_at(up.v_avg, i) = Ly[q].va + vn;
           x_at(up.u_sum, i) = Ly[q].us + un; x_at(up.v_sum, i) = Ly[q].vs + vn;
+#endif
           x_at(up.u_avgc, i) = uay[q]; x_at(up.v_avgc, i) = (Ly[q].vs + vn) / up.dom;
         }
       }
@@ -1321,16 +1361,24 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
           const double un = nux[q], vn = nvx[q];
           x_at(up.ut, qq) = zx[q];
           x_at(up.u, qq) = un; x_at(up.v, qq) = vn;
+#ifdef XCD_RSUM
+          Rua_x[q] = Lx[q].ua + un; Rva_x[q] = Lx[q].va + vn; Rus_x[q] = Lx[q].us + un; Rvs_x[q] = Lx[q].vs + vn;
+#else
           x_at(up.u_avg, qq) = Lx[q].ua + un; x_at(up.v_avg, qq) = Lx[q].va + vn;
           x_at(up.u_sum, qq) = Lx[q].us + un; x_at(up.v_sum, qq) = Lx[q].vs + vn;
+#endif
           x_at(up.u_avgc, qq) = uax[q]; x_at(up.v_avgc, qq) = vacx[q];
         }
       }
       if (rank == 0 && t == 0) {
         x_at(up.ut, tail) = utq_t;
         x_at(up.u, tail) = tau4[0]; x_at(up.v, tail) = tau4[1];
+#ifdef XCD_RSUM
+        Rtl[0] = Lt.ua + tau4[0]; Rtl[1] = Lt.va + tau4[1]; Rtl[2] = Lt.us + tau4[0]; Rtl[3] = Lt.vs + tau4[1];
+#else
         x_at(up.u_avg, tail) = Lt.ua + tau4[0]; x_at(up.v_avg, tail) = Lt.va + tau4[1];
         x_at(up.u_sum, tail) = Lt.us + tau4[0]; x_at(up.v_sum, tail) = Lt.vs + tau4[1];
+#endif
         x_at(up.u_avgc, tail) = tau4[2]; x_at(up.v_avgc, tail) = tau4[3];
       }
     };
@@ -1692,6 +1740,21 @@ __global__ __launch_bounds__(XTB) void k_lp_xcd(const XcdArgs a) {
   }
 #ifdef XCD_HALO_PROBE
   if (hp_sink == 123.456789) a.xstat[1] = -1; // (keeps the probe's sums alive)
+#endif
+#ifdef XCD_RSUM
+  if (!solo) { // the sums back to their arrays (the host reads them: restarts, the averaged iterate, the next launch)
+#pragma unroll
+    for (int q = 0; q < RM; ++q) {
+      const unsigned i = m0 + t + q * XTB;
+      if (i < m1) { x_at(up.u_avg, i) = Rua_y[q]; x_at(up.v_avg, i) = Rva_y[q]; x_at(up.u_sum, i) = Rus_y[q]; x_at(up.v_sum, i) = Rvs_y[q]; }
+    }
+#pragma unroll
+    for (int q = 0; q < RN; ++q) {
+      const unsigned j2 = n0 + t + q * XTB;
+      if (j2 < n1) { const unsigned qq = MP + j2; x_at(up.u_avg, qq) = Rua_x[q]; x_at(up.v_avg, qq) = Rva_x[q]; x_at(up.u_sum, qq) = Rus_x[q]; x_at(up.v_sum, qq) = Rvs_x[q]; }
+    }
+    if (rank == 0 && t == 0) { x_at(up.u_avg, tail) = Rtl[0]; x_at(up.v_avg, tail) = Rtl[1]; x_at(up.u_sum, tail) = Rtl[2]; x_at(up.v_sum, tail) = Rtl[3]; }
+  }
 #endif
   XP_DUMP
 }
